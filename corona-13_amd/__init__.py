@@ -1,0 +1,311 @@
+"""corona-13_amd -- MI355X-native backend for the pt/ptdl hot path of hanatos/corona-13.
+
+The product is two native libraries behind a C ABI (include/corona_mi.h):
+
+  host/libcorona_host.so   plain C: .nra2/.geo/.cam loaders, QBVH build, emitter CDF, PFM output
+  csrc/libcorona_mi.so     HIP (gfx950): the path tracing kernels + the mi_* entry points
+
+This Python module is only a ctypes view of that ABI for tests, bench.py and multi-GPU glue
+(torch.distributed owns the RCCL reduce of the framebuffer). It contains no rendering logic
+and no CPU fallback: if libcorona_mi.so is missing, `Backend()` raises.
+
+The directory name contains '-' and '.', so import it through `load_package()` in
+__graft_entry__.py (importlib) under the module name `corona13_amd`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+REPO_DIR = PKG_DIR.parent
+HOST_LIB = PKG_DIR / "host" / "libcorona_host.so"
+MI_LIB = PKG_DIR / "csrc" / "libcorona_mi.so"
+
+MI_SAMPLER_PT, MI_SAMPLER_PTDL = 0, 1
+MI_REC_MAX_VERTS, MI_REC_MAX_SPLATS = 8, 8
+
+
+# ---------------------------------------------------------------- ctypes mirrors of corona_mi.h
+class MiVtxidx(C.Structure):
+    _fields_ = [("v", C.c_uint32), ("uv", C.c_uint32)]
+
+
+class MiVtx(C.Structure):
+    _fields_ = [("v", C.c_float * 3), ("n", C.c_uint32)]
+
+
+class MiShape(C.Structure):
+    _fields_ = [("material", C.c_int32), ("num_prims", C.c_uint32),
+                ("vtxidx_base", C.c_uint32), ("vtx_base", C.c_uint32)]
+
+
+class MiNode(C.Structure):
+    _fields_ = [("aabb", (C.c_float * 4) * 6), ("child", C.c_uint64 * 4),
+                ("axis0", C.c_int32), ("axis00", C.c_int32), ("axis01", C.c_int32), ("parent", C.c_int32)]
+
+
+class MiShadeOp(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("slot", C.c_uint32), ("coeff", C.c_float * 3),
+                ("mul", C.c_float), ("roughness", C.c_float), ("pad", C.c_uint32)]
+
+
+class MiMaterial(C.Structure):
+    _fields_ = [("bsdf", C.c_uint32), ("num_ops", C.c_uint32), ("op", MiShadeOp * 4), ("param", C.c_float * 4)]
+
+
+class MiCamera(C.Structure):
+    _fields_ = [("pos", C.c_float * 3), ("a", C.c_float * 3), ("b", C.c_float * 3), ("n", C.c_float * 3),
+                ("focus", C.c_float), ("focal_length", C.c_float), ("film_width", C.c_float),
+                ("film_height", C.c_float), ("f_stop", C.c_float), ("exposure_time", C.c_float),
+                ("iso", C.c_float), ("time_scale", C.c_float)]
+
+
+class MiLights(C.Structure):
+    _fields_ = [("num_prims", C.c_uint32), ("primid", C.POINTER(C.c_uint64)), ("cdf", C.POINTER(C.c_float)),
+                ("L", C.POINTER(C.c_float)), ("p_sky", C.c_float), ("p_geo", C.c_float), ("p_vol", C.c_float)]
+
+
+class MiSceneDesc(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("abi_version", C.c_uint32),
+                ("width", C.c_uint32), ("height", C.c_uint32), ("max_verts", C.c_uint32), ("sampler", C.c_uint32),
+                ("frame", C.c_uint64),
+                ("num_nodes", C.c_uint32), ("nodes", C.POINTER(MiNode)), ("aabb", C.c_float * 6),
+                ("num_prims", C.c_uint64), ("primid", C.POINTER(C.c_uint64)),
+                ("num_shapes", C.c_uint32), ("shapes", C.POINTER(MiShape)),
+                ("num_vtxidx", C.c_uint64), ("vtxidx", C.POINTER(MiVtxidx)),
+                ("num_vtx", C.c_uint64), ("vtx", C.POINTER(MiVtx)),
+                ("num_materials", C.c_uint32), ("materials", C.POINTER(MiMaterial)),
+                ("lights", MiLights), ("cam", MiCamera),
+                ("cie_xyz", C.POINTER(C.c_float)), ("checker", C.POINTER(C.c_float)), ("metal_ior", C.POINTER(C.c_float))]
+
+
+class MiPathVertex(C.Structure):
+    _fields_ = [("prim", C.c_uint64), ("dist", C.c_float), ("x", C.c_float * 3), ("n", C.c_float * 3),
+                ("gn", C.c_float * 3), ("omega", C.c_float * 3), ("mode", C.c_uint32), ("flags", C.c_uint32),
+                ("throughput", C.c_float), ("pdf", C.c_float), ("u", C.c_float), ("v", C.c_float),
+                ("rd", C.c_float), ("rg", C.c_float), ("em", C.c_float), ("roughness", C.c_float),
+                ("eta", C.c_float), ("shader", C.c_int32)]
+
+
+class MiPathSplat(C.Structure):
+    _fields_ = [("length", C.c_int32), ("tech", C.c_int32), ("value", C.c_float), ("col", C.c_float * 3)]
+
+
+class MiPathRecord(C.Structure):
+    _fields_ = [("index", C.c_uint64), ("pixel_i", C.c_float), ("pixel_j", C.c_float), ("lambda_", C.c_float),
+                ("time", C.c_float), ("scramble", C.c_float), ("throughput", C.c_float),
+                ("length", C.c_int32), ("num_splats", C.c_int32),
+                ("splat", MiPathSplat * MI_REC_MAX_SPLATS), ("v", MiPathVertex * MI_REC_MAX_VERTS)]
+
+
+class ChOptions(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("max_verts", C.c_uint32), ("sampler", C.c_uint32),
+                ("frame", C.c_uint64), ("cam_file", C.c_char_p), ("rgb2spec_lut", C.c_char_p),
+                ("data_dir", C.c_char_p), ("iso", C.c_float), ("build_threads", C.c_int), ("verbose", C.c_int)]
+
+
+def record_dtype():
+    """numpy dtype of mi_path_record (== the reference dump harness record)."""
+    import numpy as np
+    vert = np.dtype([("prim", "<u8"), ("dist", "<f4"), ("x", "<f4", 3), ("n", "<f4", 3), ("gn", "<f4", 3),
+                     ("omega", "<f4", 3), ("mode", "<u4"), ("flags", "<u4"), ("throughput", "<f4"), ("pdf", "<f4"),
+                     ("u", "<f4"), ("v", "<f4"), ("rd", "<f4"), ("rg", "<f4"), ("em", "<f4"), ("roughness", "<f4"),
+                     ("eta", "<f4"), ("shader", "<i4")], align=True)
+    splat = np.dtype([("length", "<i4"), ("tech", "<i4"), ("value", "<f4"), ("col", "<f4", 3)])
+    rec = np.dtype([("index", "<u8"), ("pixel_i", "<f4"), ("pixel_j", "<f4"), ("lambda", "<f4"), ("time", "<f4"),
+                    ("scramble", "<f4"), ("throughput", "<f4"), ("length", "<i4"), ("num_splats", "<i4"),
+                    ("splat", splat, MI_REC_MAX_SPLATS), ("v", vert, MI_REC_MAX_VERTS)], align=True)
+    assert rec.itemsize == C.sizeof(MiPathRecord), (rec.itemsize, C.sizeof(MiPathRecord))
+    return rec
+
+
+# ---------------------------------------------------------------- host library
+_host = None
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        if not HOST_LIB.exists():
+            raise RuntimeError(f"{HOST_LIB} missing: run __graft_entry__.build() (make -C corona-13_amd)")
+        os.environ.setdefault("CORONA_MI_DATA", str(PKG_DIR / "data"))
+        h = C.CDLL(str(HOST_LIB))
+        h.ch_scene_load.argtypes = [C.c_char_p, C.POINTER(ChOptions), C.POINTER(C.c_void_p)]
+        h.ch_scene_load.restype = C.c_int
+        h.ch_scene_desc.argtypes = [C.c_void_p]
+        h.ch_scene_desc.restype = C.POINTER(MiSceneDesc)
+        h.ch_scene_set_color_coeff.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_float]
+        h.ch_scene_set_color_coeff.restype = C.c_int
+        h.ch_scene_num_shaders.argtypes = [C.c_void_p]
+        h.ch_scene_shader_name.argtypes = [C.c_void_p, C.c_int]
+        h.ch_scene_shader_name.restype = C.c_char_p
+        h.ch_scene_free.argtypes = [C.c_void_p]
+        h.ch_scene_free.restype = None
+        h.ch_scene_gain.argtypes = [C.c_void_p, C.c_uint64]
+        h.ch_scene_gain.restype = C.c_float
+        h.ch_pfm_write.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_float]
+        h.ch_rgb_to_coeff.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_char_p]
+        h.ch_rgb_to_coeff.restype = C.c_float
+        _host = h
+    return _host
+
+
+class Scene:
+    """A scene loaded by the host library (owns the mi_scene_desc)."""
+
+    def __init__(self, nra2, width=1024, height=576, max_verts=32, sampler=MI_SAMPLER_PT, frame=1,
+                 rgb2spec_lut=None, verbose=0):
+        h = host_lib()
+        opt = ChOptions(width=width, height=height, max_verts=max_verts, sampler=sampler, frame=frame,
+                        cam_file=None, rgb2spec_lut=(str(rgb2spec_lut).encode() if rgb2spec_lut else None),
+                        data_dir=str(PKG_DIR / "data").encode(), iso=0.0, build_threads=0, verbose=verbose)
+        self._ptr = C.c_void_p()
+        err = h.ch_scene_load(str(nra2).encode(), C.byref(opt), C.byref(self._ptr))
+        if err:
+            raise RuntimeError(f"ch_scene_load({nra2}) failed: {err}")
+        self._h = h
+
+    @property
+    def desc(self):
+        return self._h.ch_scene_desc(self._ptr).contents
+
+    @property
+    def desc_ptr(self):
+        return self._h.ch_scene_desc(self._ptr)
+
+    @property
+    def width(self):
+        return self.desc.width
+
+    @property
+    def height(self):
+        return self.desc.height
+
+    def gain(self, spp):
+        return self._h.ch_scene_gain(self._ptr, spp)
+
+    def shader_names(self):
+        return [self._h.ch_scene_shader_name(self._ptr, i).decode() for i in range(self._h.ch_scene_num_shaders(self._ptr))]
+
+    def set_color_coeff(self, shader_id, coeff, mul):
+        arr = (C.c_float * 3)(*coeff)
+        err = self._h.ch_scene_set_color_coeff(self._ptr, shader_id, arr, mul)
+        if err:
+            raise RuntimeError(f"set_color_coeff({shader_id}) failed: {err}")
+
+    def close(self):
+        if self._ptr:
+            self._h.ch_scene_free(self._ptr)
+            self._ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------- HIP backend (C ABI)
+_mi = None
+
+
+def mi_lib():
+    """Load libcorona_mi.so. There is deliberately no fallback: missing extension == hard error."""
+    global _mi
+    if _mi is None:
+        if not MI_LIB.exists():
+            raise RuntimeError(f"{MI_LIB} missing: the HIP extension is not built (run __graft_entry__.build())")
+        m = C.CDLL(str(MI_LIB))
+        m.mi_init.argtypes = [C.c_int]
+        m.mi_scene_create.argtypes = [C.POINTER(MiSceneDesc), C.POINTER(C.c_void_p)]
+        m.mi_scene_set_framebuffer.argtypes = [C.c_void_p, C.c_void_p]
+        m.mi_scene_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        m.mi_render.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+        m.mi_sync.argtypes = [C.c_void_p]
+        m.mi_fb_read.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        m.mi_fb_clear.argtypes = [C.c_void_p]
+        m.mi_fb_device_ptr.argtypes = [C.c_void_p]
+        m.mi_fb_device_ptr.restype = C.c_void_p
+        m.mi_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        m.mi_trace_paths.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+        m.mi_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        m.mi_scene_destroy.argtypes = [C.c_void_p]
+        m.mi_scene_destroy.restype = None
+        m.mi_shutdown.restype = None
+        m.mi_last_error.restype = C.c_char_p
+        _mi = m
+    return _mi
+
+
+MI_SYMBOLS = ["mi_init", "mi_scene_create", "mi_scene_set_framebuffer", "mi_scene_set_stream", "mi_render",
+              "mi_sync", "mi_fb_read", "mi_fb_clear", "mi_fb_device_ptr", "mi_counters", "mi_trace_paths",
+              "mi_last_kernel_ms", "mi_scene_destroy", "mi_shutdown", "mi_last_error"]
+
+
+class Backend:
+    """Device-resident scene on one MI355X, driven through the C ABI."""
+
+    def __init__(self, scene: Scene, device: int = -1):
+        self.m = mi_lib()
+        self._check(self.m.mi_init(device), "mi_init")
+        self._ptr = C.c_void_p()
+        self._check(self.m.mi_scene_create(scene.desc_ptr, C.byref(self._ptr)), "mi_scene_create")
+        self.scene = scene
+
+    def _check(self, err, what):
+        if err:
+            raise RuntimeError(f"{what} failed ({err}): {self.m.mi_last_error().decode()}")
+
+    def set_framebuffer(self, device_ptr):
+        self._check(self.m.mi_scene_set_framebuffer(self._ptr, C.c_void_p(device_ptr)), "mi_scene_set_framebuffer")
+
+    def set_stream(self, stream_handle):
+        self._check(self.m.mi_scene_set_stream(self._ptr, C.c_void_p(stream_handle)), "mi_scene_set_stream")
+
+    def render(self, first, count):
+        self._check(self.m.mi_render(self._ptr, first, count), "mi_render")
+
+    def sync(self):
+        self._check(self.m.mi_sync(self._ptr), "mi_sync")
+
+    def fb_clear(self):
+        self._check(self.m.mi_fb_clear(self._ptr), "mi_fb_clear")
+
+    def fb_read(self, accumulate_into=None):
+        import numpy as np
+        w, h = self.scene.width, self.scene.height
+        if accumulate_into is None:
+            out = np.zeros((h, w, 3), dtype=np.float32)
+            self._check(self.m.mi_fb_read(self._ptr, out.ctypes.data, 0), "mi_fb_read")
+            return out
+        self._check(self.m.mi_fb_read(self._ptr, accumulate_into.ctypes.data, 1), "mi_fb_read")
+        return accumulate_into
+
+    def counters(self):
+        arr = (C.c_uint64 * 8)()
+        self._check(self.m.mi_counters(self._ptr, arr), "mi_counters")
+        return list(arr)
+
+    def trace_paths(self, first, count):
+        import numpy as np
+        out = np.zeros(count, dtype=record_dtype())
+        self._check(self.m.mi_trace_paths(self._ptr, first, count, out.ctypes.data), "mi_trace_paths")
+        return out
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        self._check(self.m.mi_last_kernel_ms(self._ptr, C.byref(ms)), "mi_last_kernel_ms")
+        return ms.value
+
+    def close(self):
+        if self._ptr:
+            self.m.mi_scene_destroy(self._ptr)
+            self._ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,258 @@
+/* corona_mi.h -- C ABI of the MI355X path-tracing backend (libcorona_mi.so).
+ *
+ * This is the drop-in boundary for ONE hot path of hanatos/corona-13: everything the
+ * reference reaches from work_sample() (src/view.c:618-628), i.e. the loop that
+ * view_render() (src/view.c:630-695, lines 643-645) hands to its pthread pool:
+ *
+ *     for every path index i in [counter, end):  render_sample_path(i)
+ *                                                (src/render.d/gi.c:81-105)
+ *
+ * with render_sample_path -> pointsampler_mutate -> sampler_create_path (pt: src/sampler.d/pt.c:40-54,
+ * ptdl: src/sampler.d/ptdl.c:112-150) -> path_extend/path_propagate (src/pathspace.c:167-271,697-895)
+ * -> accel_intersect (src/accel.d/qbvhmp.c:1262-1390) / prims_intersect (src/prims.c:638-672)
+ * -> shader_prepare/shader_sample (src/shader.c:462-542,577-590) -> view_splat (src/view.c:455-463).
+ *
+ * The host side (scene files, QBVH build, light CDF, progression loop, PFM output)
+ * stays plain C and fills one mi_scene_desc; the backend owns a device-resident copy
+ * and a device framebuffer with the layout of the reference's fb_init(..,3,..)
+ * (include/framebuffer.h:76-113): float[3*(x + width*y)], un-normalised sums.
+ *
+ * Conventions mirror the reference: plain pointers and sizes, int return
+ * 0 = ok / negative = failure, diagnostics on stderr with an "[mi]" prefix, single
+ * calling thread per scene. No torch / C++ types cross this boundary.
+ */
+#ifndef CORONA_MI_H
+#define CORONA_MI_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_ABI_VERSION 1
+
+/* ---- error codes (negative ints, reference style: non-zero == failure) ---------- */
+#define MI_OK              0
+#define MI_ERR_ARG        -1   /* bad argument / inconsistent scene description      */
+#define MI_ERR_DEVICE     -2   /* no usable HIP device, or a HIP call failed           */
+#define MI_ERR_NOMEM      -3
+#define MI_ERR_UNSUPPORTED -4  /* scene uses a feature outside the hot-path scope      */
+
+/* ---- samplers (compile-time MOD_sampler in the reference) ----------------------- */
+#define MI_SAMPLER_PT   0      /* src/sampler.d/pt.c   */
+#define MI_SAMPLER_PTDL 1      /* src/sampler.d/ptdl.c */
+
+/* ---- primitive id: the reference's packed 64-bit primid_t
+ *      (include/corona_common.h:45-53): extra:3 | shapeid:29 | vi:28 | mb:1 | vcnt:3 */
+typedef uint64_t mi_primid;
+#define MI_PRIMID_INVALID 0xffffffffffffffffull
+#define MI_PRIMID_EXTRA(p)   ((uint32_t)((p) & 7u))
+#define MI_PRIMID_SHAPE(p)   ((uint32_t)(((p) >> 3) & 0x1fffffffu))
+#define MI_PRIMID_VI(p)      ((uint32_t)(((p) >> 32) & 0x0fffffffu))
+#define MI_PRIMID_MB(p)      ((uint32_t)(((p) >> 60) & 1u))
+#define MI_PRIMID_VCNT(p)    ((uint32_t)(((p) >> 61) & 7u))
+#define MI_PRIM_SPHERE 1       /* include/prims.h:9-18 */
+#define MI_PRIM_LINE   2
+#define MI_PRIM_TRI    3
+#define MI_PRIM_QUAD   4
+
+/* ---- geometry store (include/prims.h:20-47), flattened over shapes ----------------- */
+typedef struct mi_vtxidx { uint32_t v, uv; } mi_vtxidx;            /* prims_vtxidx_t */
+typedef struct mi_vtx    { float v[3]; uint32_t n; } mi_vtx;       /* prims_vtx_t: n = oct normal or radius bits */
+typedef struct mi_shape
+{
+  int32_t  material;          /* shader index of the shape line in the .nra2           */
+  uint32_t num_prims;
+  uint32_t vtxidx_base;       /* primid.vi is relative to this offset into vtxidx[]    */
+  uint32_t vtx_base;          /* vtxidx.v  is relative to this offset into vtx[]       */
+} mi_shape;
+
+/* ---- 4-wide BVH node as the host builder emits it (cf. qbvh_node_t, src/accel.d/qbvhmp.c:62-81,
+ *      static scene: aabb1 == aabb0). child: bit63 = leaf, then (first_prim<<5)|count, else node index. */
+#define MI_NODE_LEAF (1ull<<63)
+typedef struct mi_node
+{
+  float    aabb[6][4];        /* [0..2][c] = min xyz of child c, [3..5][c] = max xyz   */
+  uint64_t child[4];
+  int32_t  axis0, axis00, axis01;
+  int32_t  parent;
+} mi_node;
+
+/* ---- materials: the dlopen'ed shader chain of one .nra2 material, compiled to a closed set
+ *      (src/shader.c:693-757, src/shaders/{mult,color,colorcheckersg,dielectric,metal}.c) ---------- */
+#define MI_BSDF_DIFFUSE    0   /* builtin diffuse, src/shader.c:157-257          */
+#define MI_BSDF_DIELECTRIC 1   /* src/shaders/dielectric.c                       */
+#define MI_BSDF_METAL      2   /* src/shaders/metal.c                            */
+#define MI_BSDF_NONE       255 /* shader kind outside the scope; error if a shape uses it */
+
+#define MI_OP_COLOR   0        /* src/shaders/color.c:75-82                      */
+#define MI_OP_CHECKER 1        /* src/shaders/colorcheckersg.c:244-262           */
+
+#define MI_SLOT_DIFFUSE  0     /* tex_slot_t, src/shaders/texture.h              */
+#define MI_SLOT_SPECULAR 1
+#define MI_SLOT_GLOSSY   2
+#define MI_SLOT_EMISSION 3
+#define MI_SLOT_VOLUME   4
+#define MI_SLOT_ROUGHNESS 5
+#define MI_SLOT_UNUSED   6
+
+#define MI_MAX_OPS 4
+typedef struct mi_shade_op
+{
+  uint32_t kind;              /* MI_OP_*                                          */
+  uint32_t slot;              /* MI_SLOT_*                                        */
+  float    coeff[3];          /* rgb2spec sigmoid-polynomial coefficients         */
+  float    mul;               /* scale (> 1 for emission)                         */
+  float    roughness;         /* written to shading.roughness by MI_OP_COLOR      */
+  uint32_t pad;
+} mi_shade_op;
+
+typedef struct mi_material
+{
+  uint32_t    bsdf;           /* MI_BSDF_*                                        */
+  uint32_t    num_ops;        /* prepare chain, executed in order before the bsdf's own prepare */
+  mi_shade_op op[MI_MAX_OPS];
+  float       param[4];       /* dielectric: n_d, abbe ; metal: table id, -, -    */
+} mi_material;
+
+/* ---- thin-lens camera, resolved for a static camera (src/camera.d/thinlens.c:68-128,
+ *      src/view.c:903-919,938-948) -------------------------------------------------------------- */
+typedef struct mi_camera
+{
+  float pos[3];
+  float a[3], b[3], n[3];     /* normalised camera frame (right, up, forward)     */
+  float focus, focal_length;
+  float film_width, film_height;
+  float f_stop;               /* view_av2fstop(aperture_value)                    */
+  float exposure_time;        /* view_tv2time(exposure_value)                     */
+  float iso;
+  float time_scale;           /* view_sample_time: min(1, exposure/ (1/30))       */
+} mi_camera;
+
+/* ---- emitter list (src/lights.d/list.c:56-104) ---------------------------------- */
+typedef struct mi_lights
+{
+  uint32_t         num_prims;
+  const mi_primid *primid;    /* with shapeid filled in                            */
+  const float     *cdf;       /* normalised, cdf[num-1] == 1                       */
+  const float     *L;         /* per prim pdf = L/sum(L*area)                      */
+  float            p_sky, p_geo, p_vol;
+} mi_lights;
+
+/* ---- everything the backend needs ------------------------------------------------- */
+typedef struct mi_scene_desc
+{
+  uint32_t struct_size;       /* = sizeof(mi_scene_desc), checked                 */
+  uint32_t abi_version;       /* = MI_ABI_VERSION                                 */
+
+  uint32_t width, height;     /* film, already padded to multiples of 32 (src/view.c:294-296) */
+  uint32_t max_verts;         /* PATHSPACE_MAX_VERTS (include/pathspace.h:10-13)  */
+  uint32_t sampler;           /* MI_SAMPLER_*                                     */
+  uint64_t frame;             /* rt.anim_frame, seeds the per-path generator      */
+
+  uint32_t         num_nodes;
+  const mi_node   *nodes;     /* node 0 = root                                    */
+  float            aabb[6];   /* scene box (accel_aabb)                           */
+  uint64_t         num_prims;
+  const mi_primid *primid;    /* in builder order (leaves index into this)        */
+
+  uint32_t         num_shapes;
+  const mi_shape  *shapes;
+  uint64_t         num_vtxidx;
+  const mi_vtxidx *vtxidx;
+  uint64_t         num_vtx;
+  const mi_vtx    *vtx;
+
+  uint32_t           num_materials;
+  const mi_material *materials;   /* indexed by shader id                         */
+
+  mi_lights  lights;
+  mi_camera  cam;
+
+  const float *cie_xyz;       /* 96 x 3: CIE 1931 2-deg CMF, 360..830 nm step 5 + one zero row (include/spectrum.h:66-170) */
+  const float *checker;       /* 140 x 36 colour-checker reflectances, 380 nm step 10 (src/shaders/colorcheckersg.c:51) or NULL */
+  const float *metal_ior;     /* 5 x 95 x 2 (n,k) conductor tables, 360 nm step 5 (src/shaders/fresnel.h:21-27) or NULL */
+} mi_scene_desc;
+
+typedef struct mi_scene mi_scene;   /* opaque, device resident */
+
+/* Select and initialise the HIP device this process renders on (one process per GPU).
+ * device < 0: use LOCAL_RANK from the environment, else 0.   replaces: threads_init (include/threads.h:68-130) */
+int  mi_init(int device);
+
+/* Upload the scene, build the device layout, allocate + clear the device framebuffer.
+ * replaces: the per-module *_init state reachable from work_sample (accel/prims/shader/lights/view). */
+int  mi_scene_create(const mi_scene_desc *host, mi_scene **out);
+
+/* Use caller-owned device memory (3*width*height floats) as the framebuffer, e.g. a
+ * torch tensor, so that torch.distributed (RCCL) can reduce it in place. NULL = internal. */
+int  mi_scene_set_framebuffer(mi_scene *s, float *device_fb);
+
+/* Launch on this HIP stream (a hipStream_t passed as void*); NULL = the backend's own stream. */
+int  mi_scene_set_stream(mi_scene *s, void *hip_stream);
+
+/* Trace path indices [first, first+count) and splat them into the device framebuffer.
+ * Asynchronous on the scene's stream.  replaces: src/view.c:643-645 (pool dispatch + barrier). */
+int  mi_render(mi_scene *s, uint64_t first_index, uint64_t count);
+
+/* Block until all queued work of this scene has finished. */
+int  mi_sync(mi_scene *s);
+
+/* Copy (accumulate==0) or add (accumulate!=0) the un-normalised device framebuffer into
+ * host_fb[3*width*height]. Synchronous.  replaces: the shared mmap'ed fb the workers CAS-add into. */
+int  mi_fb_read(mi_scene *s, float *host_fb, int accumulate);
+
+/* Zero the device framebuffer (view_clear_frame, src/view.c:108-126). */
+int  mi_fb_clear(mi_scene *s);
+
+/* Raw device pointer of the framebuffer in use. */
+float *mi_fb_device_ptr(mi_scene *s);
+
+/* Work counters since creation, same four quantities as the reference's -DACCEL_DEBUG
+ * (src/accel.d/qbvhmp.c:83-90): [0] rays (accel_intersect calls), [1] node visits with >=1 box hit,
+ * [2] box hits, [3] primitive tests; plus [4] paths, [5] splats, [6] path vertices, [7] reserved. */
+int  mi_counters(mi_scene *s, uint64_t out[8]);
+
+/* Debug/test entry: trace `count` paths starting at `first` and write one mi_path_record per
+ * path (no splatting into the framebuffer). Used by the parity tests to compare path by path. */
+#define MI_REC_MAX_VERTS 8
+#define MI_REC_MAX_SPLATS 8
+typedef struct mi_path_vertex
+{
+  uint64_t prim;
+  float    dist;
+  float    x[3], n[3], gn[3], omega[3];
+  uint32_t mode, flags;
+  float    throughput, pdf;
+  float    u, v;
+  float    rd, rg, em, roughness;
+  float    eta;
+  int32_t  shader;
+} mi_path_vertex;
+typedef struct mi_path_splat { int32_t length, tech; float value; float col[3]; } mi_path_splat;
+typedef struct mi_path_record
+{
+  uint64_t index;
+  float    pixel_i, pixel_j, lambda, time, scramble, throughput;
+  int32_t  length, num_splats;
+  mi_path_splat  splat[MI_REC_MAX_SPLATS];
+  mi_path_vertex v[MI_REC_MAX_VERTS];
+} mi_path_record;
+int  mi_trace_paths(mi_scene *s, uint64_t first_index, uint64_t count, mi_path_record *host_out);
+
+/* Time of the last mi_render launch on the device in milliseconds (HIP events on the scene's
+ * stream), and kernel launches since creation. For bench.py's roofline figure. */
+int  mi_last_kernel_ms(mi_scene *s, float *ms);
+
+void mi_scene_destroy(mi_scene *s);
+void mi_shutdown(void);
+
+/* human readable description of the last error on this thread ("" if none) */
+const char *mi_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
