@@ -1,0 +1,125 @@
+/* o_core.h -- TEST INFRASTRUCTURE: shared types of the CPU restatement (see oracle.h).
+ * Path/vertex/edge records mirror the fields of the reference's path_t that the pt/ptdl
+ * hot path touches (include/pathspace.h:91-225, include/corona_common.h:119-141). */
+#ifndef O_CORE_H
+#define O_CORE_H
+
+#include "oracle.h"
+#include <float.h>
+#include <math.h>
+#include <string.h>
+
+#define O_MAX_VERTS 33
+
+/* vertex_scattermode_t / vertex_flags_t, include/pathspace.h:57-82 */
+enum { s_absorb = 0, s_reflect = 1, s_transmit = 2, s_volume = 4, s_fiber = 8, s_emit = 16, s_sensor = 32,
+       s_diffuse = 64, s_glossy = 128, s_specular = 256 };
+enum { s_none = 0, s_inside = 1, s_environment = 2 };
+enum { s_tech_extend = 1, s_tech_nee = 2 };   /* include/pathspace/tech.h (values only used as tags) */
+
+#define dot3(a, b) ((a)[0]*(b)[0] + (a)[1]*(b)[1] + (a)[2]*(b)[2])
+#define cross3(a, b, r) do { (r)[0] = (a)[1]*(b)[2] - (b)[1]*(a)[2]; (r)[1] = (a)[2]*(b)[0] - (b)[2]*(a)[0]; (r)[2] = (a)[0]*(b)[1] - (b)[0]*(a)[1]; } while(0)
+/* reference macros: NaN falls through to the second operand (include/corona_common.h:168-170) */
+#define OMAX(a, b) ((a) > (b) ? (a) : (b))
+#define OMIN(a, b) ((a) < (b) ? (a) : (b))
+#define OCLAMP(a, m, M) OMIN(OMAX(a, m), M)
+
+static inline void o_normalise(float *f)
+{ /* include/corona_common.h:172-176 */
+  const float len = 1.0f/sqrtf(dot3(f, f));
+  for(int k=0;k<3;k++) f[k] *= len;
+}
+
+static inline void o_get_onb(const float *n, float *u, float *v)
+{ /* include/corona_common.h:178-198 */
+  if(fabsf(n[1]) < 0.5) { const float up[3] = {0, 1, 0}; cross3(n, up, u); }
+  else                  { const float rg[3] = {1, 0, 0}; cross3(n, rg, u); }
+  o_normalise(u);
+  cross3(n, u, v);
+}
+
+static inline void o_get_scrambled_onb(const float scramble, const float *n, float *u, float *v)
+{ /* include/corona_common.h:200-215 */
+  if(fabsf(n[1]) < scramble) { const float up[3] = {0, 1, 0}; cross3(n, up, u); }
+  else                       { const float rg[3] = {1, 0, 0}; cross3(n, rg, u); }
+  o_normalise(u);
+  cross3(n, u, v);
+}
+
+typedef struct o_ray { float pos[3], dir[3], time, min_dist; mi_primid ignore; } o_ray;      /* ray_t */
+
+typedef struct o_hit
+{ /* hit_t */
+  mi_primid prim;
+  float u, v;
+  float r, s, t;
+  float a[3], b[3], n[3], x[3], gn[3];
+  int shader;
+  float dist;
+} o_hit;
+
+typedef struct o_shading { float roughness, rs, rd, rg, em; } o_shading;            /* vertex_shading_t */
+typedef struct o_volume { float ior; int shader; float mu_s, mu_t; } o_volume;     /* vertex_volume_t (vacuum/ior only) */
+
+typedef struct o_vertex
+{ /* vertex_t */
+  o_hit hit;
+  float pdf, throughput, total_throughput;
+  int tech;
+  o_shading shading;
+  o_volume interior;
+  float eta;                     /* diffgeo.eta */
+  uint32_t flags, mode, material_modes;
+} o_vertex;
+
+typedef struct o_edge
+{ /* edge_t */
+  float contribution, transmittance, pdf;
+  float omega[3];
+  float dist;
+  o_volume vol;
+} o_edge;
+
+typedef struct o_path
+{ /* path_t */
+  float lambda, throughput;
+  int length;
+  float time;
+  uint64_t index;
+  float scramble;                /* tangent_frame_scrambling */
+  float pixel_i, pixel_j;
+  o_vertex v[O_MAX_VERTS];
+  o_edge   e[O_MAX_VERTS+1];
+} o_path;
+
+typedef struct o_ctx
+{
+  const mi_scene_desc *s;
+  uint64_t rng0, rng1;           /* xorshift128+ state */
+  float *fb;
+  int atomic_fb;
+  mi_path_record *rec;
+  uint64_t cnt[8];
+} o_ctx;
+
+/* oracle_rng: src/points.d/xorshift128p.c */
+float o_rand(o_ctx *c);
+void  o_rand_seed(o_ctx *c, uint64_t index, uint64_t frame);
+
+/* oracle_geo.c */
+void  o_accel_intersect(o_ctx *c, const o_ray *ray, o_hit *hit);
+void  o_prims_get_normal(const mi_scene_desc *s, mi_primid pi, o_hit *hit);
+void  o_prims_sample(const mi_scene_desc *s, mi_primid pi, float r0, float r1, o_hit *hit);
+void  o_prims_offset_ray(const o_hit *hit, o_ray *ray);
+float o_prims_get_ray(const o_hit *h1, const o_hit *h2, o_ray *ray);
+
+/* oracle_shade.c */
+float o_shader_prepare(o_ctx *c, o_path *p, int v);
+float o_shader_sample(o_ctx *c, o_path *p);
+float o_shader_brdf(o_ctx *c, o_path *p, int v);
+float o_shader_pdf(o_ctx *c, o_path *p, int v);
+float o_path_eta_ratio(const o_path *p, int v);
+int   o_path_edge_init_volume(o_path *p, int v);
+float o_spectrum_eval(const float coeff[3], float lambda);
+
+#endif

@@ -1,0 +1,112 @@
+"""Test helpers: package loader, oracle (ctypes) binding, golden-coefficient injection.
+
+The oracle (oracle/liboracle.so) is the CPU restatement of the reference used as the CHECKER.
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch it.
+"""
+import ctypes as C
+import importlib.util
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent.parent
+GOLDEN = REPO / "tests" / "golden"
+SCENE_0010 = REPO / "scenes" / "0010_pt" / "test.nra2"
+SCENE_ROUGH = REPO / "scenes" / "0052_rough" / "test.nra2"
+
+
+def load_pkg():
+    if "corona13_amd" in sys.modules:
+        return sys.modules["corona13_amd"]
+    spec = importlib.util.spec_from_file_location("corona13_amd", REPO / "corona-13_amd" / "__init__.py")
+    m = importlib.util.module_from_spec(spec)
+    sys.modules["corona13_amd"] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+_oracle = None
+
+
+def oracle_lib():
+    global _oracle
+    if _oracle is None:
+        so = REPO / "oracle" / "liboracle.so"
+        if not so.exists():
+            subprocess.check_call(["make", "-C", str(REPO / "oracle"), "liboracle.so"])
+        pkg = load_pkg()
+        o = C.CDLL(str(so))
+        o.oracle_trace_records.argtypes = [C.POINTER(pkg.MiSceneDesc), C.c_uint64, C.c_uint64, C.c_void_p]
+        o.oracle_trace_records.restype = None
+        o.oracle_render.argtypes = [C.POINTER(pkg.MiSceneDesc), C.c_uint64, C.c_uint64, C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
+        o.oracle_render.restype = C.c_double
+        o.oracle_intersect.argtypes = [C.POINTER(pkg.MiSceneDesc), C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64)]
+        o.oracle_intersect.restype = None
+        o.oracle_rand_sequence.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
+        o.oracle_rand_sequence.restype = C.c_float
+        _oracle = o
+    return _oracle
+
+
+def oracle_records(scene, first, count):
+    pkg = load_pkg()
+    out = np.zeros(count, dtype=pkg.record_dtype())
+    oracle_lib().oracle_trace_records(scene.desc_ptr, first, count, out.ctypes.data)
+    return out
+
+
+def oracle_render(scene, first, count, threads=1):
+    fb = np.zeros((scene.height, scene.width, 3), dtype=np.float32)
+    cnt = (C.c_uint64 * 8)()
+    secs = oracle_lib().oracle_render(scene.desc_ptr, first, count, fb.ctypes.data, threads, cnt)
+    return fb, list(cnt), secs
+
+
+def golden_coeffs():
+    """rgb -> (coeff[3], mul) exactly as the reference's LUT yields them (tests/golden/rgb2spec_coeffs.json)."""
+    with open(GOLDEN / "rgb2spec_coeffs.json") as f:
+        return [json.loads(l) for l in f if l.strip()]
+
+
+def inject_reference_coeffs(scene):
+    """Replace the coefficients of the scene's `color` shaders by the reference LUT's values so that
+    hot-path comparisons are not polluted by init-time LUT differences."""
+    pkg = load_pkg()
+    names = scene.shader_names()
+    table = golden_coeffs()
+    with open(scene_path_of(scene)) as f:
+        lines = f.read().splitlines()
+    nshaders = int(lines[1].split()[0])
+    for sid in range(nshaders):
+        tok = lines[2 + sid].split('#')[0].split()
+        if tok and tok[0] == "color":
+            rgb = [float(x) for x in tok[2:5]]
+            if max(rgb) == 0.0:
+                continue
+            for e in table:
+                if np.allclose(e["rgb"], rgb, rtol=1e-6):
+                    scene.set_color_coeff(sid, e["coeff"], e["mul"])
+                    break
+            else:
+                raise KeyError(f"no golden coefficients for {rgb}")
+    return scene
+
+
+_scene_paths = {}
+
+
+def make_scene(path=SCENE_0010, inject=True, **kw):
+    pkg = load_pkg()
+    s = pkg.Scene(path, **kw)
+    _scene_paths[id(s)] = path
+    if inject:
+        inject_reference_coeffs(s)
+    return s
+
+
+def scene_path_of(scene):
+    return _scene_paths[id(scene)]
