@@ -1,0 +1,72 @@
+/* mi_device.h -- device-resident scene layout of the MI355X backend (HBM / LDS).
+ *
+ *  nodes      SoA of 16-byte lanes, node-major inside each field (stage to LDS; a wave whose lanes sit in
+ *             different nodes then spreads over all sixteen 16-B LDS slots instead of two):
+ *               field 0..2  min x,y,z of the 4 children       field 3..5  max x,y,z
+ *               field 6     4 child links: bit31 leaf | first_prim<<5 | count, else node index
+ *             + one dword per node: axis0 | axis00<<2 | axis01<<4
+ *             = 116 B per node (reference qbvh_node_t: 256 B, src/accel.d/qbvhmp.c:62-81)
+ *  prims      one 64-B record per primitive in builder (leaf) order, pre-resolved at upload so an
+ *             intersection test is ONE aligned fetch instead of primid -> vtxidx -> vtx
+ *             (src/prims.c:638-672, include/geo.h:120-138)
+ *  primshade  one 48-B record per primitive, touched once per path vertex (normals, uv, material)
+ */
+#ifndef MI_DEVICE_H
+#define MI_DEVICE_H
+
+#include "corona_mi.h"
+
+#define MI_LEAF32 0x80000000u
+#define MI_NODE_FIELDS 7
+
+struct DPrim                       /* 64 B */
+{
+  float v[4][3];                   /* tri/quad: vertices. sphere: v[0] centre, v[1][0] radius. line: v[0], v[1], v[2][0]=r0, v[2][1]=r1 */
+  uint32_t type;                   /* vcnt: 1 sphere, 2 line, 3 tri, 4 quad */
+  uint32_t pad[3];
+};
+
+struct DPrimShade                  /* 48 B */
+{
+  uint32_t n[4];                   /* oct-encoded vertex normals */
+  uint32_t uv[4];                  /* half2 uv per vertex (11/11/10 for lines) */
+  uint64_t primid;                 /* the reference's packed primid (records, medium stack shape id) */
+  uint32_t material;
+  uint32_t pad;
+};
+
+struct DMaterial
+{
+  uint32_t bsdf, num_ops;
+  mi_shade_op op[MI_MAX_OPS];
+  float param[4];
+};
+
+struct DScene
+{
+  /* film */
+  uint32_t width, height, max_verts, sampler;
+  uint64_t frame;
+  /* accel */
+  uint32_t num_nodes, num_prims;
+  const float4  *nodes;            /* [MI_NODE_FIELDS][num_nodes] */
+  const uint32_t *node_axes;       /* [num_nodes] */
+  const DPrim  *prims;
+  const DPrimShade *primshade;
+  float aabb[6];
+  float far_dist;                  /* 2 * largest box extent, src/pathspace.c:867-870 */
+  /* materials / lights / camera / tables */
+  const DMaterial *materials;
+  uint32_t num_lights;
+  const uint32_t *light_prim;      /* builder-order primitive index of each emitter prim */
+  const float *light_cdf, *light_L;
+  float p_sky, p_geo, p_vol;
+  mi_camera cam;
+  const float *cie_xyz, *checker, *metal_ior;
+  /* output */
+  float *fb;
+  unsigned long long *counters;    /* [8] */
+  unsigned long long *work;        /* next path index */
+};
+
+#endif

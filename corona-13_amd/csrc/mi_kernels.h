@@ -1,0 +1,978 @@
+/* mi_kernels.h -- HIP device code of the pt/ptdl path tracing hot path for gfx950 (MI355X).
+ *
+ * One persistent kernel; every lane owns one path at a time and runs a small state machine
+ *      NEW -> [ EXTEND-ray -> traverse -> shade ( -> SHADOW-ray -> traverse -> connect ) ]* -> NEW
+ * so a lane whose path ends re-fills itself immediately (wave64 ballot + prefix rank, one atomic per
+ * wave) instead of idling until the longest path of the wave is done. There is exactly one traversal
+ * site in the loop; extension and shadow rays of different lanes share it.
+ *
+ * Memory placement (see mi_device.h): BVH nodes staged once per workgroup into LDS (SoA of 16-byte
+ * lanes so that divergent lanes spread over all LDS slots), per-lane traversal stack in LDS
+ * ([entry][thread] so a wave's accesses are conflict free), primitives as single 64-B records from
+ * L2/HBM, framebuffer splats as hardware float atomics. MFMA is not used: there is no dense
+ * contraction anywhere in this path.
+ *
+ * Arithmetic follows the reference operation by operation (fp contraction off) so that a path with
+ * the same random numbers takes the same branches:
+ *   camera      src/camera.d/thinlens.c:68-128          rng    src/points.d/xorshift128p.c:53-74
+ *   traversal   src/accel.d/qbvhmp.c:1188-1390          prims  src/prims.c:638-672, include/geo/{triangle,sphere,line}.h
+ *   path        src/pathspace.c:80-292,697-895          pt     src/sampler.d/pt.c:30-54
+ *   shading     src/shader.c:157-257,462-590, src/shaders/{color,colorcheckersg,dielectric,metal}.c, ggx.h
+ *   emitters    src/lights.d/list.c:106-275             nee    include/pathspace/nee.h:87-243, src/sampler.d/ptdl.c:78-150
+ *   splat       src/view.c:455-463, include/spectrum.h:172-203, include/filter/blackmanharris.h:28-77
+ */
+#ifndef MI_KERNELS_H
+#define MI_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <math.h>
+#include "mi_device.h"
+
+#define MI_PI_D 3.14159265358979323846
+#define MI_PI_F 3.14159274101257324219f   /* (float)M_PI */
+
+/* vertex_scattermode_t / vertex_flags_t, include/pathspace.h:57-82 */
+enum { s_absorb = 0, s_reflect = 1, s_transmit = 2, s_volume = 4, s_fiber = 8, s_emit = 16, s_sensor = 32,
+       s_diffuse = 64, s_glossy = 128, s_specular = 256 };
+enum { s_none = 0, s_inside = 1, s_environment = 2 };
+enum { s_tech_extend = 1, s_tech_nee = 2 };
+
+/* reference MIN/MAX macros: NaN falls through to the second operand */
+#define DMAX(a, b) ((a) > (b) ? (a) : (b))
+#define DMIN(a, b) ((a) < (b) ? (a) : (b))
+#define DCLAMP(a, m, M) DMIN(DMAX(a, m), M)
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 mk3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ float dot3(const V3 a, const V3 b) { return a.x*b.x + a.y*b.y + a.z*b.z; }
+__device__ __forceinline__ V3 cross3(const V3 a, const V3 b)
+{ /* crossproduct macro, include/corona_common.h:161-164 */
+  return mk3(a.y*b.z - b.y*a.z, a.z*b.x - b.z*a.x, a.x*b.y - b.x*a.y);
+}
+__device__ __forceinline__ V3 sub3(const V3 a, const V3 b) { return mk3(a.x-b.x, a.y-b.y, a.z-b.z); }
+__device__ __forceinline__ V3 scale3(const V3 a, float s) { return mk3(a.x*s, a.y*s, a.z*s); }
+__device__ __forceinline__ V3 neg3(const V3 a) { return mk3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ V3 normalise3(const V3 a)
+{ /* normalise, include/corona_common.h:172-176 */
+  const float len = 1.0f/sqrtf(dot3(a, a));
+  return scale3(a, len);
+}
+__device__ __forceinline__ V3 ld3(const float *p) { return mk3(p[0], p[1], p[2]); }
+
+__device__ __forceinline__ void get_onb(const V3 n, V3 &u, V3 &v)
+{ /* get_onb, include/corona_common.h:178-198 */
+  if(fabsf(n.y) < 0.5) u = cross3(n, mk3(0, 1, 0));
+  else                 u = cross3(n, mk3(1, 0, 0));
+  u = normalise3(u);
+  v = cross3(n, u);
+}
+__device__ __forceinline__ void get_scrambled_onb(float scramble, const V3 n, V3 &u, V3 &v)
+{ /* get_scrambled_onb, include/corona_common.h:200-215 */
+  if(fabsf(n.y) < scramble) u = cross3(n, mk3(0, 1, 0));
+  else                      u = cross3(n, mk3(1, 0, 0));
+  u = normalise3(u);
+  v = cross3(n, u);
+}
+
+/* ------------------------------------------------------------------------------------------ rng */
+struct Rng { unsigned long long s0, s1; };
+__device__ __forceinline__ float rng_next(Rng &r)
+{ /* points_rand, src/points.d/xorshift128p.c:61-74 */
+  unsigned long long s1 = r.s0;
+  const unsigned long long s0 = r.s1;
+  r.s0 = s0;
+  s1 ^= s1 << 23;
+  s1 ^= s1 >> 17;
+  s1 ^= s0;
+  s1 ^= s0 >> 26;
+  r.s1 = s1;
+  const uint32_t v = 0x3f800000u | (uint32_t)((r.s0 + r.s1) >> 41);
+  return __uint_as_float(v) - 1.0f;
+}
+__device__ __forceinline__ void rng_seed(Rng &r, unsigned long long index, unsigned long long frame)
+{ /* points_set_state, src/points.d/xorshift128p.c:53-59 with thread id 0 (src/render.d/gi.c:88) */
+  r.s0 = 1 + index;
+  r.s1 = 2 + frame;
+  for(int k=0;k<10;k++) (void)rng_next(r);
+}
+
+/* ------------------------------------------------------------------------------------------ hit */
+struct Hit
+{
+  uint32_t prim;       /* builder-order primitive index, 0xffffffff = none */
+  float dist, u, v;
+};
+#define MI_NOPRIM 0xffffffffu
+
+/* ------------------------------------------------------------------------------------------ primitives */
+__device__ __forceinline__ bool tri_intersect(const V3 v0, const V3 v1, const V3 v2, const V3 o, const V3 d, Hit &hit, uint32_t prim)
+{ /* geo_tri_intersect, include/geo/triangle.h:263-305 (min_dist == 0) */
+  const V3 e1 = sub3(v1, v0), e2 = sub3(v2, v0);
+  const V3 pv = cross3(d, e2);
+  const float det = dot3(e1, pv);
+  const float inv_det = 1.0f/det;
+  const V3 tv = sub3(o, v0);
+  const float v = dot3(tv, pv)*inv_det;
+  if(v < 0.0f || v > 1.0f) return false;
+  const V3 qv = cross3(tv, e1);
+  const float u = dot3(d, qv)*inv_det;
+  if(u < 0.0f || u + v > 1.0f) return false;
+  const float dist = dot3(e2, qv)*inv_det;
+  if(dist > 0.0f && dist <= hit.dist)
+  {
+    hit.dist = dist; hit.prim = prim; hit.u = u; hit.v = v;
+    return true;
+  }
+  return false;
+}
+
+__device__ __forceinline__ float sphere_t(const V3 c, float radius, const V3 ro, const V3 rd)
+{ /* _geo_sphere_intersect, include/geo/sphere.h:112-144 */
+  const float a = dot3(rd, rd);
+  const V3 o = sub3(ro, c);
+  const float b = 2.0f*dot3(o, rd);
+  const float cc = dot3(o, o) - radius*radius;
+  if(a == 0)
+  {
+    if(b != 0) return -cc/b;
+    return -FLT_MAX;
+  }
+  const float discrim = b*b - 4.0f*a*cc;
+  if(discrim < 0) return -FLT_MAX;
+  const float sq = sqrtf(discrim);
+  const float temp = b < 0 ? -0.5f*(b - sq) : -0.5f*(b + sq);
+  const float x0 = temp/a, x1 = cc/temp;
+  if(x0 <= 0.0f) return x1;
+  else if(x1 <= 0.0f) return x0;
+  else return fminf(x0, x1);
+}
+
+__device__ __noinline__ void line_intersect(const DPrim &p, const V3 ro, const V3 rd, Hit &hit, uint32_t prim, uint32_t ignore)
+{ /* geo_line_intersect + _geo_line_intersect_{cylinder,cone}, include/geo/line.h:313-505 (hair strips out of scope) */
+  const V3 v0 = ld3(p.v[0]), v1 = ld3(p.v[1]);
+  const float r0 = p.v[2][0], r1 = p.v[2][1];
+  const bool linestrip = DMAX(r0, r1) <= 1e-2f;
+  if(linestrip && ignore == prim) return;
+  V3 d = sub3(v1, v0);
+  if(fabsf(r1-r0) < 1e-3)
+  {
+    const float dlen = sqrtf(dot3(d, d));
+    d = scale3(d, 1.0f/dlen);
+    V3 a, b; get_onb(d, a, b);
+    float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f, w0 = 0.0f, w1 = 0.0f, w2 = 0.0f;
+    const float px[3] = {ro.x - v0.x, ro.y - v0.y, ro.z - v0.z}, dx[3] = {rd.x, rd.y, rd.z};
+    const float dd[3] = {d.x, d.y, d.z}, aa[3] = {a.x, a.y, a.z}, bb[3] = {b.x, b.y, b.z};
+#pragma unroll
+    for(int k=0;k<3;k++)
+    {
+      o0 += px[k]*dd[k]; o1 += px[k]*aa[k]; o2 += px[k]*bb[k];
+      w0 += dx[k]*dd[k]; w1 += dx[k]*aa[k]; w2 += dx[k]*bb[k];
+    }
+    const float A = w1*w1 + w2*w2;
+    const float B = 2.0f*(o1*w1 + o2*w2);
+    const float C = o1*o1 + o2*o2 - r0*r0;
+    const float discr = (float)((double)(B*B) - 4.0*(double)A*(double)C);
+    if(discr < 0.0) return;
+    const float sq = sqrtf(discr);
+    const float temp = B < 0 ? -0.5f*(B - sq) : -0.5f*(B + sq);
+    const float t0 = temp/A, t1 = C/temp;
+    float t, out0, out1, out2;
+    bool ok = false;
+    if(t0 <= 0.0f || t1 <= 0.0f)
+    {
+      t = t0 <= 0.0f ? t1 : t0;
+      out0 = o0 + t*w0; out1 = o1 + t*w1; out2 = o2 + t*w2;
+      ok = out0 >= 0.0 && out0 <= dlen;
+    }
+    else
+    {
+      t = fminf(t0, t1);
+      out0 = o0 + t*w0; out1 = o1 + t*w1; out2 = o2 + t*w2;
+      ok = out0 >= 0.0 && out0 <= dlen;
+      if(!ok)
+      {
+        t = fmaxf(t0, t1);
+        out0 = o0 + t*w0; out1 = o1 + t*w1; out2 = o2 + t*w2;
+        ok = out0 >= 0.0 && out0 <= dlen;
+      }
+    }
+    if(!ok) return;
+    if(t > 0.0f && t < hit.dist)
+    {
+      hit.dist = t; hit.prim = prim;
+      hit.u = out0/dlen;
+      hit.v = (float)((double)atan2f(out1, out2)/(2.0f*MI_PI_D));
+    }
+  }
+  else
+  {
+    const float d_len = sqrtf(dot3(d, d));
+    d = mk3((float)(d.x*(1.0/d_len)), (float)(d.y*(1.0/d_len)), (float)(d.z*(1.0/d_len)));
+    const float cos_dr = dot3(d, rd);
+    const float cos_a2 = d_len*d_len/((r1-r0)*(r1-r0) + d_len*d_len);
+    const float tt = -r0*d_len/(r1-r0);
+    const V3 tip = mk3(v0.x + tt*d.x, v0.y + tt*d.y, v0.z + tt*d.z);
+    const V3 o = sub3(ro, tip);
+    const float cos_do = dot3(d, o);
+    const float cos_ro = dot3(rd, o);
+    const float cos_oo = dot3(o, o);
+    const float c2 = cos_dr*cos_dr - cos_a2;
+    const float c1 = cos_dr*cos_do - cos_a2*cos_ro;
+    const float c0 = cos_do*cos_do - cos_a2*cos_oo;
+    float tmin = -1.0f, dist = hit.dist, hu = hit.u, hv = hit.v;
+    if(fabsf(c2) > 0.0)
+    {
+      const float discr = c1*c1 - c0*c2;
+      if(discr < 0.0f) return;
+      const float root = sqrtf(discr);
+      for(int i=-1;i<2;i+=2)
+      {
+        const float t = (-c1 + i*root)/c2;
+        if(t > 0.0 && t < dist)
+        {
+          const V3 x = mk3(ro.x + t*rd.x - v0.x, ro.y + t*rd.y - v0.y, ro.z + t*rd.z - v0.z);
+          const float dt = dot3(x, d);
+          if(dt >= 0.0f && dt <= d_len)
+          {
+            hu = dt/d_len;
+            V3 a, b; get_onb(d, a, b);
+            hv = (float)((double)atan2f(dot3(a, x), dot3(b, x))/(2.0f*MI_PI_D));
+            tmin = dist = t;
+          }
+        }
+      }
+    }
+    /* the reference writes u/v as soon as a root is accepted, then commits dist/prim if t > min_dist */
+    hit.u = hu; hit.v = hv;
+    if((linestrip && tmin > 1e-3f) || (!linestrip && tmin > 0.0f))
+    {
+      hit.dist = tmin; hit.prim = prim;
+    }
+  }
+}
+
+__device__ __forceinline__ void prim_intersect(const DPrim *prims, uint32_t prim, const V3 o, const V3 d, uint32_t ignore, Hit &hit)
+{ /* prims_intersect, src/prims.c:638-672 */
+  const DPrim &p = prims[prim];
+  const uint32_t type = p.type;
+  if(type >= MI_PRIM_TRI)
+  {
+    if(prim == ignore) return;                                   /* triangle.h:271 */
+    const V3 v0 = ld3(p.v[0]), v1 = ld3(p.v[1]), v2 = ld3(p.v[2]);
+    if(type == MI_PRIM_TRI) tri_intersect(v0, v1, v2, o, d, hit, prim);
+    else
+    {
+      if(tri_intersect(v0, v1, v2, o, d, hit, prim)) { hit.v += hit.u; return; }
+      const V3 v3 = ld3(p.v[3]);
+      if(tri_intersect(v0, v2, v3, o, d, hit, prim)) hit.u += hit.v;
+    }
+  }
+  else if(type == MI_PRIM_SPHERE)
+  { /* geo_sphere_intersect, include/geo/sphere.h:146-166; u,v are recomputed at shading time */
+    const float t = sphere_t(ld3(p.v[0]), p.v[1][0], o, d);
+    if(t > 0.0f && t < hit.dist) { hit.dist = t; hit.prim = prim; }
+  }
+  else if(type == MI_PRIM_LINE) line_intersect(p, o, d, hit, prim, ignore);
+}
+
+/* ------------------------------------------------------------------------------------------ traversal */
+struct Lds
+{
+  const float4 *nodes;      /* [MI_NODE_FIELDS][num_nodes] in LDS */
+  const uint32_t *axes;     /* [num_nodes] in LDS */
+  uint2 *stack;             /* [STACK][BLOCK] in LDS, this thread's column */
+  uint32_t num_nodes;
+};
+
+template<int BLOCK, int STACK>
+__device__ __forceinline__ void accel_intersect(const Lds &lds, const DPrim *prims, const V3 o, const V3 d, uint32_t ignore,
+                                                Hit &hit, uint32_t *cnt)
+{ /* accel_intersect, src/accel.d/qbvhmp.c:1262-1390 (static boxes) */
+  cnt[0]++;
+  const uint32_t near_x = __float_as_uint(d.x) >> 31, near_y = __float_as_uint(d.y) >> 31, near_z = __float_as_uint(d.z) >> 31;
+  const uint32_t nearbits = near_x | (near_y << 1) | (near_z << 2);
+  const float idx = 1.0f/d.x, idy = 1.0f/d.y, idz = 1.0f/d.z;
+  const uint32_t N = lds.num_nodes;
+  int sp = 0;
+  uint32_t node = 0;
+  uint32_t current;
+  while(true)
+  {
+    /* 4 child slabs, qbvhmp.c:1188-1246; SSE min/max semantics (second operand on NaN) via ordered compares */
+    const float4 mnx = lds.nodes[0*N + node], mny = lds.nodes[1*N + node], mnz = lds.nodes[2*N + node];
+    const float4 mxx = lds.nodes[3*N + node], mxy = lds.nodes[4*N + node], mxz = lds.nodes[5*N + node];
+    const uint4 child = *(const uint4 *)&lds.nodes[6*N + node];
+    float tmin[4];
+    uint32_t mask = 0;
+    const float bx0[4] = {mnx.x, mnx.y, mnx.z, mnx.w}, bx1[4] = {mxx.x, mxx.y, mxx.z, mxx.w};
+    const float by0[4] = {mny.x, mny.y, mny.z, mny.w}, by1[4] = {mxy.x, mxy.y, mxy.z, mxy.w};
+    const float bz0[4] = {mnz.x, mnz.y, mnz.z, mnz.w}, bz1[4] = {mxz.x, mxz.y, mxz.z, mxz.w};
+#pragma unroll
+    for(int j=0;j<4;j++)
+    {
+      float lo = 0.0f, hi = hit.dist;
+      float t0 = (bx0[j] - o.x)*idx, t1 = (bx1[j] - o.x)*idx;
+      float mn = t0 < t1 ? t0 : t1, mx = t0 > t1 ? t0 : t1;
+      lo = lo > mn ? lo : mn; hi = hi < mx ? hi : mx;
+      t0 = (by0[j] - o.y)*idy; t1 = (by1[j] - o.y)*idy;
+      mn = t0 < t1 ? t0 : t1; mx = t0 > t1 ? t0 : t1;
+      lo = lo > mn ? lo : mn; hi = hi < mx ? hi : mx;
+      t0 = (bz0[j] - o.z)*idz; t1 = (bz1[j] - o.z)*idz;
+      mn = t0 < t1 ? t0 : t1; mx = t0 > t1 ? t0 : t1;
+      lo = lo > mn ? lo : mn; hi = hi < mx ? hi : mx;
+      tmin[j] = lo;
+      mask |= (lo <= hi ? 1u : 0u) << j;
+    }
+    bool have = false;
+    if(mask)
+    {
+      cnt[1]++;
+      cnt[2] += __popc(mask);
+      /* front-to-back order from split axes and ray signs, qbvhmp.c:1313-1320 */
+      const uint32_t ax = lds.axes[node];
+      const uint32_t axis0 = ax & 3u;
+      const uint32_t near0 = (nearbits >> axis0) & 1u, far0 = near0 ^ 1u;
+      const uint32_t axis1n = near0 ? ((ax >> 4) & 3u) : ((ax >> 2) & 3u);
+      const uint32_t axis1f = near0 ? ((ax >> 2) & 3u) : ((ax >> 4) & 3u);
+      const uint32_t near1f = (nearbits >> axis1f) & 1u, near1n = (nearbits >> axis1n) & 1u;
+      const uint32_t n11 = (far0 << 1) | (near1f ^ 1u);
+      const uint32_t n10 = (far0 << 1) | near1f;
+      const uint32_t n01 = (near0 << 1) | (near1n ^ 1u);
+      const uint32_t n00 = (near0 << 1) | near1n;
+      const uint32_t ch[4] = {child.x, child.y, child.z, child.w};
+      /* first hit child in order n00,n01,n10,n11 becomes current; the later ones are pushed far-first */
+      const uint32_t order[4] = {n00, n01, n10, n11};
+      int firstk = 4;
+#pragma unroll
+      for(int k=3;k>=0;k--) if((mask >> order[k]) & 1u) firstk = k;
+#pragma unroll
+      for(int k=3;k>=1;k--)
+      {
+        const uint32_t n = order[k];
+        if(k > firstk && ((mask >> n) & 1u))
+        {
+          lds.stack[sp*BLOCK] = make_uint2(ch[n], __float_as_uint(tmin[n]));
+          sp++;
+        }
+      }
+      current = ch[order[firstk & 3]];
+      have = true;
+    }
+    if(!have)
+    {
+      bool found = false;
+      while(sp > 0)
+      {
+        sp--;
+        const uint2 e = lds.stack[sp*BLOCK];
+        if(!(__uint_as_float(e.y) > hit.dist)) { current = e.x; found = true; break; }
+      }
+      if(!found) return;
+    }
+    while(current & MI_LEAF32)
+    {
+      uint32_t idxp = (current ^ MI_LEAF32) >> 5;
+      const uint32_t num = current & 31u;
+      for(uint32_t i=0;i<num;i++)
+      {
+        cnt[3]++;
+        prim_intersect(prims, idxp, o, d, ignore, hit);
+        idxp++;
+      }
+      bool found = false;
+      while(sp > 0)
+      {
+        sp--;
+        const uint2 e = lds.stack[sp*BLOCK];
+        if(!(__uint_as_float(e.y) > hit.dist)) { current = e.x; found = true; break; }
+      }
+      if(!found) return;
+    }
+    node = current;
+  }
+}
+
+/* ------------------------------------------------------------------------------------------ geometry at the hit */
+__device__ __forceinline__ V3 decode_normal(uint32_t enc)
+{ /* geo_decode_normal, include/geo.h:24-44 */
+  const uint32_t p0 = enc & 0xffffu, p1 = enc >> 16;
+  const uint32_t v0 = 0x3f800000u | ((p0 & 0x7fffu) << 8);
+  const uint32_t v1 = 0x3f800000u | ((p1 & 0x7fffu) << 8);
+  float x = __uint_as_float(__float_as_uint(2.0f*__uint_as_float(v0) - 2.0f) | ((p0 & 0x8000u) << 16));
+  float y = __uint_as_float(__float_as_uint(2.0f*__uint_as_float(v1) - 2.0f) | ((p1 & 0x8000u) << 16));
+  const float z = 1.0f - (fabsf(x) + fabsf(y));
+  if(z < 0.0f)
+  {
+    const float oldx = x;
+    x = (1.0f - fabsf(y)) * ((oldx < 0.0f) ? -1.0f : 1.0f);
+    y = (1.0f - fabsf(oldx)) * ((y < 0.0f) ? -1.0f : 1.0f);
+  }
+  return normalise3(mk3(x, y, z));
+}
+
+__device__ __forceinline__ float half2float(uint32_t h)
+{ /* half_to_float, include/half.h:57-80 */
+  const uint32_t sign = (h & 0x8000u) << 16;
+  uint32_t o = (h & 0x7fffu) << 13;
+  const uint32_t ex = 0x0f800000u & o;
+  o += (127 - 15) << 23;
+  if(ex == 0x0f800000u) o += (128 - 16) << 23;
+  else if(ex == 0)
+  {
+    o += 1 << 23;
+    o = __float_as_uint(__uint_as_float(o) - __uint_as_float(113u << 23));
+  }
+  return __uint_as_float(o | sign);
+}
+
+struct Surf
+{
+  V3 x, n, gn, a, b;
+  float u, v, s, t;
+  uint32_t flags;
+};
+
+__device__ __forceinline__ void tri_normal(const V3 v0, const V3 v1, const V3 v2, const V3 n0, const V3 n1, const V3 n2, float u, float v, Surf &sf)
+{ /* geo_tri_get_normal, include/geo/triangle.h:63-82 */
+  sf.gn = normalise3(mk3((v1.y-v0.y)*(v2.z-v0.z) - (v1.z-v0.z)*(v2.y-v0.y),
+                         (v1.z-v0.z)*(v2.x-v0.x) - (v1.x-v0.x)*(v2.z-v0.z),
+                         (v1.x-v0.x)*(v2.y-v0.y) - (v1.y-v0.y)*(v2.x-v0.x)));
+  const float w = 1.0f - u - v;
+  sf.n = normalise3(mk3(u*n2.x + v*n1.x + w*n0.x, u*n2.y + v*n1.y + w*n0.y, u*n2.z + v*n1.z + w*n0.z));
+}
+
+__device__ __forceinline__ void surface_setup(const DScene &sc, uint32_t prim, const V3 omega, float scramble, Surf &sf)
+{ /* prims_get_normal_time (src/prims.c:254-366) + manifold_init (include/pathspace/manifold.h:215-232) */
+  const DPrim &p = sc.prims[prim];
+  const DPrimShade &ps = sc.primshade[prim];
+  const uint32_t type = p.type;
+  if(type == MI_PRIM_SPHERE)
+  { /* sphere.h:51-62,160-161 */
+    const V3 c = ld3(p.v[0]);
+    const float radius = p.v[1][0];
+    sf.u = (float)((double)atan2f((sf.x.y-c.y)/radius, (sf.x.x-c.x)/radius)/(2.0f*MI_PI_D));
+    sf.v = (float)((double)acosf(DCLAMP((sf.x.z-c.z)/radius, -1.0f, 1.0f))/MI_PI_D);
+    sf.gn = normalise3(sub3(sf.x, c));
+    sf.n = sf.gn;
+  }
+  else if(type == MI_PRIM_LINE)
+  { /* line.h:123-161 */
+    const V3 v0 = ld3(p.v[0]), v1 = ld3(p.v[1]);
+    const float r0 = p.v[2][0], r1 = p.v[2][1];
+    if(fabsf(r0-r1) < 1e-3f && r0 < 0.01f) { sf.n = sf.gn = mk3(0, 0, 0); }
+    else
+    {
+      V3 d = sub3(v1, v0);
+      const float ilen_d = 1.0f/sqrtf(dot3(d, d));
+      d = scale3(d, ilen_d);
+      V3 a, b; get_onb(d, a, b);
+      const float phi = (float)(2.0*MI_PI_D*(double)sf.v);
+      float sinphi, cosphi;
+      sincosf(phi, &sinphi, &cosphi);
+      const V3 n = mk3(a.x*sinphi + b.x*cosphi, a.y*sinphi + b.y*cosphi, a.z*sinphi + b.z*cosphi);
+      const float rr = r1 - r0;
+      if(fabsf(rr) < 1e-3) sf.n = n;
+      else sf.n = normalise3(mk3(n.x - d.x*(r1-r0)*ilen_d, n.y - d.y*(r1-r0)*ilen_d, n.z - d.z*(r1-r0)*ilen_d));
+      sf.gn = sf.n;
+    }
+  }
+  else
+  {
+    const V3 v0 = ld3(p.v[0]), v2 = ld3(p.v[2]);
+    const V3 n0 = decode_normal(ps.n[0]), n2 = decode_normal(ps.n[2]);
+    if(type == MI_PRIM_TRI)
+      tri_normal(v0, ld3(p.v[1]), v2, n0, decode_normal(ps.n[1]), n2, sf.u, sf.v, sf);
+    else if(sf.v >= sf.u)
+      tri_normal(v0, ld3(p.v[1]), v2, n0, decode_normal(ps.n[1]), n2, sf.u, sf.v - sf.u, sf);
+    else
+      tri_normal(v0, v2, ld3(p.v[3]), n0, n2, decode_normal(ps.n[3]), sf.u - sf.v, sf.v, sf);
+  }
+  /* texture coordinates, src/prims.c:300-365 */
+  if(ps.uv[0] == 0) { sf.s = sf.u; sf.t = sf.v; }
+  else if(type == MI_PRIM_SPHERE)
+  {
+    sf.s = sf.u + half2float(ps.uv[0] & 0xffffu);
+    sf.t = sf.v + half2float(ps.uv[0] >> 16);
+  }
+  else if(type == MI_PRIM_LINE)
+  {
+    sf.s = (ps.uv[0] >> 21)/2048.0f;
+    sf.t = ((ps.uv[0] & 0x1ffc00u) >> 10)/2048.0f;
+  }
+  else
+  {
+    const float u0s = half2float(ps.uv[0] & 0xffffu), u0t = half2float(ps.uv[0] >> 16);
+    const float u2s = half2float(ps.uv[2] & 0xffffu), u2t = half2float(ps.uv[2] >> 16);
+    if(type == MI_PRIM_TRI)
+    {
+      const float u1s = half2float(ps.uv[1] & 0xffffu), u1t = half2float(ps.uv[1] >> 16);
+      sf.s = (1.0f-sf.u-sf.v)*u0s + sf.v*u1s + sf.u*u2s;
+      sf.t = (1.0f-sf.u-sf.v)*u0t + sf.v*u1t + sf.u*u2t;
+    }
+    else if(sf.v >= sf.u)
+    {
+      const float u1s = half2float(ps.uv[1] & 0xffffu), u1t = half2float(ps.uv[1] >> 16);
+      const float u = sf.u, v = sf.v - sf.u;
+      sf.s = (1.0f-u-v)*u0s + v*u1s + u*u2s;
+      sf.t = (1.0f-u-v)*u0t + v*u1t + u*u2t;
+    }
+    else
+    {
+      const float u3s = half2float(ps.uv[3] & 0xffffu), u3t = half2float(ps.uv[3] >> 16);
+      const float u = sf.u - sf.v, v = sf.v;
+      sf.s = (1.0f-u-v)*u0s + v*u2s + u*u3s;
+      sf.t = (1.0f-u-v)*u0t + v*u2t + u*u3t;
+    }
+  }
+  /* flip towards the ray, tangent frame */
+  sf.flags = s_none;
+  if(dot3(omega, sf.gn) > 0.0f) { sf.n = neg3(sf.n); sf.flags |= s_inside; }
+  get_scrambled_onb(scramble, sf.n, sf.a, sf.b);
+}
+
+/* ------------------------------------------------------------------------------------------ spectra, shading inputs */
+struct Shading { float roughness, rs, rd, rg, em; };
+
+__device__ __forceinline__ float spectrum_eval(const float *coeff, float lambda)
+{ /* rgb2spec_eval_fast, include/rgb2spec.h:145-149 (exact rsqrt instead of rsqrtss) */
+  const float x = (coeff[0]*lambda + coeff[1])*lambda + coeff[2];
+  const float y = 1.0f/sqrtf(x*x + 1.0f);
+  return .5f*x*y + .5f;
+}
+
+__device__ __forceinline__ float eta_from_abbe(float n_d, float V_d, float lambda)
+{ /* include/spectrum.h:40-63 */
+  float A, B;
+  if(V_d == 0.0f) { A = n_d; B = 0.0f; }
+  else
+  {
+    const float l_C = .6563f, l_F = .4861f, l_D = .587561f;
+    const float c = (l_C*l_C * l_F*l_F)/(l_C*l_C - l_F*l_F);
+    B = (n_d - 1.0f)/V_d * c;
+    A = n_d - B/(l_D*l_D);
+  }
+  return A + (B*1e6f)/(lambda*lambda);
+}
+
+__device__ __forceinline__ void set_slot(Shading &sh, uint32_t slot, float val)
+{ /* tex_set_slot, src/shaders/texture.h:34-66 */
+  if(slot == MI_SLOT_DIFFUSE) sh.rd = val;
+  else if(slot == MI_SLOT_SPECULAR) sh.rs = val;
+  else if(slot == MI_SLOT_GLOSSY) sh.rg = val;
+  else if(slot == MI_SLOT_ROUGHNESS) sh.roughness = val;
+  else if(slot == MI_SLOT_EMISSION) sh.em = val;
+}
+
+__device__ __forceinline__ void run_prepare_ops(const DScene &sc, const DMaterial &m, const Surf &sf, float lambda, Shading &sh)
+{ /* mult.c:154-167 -> color.c:75-82 / colorcheckersg.c:244-262 */
+  sh.roughness = 1.0f; sh.rs = sh.rd = sh.rg = sh.em = 0.0f;
+  for(uint32_t k=0;k<m.num_ops;k++)
+  {
+    const mi_shade_op &op = m.op[k];
+    if(op.kind == MI_OP_COLOR)
+    {
+      sh.roughness = op.roughness;
+      const float val = op.mul*spectrum_eval(op.coeff, lambda);
+      if(op.slot == MI_SLOT_EMISSION) set_slot(sh, op.slot, val);
+      else if(op.slot != MI_SLOT_UNUSED) set_slot(sh, op.slot, DCLAMP(val, 0.0f, 1.0f));
+    }
+    else
+    {
+      const float u = sf.s, t = sf.t;
+      const int i = (int)(14.0f*u) % 14, j = (int)(10.0f*t) % 10;
+      float val;
+      const float fu = fmodf(14.0f*u, 1.0f), ft = fmodf(10.0f*t, 1.0f);
+      if(fu < 0.1f || fu > 0.9f || ft < 0.1f || ft > 0.9f) val = 0.3f;
+      else
+      {
+        const int l = (int)((lambda - 380.0f)/10.0f);
+        if(l < 0 || l >= 36) val = 0.0f;
+        else val = sc.checker[36*(14*j + i) + l];
+      }
+      set_slot(sh, op.slot, val);
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------------------------ nested dielectrics */
+/* _path_edge_medium (src/pathspace.c:80-115) keeps, per query, the multiset of shapes the path is inside of and
+ * returns the one with the smallest shape id. The reference recomputes it from the vertex history every time;
+ * we carry the multiset along the path (<= MI_MEDIA entries of 8-bit shape ids, packed) -- same result. */
+#define MI_MEDIA 8
+struct Media
+{
+  unsigned long long ids;   /* MI_MEDIA x 8 bit shape ids */
+  uint32_t count;
+  uint32_t broken;          /* nesting broke (kill the path when the medium is needed) */
+};
+
+__device__ __forceinline__ void media_apply(Media &m, uint32_t shape, bool inside)
+{ /* one transmission event at a vertex on `shape` */
+  if(!inside)
+  {
+    if(m.count < MI_MEDIA) { m.ids |= (unsigned long long)shape << (8*m.count); m.count++; }
+    else m.broken = 1;      /* deeper nesting than we carry: treated as broken (counted, never seen in scope) */
+  }
+  else
+  {
+    /* search from the top for the shape, replace it by the last entry */
+    int found = -1;
+    for(int k=(int)m.count-1;k>=0;k--) if(((m.ids >> (8*k)) & 0xffu) == shape) { found = k; break; }
+    if(found < 0) { m.broken = 1; return; }
+    m.count--;
+    const unsigned long long last = (m.ids >> (8*m.count)) & 0xffu;
+    m.ids &= ~(0xffull << (8*found));
+    m.ids |= last << (8*found);
+    m.ids &= ~(0xffull << (8*m.count));
+  }
+}
+
+__device__ __forceinline__ int media_top_shape(const Media &m)
+{ /* smallest shape id in the set, -1 = exterior (vacuum) */
+  int best = -1;
+  for(uint32_t k=0;k<m.count;k++)
+  {
+    const int s = (int)((m.ids >> (8*k)) & 0xffu);
+    if(best < 0 || s < best) best = s;
+  }
+  return best;
+}
+
+/* ior of the interior of `shape` as its prepare() would set it (dielectric.c:72, vacuum otherwise) */
+__device__ __forceinline__ float shape_interior_ior(const DScene &sc, const uint32_t *shape_material, int shape, float lambda)
+{
+  if(shape < 0) return 1.0f;
+  const DMaterial &m = sc.materials[shape_material[shape]];
+  if(m.bsdf == MI_BSDF_DIELECTRIC) return eta_from_abbe(m.param[0], m.param[1], lambda);
+  return 1.0f;
+}
+
+/* ------------------------------------------------------------------------------------------ GGX, src/shaders/ggx.h */
+__device__ __forceinline__ float ggx_G1(const V3 w, const V3 n, float roughness)
+{ /* ggx.h:29-36 */
+  const float r2 = roughness*roughness;
+  const float cos_th = fabsf(dot3(w, n));
+  const float sin_th = sqrtf(fmaxf(0.0f, 1.0f - cos_th*cos_th));
+  const float tan_th = sin_th/cos_th;
+  return 2.0f/(1.0f + sqrtf(1.0f + r2*tan_th*tan_th));
+}
+__device__ __forceinline__ float ggx_G1_cos(float cos_wn, float roughness)
+{ /* ggx.h:38-46 */
+  const float r2 = roughness*roughness;
+  const float sin_wn = sqrtf(DCLAMP(1.0f - cos_wn*cos_wn, 0.0f, 1.0f));
+  const float tan_th = sin_wn/cos_wn;
+  return 2.0f/(1.0f + sqrtf(1.0f + r2*tan_th*tan_th));
+}
+__device__ __forceinline__ void ggx_sample11(float tan_theta_i, float U1, float U2, float &slope_x, float &slope_y)
+{ /* ggx.h:59-110 */
+  if(tan_theta_i < 0.0001f)
+  {
+    const float r = sqrtf(U1/fmaxf(1e-8f, 1-U1));
+    const float phi = (float)(2.0f*MI_PI_D*(double)U2);
+    slope_x = r*cosf(phi);
+    slope_y = r*sinf(phi);
+    return;
+  }
+  const float a = 1.0f/tan_theta_i;
+  const float G1 = 2.0f/(1.0f + sqrtf(1.0f + 1.0f/(a*a)));
+  const float A = 2.0f*U1/G1 - 1.0f;
+  const float tmp = 1.0f/(A*A - 1.0f);
+  const float B = tan_theta_i;
+  const float D = sqrtf(fmaxf(0.0f, B*B*tmp*tmp - (A*A - B*B)*tmp));
+  float sx1 = B*tmp - D, sx2 = B*tmp + D;
+  if(!(fabsf(sx1) < FLT_MAX)) sx1 = 0.0f;
+  if(!(fabsf(sx2) < FLT_MAX)) sx2 = 0.0f;
+  slope_x = (A < 0.0f || sx2*tan_theta_i > 1.0f) ? sx1 : sx2;
+  float S;
+  if(U2 > 0.5f) { S = 1.0f;  U2 = 2.0f*(U2 - 0.5f); }
+  else          { S = -1.0f; U2 = 2.0f*(0.5f - U2); }
+  const float z = (U2*(U2*(U2*(-0.365728915865723f) + 0.790235037209296f) - 0.424965825137544f) + 0.000152998850436920f) /
+                  (U2*(U2*(U2*(U2*0.169507819808272f - 0.397203533833404f) - 0.232500544458471f) + 1.0f) - 0.539825872510702f);
+  slope_y = S*z*sqrtf((float)(1.0 + (double)(slope_x*slope_x)));
+}
+__device__ __forceinline__ V3 ggx_sample_h(const V3 wi, float rx, float ry, float U1, float U2)
+{ /* ggx.h:115-162 */
+  const V3 wi_ = normalise3(mk3(rx*wi.x, ry*wi.y, fabsf(wi.z)));
+  float tan_theta = 0.0f, sin_phi = 0.0f, cos_phi = 1.0f;
+  if(wi_.z < 0.99999)
+  {
+    const float len = sqrtf(wi_.x*wi_.x + wi_.y*wi_.y);
+    tan_theta = len/wi_.z;
+    sin_phi = wi_.y/len;
+    cos_phi = wi_.x/len;
+  }
+  float slope_x, slope_y;
+  ggx_sample11(tan_theta, U1, U2, slope_x, slope_y);
+  const float tmp = cos_phi*slope_x - sin_phi*slope_y;
+  slope_y = sin_phi*slope_x + cos_phi*slope_y;
+  slope_x = tmp;
+  slope_x = rx*slope_x;
+  slope_y = ry*slope_y;
+  const float inv_h = sqrtf((float)((double)(slope_x*slope_x + slope_y*slope_y) + 1.0));
+  V3 h = mk3(-slope_x/inv_h, -slope_y/inv_h, (float)(1.0/(double)inv_h));
+  if(!(inv_h > 0.0)) h = mk3(0.0f, 1.0f, 0.0f);
+  return h;
+}
+__device__ __forceinline__ float ggx_pdf_h(const V3 wi, const V3 h, const V3 n, float roughness)
+{ /* ggx.h:167-182 */
+  const float r2 = roughness*roughness;
+  const float cos_th = fabsf(dot3(h, n));
+  const float sin_th = sqrtf(fmaxf(0.0f, 1.0f - cos_th*cos_th));
+  const float tan_th = sin_th/cos_th;
+  const double A2 = (double)(r2 + tan_th*tan_th);
+  const float D_h = (float)((double)r2/(MI_PI_D*(double)cos_th*(double)cos_th*(double)cos_th*(double)cos_th*A2*A2));
+  const float G1 = ggx_G1(wi, n, roughness);
+  return fabsf(G1*dot3(wi, h)*D_h/dot3(wi, n));
+}
+__device__ __forceinline__ float ggx_pdf_h_cos(float cosh, float cos_in, float cosr, float roughness)
+{ /* ggx.h:184-201 */
+  const float r2 = roughness*roughness;
+  const float cosh2 = cosh*cosh;
+  const float sin_th = sqrtf(DCLAMP(1.0f - cosh2, 0.0f, 1.0f));
+  const float tan_th = sin_th/fabsf(cosh);
+  const float den = tan_th*tan_th + r2;
+  const float ct4 = cosh2*cosh2;
+  const float D_h = (float)((double)r2/((MI_PI_D*(double)ct4)*(double)(den*den)));
+  const float G1 = ggx_G1_cos(cos_in, roughness);
+  return fabsf((G1*cosr)*(D_h/cos_in));
+}
+
+#define HALFVEC_COS_THR .999
+#define GLOSSY_THR 1e-3f
+
+__device__ __forceinline__ float fresnel_dielectric(float n1, float n2, float cosr, float cost)
+{ /* dielectric.c:83-94 */
+  if(cost <= 0.0f) return 1.0f;
+  const float r1 = n1*cosr, r2 = n2*cosr, t1 = n1*cost, t2 = n2*cost;
+  const float Rs = (r1 - t2)/(r1 + t2);
+  const float Rp = (t1 - r2)/(t1 + r2);
+  return DCLAMP((Rs*Rs + Rp*Rp)*.5f, 0.0f, 1.0f);
+}
+
+__device__ __forceinline__ float fresnel_metal(float n1, float n2, float k2, float cosr)
+{ /* metal.c:79-157 */
+  const float etar =   (n1*n2)/(n2*n2 + k2*k2);
+  const float etai = -((n1*k2)/(n2*n2 + k2*k2));
+  const float eta2r = etar*etar - etai*etai;
+  const float eta2i = (2.0f*etar)*etai;
+  const float sinr = 1.0f - cosr*cosr;
+  const float cost2r = 1.0f - eta2r*sinr;
+  const float cost2i = eta2i*(-sinr);
+  const float len = sqrtf(cost2r*cost2r + cost2i*cost2i);
+  const float costr = sqrtf(0.5f*(cost2r + len));
+  float costi = sqrtf(0.5f*(len - cost2r));
+  if(cost2i < 0.0f) costi = -costi;
+  const float n1cosr = n1*cosr, n2cosrr = n2*cosr, n2cosri = k2*cosr;
+  const float n1costr = n1*costr, n1costi = n1*costi;
+  const float n2costr = n2*costr - k2*costi;
+  const float n2costi = k2*costr + n2*costi;
+  const float Rs2 = ((n1cosr - n2costr)*(n1cosr - n2costr) + n2costi*n2costi) /
+                    ((n1cosr + n2costr)*(n1cosr + n2costr) + n2costi*n2costi);
+  const float Rp2 = ((n1costr - n2cosrr)*(n1costr - n2cosrr) + (n1costi - n2cosri)*(n1costi - n2cosri)) /
+                    ((n1costr + n2cosrr)*(n1costr + n2cosrr) + (n1costi + n2cosri)*(n1costi + n2cosri));
+  return DCLAMP((Rs2 + Rp2)*.5f, 0.0f, 1.0f);
+}
+
+/* ------------------------------------------------------------------------------------------ bsdf sampling */
+struct BsdfSample
+{
+  V3 omega;          /* e[v+1].omega (not yet normalised by shader_sample) */
+  float pdf;         /* v[v+1].pdf as set by the plugin (projected solid angle) */
+  float weight;      /* returned throughput factor */
+  uint32_t mode;     /* v[v].mode after sampling */
+};
+
+__device__ __forceinline__ void sample_diffuse(Rng &rng, const Surf &sf, const Shading &sh, uint32_t mode_in, BsdfSample &bs)
+{ /* sample_d, src/shader.c:165-205 */
+  const float x1 = rng_next(rng);
+  const float x2 = rng_next(rng);
+  const float sq = sqrtf(x1);
+  const float c0 = sqrtf((float)(1.0 - (double)x1));
+  const float ang = (float)(2*MI_PI_D*(double)x2);
+  const float c1 = sq*cosf(ang), c2 = sq*sinf(ang);
+  bs.omega = mk3(c0*sf.n.x + c1*sf.a.x + c2*sf.b.x, c0*sf.n.y + c1*sf.a.y + c2*sf.b.y, c0*sf.n.z + c1*sf.a.z + c2*sf.b.z);
+  bs.pdf = (float)(1.0f/MI_PI_D);
+  bs.mode = mode_in;
+  bs.weight = 0.0f;
+  const float cos_out_ng = dot3(sf.gn, bs.omega);
+  if(sf.flags & s_inside) { if(cos_out_ng >= 0.0f) return; }
+  else if(cos_out_ng <= 0.0f) return;
+  bs.weight = sh.rd;
+  if(bs.weight > 0.0f) bs.mode = s_diffuse | s_reflect;
+}
+
+__device__ __forceinline__ void sample_dielectric(Rng &rng, const Surf &sf, const Shading &sh, const V3 wi, float eta_ratio,
+                                                  uint32_t mode_in, BsdfSample &bs)
+{ /* sample, dielectric.c:240-415 (MF_COUNT == 1) */
+  bs.mode = mode_in; bs.weight = 0.0f; bs.pdf = 1.0f; bs.omega = mk3(0, 0, 0);
+  if(eta_ratio < 0.0f) return;
+  if(fabsf(1.0f - eta_ratio/1.0f) < 1e-3f)
+  {
+    bs.omega = wi;
+    bs.mode = s_specular | s_transmit;
+    bs.pdf = 1.0f;
+    bs.weight = sh.rg;
+    return;
+  }
+  const V3 n = sf.n;
+  float pdf_h = 1.0f;
+  V3 h = n;
+  const float r = sh.roughness;
+  const float cos_in = -dot3(sf.n, wi);
+  if(r > GLOSSY_THR)
+  {
+    const V3 wit = mk3(-dot3(sf.a, wi), -dot3(sf.b, wi), cos_in);
+    const float U2 = rng_next(rng);          /* argument evaluation order of the reference build, SURVEY app. B */
+    const float U1 = rng_next(rng);
+    const V3 ht = ggx_sample_h(wit, r, r, U1, U2);
+    h = mk3(ht.x*sf.a.x + ht.y*sf.b.x + ht.z*n.x, ht.x*sf.a.y + ht.y*sf.b.y + ht.z*n.y, ht.x*sf.a.z + ht.y*sf.b.z + ht.z*n.z);
+    pdf_h = ggx_pdf_h(wi, h, n, r);
+  }
+  float pdf = pdf_h;
+  const float cosr = -dot3(wi, h);
+  if(cosr <= 0.0f) return;
+  const float n1 = eta_ratio, n2 = 1.0f;
+  const float nr = n1/n2;
+  const float cost2 = 1.0f - (nr*nr)*(1.0f - cosr*cosr);
+  const float cost = cost2 <= 0.0f ? 0.0f : sqrtf(cost2);
+  const float R = fresnel_dielectric(n1, n2, cosr, cost);
+  if(rng_next(rng) <= R)
+  {
+    bs.mode = s_reflect;
+    bs.omega = mk3(wi.x + 2.0f*cosr*h.x, wi.y + 2.0f*cosr*h.y, wi.z + 2.0f*cosr*h.z);
+    if(dot3(bs.omega, n) <= 0.0f) return;
+    pdf *= 1.0f/(4.0f*cosr);
+    if(r > GLOSSY_THR)
+    {
+      bs.pdf = R*(pdf/fabsf(dot3(bs.omega, n)));
+      bs.mode |= s_glossy;
+      if(dot3(bs.omega, n)*dot3(bs.omega, h) < 0.0f) return;
+      bs.weight = sh.rg*ggx_G1(bs.omega, n, sh.roughness);
+      return;
+    }
+    bs.pdf = R;
+    bs.mode = s_reflect | s_specular;
+    bs.weight = sh.rg;
+  }
+  else
+  {
+    if(cost2 <= 0.0f) return;
+    const float f = eta_ratio*cosr - cost;
+    bs.omega = normalise3(mk3(wi.x*eta_ratio + f*h.x, wi.y*eta_ratio + f*h.y, wi.z*eta_ratio + f*h.z));
+    if(dot3(bs.omega, n) >= 0.0f) return;
+    if(r <= GLOSSY_THR)
+    {
+      bs.pdf = 1.0f - R;
+      bs.mode = s_specular | s_transmit;
+      bs.weight = sh.rg;
+      return;
+    }
+    const float denom = n1*cosr - n2*cost;
+    pdf *= n2*n2*cost/(denom*denom);
+    bs.pdf = (pdf*(1.0f - R))/fabsf(dot3(bs.omega, n));
+    bs.mode = s_transmit | s_glossy;
+    bs.weight = sh.rg*ggx_G1(bs.omega, n, sh.roughness);
+  }
+}
+
+__device__ __forceinline__ void sample_metal(const DScene &sc, Rng &rng, const Surf &sf, const Shading &sh, const V3 wi, float n1,
+                                             int mat, float lambda, uint32_t mode_in, BsdfSample &bs)
+{ /* sample, metal.c:219-265 */
+  bs.mode = mode_in; bs.weight = 0.0f; bs.pdf = 1.0f; bs.omega = mk3(0, 0, 0);
+  const V3 n = sf.n;
+  V3 h = n;
+  float pdf_h = 1.0f;
+  const float r = sh.roughness;
+  if(r > 1e-4f)
+  {
+    const V3 wit = mk3(-dot3(sf.a, wi), -dot3(sf.b, wi), -dot3(n, wi));
+    const float U2 = rng_next(rng);
+    const float U1 = rng_next(rng);
+    const V3 ht = ggx_sample_h(wit, r, r, U1, U2);
+    h = mk3(ht.x*sf.a.x + ht.y*sf.b.x + ht.z*n.x, ht.x*sf.a.y + ht.y*sf.b.y + ht.z*n.y, ht.x*sf.a.z + ht.y*sf.b.z + ht.z*n.z);
+    pdf_h = ggx_pdf_h(wi, h, n, r);
+  }
+  float pdf = pdf_h;
+  const float cosr = -dot3(wi, h);
+  if(!(cosr > 0.0f)) return;
+  const int i = (int)DCLAMP((lambda - 360.0f)/5.0f, 0, 94);              /* fresnel.h:519-531 */
+  const float n2 = sc.metal_ior[(mat*95 + i)*2 + 0], k2 = -sc.metal_ior[(mat*95 + i)*2 + 1];
+  const float R = fresnel_metal(n1, n2, k2, cosr);
+  bs.mode = s_reflect;
+  bs.omega = mk3(wi.x + 2.0f*cosr*h.x, wi.y + 2.0f*cosr*h.y, wi.z + 2.0f*cosr*h.z);
+  if(dot3(bs.omega, n) <= 0.0f) return;
+  pdf *= 1.0f/(4.0f*cosr);
+  if(r > 1e-4f)
+  {
+    bs.pdf = pdf/fabsf(dot3(bs.omega, n));
+    bs.mode |= s_glossy;
+    if(dot3(bs.omega, n)*dot3(bs.omega, h) < 0.0f) return;
+    bs.weight = R*(sh.rg*ggx_G1(bs.omega, n, sh.roughness));
+    return;
+  }
+  bs.mode |= s_specular;
+  bs.weight = R*sh.rg;
+}
+
+/* ------------------------------------------------------------------------------------------ splat */
+__device__ __forceinline__ float bh_w(float n)
+{ /* filter_bh_w, include/filter/blackmanharris.h:28-41 */
+  const float NN = 4.0f;
+  if(n > NN-1.0f || n < 0.0f) return 0.0f;
+  const float a0 = 0.35875, a1 = 0.48829, a2 = 0.14128, a3 = 0.01168;
+  const float N_1 = 1.0f/(NN-1.0f);
+  const float cos1 = cosf((float)(2.0f*MI_PI_D*(double)n*(double)N_1));
+  const float cos2 = cosf((float)(4.0f*MI_PI_D*(double)n*(double)N_1));
+  const float cos3 = cosf((float)(6.0f*MI_PI_D*(double)n*(double)N_1));
+  return a0 - a1*cos1 + a2*cos2 - a3*cos3;
+}
+
+__device__ __forceinline__ bool splat_value_ok(float value)
+{ /* view_splat, src/view.c:455-463 */
+  return (value > 0.0f) && (value < FLT_MAX) && (value == value);
+}
+
+__device__ __forceinline__ void spectrum_to_xyz(const DScene &sc, float lambda, float value, float *col)
+{ /* spectrum_p_to_camera, include/spectrum.h:172-203 */
+  float f = (lambda - 360)/5;
+  const int i = (int)f;
+  f -= i;
+  for(int k=0;k<3;k++) col[k] = ((1-f)*sc.cie_xyz[3*i+k] + f*sc.cie_xyz[3*(i+1)+k])*value;
+}
+
+__device__ __noinline__ void splat_bh(const DScene &sc, float pi, float pj, const float *col)
+{ /* filter_blackmanharris_splat, include/filter/blackmanharris.h:43-77 + box.h:23-36 */
+  const int wd = (int)sc.width, ht = (int)sc.height;
+  const int x0 = (int)(pi - 1.5f), y0 = (int)(pj - 1.5f);
+  const int u0 = -x0 < 0 ? 0 : -x0, v0 = -y0 < 0 ? 0 : -y0;
+  const int u4 = x0 + 4 > wd ? wd - x0 : 4, v4 = y0 + 4 > ht ? ht - y0 : 4;
+  float w[16];
+  float weight = 0.0f;
+  for(int v=0;v<4;v++) for(int u=0;u<4;u++)
+  {
+    float f = 0.0f;
+    if(v >= v0 && v < v4 && u >= u0 && u < u4)
+    {
+      const float uu = (x0 + u + .5f) - pi, vv = (y0 + v + .5f) - pj;
+      f = bh_w(sqrtf(uu*uu + vv*vv) + 1.5f);
+      weight += f;
+    }
+    w[4*v+u] = f;
+  }
+  if(weight <= 0) return;
+  weight = 1.0f/weight;
+  for(int v=0;v<4;v++) for(int u=0;u<4;u++)
+  {
+    if(v >= v0 && v < v4 && u >= u0 && u < u4)
+    {
+      const float f = weight*w[4*v+u];
+      float *px = sc.fb + 3*((size_t)(x0+u) + (size_t)wd*(y0+v));
+      atomicAdd(px+0, col[0]*f);
+      atomicAdd(px+1, col[1]*f);
+      atomicAdd(px+2, col[2]*f);
+    }
+  }
+}
+
+#endif

@@ -107,8 +107,8 @@ static int o_sphere_intersect(const mi_scene_desc *s, mi_primid pi, const o_ray 
   {
     hit->dist = t; hit->prim = pi;
     for(int k=0;k<3;k++) hit->x[k] = ray->pos[k] + t*ray->dir[k];
-    hit->u = atan2f((hit->x[1]-c->v[1])/radius, (hit->x[0]-c->v[0])/radius)/(2.0f*(float)M_PI);
-    hit->v = acosf(OCLAMP((hit->x[2]-c->v[2])/radius, -1.0f, 1.0f))/(float)M_PI;
+    hit->u = atan2f((hit->x[1]-c->v[1])/radius, (hit->x[0]-c->v[0])/radius)/(2.0f*M_PI);
+    hit->v = acosf(OCLAMP((hit->x[2]-c->v[2])/radius, -1.0f, 1.0f))/M_PI;
     return 1;
   }
   return 0;
@@ -197,7 +197,7 @@ static float o_cone_t(const float *v0, const float *v1, float r0, float r1, cons
             hit->u = dt/d_len;
             float a[3], b[3];
             o_get_onb(d, a, b);
-            hit->v = atan2f(dot3(a, x), dot3(b, x))/(2.0f*(float)M_PI);
+            hit->v = atan2f(dot3(a, x), dot3(b, x))/(2.0f*M_PI);
           }
           tmin = dist = t;
         }
@@ -221,7 +221,7 @@ static int o_line_intersect(const mi_scene_desc *s, mi_primid pi, const o_ray *r
     {
       hit->dist = t; hit->prim = pi;
       hit->u = out[0]/len;
-      hit->v = atan2f(out[1], out[2])/(2.0f*(float)M_PI);
+      hit->v = atan2f(out[1], out[2])/(2.0f*M_PI);
       return 1;
     }
   }
@@ -521,9 +521,9 @@ static void o_prims_retime(const mi_scene_desc *s, mi_primid pi, o_hit *hit)
     const mi_vtx *c = o_vtx(s, pi, 0);
     const float r = o_bits2float(c->n);
     const float x1 = -(cosf(hit->v*M_PI)-1.f)/2.f, x2 = hit->u;
-    const float z = 1.f - 2.f*x1, rr = sqrtf(fmaxf(0.0f, 1.f - z*z));
-    float sn, cs; sincosf(2.f*(float)M_PI*x2, &sn, &cs);
-    const float d[3] = { rr*cs, rr*sn, z };
+    const float z = 1.f - 2.f*x1, rr = sqrtf(1.f - z*z);
+    const float phis = 2.f*M_PI*x2;
+    const float d[3] = { rr*cosf(phis), rr*sinf(phis), z };
     for(int k=0;k<3;k++) hit->x[k] = c->v[k] + r*d[k];
   }
   else if(vcnt == MI_PRIM_LINE)

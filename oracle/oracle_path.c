@@ -457,11 +457,11 @@ static float o_lights_sample_next_event(o_ctx *c, o_path *p)
   if(p->v[v].shading.roughness > 1.0f-1e-4f) p->v[v].material_modes = p->v[v].mode = s_emit | s_diffuse;
   else p->v[v].material_modes = p->v[v].mode = s_emit | s_glossy;
   float edf = p->v[v].shading.em/p->v[v].pdf;
-  if(p->v[v].shading.roughness > 1.0f-1e-4f) edf = edf*(float)(1.0f/M_PI);
+  if(p->v[v].shading.roughness > 1.0f-1e-4f) edf = edf*(1.0f/M_PI);
   else
   {
     const float phongexp = 2.0f/(p->v[v].shading.roughness*p->v[v].shading.roughness) - 2.0f;
-    edf = edf*(float)(powf(-dot3(p->v[v].hit.gn, p->e[v].omega), phongexp)*(phongexp + 2.0f)/(2.0f*M_PI));
+    edf = edf*(powf(-dot3(p->v[v].hit.gn, p->e[v].omega), phongexp)*(phongexp + 2.0f)/(2.0f*M_PI));
   }
   return edf;
 }

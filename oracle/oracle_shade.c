@@ -201,7 +201,7 @@ static float o_brdf_diffuse(o_path *p, int v)
   const float cos_out_ng = dot3(p->v[v].hit.gn, p->e[v+1].omega);
   if(p->v[v].flags & s_inside) { if(cos_out_ng >= 0.0f) return 0.0f; }
   else if(cos_out_ng <= 0.0f) return 0.0f;
-  return p->v[v].shading.rd * (float)(1.0f/M_PI);
+  return p->v[v].shading.rd * (1.0f/M_PI);
 }
 
 /* ---------------------------------------------------------------- GGX, src/shaders/ggx.h */
@@ -295,7 +295,7 @@ static float o_ggx_pdf_h_cos(float cosh, float cos_in, float cosr, float roughne
   const float tan_th = sin_th/fabsf(cosh);
   const float den = tan_th*tan_th + r2;
   const float ct4 = cosh2*cosh2;
-  const float D_h = r2/(((float)M_PI*ct4)*(den*den));
+  const float D_h = r2/((M_PI*ct4)*(den*den));   /* mf_set1(M_PI) is a double in the scalar build */
   const float G1 = o_ggx_G1_cos(cos_in, roughness);
   return fabsf((G1*cosr)*(D_h/cos_in));
 }
