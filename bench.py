@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""bench.py -- Msamples/s of the pt hot path on regression/0010_pt at 1280x720, 64 spp, max depth 8
+(BASELINE.json config 2) on N MI355X of one node.
+
+A "step" is one whole frame: 64 spp x 1280x736 (the film is padded to multiples of 32 like the
+reference, src/view.c:294-296) = 60 293 120 camera paths traced by the HIP kernel into a
+device-resident framebuffer, INCLUDING the framebuffer reduce across ranks (RCCL all-reduce over
+xGMI, the only collective of this path) -- the timing window of the reference's "elapsed wallclock
+prog" (src/view.c:634,687-688). Scene upload, BVH build and file output are outside, as in the reference.
+Inputs (scene, tables) are resident in HBM when the timed region starts.
+
+N > 1: one process per GPU (torch.distributed, backend nccl == RCCL). Paths are independent, so every
+rank renders its own contiguous range of path indices with no data-path collective; scaling is WEAK
+(each GPU renders a full 64-spp frame's worth of distinct indices, the job is N x 64 spp).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+sys.path.insert(0, str(REPO / "tests"))
+
+W, H, SPP, MAX_VERTS = 1280, 720, 64, 8
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def cpu_baseline(scene):
+    """CPU number reported beside the GPU result, on a bounded sample of the same workload.
+    kind "reference": the real corona-13 binary built from /root/reference in the build container
+    (oracle/_ref/, shipped as a built artefact), all host cores, sfmt + rand like regression/0010_pt/config.mk;
+    kind "port": our CPU restatement (oracle/liboracle.so) if the reference binary is not there."""
+    cores = os.cpu_count() or 1
+    ref = REPO / "oracle" / "_ref"
+    binary = ref / "corona_pt_sfmt_mv8"
+    spp = 16 if cores <= 16 else 64
+    if binary.exists() and (ref / "data" / "ergb2spec.coeff").exists():
+        work = Path(tempfile.mkdtemp(prefix="corona_cpu_"))
+        try:
+            shutil.copytree(REPO / "scenes", work / "scenes")
+            env = dict(os.environ, LD_LIBRARY_PATH=str(ref / "shaders_mv8"))
+            subprocess.run([str(binary), str(work / "scenes" / "0010_pt" / "test.nra2"), "-s", str(spp), "--batch", str(spp),
+                            "-w", str(W), "-h", str(H), "-t", str(cores), "-x", "_cpu"], cwd=ref, env=env,
+                           capture_output=True, text=True, timeout=600, check=True)
+            side = (work / "scenes" / "0010_pt" / "test_cpu_fb00.pfm.txt").read_text()
+            secs = float(re.search(r"elapsed wallclock prog ([\d.]+)s", side).group(1))
+            n = spp * scene.width * scene.height
+            return {"value": n / secs / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "reference",
+                    "sample": f"{spp} spp of the same 1280x736 frame ({n} paths), reference binary, {secs:.2f} s"}
+        except Exception as e:          # fall through to the port
+            print(f"[bench] reference cpu baseline failed: {e}", file=sys.stderr)
+        finally:
+            shutil.rmtree(work, ignore_errors=True)
+    from helpers import oracle_render
+    n = 4 * scene.width * scene.height
+    _, _, secs = oracle_render(scene, 0, n, threads=cores)
+    return {"value": n / secs / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": f"4 spp of the same 1280x736 frame ({n} paths), oracle/liboracle.so, {secs:.2f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from __graft_entry__ import load_package
+    from helpers import SCENE_0010, make_scene
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    pkg = load_package()
+    scene = make_scene(SCENE_0010, width=W, height=H, max_verts=MAX_VERTS)
+    be = pkg.Backend(scene, device=local_rank)
+    per_frame = SPP * scene.width * scene.height
+    fb = torch.zeros((scene.height, scene.width, 3), dtype=torch.float32, device=f"cuda:{local_rank}")
+    stream = torch.cuda.current_stream()
+    be.set_framebuffer(fb.data_ptr())
+    be.set_stream(stream.cuda_stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(k):
+        # rank r renders its own contiguous block of path indices of "frame" k: no data-path collective
+        first = (k * world + rank) * per_frame
+        be.render(first, per_frame)
+        if world > 1:
+            dist.all_reduce(fb, op=dist.ReduceOp.SUM)      # framebuffer reduce over xGMI (RCCL)
+
+    for k in range(args.warmup):
+        step(k)
+    barrier()
+    kernel_ms = []
+    c0 = be.counters()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k)
+        kernel_ms.append(None)
+    barrier()
+    t1 = time.perf_counter()
+    c1 = be.counters()
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # kernel duration with HIP events on the launch stream: re-run K launches un-overlapped, outside the timed region
+    durs = []
+    for k in range(max(3, min(args.steps, 5))):
+        be.render((1000 + k) * per_frame, per_frame)
+        be.sync()
+        durs.append(be.last_kernel_ms())
+    kms = sum(durs) / len(durs)
+    dc = [b - a for a, b in zip(c0, c1)]
+    paths = dc[4]
+    # algorithmic bytes per sample, SURVEY 8(d): 128 B per node visit + 104 B per primitive test + 384 B per splat
+    bytes_per_sample = (128.0 * dc[1] + 104.0 * dc[3] + 384.0 * dc[5]) / max(paths, 1)
+    achieved = bytes_per_sample * per_frame / (kms * 1e-3) / 1e9
+
+    if rank == 0:
+        total = args.steps * per_frame * world
+        out = {
+            "metric": "Msamples/sec (and ms/frame) at 1280x720, 64 spp, regression/0010_pt",
+            "value": total / elapsed / 1e6,
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic: regression/0010_pt scene (6 of 7 shapes, scenes/0010_pt), per-path xorshift128+ seeds",
+            "config": {"workload": "configs[1]: regression/0010_pt test.nra2, pt sampler, 1280x720 (padded 1280x736), 64 spp, max depth 8",
+                       "paths_per_step_per_gpu": per_frame, "sharding": f"path-index ranges x{world}, framebuffer all-reduce"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "mi_path_kernel<false>", "kernel_ms": kms,
+                         "algorithmic_bytes_per_sample": bytes_per_sample,
+                         "work_per_sample": {"rays": dc[0] / paths, "node_visits": dc[1] / paths, "prim_tests": dc[3] / paths, "splats": dc[5] / paths}},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(scene)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    be.close()
+
+
+if __name__ == "__main__":
+    main()

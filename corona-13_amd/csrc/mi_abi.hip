@@ -35,7 +35,14 @@ struct PathState
   int length;               /* number of complete vertices */
   Rng rng;
   unsigned long long index;
-  uint32_t active;
+  uint32_t active;          /* path alive: an extension ray is waiting to be traced */
+  /* ptdl: pending shadow ray of the next-event estimate made at the last vertex */
+  uint32_t sh_pending;
+  uint32_t prev_material_modes;
+  V3 sh_org, sh_dir;
+  float sh_dist, sh_value;
+  uint32_t sh_light, sh_ignore;
+  int sh_length;
 };
 
 template<bool RECORD>
@@ -54,9 +61,9 @@ __device__ __forceinline__ void rec_vertex(mi_path_record *rec, int v, uint64_t 
   d.rd = sh.rd; d.rg = sh.rg; d.em = sh.em; d.roughness = sh.roughness; d.eta = eta; d.shader = shader;
 }
 
-template<bool RECORD>
+template<bool RECORD, bool PTDL>
 __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned long long first, unsigned long long count,
-                                                           const uint32_t *shape_material, mi_path_record *records)
+                                                           const uint32_t *shape_material, const float *shape_L, mi_path_record *records)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t N = sc.num_nodes;
@@ -76,6 +83,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
   uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   PathState ps;
   ps.active = 0;
+  ps.sh_pending = 0;
   bool exhausted = false;
   const unsigned lane = __lane_id();
 
@@ -84,7 +92,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
     /* ------------------------------------------------------------ refill idle lanes (wave-level compaction of the work queue) */
     if(!exhausted)
     {
-      const bool want = !ps.active;
+      const bool want = !ps.active && !ps.sh_pending;
       const unsigned long long m = __ballot(want);
       if(m)
       {
@@ -152,6 +160,8 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
             ps.media.ids = 0; ps.media.count = 0; ps.media.broken = 0;
             ps.length = 1;
             ps.active = 1;
+            ps.prev_material_modes = s_sensor;
+            cnt[6]++;                                  /* the sensor vertex */
             if(RECORD)
             {
               mi_path_record *rec = records + i;
@@ -165,15 +175,45 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
         }
       }
     }
-    if(!__any(ps.active)) break;
+    if(!__any(ps.active || ps.sh_pending)) break;
 
-    /* ------------------------------------------------------------ one ray per active lane */
+    /* ------------------------------------------------------------ one ray per busy lane: a pending shadow ray first, else the extension ray */
+    const bool do_shadow = PTDL && ps.sh_pending;
     Hit hit;
-    hit.prim = MI_NOPRIM; hit.dist = FLT_MAX; hit.u = hit.v = 0.0f;
-    if(ps.active) accel_intersect<MI_BLOCK, MI_STACK>(lds, sc.prims, ps.org, ps.dir, ps.ignore, hit, cnt);
+    hit.prim = MI_NOPRIM; hit.dist = do_shadow ? ps.sh_dist : FLT_MAX; hit.u = hit.v = 0.0f;
+    if(do_shadow || ps.active)
+      accel_intersect<MI_BLOCK, MI_STACK>(lds, sc.prims, do_shadow ? ps.sh_org : ps.org, do_shadow ? ps.sh_dir : ps.dir,
+                                          do_shadow ? ps.sh_ignore : ps.ignore, hit, cnt);
 
+    if(do_shadow)
+    { /* path_visible, src/pathspace.c:311-344: closest hit up to the emitter's primitive (all surfaces in scope are opaque) */
+      ps.sh_pending = 0;
+      const bool visible = (hit.dist >= ps.sh_dist) || (hit.prim == MI_NOPRIM) || (hit.prim == ps.sh_light);
+      if(visible)
+      {
+        const float value = ps.sh_value;
+        const bool ok = splat_value_ok(value);
+        float col[3] = {0.0f, 0.0f, 0.0f};
+        if(ok) spectrum_to_xyz(sc, ps.lambda, value, col);
+        if(RECORD)
+        {
+          mi_path_record *rec = records + (ps.index - first);
+          if(rec->num_splats < MI_REC_MAX_SPLATS)
+          {
+            mi_path_splat &sp = rec->splat[rec->num_splats++];
+            sp.length = ps.sh_length; sp.tech = s_tech_nee; sp.value = value;
+            sp.col[0] = col[0]; sp.col[1] = col[1]; sp.col[2] = col[2];
+          }
+        }
+        if(ok)
+        {
+          cnt[5]++;
+          if(!RECORD) splat_bh(sc, ps.pixel_i, ps.pixel_j, col);
+        }
+      }
+    }
     /* ------------------------------------------------------------ finish vertex v, then sample the next direction */
-    if(ps.active)
+    else if(ps.active)
     {
       mi_path_record *rec = RECORD ? records + (ps.index - first) : nullptr;
       const int v = ps.length;                         /* index of the vertex being created */
@@ -250,6 +290,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
           /* path_extend tail, src/pathspace.c:261-270 */
           const float G = ps.prev_cos*fabsf(dot3(sf.n, omega))/(hit.dist*hit.dist);
           const float vpdf = ps.pdf*G;
+          const double pp_before = ps.pdfprod;
           ps.pdfprod *= (double)vpdf;
           ps.length++;
           cnt[6]++;
@@ -278,10 +319,22 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
             rec->length = ps.length; rec->throughput = path_throughput;
           }
           if(mode & s_emit)
-          { /* sampler_create_path, src/sampler.d/pt.c:45-52 */
-            const float fp = (float)ps.pdfprod;
-            const float w = fp/fp;
-            const float value = w*path_throughput;
+          { /* sampler_create_path: src/sampler.d/pt.c:45-52 / src/sampler.d/ptdl.c:116-121 */
+            float w;
+            if(PTDL)
+            { /* balance heuristic against next event estimation, ptdl.c:78-88 + nee_pdf, include/pathspace/nee.h:21-47 */
+              float nee = 0.0f;
+              if(ps.length >= 3 && (ps.prev_material_modes & (s_diffuse | s_glossy)) && sc.p_geo > 0) nee = sc.p_geo*shape_L[shape];
+              const double pp = pp_before;
+              const double our = (double)vpdf*pp, other = (double)(1.0f*nee)*pp;
+              w = (float)our/(float)(other + our);
+            }
+            else
+            {
+              const float fp = (float)ps.pdfprod;
+              w = fp/fp;
+            }
+            const float value = PTDL ? path_throughput*w : w*path_throughput;
             const bool ok = splat_value_ok(value);
             float col[3] = {0.0f, 0.0f, 0.0f};
             if(ok) spectrum_to_xyz(sc, ps.lambda, value, col);
@@ -296,7 +349,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
               cnt[5]++;
               if(!RECORD) splat_bh(sc, ps.pixel_i, ps.pixel_j, col);
             }
-            if(ps.length > 3)
+            if(!PTDL && ps.length > 3)
             { /* path_russian_roulette, src/pathspace.c:273-292 */
               const float p_survival = DMIN(1.0f, vthr/ps.prev_throughput);
               const float rr = rng_next(ps.rng);
@@ -306,6 +359,92 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
               {
                 rec->v[v].throughput = vthr;
                 rec->v[v].pdf = alive ? vpdf*p_survival : vpdf*(1.0f-p_survival);
+              }
+            }
+          }
+          if(PTDL && ps.length >= (int)sc.max_verts) alive = false;           /* ptdl.c:122 */
+          if(PTDL && alive)
+          { /* next event estimation at vertex v: ptdl.c:136-148, nee_sample include/pathspace/nee.h:87-243 */
+            (void)rng_next(ps.rng);                                            /* points_rand < nee_probability == 1 */
+            if(material_modes & (s_diffuse | s_glossy))
+            {
+              const float rnd = rng_next(ps.rng);
+              if(!(rnd < sc.p_sky) && rnd < sc.p_sky + sc.p_geo)
+              { /* lights_sample_next_event, src/lights.d/list.c:130-174 (arguments drawn right to left) */
+                const float r3 = rng_next(ps.rng);
+                const float r2 = rng_next(ps.rng);
+                const float r1 = rng_next(ps.rng);
+                const uint32_t t = sample_cdf(sc.light_cdf, (int)sc.num_lights, r1);
+                const uint32_t lp = sc.light_prim[t];
+                Surf ls;
+                ls.x = prim_sample(sc.prims[lp], r2, r3, ls.u, ls.v);
+                V3 ol = sub3(ls.x, sf.x);
+                const float ldist = sqrtf(dot3(ol, ol));
+                const double il = 1./(double)ldist;
+                ol = mk3((float)((double)ol.x*il), (float)((double)ol.y*il), (float)((double)ol.z*il));
+                surface_setup(sc, lp, ol, ps.scramble, ls);
+                const DPrimShade &lshade = sc.primshade[lp];
+                Shading lsh;
+                run_prepare_ops(sc, sc.materials[lshade.material], ls, ps.lambda, lsh);
+                float lpdf = sc.light_L[t];
+                float edf = lsh.em/lpdf;
+                if(lsh.roughness > 1.0f-1e-4f) edf = (float)((double)edf*((double)1.0f/MI_PI_D));
+                else
+                {
+                  const float phongexp = 2.0f/(lsh.roughness*lsh.roughness) - 2.0f;
+                  const V3 lgn = (ls.flags & s_inside) ? ls.gn : ls.gn;
+                  edf = (float)((double)edf*((double)(powf(-dot3(lgn, ol), phongexp)*(phongexp + 2.0f))/(2.0f*MI_PI_D)));
+                }
+                lpdf = lpdf*sc.p_geo;
+                edf = edf/sc.p_geo;
+                if(edf > 0.0f)
+                {
+                  BsdfEval be;
+                  if(mat.bsdf == MI_BSDF_DIFFUSE) be = brdf_diffuse(sf, sh, ol);
+                  else if(mat.bsdf == MI_BSDF_DIELECTRIC) be = brdf_dielectric(sf, sh, omega, ol, eta_ratio);
+                  else be = brdf_metal(sc, sf, sh, omega, ol, ps.cur_ior, (int)mat.param[0], ps.lambda);
+                  bool okn = be.value > 0.0f;
+                  if(okn && (be.mode & s_transmit))
+                  { /* path_edge_init_volume on the connection edge */
+                    Media hyp = ps.media;
+                    media_apply(hyp, shape, (sf.flags & s_inside) != 0);
+                    if(hyp.broken) okn = false;
+                  }
+                  if(okn)
+                  { /* prims_get_ray, src/prims.c:390-492 */
+                    const float eps = 1e-4f*DMAX(DMAX(.5f, fabsf(sf.x.x)), DMAX(fabsf(sf.x.y), fabsf(sf.x.z)));
+                    V3 rd = sub3(ls.x, sf.x);
+                    rd = scale3(rd, 1.0f/sqrtf(dot3(rd, rd)));
+                    const V3 ro = mk3(sf.x.x + eps*rd.x, sf.x.y + eps*rd.y, sf.x.z + eps*rd.z);
+                    const V3 dv = mk3(ls.x.x - eps*rd.x - ro.x, ls.x.y - eps*rd.y - ro.y, ls.x.z - eps*rd.z - ro.z);
+                    const float total_dist = sqrtf(dot3(dv, dv));
+                    if(!(dot3(ls.gn, rd) >= 0) && total_dist > 0.0f)
+                    {
+                      const float Gn = fabsf(dot3(sf.n, ol))*fabsf(dot3(ls.n, ol))/(ldist*ldist);
+                      float tn = ((vthr*be.value)*(1.0f*edf))*Gn;
+                      tn = tn + (vthr*be.value)*((0.0f*Gn)/lpdf);
+                      const float wn = lpdf/(lpdf + 0.0f/1.0f);
+                      tn = tn*wn;
+                      /* sampler_mis(path, rr*pdf_nee, path_pdf_extend(path, v+1)), ptdl.c:143-146 */
+                      float pb;
+                      if(mat.bsdf == MI_BSDF_DIFFUSE) pb = (float)(1.0f/MI_PI_D);
+                      else if(mat.bsdf == MI_BSDF_DIELECTRIC) pb = pdf_dielectric(sf, sh, omega, ol, eta_ratio, be.mode);
+                      else pb = pdf_metal(sf, sh, omega, ol, be.mode);
+                      const float pe = (1.0f*pb)*Gn;
+                      const double pp = ps.pdfprod;
+                      const double our = (double)(1.0f*lpdf)*pp, other = (double)pe*pp;
+                      const float wm = (float)our/(float)(other + our);
+                      if(tn/1.0f > 0.0f)
+                      {
+                        ps.sh_pending = 1;
+                        ps.sh_org = ro; ps.sh_dir = rd; ps.sh_dist = total_dist;
+                        ps.sh_light = lp; ps.sh_ignore = hit.prim;
+                        ps.sh_value = (tn/1.0f)*wm;
+                        ps.sh_length = ps.length + 1;
+                      }
+                    }
+                  }
+                }
               }
             }
           }
@@ -357,6 +496,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
               ps.prev_cos = fabsf(dot3(sf.n, bs.omega));
               ps.prev_throughput = vthr;
               ps.prev_mode = vmode;
+              ps.prev_material_modes = material_modes;
               ps.throughput = nthr;
               ps.pdf = bs.pdf;
             }
@@ -397,7 +537,7 @@ struct mi_scene
   DScene d;
   uint32_t width, height;
   void *d_nodes, *d_axes, *d_prims, *d_primshade, *d_materials, *d_light_prim, *d_light_cdf, *d_light_L;
-  void *d_cie, *d_checker, *d_metal, *d_counters, *d_work, *d_shape_material;
+  void *d_cie, *d_checker, *d_metal, *d_counters, *d_work, *d_shape_material, *d_shape_L;
   float *d_fb_own, *d_fb;
   hipStream_t stream_own, stream;
   hipEvent_t ev0, ev1;
@@ -459,7 +599,6 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   if(!h->width || !h->height || (h->width & 31) || (h->height & 31)) return fail(MI_ERR_ARG, "film size must be a non-zero multiple of 32");
   if(h->max_verts < 2 || h->max_verts > 32) return fail(MI_ERR_ARG, "max_verts must be in [2,32]");
   if(h->sampler != MI_SAMPLER_PT && h->sampler != MI_SAMPLER_PTDL) return fail(MI_ERR_ARG, "unknown sampler");
-  if(h->sampler == MI_SAMPLER_PTDL) return fail(MI_ERR_UNSUPPORTED, "ptdl sampler is not built into this version of the backend");
   if(!h->num_nodes || !h->nodes || !h->cie_xyz) return fail(MI_ERR_ARG, "scene has no nodes / tables");
   if(h->num_shapes > 255) return fail(MI_ERR_UNSUPPORTED, "more than 255 shapes");
   if(h->num_prims >= (1u << 26)) return fail(MI_ERR_UNSUPPORTED, "more than 2^26 primitives");
@@ -543,6 +682,12 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   }
   std::vector<uint32_t> shape_mat(h->num_shapes ? h->num_shapes : 1);
   for(uint32_t i=0;i<h->num_shapes;i++) shape_mat[i] = (uint32_t)h->shapes[i].material;
+  std::vector<float> shape_L(h->num_shapes ? h->num_shapes : 1, 0.0f);
+  for(uint32_t k=0;k<h->lights.num_prims;k++)
+  {
+    const uint32_t sid = MI_PRIMID_SHAPE(h->lights.primid[k]);
+    if(sid < h->num_shapes && shape_L[sid] == 0.0f) shape_L[sid] = h->lights.L[k];   /* lights_pdf_next_event: L of the shape */
+  }
   /* emitters: original primid -> builder-order index */
   std::vector<uint32_t> lprim(h->lights.num_prims ? h->lights.num_prims : 1);
   for(uint32_t k=0;k<h->lights.num_prims;k++)
@@ -561,6 +706,7 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   UP(d_primshade, pshade.data(), pshade.size());
   UP(d_materials, mats.data(), mats.size());
   UP(d_shape_material, shape_mat.data(), shape_mat.size());
+  UP(d_shape_L, shape_L.data(), shape_L.size());
   UP(d_light_prim, lprim.data(), lprim.size());
   UP(d_light_cdf, h->lights.cdf, (size_t)h->lights.num_prims);
   UP(d_light_L, h->lights.L, (size_t)h->lights.num_prims);
@@ -598,8 +744,10 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   const size_t node_bytes = (((size_t)MI_NODE_FIELDS*N*16 + (size_t)N*4) + 15) & ~(size_t)15;
   s->lds_bytes = node_bytes + (size_t)MI_STACK*MI_BLOCK*sizeof(uint2);
   if(s->lds_bytes > 160*1024) { mi_scene_destroy(s); return fail(MI_ERR_UNSUPPORTED, "BVH does not fit the LDS-resident traversal of this build"); }
-  if(hipFuncSetAttribute((const void *)mi_path_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess ||
-     hipFuncSetAttribute((const void *)mi_path_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess)
+  if(hipFuncSetAttribute((const void *)mi_path_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess ||
+     hipFuncSetAttribute((const void *)mi_path_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess ||
+     hipFuncSetAttribute((const void *)mi_path_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess ||
+     hipFuncSetAttribute((const void *)mi_path_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess)
   { mi_scene_destroy(s); return fail(MI_ERR_DEVICE, "cannot raise the dynamic LDS limit"); }
   hipDeviceProp_t prop;
   if(hipGetDeviceProperties(&prop, g_device) != hipSuccess) { mi_scene_destroy(s); return fail(MI_ERR_DEVICE, "hipGetDeviceProperties failed"); }
@@ -635,8 +783,14 @@ extern "C" int mi_render(mi_scene *s, uint64_t first_index, uint64_t count)
   const uint64_t need = (count + MI_BLOCK - 1)/MI_BLOCK;
   if((uint64_t)grid > need) grid = (int)need;
   HIPCHK(hipEventRecord(s->ev0, s->stream));
-  hipLaunchKernelGGL(mi_path_kernel<false>, dim3(grid), dim3(MI_BLOCK), s->lds_bytes, s->stream,
-                     s->d, (unsigned long long)first_index, (unsigned long long)count, (const uint32_t *)s->d_shape_material, (mi_path_record *)nullptr);
+  if(s->d.sampler == MI_SAMPLER_PTDL)
+    hipLaunchKernelGGL((mi_path_kernel<false, true>), dim3(grid), dim3(MI_BLOCK), s->lds_bytes, s->stream,
+                       s->d, (unsigned long long)first_index, (unsigned long long)count, (const uint32_t *)s->d_shape_material,
+                       (const float *)s->d_shape_L, (mi_path_record *)nullptr);
+  else
+    hipLaunchKernelGGL((mi_path_kernel<false, false>), dim3(grid), dim3(MI_BLOCK), s->lds_bytes, s->stream,
+                       s->d, (unsigned long long)first_index, (unsigned long long)count, (const uint32_t *)s->d_shape_material,
+                       (const float *)s->d_shape_L, (mi_path_record *)nullptr);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(s->ev1, s->stream));
   s->have_timing = 1;
@@ -695,8 +849,14 @@ extern "C" int mi_trace_paths(mi_scene *s, uint64_t first_index, uint64_t count,
     int grid = s->grid;
     const uint64_t need = (count + MI_BLOCK - 1)/MI_BLOCK;
     if((uint64_t)grid > need) grid = (int)need;
-    hipLaunchKernelGGL(mi_path_kernel<true>, dim3(grid), dim3(MI_BLOCK), s->lds_bytes, s->stream,
-                       s->d, (unsigned long long)first_index, (unsigned long long)count, (const uint32_t *)s->d_shape_material, (mi_path_record *)d_rec);
+    if(s->d.sampler == MI_SAMPLER_PTDL)
+      hipLaunchKernelGGL((mi_path_kernel<true, true>), dim3(grid), dim3(MI_BLOCK), s->lds_bytes, s->stream,
+                         s->d, (unsigned long long)first_index, (unsigned long long)count, (const uint32_t *)s->d_shape_material,
+                         (const float *)s->d_shape_L, (mi_path_record *)d_rec);
+    else
+      hipLaunchKernelGGL((mi_path_kernel<true, false>), dim3(grid), dim3(MI_BLOCK), s->lds_bytes, s->stream,
+                         s->d, (unsigned long long)first_index, (unsigned long long)count, (const uint32_t *)s->d_shape_material,
+                         (const float *)s->d_shape_L, (mi_path_record *)d_rec);
     e = hipGetLastError();
   }
   if(e == hipSuccess) e = hipStreamSynchronize(s->stream);
@@ -719,7 +879,7 @@ extern "C" void mi_scene_destroy(mi_scene *s)
 {
   if(!s) return;
   void *bufs[] = { s->d_nodes, s->d_axes, s->d_prims, s->d_primshade, s->d_materials, s->d_light_prim, s->d_light_cdf, s->d_light_L,
-                   s->d_cie, s->d_checker, s->d_metal, s->d_counters, s->d_work, s->d_shape_material, s->d_fb_own };
+                   s->d_cie, s->d_checker, s->d_metal, s->d_counters, s->d_work, s->d_shape_material, s->d_shape_L, s->d_fb_own };
   for(void *b : bufs) if(b) hipFree(b);
   if(s->stream_own) hipStreamDestroy(s->stream_own);
   if(s->ev0) hipEventDestroy(s->ev0);

@@ -915,6 +915,272 @@ __device__ __forceinline__ void sample_metal(const DScene &sc, Rng &rng, const S
   bs.weight = R*sh.rg;
 }
 
+/* ------------------------------------------------------------------------------------------ bsdf evaluation / pdf (ptdl) */
+struct BsdfEval { float value; uint32_t mode; };
+
+__device__ __forceinline__ BsdfEval brdf_diffuse(const Surf &sf, const Shading &sh, const V3 wo)
+{ /* brdf_d, src/shader.c:207-252 (path tracing direction) */
+  BsdfEval r; r.mode = s_diffuse | s_reflect; r.value = 0.0f;
+  const float cos_out_ns = dot3(sf.n, wo);
+  if(cos_out_ns <= 0) return r;
+  const float cos_out_ng = dot3(sf.gn, wo);
+  if(sf.flags & s_inside) { if(cos_out_ng >= 0.0f) return r; }
+  else if(cos_out_ng <= 0.0f) return r;
+  r.value = (float)((double)sh.rd*((double)1.0f/MI_PI_D));
+  return r;
+}
+
+__device__ __forceinline__ BsdfEval brdf_dielectric(const Surf &sf, const Shading &sh, const V3 wi, const V3 wo, float eta_ratio)
+{ /* brdf, dielectric.c:418-541 (scalar) */
+  BsdfEval res; res.value = 0.0f; res.mode = s_absorb;
+  const V3 n = sf.n;
+  const float cos_in  = -dot3(n, wi);
+  const float cos_out =  dot3(n, wo);
+  if(eta_ratio < 0.0f) return res;
+  const float n1 = eta_ratio, n2 = 1.0f;
+  const bool index_matched = fabsf(1.0f - n1/n2) < 1e-3f;
+  if(cos_out == 0.0f || cos_in == 0.0f) return res;
+  if(!index_matched && (cos_in*cos_out > 0)) res.mode = s_reflect;
+  else res.mode = s_transmit;
+  const float r = sh.roughness;
+  if((r > GLOSSY_THR) && !index_matched) res.mode |= s_glossy;
+  else res.mode |= s_specular;
+  if(index_matched)
+  {
+    const float dot_wo_n = dot3(wo, n);
+    const V3 h = normalise3(mk3(-wi.x + wo.x - 2.0f*dot_wo_n*n.x, -wi.y + wo.y - 2.0f*dot_wo_n*n.y, -wi.z + wo.z - 2.0f*dot_wo_n*n.z));
+    const float cosh = dot3(h, n);
+    if(cosh < 0.0f) return res;
+    if(cosh < HALFVEC_COS_THR) return res;
+    res.value = sh.rg;
+    return res;
+  }
+  else if(res.mode & s_reflect)
+  {
+    const V3 h = normalise3(mk3(-wi.x + wo.x, -wi.y + wo.y, -wi.z + wo.z));
+    const float cosh = dot3(h, n);
+    if(cosh < 0.0f) return res;
+    const float DG1 = (res.mode & s_specular) ? 1.0f : ggx_pdf_h(wi, h, n, r);
+    if(DG1 == 0) return res;
+    const float cosr = -dot3(h, wi);
+    if(cosr < 0.0f) return res;
+    const float nr = n1/n2;
+    const float cost2 = 1.0f - (nr*nr)*(1.0f - cosr*cosr);
+    const float cost = cost2 <= 0.0f ? 0.0f : sqrtf(cost2);
+    const float R = fresnel_dielectric(n1, n2, cosr, cost);
+    const float G1 = ggx_G1(wo, n, r);
+    if(res.mode & s_glossy) { res.value = (sh.rg*R)*(DG1*G1/(4.0f*fabsf(cosr*cos_out))); return res; }
+    if(cosh < HALFVEC_COS_THR) return res;
+    res.value = sh.rg*R;
+    return res;
+  }
+  else
+  {
+    bool mask = false;
+    float h0 = n1*wi.x - n2*wo.x, h1 = n1*wi.y - n2*wo.y, h2 = n1*wi.z - n2*wo.z;
+    const float hilen = 1.0f/sqrtf(h0*h0 + (h1*h1 + h2*h2));
+    h0 *= hilen; h1 *= hilen; h2 *= hilen;
+    float cosh2 = h0*n.x + (h1*n.y + h2*n.z);
+    const bool cosh_lt0 = cosh2 < 0.0f;
+    mask |= cosh_lt0 && (n1 < n2);
+    mask |= !cosh_lt0 && (n2 < n1);
+    if(cosh_lt0) { cosh2 = -cosh2; h0 = -h0; h1 = -h1; h2 = -h2; }
+    const float cosr2 = h0*-wi.x + (h1*-wi.y + h2*-wi.z);
+    mask |= cosr2 <= 0.0f;
+    const float nr = n1/n2;
+    const float cost2 = 1.0f - (nr*nr)*(1.0f - cosr2*cosr2);
+    const float cost = cost2 <= 0.0f ? 0.0f : sqrtf(cost2);
+    const float R2 = fresnel_dielectric(n1, n2, cosr2, cost);
+    const float DG1 = ggx_pdf_h_cos(cosh2, cos_in, cosr2, r);
+    const float G1 = ggx_G1_cos(cos_in, r);
+    const float cos_hwo = h0*wo.x + (h1*wo.y + h2*wo.z);
+    mask |= cos_hwo >= 0.0f;
+    float denom = n1*cosr2 - n2*cost;
+    denom = denom*denom;
+    if(cos_in == 0.0f) return res;
+    if(res.mode & s_glossy)
+    {
+      res.value = mask ? 0.0f : ((sh.rg*(1.0f - R2))*((n2*n2)*(cost*(DG1*(G1*(1.0f/fabsf(cos_out)))))))/denom;
+      return res;
+    }
+    mask |= cosh2 < HALFVEC_COS_THR;
+    res.value = mask ? 0.0f : sh.rg*DCLAMP(1.0f - R2, 0.0f, 1.0f);
+    return res;
+  }
+}
+
+__device__ __forceinline__ float pdf_dielectric(const Surf &sf, const Shading &sh, const V3 wi, const V3 wo, float eta, uint32_t mode)
+{ /* pdf, dielectric.c:96-237 (forward direction) */
+  const V3 n = sf.n;
+  const float cos_in  = -dot3(n, wi);
+  const float cos_out =  dot3(n, wo);
+  if(cos_in*cos_out == 0.0f) return 0.0f;
+  if(cos_out > 0.0f && !(mode & s_reflect))  return 0.0f;
+  if(cos_out < 0.0f && !(mode & s_transmit)) return 0.0f;
+  if(eta < 0.0f) return 0.0f;
+  const float n1 = eta, n2 = 1.0f;
+  bool mask = false;
+  float cosr = 0.0f, cosh = 0.0f;
+  V3 h;
+  if(fabsf(1.0f - n1/n2) < 1e-3f)
+  {
+    const float dot_wo_n = dot3(wo, n);
+    h = normalise3(mk3(-wi.x + wo.x - 2.0f*dot_wo_n*n.x, -wi.y + wo.y - 2.0f*dot_wo_n*n.y, -wi.z + wo.z - 2.0f*dot_wo_n*n.z));
+    cosh = dot3(h, n);
+    if(mode != (s_transmit | s_specular)) return 0.0f;
+    if(cosh < HALFVEC_COS_THR) return 0.0f;
+    return 1.0f;
+  }
+  else if(mode & s_reflect)
+  {
+    h = normalise3(sub3(wi, wo));
+    cosh = fabsf(dot3(h, n));
+    cosr = fabsf(dot3(h, wi));
+  }
+  else
+  {
+    float h0 = n1*wi.x - n2*wo.x, h1 = n1*wi.y - n2*wo.y, h2 = n1*wi.z - n2*wo.z;
+    const float hilen = 1.0f/sqrtf(h0*h0 + (h1*h1 + h2*h2));
+    h0 *= hilen; h1 *= hilen; h2 *= hilen;
+    if(n2 < n1) { h0 = -h0; h1 = -h1; h2 = -h2; }
+    h = mk3(h0, h1, h2);
+    cosh = h0*n.x + (h1*n.y + h2*n.z);
+    mask |= cosh < 0.0f;
+    cosr = h0*-wi.x + (h1*-wi.y + h2*-wi.z);
+    mask |= cosr <= 0.0f;
+  }
+  const float nr = n1/n2;
+  const float cost2 = 1.0f - (nr*nr)*(1.0f - cosr*cosr);
+  const float cost = cost2 <= 0.0f ? 0.0f : sqrtf(cost2);
+  const float R = fresnel_dielectric(n1, n2, cosr, cost);
+  float pdf = 1.0f;
+  if(mode & s_reflect)
+  {
+    if(mode & s_specular) { mask |= cosh < HALFVEC_COS_THR; return mask ? 0.0f : R; }
+    pdf = pdf*(1.0f/(4.0f*fabsf(dot3(wo, h))));
+    pdf = pdf*R;
+  }
+  else
+  {
+    if(mode & s_specular) { mask |= cosh < HALFVEC_COS_THR; return mask ? 0.0f : DCLAMP(1.0f - R, 0.0f, 1.0f); }
+    const float denom = n1*cosr - n2*cost;
+    pdf = pdf*(((n2*n2)*cost)/(denom*denom));
+    pdf = pdf*DCLAMP(1.0f - R, 0.0f, 1.0f);
+  }
+  pdf = pdf*ggx_pdf_h_cos(cosh, cos_in, cosr, sh.roughness);
+  pdf = pdf/fabsf(cos_out);
+  mask |= !(pdf > 0.0f);
+  return mask ? 0.0f : pdf;
+}
+
+__device__ __forceinline__ BsdfEval brdf_metal(const DScene &sc, const Surf &sf, const Shading &sh, const V3 wi, const V3 wo, float n1, int mat, float lambda)
+{ /* brdf, metal.c:268-310 */
+  BsdfEval res; res.value = 0.0f; res.mode = s_absorb;
+  const V3 n = sf.n;
+  const float cos_in = -dot3(n, wi), cos_out = dot3(n, wo);
+  if(cos_out <= 0.0f || cos_in <= 0.0f) return res;
+  res.mode = s_reflect;
+  const float r = sh.roughness;
+  if(r > 1e-4f) res.mode |= s_glossy; else res.mode |= s_specular;
+  const V3 h = normalise3(mk3(-wi.x + wo.x, -wi.y + wo.y, -wi.z + wo.z));
+  const float cosh = dot3(h, n);
+  if(cosh < 0.0f) return res;
+  const float DG1 = ggx_pdf_h(wi, h, n, r);
+  if(DG1 == 0) return res;
+  const float cosr = -dot3(h, wi);
+  if(cosr < 0.0f) return res;
+  const int i = (int)DCLAMP((lambda - 360.0f)/5.0f, 0, 94);
+  const float n2 = sc.metal_ior[(mat*95 + i)*2 + 0], k2 = -sc.metal_ior[(mat*95 + i)*2 + 1];
+  const float R = fresnel_metal(n1, n2, k2, cosr);
+  const float G1 = ggx_G1(wo, n, r);
+  if(res.mode & s_glossy) { res.value = (sh.rg*R)*(DG1*G1/(4.0f*fabsf(cosr*cos_out))); return res; }
+  if(cosh < HALFVEC_COS_THR) return res;
+  res.value = sh.rg*R;
+  return res;
+}
+
+__device__ __forceinline__ float pdf_metal(const Surf &sf, const Shading &sh, const V3 wi, const V3 wo, uint32_t mode)
+{ /* pdf, metal.c:170-216 */
+  if(!(mode & s_reflect)) return 0.0f;
+  const V3 n = sf.n;
+  const float cos_in = -dot3(n, wi), cos_out = dot3(n, wo);
+  if(cos_in < 0.0f) return 0.0f;
+  if(cos_out < 0.0f) return 0.0f;
+  const V3 h = normalise3(sub3(wi, wo));
+  if(mode & s_specular)
+  {
+    const float cosh = fabsf(dot3(h, n));
+    if(cosh < HALFVEC_COS_THR) return 0.0f;
+    return 1.0f;
+  }
+  float pdf = 1.0f/(4.0f*fabsf(dot3(wo, h)));
+  pdf *= ggx_pdf_h(wi, h, n, sh.roughness);
+  pdf /= fabsf(cos_out);
+  if(!(pdf > 0.0f)) return 0.0f;
+  return pdf;
+}
+
+/* ------------------------------------------------------------------------------------------ emitter sampling (ptdl) */
+__device__ __forceinline__ uint32_t sample_cdf(const float *cdf, int num, float rand)
+{ /* sample_cdf, include/sampler_common.h:206-226 */
+  unsigned int mn = 0, mx = num;
+  unsigned int t = mx/2;
+  while(t != mn)
+  {
+    if(cdf[t] <= rand) mn = t;
+    else mx = t;
+    t = (mn + mx)/2;
+  }
+  if(mx < (unsigned)num && cdf[t] <= rand) t = mx;
+  return t;
+}
+
+__device__ __forceinline__ V3 tri_retime(const V3 v0, const V3 v1, const V3 v2, float u, float v)
+{ /* geo_tri_retime, include/geo/triangle.h:51-61 */
+  const float w = 1.0f - u - v;
+  return mk3(w*v0.x + v*v1.x + u*v2.x, w*v0.y + v*v1.y + u*v2.y, w*v0.z + v*v1.z + u*v2.z);
+}
+
+__device__ __forceinline__ V3 prim_sample(const DPrim &p, float r0, float r1, float &hu, float &hv)
+{ /* prims_sample + prims_retime, src/prims.c:178-252 */
+  const uint32_t type = p.type;
+  if(type == MI_PRIM_QUAD)
+  {
+    hu = r0; hv = r1;
+    if(hv >= hu) return tri_retime(ld3(p.v[0]), ld3(p.v[1]), ld3(p.v[2]), hu, hv - hu);
+    return tri_retime(ld3(p.v[0]), ld3(p.v[2]), ld3(p.v[3]), hu - hv, hv);
+  }
+  if(type == MI_PRIM_TRI)
+  {
+    const float a = sqrtf(r0);
+    hu = r1*a; hv = (1.0f-r1)*a;
+    return tri_retime(ld3(p.v[0]), ld3(p.v[1]), ld3(p.v[2]), hu, hv);
+  }
+  if(type == MI_PRIM_SPHERE)
+  { /* geo_sphere_retime, include/geo/sphere.h:38-49 */
+    hu = r0; hv = (float)((double)acosf(r1)/MI_PI_D);
+    const float x1 = (float)((double)(-(cosf((float)((double)hv*MI_PI_D))-1.f))/2.0), x2 = hu;
+    const float z = 1.f - 2.f*x1, rr = sqrtf(1.f - z*z);
+    const float phi = (float)(2.f*MI_PI_D*(double)x2);
+    const float radius = p.v[1][0];
+    return mk3(p.v[0][0] + radius*(rr*cosf(phi)), p.v[0][1] + radius*(rr*sinf(phi)), p.v[0][2] + radius*z);
+  }
+  /* line: geo_line_retime, include/geo/line.h:88-121 */
+  hu = r0; hv = r1;
+  const V3 v0 = ld3(p.v[0]), v1 = ld3(p.v[1]);
+  const float lr0 = p.v[2][0], lr1 = p.v[2][1];
+  float y;
+  if(fabsf(lr1-lr0) < 1e-3f) y = hu;
+  else y = (sqrtf((lr1*lr1 - lr0*lr0)*hu + lr0*lr0) - lr0)/(lr1-lr0);
+  const float phi = (float)(2.0*MI_PI_D*(double)hv);
+  float sinphi, cosphi; sincosf(phi, &sinphi, &cosphi);
+  V3 d = sub3(v1, v0);
+  d = scale3(d, 1.0f/sqrtf(dot3(d, d)));
+  V3 a, b; get_onb(d, a, b);
+  return mk3(v0.x + (v1.x - v0.x)*y + a.x*sinphi + b.x*cosphi, v0.y + (v1.y - v0.y)*y + a.y*sinphi + b.y*cosphi,
+             v0.z + (v1.z - v0.z)*y + a.z*sinphi + b.z*cosphi);
+}
+
 /* ------------------------------------------------------------------------------------------ splat */
 __device__ __forceinline__ float bh_w(float n)
 { /* filter_bh_w, include/filter/blackmanharris.h:28-41 */

@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ from the REAL reference (hanatos/corona-13).
+
+Runs only in the build container: needs oracle/_ref/ (built by `make -C oracle ref` from the
+sources under /root/reference) and writes small data files that are committed:
+
+  rgb2spec_coeffs.json       reference LUT coefficients for the colours used by the test scenes
+  tree_0010.npz              QBVH of regression/0010_pt as built by the reference (topology, boxes, prim order)
+  paths_<cfg>.npz            per-path records of the first N path indices (xorshift128p, -t 1: bit-reproducible)
+  counters.json              -DACCEL_DEBUG work counters (rays, node visits, box hits, prim tests) for 1 spp
+  tilemeans_<cfg>.npz        32x32 tile means + image means of high-spp reference renders (statistical oracle)
+
+Usage: python3 tests/golden/make_golden.py [quick|paths|images|all]
+"""
+import json
+import os
+import re
+import shutil
+import struct
+import subprocess
+import sys
+import tempfile
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent.parent.parent
+REF = REPO / "oracle" / "_ref"
+GOLD = REPO / "tests" / "golden"
+sys.path.insert(0, str(REPO / "tests"))
+
+
+def run_ref(binary, mv, scene, args, env=None, work=None):
+    """run a reference binary on a scratch copy of scenes/ (it writes next to the scene file)"""
+    work = Path(work or tempfile.mkdtemp(prefix="corona_ref_"))
+    if not (work / "scenes").exists():
+        shutil.copytree(REPO / "scenes", work / "scenes")
+    e = dict(os.environ)
+    e["LD_LIBRARY_PATH"] = str(REF / f"shaders_mv{mv}")
+    e.update(env or {})
+    cmd = [str(REF / binary), str(work / "scenes" / scene / "test.nra2")] + args
+    out = subprocess.run(cmd, cwd=REF, env=e, capture_output=True, text=True)
+    if out.returncode:
+        raise RuntimeError(out.stdout + out.stderr)
+    return work, out.stdout + out.stderr
+
+
+def read_pfm(fn):
+    with open(fn, "rb") as f:
+        assert f.readline().strip() == b"PF"
+        w, h = map(int, f.readline().split())
+        f.readline()
+        return np.frombuffer(f.read(), dtype="<f4").reshape(h, w, 3)
+
+
+def dump_paths(name, binary, mv, scene, w, h, n):
+    from helpers import load_pkg
+    pkg = load_pkg()
+    work = Path(tempfile.mkdtemp(prefix="corona_ref_"))
+    fn = work / "paths.bin"
+    run_ref(binary, mv, scene, ["-s", "1", "-w", str(w), "-h", str(h), "-t", "1", "-x", "_dump"],
+            env={"CORONA_DUMP_N": str(n), "CORONA_DUMP_FILE": str(fn), "CORONA_DUMP_TREE": str(work / "tree.bin")}, work=work)
+    raw = fn.read_bytes()
+    hdr = np.frombuffer(raw, dtype="<u4", count=4)
+    dt = pkg.record_dtype()
+    assert hdr[1] == dt.itemsize
+    rec = np.frombuffer(raw, dtype=dt, offset=16)[:n]
+    np.savez_compressed(GOLD / f"paths_{name}.npz", records=rec, width=w, height=h, max_verts=mv)
+    print("wrote", name, len(rec), "records")
+    return work
+
+
+def dump_tree(work):
+    d = (work / "tree.bin").read_bytes()
+    magic, nn, npr = struct.unpack("<QQQ", d[:24])
+    off = 24
+    aabb = np.frombuffer(d, dtype="<f4", count=6, offset=off); off += 24
+    node_dt = np.dtype([("box", "<f4", (6, 4)), ("child", "<u8", 4), ("ax", "<i4", 4)])
+    nodes = np.frombuffer(d, dtype=node_dt, count=nn, offset=off); off += nn * node_dt.itemsize
+    prim = np.frombuffer(d, dtype="<u8", count=npr, offset=off)
+    np.savez_compressed(GOLD / "tree_0010.npz", aabb=aabb, box=nodes["box"], child=nodes["child"], ax=nodes["ax"], primid=prim)
+    print("wrote tree", nn, "nodes")
+
+
+def counters():
+    out = {}
+    for name, binary in [("pt_mv8", "corona_pt_xs_mv8_dbg"), ("ptdl_mv8", "corona_ptdl_xs_mv8_dbg")]:
+        _, log = run_ref(binary, 8, "0010_pt", ["-s", "1", "-w", "1280", "-h", "720", "-t", "1", "-x", "_dbg"])
+        m = re.search(r"accel_intersect: (\d+) aabb_intersect (\d+) / (\d+) prims_intersect (\d+)", log)
+        out[name] = {"paths": 1280 * 736, "rays": int(m.group(1)), "box_hits": int(m.group(2)),
+                     "node_visits": int(m.group(3)), "prim_tests": int(m.group(4))}
+    (GOLD / "counters.json").write_text(json.dumps(out, indent=1))
+    print(out)
+
+
+def tilemeans(name, binary, mv, scene, w, h, spp, threads=8):
+    work, log = run_ref(binary, mv, scene, ["-s", str(spp), "--batch", "16", "-w", str(w), "-h", str(h), "-t", str(threads), "-x", "_img"])
+    img = read_pfm(work / "scenes" / scene / "test_img_fb00.pfm")
+    H, W, _ = img.shape
+    tiles = img.reshape(H // 32, 32, W // 32, 32, 3).mean(axis=(1, 3))
+    side = (work / "scenes" / scene / "test_img_fb00.pfm.txt").read_text()
+    m = re.search(r"elapsed wallclock prog ([\d.]+)s", side)
+    np.savez_compressed(GOLD / f"tilemeans_{name}.npz", tiles=tiles.astype(np.float32), mean=img.mean(axis=(0, 1)),
+                        spp=spp, width=W, height=H, max_verts=mv, seconds=float(m.group(1)) if m else 0.0, threads=threads)
+    print("wrote tilemeans", name, img.mean(axis=(0, 1)), "in", m.group(1) if m else "?", "s")
+    shutil.rmtree(work, ignore_errors=True)
+
+
+def main():
+    what = sys.argv[1] if len(sys.argv) > 1 else "quick"
+    if what in ("quick", "paths", "all"):
+        work = dump_paths("pt_mv8", "dump_pt_xs_mv8", 8, "0010_pt", 1280, 720, 3000)
+        dump_tree(work)
+        dump_paths("ptdl_mv8", "dump_ptdl_xs_mv8", 8, "0010_pt", 1280, 720, 3000)
+        dump_paths("pt_mv4_256", "dump_pt_xs_mv4", 4, "0010_pt", 256, 256, 2000)
+        dump_paths("rough_mv32", "dump_pt_xs_mv32", 32, "0052_rough", 1280, 720, 2000)
+        counters()
+    if what in ("images", "all"):
+        tilemeans("pt_mv8", "corona_pt_sfmt_mv8", 8, "0010_pt", 1280, 720, 2048)
+        tilemeans("ptdl_mv8", "corona_ptdl_sfmt_mv8", 8, "0010_pt", 1280, 720, 512)
+        tilemeans("rough_mv32", "corona_pt_sfmt_mv32", 32, "0052_rough", 1280, 720, 512)
+        tilemeans("pt_mv4_256", "corona_pt_sfmt_mv4", 4, "0010_pt", 256, 256, 4096)
+
+
+if __name__ == "__main__":
+    main()

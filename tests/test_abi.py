@@ -1,0 +1,39 @@
+"""The C-ABI library must load without a GPU and export exactly what include/corona_mi.h declares."""
+import ctypes as C
+import re
+
+from helpers import REPO, load_pkg
+
+pkg = load_pkg()
+
+
+def declared_functions():
+    text = (REPO / "include" / "corona_mi.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mi_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_exported():
+    names = declared_functions()
+    assert "mi_render" in names and "mi_scene_create" in names
+    lib = C.CDLL(str(pkg.MI_LIB))
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in corona_mi.h but not exported"
+    assert sorted(pkg.MI_SYMBOLS) == names
+
+
+def test_struct_sizes_match_header():
+    # sizes as laid out by the C compiler for include/corona_mi.h (x86-64)
+    assert C.sizeof(pkg.MiNode) == 144
+    assert C.sizeof(pkg.MiShadeOp) == 32 and C.sizeof(pkg.MiMaterial) == 152
+    assert C.sizeof(pkg.MiCamera) == 80
+    assert C.sizeof(pkg.MiPathVertex) == 112 and C.sizeof(pkg.MiPathSplat) == 24
+    assert C.sizeof(pkg.MiPathRecord) == 40 + 8 * 24 + 8 * 112
+
+
+def test_product_never_imports_oracle():
+    """The product path must not route through the CPU oracle."""
+    for p in (REPO / "corona-13_amd").rglob("*"):
+        if p.suffix in (".py", ".c", ".h", ".hip", ".cpp") or p.name == "Makefile":
+            txt = p.read_text(errors="ignore")
+            assert "liboracle" not in txt and "oracle/" not in txt.replace("oracle/_ref", ""), p

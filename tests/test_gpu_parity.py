@@ -1,0 +1,204 @@
+"""-m gpu: the HIP path (through the C ABI) against the oracle on the same path indices, plus
+size-independent properties at BASELINE.json's full size.
+
+Tolerances (float32, fp contraction off on both sides, libm differences in sin/cos/atan2/acos/pow only):
+  * camera sample exact; identical vertex count and primitive sequence for >= 99.9 % of paths
+  * per-vertex throughput relative deviation: 99.9th percentile < 1e-3
+  * 1-spp image vs the oracle image: per-pixel L2 (pfmdiff RMSE on gain-scaled XYZ) < 0.05
+    (noise floor between two independent 64-spp renders of the reference itself: 4.34)
+"""
+import json
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, SCENE_0010, SCENE_ROUGH, load_pkg, make_scene, oracle_records, oracle_render
+
+pkg = load_pkg()
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return np.abs(a - b) / np.maximum(1e-20, np.maximum(np.abs(a), np.abs(b)))
+
+
+CASES = [
+    ("cfg2 pt 1280x720 mv8", SCENE_0010, pkg.MI_SAMPLER_PT, 1280, 720, 8, 20000),
+    ("cfg1 pt 256x256 mv4", SCENE_0010, pkg.MI_SAMPLER_PT, 256, 256, 4, 8000),
+    ("cfg3 ptdl 1280x720 mv8", SCENE_0010, pkg.MI_SAMPLER_PTDL, 1280, 720, 8, 20000),
+    ("cfg4 rough dielectric mv32", SCENE_ROUGH, pkg.MI_SAMPLER_PT, 1280, 720, 32, 8000),
+]
+
+
+@pytest.mark.parametrize("name,scene_path,sampler,w,h,mv,n", CASES)
+def test_paths_match_oracle(name, scene_path, sampler, w, h, mv, n):
+    scene = make_scene(scene_path, width=w, height=h, max_verts=mv, sampler=sampler)
+    be = pkg.Backend(scene)
+    first = 12345
+    gpu = be.trace_paths(first, n)
+    ora = oracle_records(scene, first, n)
+    assert np.array_equal(gpu["index"], ora["index"])
+    for f in ("pixel_i", "pixel_j", "lambda", "time", "scramble"):
+        assert np.abs(gpu[f] - ora[f]).max() <= 1e-5, f
+    same = gpu["length"] == ora["length"]
+    assert same.mean() >= 0.999
+    assert (gpu["num_splats"] == ora["num_splats"]).mean() >= 0.999
+    for k in range(1, 8):
+        m = same & (ora["length"] > k)
+        if not m.sum():
+            continue
+        assert (gpu["v"]["prim"][m, k] == ora["v"]["prim"][m, k]).mean() >= 0.999
+        dx = np.abs(gpu["v"]["x"][m, k] - ora["v"]["x"][m, k]).max(axis=1)
+        # positions drift with every glossy bounce (libm sin/cos/atan2 differ in the last ulp between host and device)
+        assert np.quantile(dx, 0.999) < (2e-3 if k <= 2 else 1e-2)
+        assert np.quantile(rel(gpu["v"]["throughput"][m, k], ora["v"]["throughput"][m, k]), 0.999) < 1e-3
+        assert (gpu["v"]["flags"][m, k] == ora["v"]["flags"][m, k]).mean() >= 0.999
+    m = same & (gpu["num_splats"] == ora["num_splats"]) & (ora["num_splats"] > 0)
+    if m.sum():
+        assert np.quantile(rel(gpu["splat"]["value"][m, 0], ora["splat"]["value"][m, 0]), 0.99) < 1e-3
+    be.close()
+
+
+def test_paths_match_reference_golden():
+    """directly against the records dumped from the real reference"""
+    g = np.load(GOLDEN / "paths_pt_mv8.npz")
+    ref = g["records"]
+    scene = make_scene(SCENE_0010, width=1280, height=720, max_verts=8)
+    be = pkg.Backend(scene)
+    gpu = be.trace_paths(0, len(ref))
+    same = gpu["length"] == ref["length"]
+    assert same.mean() >= 0.998
+    assert (gpu["num_splats"] == ref["num_splats"]).mean() >= 0.995
+    for k in range(1, 8):
+        m = same & (ref["length"] > k)
+        if m.sum():
+            assert (gpu["v"]["prim"][m, k] == ref["v"]["prim"][m, k]).mean() >= 0.999
+    e_ref, e_gpu = ref["splat"]["col"].sum(axis=(0, 1)), gpu["splat"]["col"].sum(axis=(0, 1))
+    assert np.all(np.abs(e_ref - e_gpu) <= 2e-3 * np.abs(e_ref).max())
+    be.close()
+
+
+def test_image_matches_oracle_1spp():
+    scene = make_scene(SCENE_0010, width=1280, height=720, max_verts=8)
+    be = pkg.Backend(scene)
+    n = scene.width * scene.height
+    be.render(0, n)
+    fb = be.fb_read()
+    ofb, ocnt, _ = oracle_render(scene, 0, n, threads=8)
+    gain = scene.gain(1)
+    rmse = np.sqrt((((fb - ofb) * gain) ** 2).sum() / n)           # tools/img/pfmdiff.c:75-86
+    assert rmse < 0.05, rmse
+    assert np.allclose(fb.sum(axis=(0, 1)), ofb.sum(axis=(0, 1)), rtol=1e-3)
+    # same traversal work as the oracle (and through it the reference's -DACCEL_DEBUG counters)
+    cnt = be.counters()
+    assert cnt[4] == n
+    for k in range(4):
+        assert abs(cnt[k] - ocnt[k]) <= 1e-3 * ocnt[k], (k, cnt[k], ocnt[k])
+    gold = json.loads((GOLDEN / "counters.json").read_text())["pt_mv8"]
+    for k, key in ((0, "rays"), (1, "node_visits"), (2, "box_hits"), (3, "prim_tests")):
+        assert abs(cnt[k] - gold[key]) <= 3e-3 * gold[key], (key, cnt[k], gold[key])
+    be.close()
+
+
+def test_ptdl_image_matches_oracle_1spp():
+    """BASELINE config 3 (0011_ptdl: next event estimation + shadow rays)"""
+    scene = make_scene(SCENE_0010, width=1280, height=720, max_verts=8, sampler=pkg.MI_SAMPLER_PTDL)
+    be = pkg.Backend(scene)
+    n = scene.width * scene.height
+    be.render(0, n)
+    fb = be.fb_read()
+    ofb, ocnt, _ = oracle_render(scene, 0, n, threads=8)
+    gain = scene.gain(1)
+    rmse = np.sqrt((((fb - ofb) * gain) ** 2).sum() / n)
+    assert rmse < 0.5, rmse                       # a handful of shadow rays grazing the emitter edge may flip
+    assert np.allclose(fb.sum(axis=(0, 1)), ofb.sum(axis=(0, 1)), rtol=2e-3)
+    cnt = be.counters()
+    for k in (0, 1, 2, 3, 5):
+        assert abs(cnt[k] - ocnt[k]) <= 2e-3 * ocnt[k], (k, cnt[k], ocnt[k])
+    gold = json.loads((GOLDEN / "counters.json").read_text())["ptdl_mv8"]
+    for k, key in ((0, "rays"), (1, "node_visits"), (2, "box_hits"), (3, "prim_tests")):
+        assert abs(cnt[k] - gold[key]) <= 3e-3 * gold[key], (key, cnt[k], gold[key])
+    # 64 spp mean vs the reference's own 64-spp ptdl value (1.0743, 1.0716, 1.0624), BASELINE.md
+    be.fb_clear()
+    be.render(0, 64 * n)
+    mean = (be.fb_read() * scene.gain(64)).mean(axis=(0, 1))
+    assert np.all(np.abs(mean - np.array([1.0743, 1.0716, 1.0624])) < 0.01), mean
+    be.close()
+
+
+def test_full_size_properties_cfg2():
+    """1280x720, 64 spp, max depth 8 (BASELINE config 2): properties that do not need the oracle."""
+    scene = make_scene(SCENE_0010, width=1280, height=720, max_verts=8)
+    be = pkg.Backend(scene)
+    per = scene.width * scene.height
+    spp = 64
+    be.render(0, spp * per)
+    full = be.fb_read()
+    cnt = be.counters()
+    assert cnt[4] == spp * per
+    assert np.isfinite(full).all() and (full >= 0).all()
+    # additivity over index ranges: one launch == many launches (up to float atomic order)
+    be.fb_clear()
+    for s in range(0, spp, 16):
+        be.render(s * per, 16 * per)
+    parts = be.fb_read()
+    assert np.allclose(full.sum(axis=(0, 1)), parts.sum(axis=(0, 1)), rtol=2e-5)
+    gain = scene.gain(spp)
+    assert np.sqrt((((full - parts) * gain) ** 2).sum() / per) < 1e-3
+    # mean image vs the reference's own 64-spp value (1.0675, 1.0683, 1.0539 +- noise)
+    mean = (full * gain).mean(axis=(0, 1))
+    assert np.all(np.abs(mean - np.array([1.0675, 1.0683, 1.0539])) < 0.02), mean
+    fn = GOLDEN / "tilemeans_pt_mv8.npz"
+    if fn.exists():
+        g = np.load(fn)
+        tiles = (full * gain).reshape(scene.height // 32, 32, scene.width // 32, 32, 3).mean(axis=(1, 3))
+        assert np.all(np.abs(mean - g["mean"]) < 0.015), (mean, g["mean"])
+        # robust per-tile agreement: median over tiles of the relative deviation of tile luminance
+        devs = np.abs(tiles[..., 1] - g["tiles"][..., 1]) / np.maximum(g["tiles"][..., 1], 1e-3)
+        assert np.median(devs) < 0.05
+    be.close()
+
+
+def test_edge_cases():
+    scene = make_scene(SCENE_0010, width=32, height=32, max_verts=2)       # smallest film, shortest paths
+    be = pkg.Backend(scene)
+    be.render(0, 0)                                                         # empty range is a no-op
+    assert be.fb_read().sum() == 0
+    be.render(7, 1)                                                         # single path, ragged start
+    assert be.counters()[4] == 1
+    be.render(1 << 40, 1000)                                                # 64-bit path indices
+    assert be.counters()[4] == 1001
+    rec = be.trace_paths(1 << 40, 100)
+    assert (rec["length"] <= 2).all() and (rec["index"] >= (1 << 40)).all()
+    ora = oracle_records(scene, 1 << 40, 100)
+    assert np.array_equal(rec["length"], ora["length"])
+    be.close()
+
+
+def test_max_depth_32_deep_paths():
+    scene = make_scene(SCENE_ROUGH, width=1280, height=720, max_verts=32)
+    be = pkg.Backend(scene)
+    n = 200000
+    be.render(0, n)
+    cnt = be.counters()
+    ofb, ocnt, _ = oracle_render(scene, 0, n, threads=8)
+    fb = be.fb_read()
+    assert abs(cnt[6] - ocnt[6]) <= 2e-3 * ocnt[6]                           # total path vertices
+    assert np.allclose(fb.sum(axis=(0, 1)), ofb.sum(axis=(0, 1)), rtol=5e-3)
+    be.close()
+
+
+def test_errors_are_reported():
+    scene = make_scene(SCENE_0010, width=64, height=64, max_verts=8)
+    d = scene.desc_ptr
+    m = pkg.mi_lib()
+    import ctypes as C
+    out = C.c_void_p()
+    old = d.contents.max_verts
+    d.contents.max_verts = 1
+    assert m.mi_scene_create(d, C.byref(out)) < 0 and m.mi_last_error()
+    d.contents.max_verts = old
+    d.contents.struct_size = 3
+    assert m.mi_scene_create(d, C.byref(out)) < 0
+    d.contents.struct_size = C.sizeof(pkg.MiSceneDesc)
+    assert m.mi_render(None, 0, 1) < 0

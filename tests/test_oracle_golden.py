@@ -1,0 +1,130 @@
+"""Pin the oracle (oracle/liboracle.so, our CPU restatement) against the REAL reference.
+
+tests/golden/paths_*.npz were dumped from hanatos/corona-13 itself (oracle/_ref, built from
+/root/reference by oracle/Makefile, run with MOD_points=xorshift128p -t 1 => bit-reproducible) by
+tests/golden/make_golden.py. The oracle traces the same path indices with the same random numbers.
+
+Floating point: the reference is compiled -O3 -ffast-math (reassociation, FMA, rsqrtss in
+rgb2spec_eval_fast), so agreement is not bitwise. Stated tolerances:
+  * camera sample (pixel, wavelength, time)      exact to 1e-4 absolute
+  * >= 99.8 % of paths: identical vertex count and identical primitive per vertex
+  * >= 99.5 % of paths: identical number of splats (ptdl: shadow rays grazing the emitter may flip)
+  * median relative deviation of splat values < 5e-4, 99th percentile < 5e-2 (GGX roughness 0.04 on
+    a sphere 17 dm away amplifies the 1e-4 hit-point noise of the float quadratic)
+  * total splatted energy of the set within 1.5e-3 relative (pt) / 1e-2 (ptdl)
+"""
+import json
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, SCENE_0010, SCENE_ROUGH, load_pkg, make_scene, oracle_lib, oracle_records, oracle_render
+
+pkg = load_pkg()
+
+CASES = [
+    ("pt_mv8", pkg.MI_SAMPLER_PT, SCENE_0010, 1.5e-3),
+    ("ptdl_mv8", pkg.MI_SAMPLER_PTDL, SCENE_0010, 1e-2),
+    ("pt_mv4_256", pkg.MI_SAMPLER_PT, SCENE_0010, 1.5e-3),       # BASELINE config 1
+    ("rough_mv32", pkg.MI_SAMPLER_PT, SCENE_ROUGH, 1.5e-3),      # BASELINE config 4 (0052 parameters)
+]
+
+
+def rel(a, b):
+    return np.abs(a - b) / np.maximum(1e-20, np.maximum(np.abs(a), np.abs(b)))
+
+
+@pytest.mark.parametrize("name,sampler,scene_path,etol", CASES)
+def test_oracle_matches_reference_paths(name, sampler, scene_path, etol):
+    g = np.load(GOLDEN / f"paths_{name}.npz")
+    ref = g["records"]
+    s = make_scene(scene_path, width=int(g["width"]), height=int(g["height"]), max_verts=int(g["max_verts"]), sampler=sampler)
+    ora = oracle_records(s, 0, len(ref))
+    for f, tol in (("pixel_i", 1e-4), ("pixel_j", 1e-4), ("lambda", 1e-4), ("time", 1e-6), ("scramble", 1e-6)):
+        assert np.abs(ref[f] - ora[f]).max() <= tol, f
+    same_len = ref["length"] == ora["length"]
+    assert same_len.mean() >= 0.998
+    for k in range(1, 8):
+        m = same_len & (ref["length"] > k)
+        if m.sum():
+            assert (ref["v"]["prim"][m, k] == ora["v"]["prim"][m, k]).mean() >= 0.999
+            assert (ref["v"]["mode"][m, k] == ora["v"]["mode"][m, k]).mean() >= 0.998
+    same_splats = ref["num_splats"] == ora["num_splats"]
+    assert same_splats.mean() >= 0.995
+    both = same_len & same_splats
+    devs = []
+    for k in range(ref["splat"].shape[1]):
+        m = both & (ref["num_splats"] > k)
+        if m.sum():
+            assert (ref["splat"]["length"][m, k] == ora["splat"]["length"][m, k]).all()
+            devs.append(rel(ref["splat"]["value"][m, k], ora["splat"]["value"][m, k]))
+    devs = np.concatenate(devs)
+    assert np.median(devs) < 5e-4 and np.quantile(devs, 0.99) < 5e-2
+    e_ref, e_ora = ref["splat"]["col"][both].sum(axis=(0, 1)), ora["splat"]["col"][both].sum(axis=(0, 1))
+    assert np.all(np.abs(e_ref - e_ora) <= etol * np.abs(e_ref).max())
+
+
+def test_first_vertex_geometry_close():
+    g = np.load(GOLDEN / "paths_pt_mv8.npz")
+    ref = g["records"]
+    s = make_scene(SCENE_0010, width=1280, height=720, max_verts=8)
+    ora = oracle_records(s, 0, len(ref))
+    m = (ref["length"] > 1) & (ora["length"] > 1)
+    dx = np.abs(ref["v"]["x"][m, 1] - ora["v"]["x"][m, 1]).max(axis=1)
+    assert np.quantile(dx, 0.999) < 1e-3 and dx.max() < 5e-3       # dm; sphere hits 17 dm away carry ~1e-4 noise
+    assert rel(ref["v"]["throughput"][m, 1], ora["v"]["throughput"][m, 1]).max() < 1e-5
+
+
+def test_rng_known_answers():
+    """xorshift128+ seeded per path index (src/points.d/xorshift128p.c:53-74): the camera sample of the golden
+    records is a direct function of draws 6..9, so the generator is pinned by them."""
+    g = np.load(GOLDEN / "paths_pt_mv8.npz")
+    ref = g["records"][:64]
+    o = oracle_lib()
+    for r in ref:
+        seq = np.zeros(9, dtype=np.float32)
+        o.oracle_rand_sequence(int(r["index"]), 1, 9, seq.ctypes.data)
+        assert abs(0.1 + seq[0] * 0.8 - r["scramble"]) < 1e-6
+        assert abs(360 + 470 * seq[1] - r["lambda"]) < 1e-4
+        assert abs(min(seq[5] * 1280, 1280 - 1e-4) - r["pixel_i"]) < 1e-4
+        assert abs(min(seq[6] * 736, 736 - 1e-4) - r["pixel_j"]) < 1e-4
+    assert ((0 <= seq) & (seq < 1)).all()
+
+
+def test_traversal_work_counters_match_reference():
+    """-DACCEL_DEBUG totals of the reference for path indices [0, 1280*736) (tests/golden/counters.json)
+    vs the oracle over the same indices: rays, node visits, box hits, prim tests within 0.2 %."""
+    gold = json.loads((GOLDEN / "counters.json").read_text())
+    for name, sampler in (("pt_mv8", pkg.MI_SAMPLER_PT), ("ptdl_mv8", pkg.MI_SAMPLER_PTDL)):
+        s = make_scene(SCENE_0010, width=1280, height=720, max_verts=8, sampler=sampler)
+        n = gold[name]["paths"]
+        _, cnt, _ = oracle_render(s, 0, n, threads=8)
+        assert cnt[4] == n
+        for k, key in ((0, "rays"), (1, "node_visits"), (2, "box_hits"), (3, "prim_tests")):
+            assert abs(cnt[k] - gold[name][key]) <= 2e-3 * gold[name][key], (name, key, cnt[k], gold[name][key])
+
+
+def _tile_stats(fb, gain):
+    H, W, _ = fb.shape
+    return (fb * gain).reshape(H // 32, 32, W // 32, 32, 3).mean(axis=(1, 3))
+
+
+@pytest.mark.parametrize("name,sampler,scene_path,mv,w,h,spp", [
+    ("pt_mv4_256", pkg.MI_SAMPLER_PT, SCENE_0010, 4, 256, 256, 64),
+])
+def test_oracle_image_statistics_vs_reference_render(name, sampler, scene_path, mv, w, h, spp):
+    """Statistical oracle: high-spp render of the real reference (sfmt, all cores) reduced to 32x32 tile means.
+    The oracle's `spp` render must agree in the image mean within 3 standard errors estimated from the
+    tile-to-tile scatter (pure pt with a tiny emitter is firefly dominated, hence the robust statistic)."""
+    fn = GOLDEN / f"tilemeans_{name}.npz"
+    if not fn.exists():
+        pytest.skip("tile-mean fixture not generated")
+    g = np.load(fn)
+    s = make_scene(scene_path, width=w, height=h, max_verts=mv, sampler=sampler)
+    fb, _, _ = oracle_render(s, 0, spp * s.width * s.height, threads=8)
+    tiles = _tile_stats(fb, s.gain(spp))
+    ref = g["tiles"]
+    # compare medians of tile luminance (robust against fireflies)
+    assert abs(np.median(tiles[..., 1]) - np.median(ref[..., 1])) < 0.1 * np.median(ref[..., 1])
+    # and the plain mean within a generous factor given the noise floor at this spp
+    assert abs(tiles[..., 1].mean() - ref[..., 1].mean()) < 0.35 * ref[..., 1].mean()
