@@ -21,7 +21,7 @@ from pathlib import Path
 PKG_DIR = Path(__file__).resolve().parent
 REPO_DIR = PKG_DIR.parent
 HOST_LIB = PKG_DIR / "host" / "libcorona_host.so"
-MI_LIB = PKG_DIR / "csrc" / "libcorona_mi.so"
+MI_LIB = Path(os.environ.get("CORONA_MI_LIB", PKG_DIR / "csrc" / "libcorona_mi.so"))   # override: kernel-variant experiments only
 
 MI_SAMPLER_PT, MI_SAMPLER_PTDL = 0, 1
 MI_REC_MAX_VERTS, MI_REC_MAX_SPLATS = 8, 8

@@ -10,8 +10,12 @@
 #include <string.h>
 #include <vector>
 
-#define MI_BLOCK 512
-#define MI_STACK 24
+#ifndef MI_BLOCK
+#define MI_BLOCK 1024    /* threads per workgroup: 16 waves/CU = 4 per SIMD (128 VGPRs each) */
+#endif
+#ifndef MI_STACK
+#define MI_STACK 12      /* LDS traversal stack entries per lane; deeper entries overflow to HBM (mi_device.h) */
+#endif
 
 /* ======================================================================================= kernel */
 struct PathState
@@ -63,7 +67,8 @@ __device__ __forceinline__ void rec_vertex(mi_path_record *rec, int v, uint64_t 
 
 template<bool RECORD, bool PTDL>
 __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned long long first, unsigned long long count,
-                                                           const uint32_t *shape_material, const float *shape_L, mi_path_record *records)
+                                                           const uint32_t *shape_material, const float *shape_L, mi_path_record *records,
+                                                           uint2 *stack_overflow)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t N = sc.num_nodes;
@@ -79,6 +84,8 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
 
   Lds lds;
   lds.nodes = lds_nodes; lds.axes = lds_axes; lds.stack = lds_stack + threadIdx.x; lds.num_nodes = N;
+  lds.overflow_stride = gridDim.x*MI_BLOCK;
+  lds.overflow = stack_overflow + (size_t)blockIdx.x*MI_BLOCK + threadIdx.x;
 
   uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   PathState ps;
@@ -178,6 +185,8 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
     if(!__any(ps.active || ps.sh_pending)) break;
 
     /* ------------------------------------------------------------ one ray per busy lane: a pending shadow ray first, else the extension ray */
+    bool splat_req = false;
+    float splat_c0 = 0.0f, splat_c1 = 0.0f, splat_c2 = 0.0f;
     const bool do_shadow = PTDL && ps.sh_pending;
     Hit hit;
     hit.prim = MI_NOPRIM; hit.dist = do_shadow ? ps.sh_dist : FLT_MAX; hit.u = hit.v = 0.0f;
@@ -208,7 +217,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
         if(ok)
         {
           cnt[5]++;
-          if(!RECORD) splat_bh(sc, ps.pixel_i, ps.pixel_j, col);
+          if(!RECORD) { splat_req = true; splat_c0 = col[0]; splat_c1 = col[1]; splat_c2 = col[2]; }
         }
       }
     }
@@ -347,7 +356,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
             if(ok)
             {
               cnt[5]++;
-              if(!RECORD) splat_bh(sc, ps.pixel_i, ps.pixel_j, col);
+              if(!RECORD) { splat_req = true; splat_c0 = col[0]; splat_c1 = col[1]; splat_c2 = col[2]; }
             }
             if(!PTDL && ps.length > 3)
             { /* path_russian_roulette, src/pathspace.c:273-292 */
@@ -505,14 +514,18 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
       }
       if(!alive) { ps.active = 0; cnt[4]++; }
     }
+    /* ------------------------------------------------------------ splats of this iteration, cooperatively */
+    if(!RECORD) splat_wave(sc, splat_req, ps.pixel_i, ps.pixel_j, splat_c0, splat_c1, splat_c2);
   }
 
+  atomicMax(sc.counters + 7, (unsigned long long)cnt[7]);     /* deepest traversal stack use */
   /* ------------------------------------------------------------ flush work counters: wave reduction, one atomic per wave */
 #pragma unroll
   for(int k=0;k<8;k++)
   {
     unsigned long long c = cnt[k];
     for(int off=32;off>0;off>>=1) c += __shfl_down(c, off);
+    if(k == 7) continue;                    /* slot 7 is a maximum, flushed above */
     if(lane == 0 && c) atomicAdd(sc.counters + k, c);
   }
 }
@@ -537,7 +550,7 @@ struct mi_scene
   DScene d;
   uint32_t width, height;
   void *d_nodes, *d_axes, *d_prims, *d_primshade, *d_materials, *d_light_prim, *d_light_cdf, *d_light_L;
-  void *d_cie, *d_checker, *d_metal, *d_counters, *d_work, *d_shape_material, *d_shape_L;
+  void *d_cie, *d_checker, *d_metal, *d_counters, *d_work, *d_shape_material, *d_shape_L, *d_overflow;
   float *d_fb_own, *d_fb;
   hipStream_t stream_own, stream;
   hipEvent_t ev0, ev1;
@@ -604,7 +617,8 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   if(h->num_prims >= (1u << 26)) return fail(MI_ERR_UNSUPPORTED, "more than 2^26 primitives");
 
   const int depth = tree_depth(h, 0, 0);
-  if(3*(depth+1) > MI_STACK) return fail(MI_ERR_UNSUPPORTED, "BVH too deep for the LDS traversal stack of this build");
+  if(depth > 200) return fail(MI_ERR_ARG, "BVH deeper than 200 levels or cyclic");
+  const int stack_need = 3*(depth+1);                       /* at most 3 pushes per inner node on the way down */
 
   mi_scene *s = (mi_scene *)calloc(1, sizeof(mi_scene));
   if(!s) return fail(MI_ERR_NOMEM, "out of host memory");
@@ -755,6 +769,11 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   if(per_cu < 1) per_cu = 1;
   if(per_cu*MI_BLOCK > 2048) per_cu = 2048/MI_BLOCK;
   s->grid = prop.multiProcessorCount*per_cu;
+  {
+    const size_t extra = stack_need > MI_STACK ? (size_t)(stack_need - MI_STACK) : 1;
+    if(hipMalloc(&s->d_overflow, extra*(size_t)s->grid*MI_BLOCK*sizeof(uint2)) != hipSuccess)
+    { mi_scene_destroy(s); return fail(MI_ERR_NOMEM, "cannot allocate the traversal stack overflow area"); }
+  }
   *out = s;
   return MI_OK;
 }
@@ -786,11 +805,11 @@ extern "C" int mi_render(mi_scene *s, uint64_t first_index, uint64_t count)
   if(s->d.sampler == MI_SAMPLER_PTDL)
     hipLaunchKernelGGL((mi_path_kernel<false, true>), dim3(grid), dim3(MI_BLOCK), s->lds_bytes, s->stream,
                        s->d, (unsigned long long)first_index, (unsigned long long)count, (const uint32_t *)s->d_shape_material,
-                       (const float *)s->d_shape_L, (mi_path_record *)nullptr);
+                       (const float *)s->d_shape_L, (mi_path_record *)nullptr, (uint2 *)s->d_overflow);
   else
     hipLaunchKernelGGL((mi_path_kernel<false, false>), dim3(grid), dim3(MI_BLOCK), s->lds_bytes, s->stream,
                        s->d, (unsigned long long)first_index, (unsigned long long)count, (const uint32_t *)s->d_shape_material,
-                       (const float *)s->d_shape_L, (mi_path_record *)nullptr);
+                       (const float *)s->d_shape_L, (mi_path_record *)nullptr, (uint2 *)s->d_overflow);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(s->ev1, s->stream));
   s->have_timing = 1;
@@ -852,11 +871,11 @@ extern "C" int mi_trace_paths(mi_scene *s, uint64_t first_index, uint64_t count,
     if(s->d.sampler == MI_SAMPLER_PTDL)
       hipLaunchKernelGGL((mi_path_kernel<true, true>), dim3(grid), dim3(MI_BLOCK), s->lds_bytes, s->stream,
                          s->d, (unsigned long long)first_index, (unsigned long long)count, (const uint32_t *)s->d_shape_material,
-                         (const float *)s->d_shape_L, (mi_path_record *)d_rec);
+                         (const float *)s->d_shape_L, (mi_path_record *)d_rec, (uint2 *)s->d_overflow);
     else
       hipLaunchKernelGGL((mi_path_kernel<true, false>), dim3(grid), dim3(MI_BLOCK), s->lds_bytes, s->stream,
                          s->d, (unsigned long long)first_index, (unsigned long long)count, (const uint32_t *)s->d_shape_material,
-                         (const float *)s->d_shape_L, (mi_path_record *)d_rec);
+                         (const float *)s->d_shape_L, (mi_path_record *)d_rec, (uint2 *)s->d_overflow);
     e = hipGetLastError();
   }
   if(e == hipSuccess) e = hipStreamSynchronize(s->stream);
@@ -879,7 +898,7 @@ extern "C" void mi_scene_destroy(mi_scene *s)
 {
   if(!s) return;
   void *bufs[] = { s->d_nodes, s->d_axes, s->d_prims, s->d_primshade, s->d_materials, s->d_light_prim, s->d_light_cdf, s->d_light_L,
-                   s->d_cie, s->d_checker, s->d_metal, s->d_counters, s->d_work, s->d_shape_material, s->d_shape_L, s->d_fb_own };
+                   s->d_cie, s->d_checker, s->d_metal, s->d_counters, s->d_work, s->d_shape_material, s->d_shape_L, s->d_overflow, s->d_fb_own };
   for(void *b : bufs) if(b) hipFree(b);
   if(s->stream_own) hipStreamDestroy(s->stream_own);
   if(s->ev0) hipEventDestroy(s->ev0);

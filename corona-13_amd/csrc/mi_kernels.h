@@ -252,21 +252,49 @@ __device__ __noinline__ void line_intersect(const DPrim &p, const V3 ro, const V
   }
 }
 
+__device__ __forceinline__ void triquad_intersect(const DPrim &p, uint32_t type, const V3 o, const V3 d, Hit &hit, uint32_t prim)
+{ /* prims_intersect for tris and quads, src/prims.c:645-663: quad = tri(v0,v1,v2), and only if that misses tri(v0,v2,v3).
+     Both triangles are evaluated without branches (same arithmetic as geo_tri_intersect, include/geo/triangle.h:263-305)
+     and the reference's priority is applied afterwards, so a wave does not diverge on which half was hit. */
+  const V3 v0 = ld3(p.v[0]), v1 = ld3(p.v[1]), v2 = ld3(p.v[2]), v3 = ld3(p.v[3]);
+  const V3 tv = sub3(o, v0);
+  const V3 e02 = sub3(v2, v0);
+  /* triangle A: edge1 = v1-v0, edge2 = v2-v0 */
+  const V3 eA1 = sub3(v1, v0);
+  const V3 pA = cross3(d, e02);
+  const float invA = 1.0f/dot3(eA1, pA);
+  const float vA = dot3(tv, pA)*invA;
+  const V3 qA = cross3(tv, eA1);
+  const float uA = dot3(d, qA)*invA;
+  const float tA = dot3(e02, qA)*invA;
+  const bool hitA = !(vA < 0.0f || vA > 1.0f) && !(uA < 0.0f || uA + vA > 1.0f) && (tA > 0.0f && tA <= hit.dist);
+  /* triangle B: edge1 = v2-v0, edge2 = v3-v0 */
+  const V3 eB2 = sub3(v3, v0);
+  const V3 pB = cross3(d, eB2);
+  const float invB = 1.0f/dot3(e02, pB);
+  const float vB = dot3(tv, pB)*invB;
+  const V3 qB = cross3(tv, e02);
+  const float uB = dot3(d, qB)*invB;
+  const float tB = dot3(eB2, qB)*invB;
+  const bool hitB = (type == MI_PRIM_QUAD) && !(vB < 0.0f || vB > 1.0f) && !(uB < 0.0f || uB + vB > 1.0f) && (tB > 0.0f && tB <= hit.dist);
+  if(hitA)
+  {
+    hit.dist = tA; hit.prim = prim; hit.u = uA;
+    hit.v = (type == MI_PRIM_QUAD) ? vA + uA : vA;              /* tri (v0 v1 v2) uv => quad uv = (u, v+u) */
+  }
+  else if(hitB)
+  {
+    hit.dist = tB; hit.prim = prim; hit.u = uB + vB; hit.v = vB;  /* tri (v0 v2 v3) uv => quad uv = (u+v, v) */
+  }
+}
+
 __device__ __forceinline__ void prim_intersect(const DPrim *prims, uint32_t prim, const V3 o, const V3 d, uint32_t ignore, Hit &hit)
 { /* prims_intersect, src/prims.c:638-672 */
   const DPrim &p = prims[prim];
   const uint32_t type = p.type;
   if(type >= MI_PRIM_TRI)
   {
-    if(prim == ignore) return;                                   /* triangle.h:271 */
-    const V3 v0 = ld3(p.v[0]), v1 = ld3(p.v[1]), v2 = ld3(p.v[2]);
-    if(type == MI_PRIM_TRI) tri_intersect(v0, v1, v2, o, d, hit, prim);
-    else
-    {
-      if(tri_intersect(v0, v1, v2, o, d, hit, prim)) { hit.v += hit.u; return; }
-      const V3 v3 = ld3(p.v[3]);
-      if(tri_intersect(v0, v2, v3, o, d, hit, prim)) hit.u += hit.v;
-    }
+    if(prim != ignore) triquad_intersect(p, type, o, d, hit, prim);   /* triangle.h:271 */
   }
   else if(type == MI_PRIM_SPHERE)
   { /* geo_sphere_intersect, include/geo/sphere.h:146-166; u,v are recomputed at shading time */
@@ -282,96 +310,108 @@ struct Lds
   const float4 *nodes;      /* [MI_NODE_FIELDS][num_nodes] in LDS */
   const uint32_t *axes;     /* [num_nodes] in LDS */
   uint2 *stack;             /* [STACK][BLOCK] in LDS, this thread's column */
+  uint2 *overflow;          /* [extra][total threads] in HBM, this thread's column: entries beyond STACK (rare) */
+  uint32_t overflow_stride;
   uint32_t num_nodes;
 };
 
 template<int BLOCK, int STACK>
+__device__ __forceinline__ void stack_push(const Lds &lds, int sp, uint2 e)
+{
+  if(sp < STACK) lds.stack[sp*BLOCK] = e;
+  else lds.overflow[(size_t)(sp - STACK)*lds.overflow_stride] = e;
+}
+template<int BLOCK, int STACK>
+__device__ __forceinline__ uint2 stack_pop(const Lds &lds, int sp)
+{
+  if(sp < STACK) return lds.stack[sp*BLOCK];
+  return lds.overflow[(size_t)(sp - STACK)*lds.overflow_stride];
+}
+
+#define SEL4(n, a0, a1, a2, a3) ((n) == 0 ? (a0) : (n) == 1 ? (a1) : (n) == 2 ? (a2) : (a3))
+
+template<int BLOCK, int STACK>
 __device__ __forceinline__ void accel_intersect(const Lds &lds, const DPrim *prims, const V3 o, const V3 d, uint32_t ignore,
                                                 Hit &hit, uint32_t *cnt)
-{ /* accel_intersect, src/accel.d/qbvhmp.c:1262-1390 (static boxes) */
+{ /* accel_intersect, src/accel.d/qbvhmp.c:1262-1390 (static boxes), as a "while-while" loop: every lane first
+     descends inner nodes until it holds a leaf, then all lanes intersect their leaves together */
   cnt[0]++;
   const uint32_t near_x = __float_as_uint(d.x) >> 31, near_y = __float_as_uint(d.y) >> 31, near_z = __float_as_uint(d.z) >> 31;
   const uint32_t nearbits = near_x | (near_y << 1) | (near_z << 2);
   const float idx = 1.0f/d.x, idy = 1.0f/d.y, idz = 1.0f/d.z;
   const uint32_t N = lds.num_nodes;
   int sp = 0;
-  uint32_t node = 0;
-  uint32_t current;
-  while(true)
+  uint32_t current = 0;       /* node 0 = root */
+  bool done = false;
+  while(!done)
   {
-    /* 4 child slabs, qbvhmp.c:1188-1246; SSE min/max semantics (second operand on NaN) via ordered compares */
-    const float4 mnx = lds.nodes[0*N + node], mny = lds.nodes[1*N + node], mnz = lds.nodes[2*N + node];
-    const float4 mxx = lds.nodes[3*N + node], mxy = lds.nodes[4*N + node], mxz = lds.nodes[5*N + node];
-    const uint4 child = *(const uint4 *)&lds.nodes[6*N + node];
-    float tmin[4];
-    uint32_t mask = 0;
-    const float bx0[4] = {mnx.x, mnx.y, mnx.z, mnx.w}, bx1[4] = {mxx.x, mxx.y, mxx.z, mxx.w};
-    const float by0[4] = {mny.x, mny.y, mny.z, mny.w}, by1[4] = {mxy.x, mxy.y, mxy.z, mxy.w};
-    const float bz0[4] = {mnz.x, mnz.y, mnz.z, mnz.w}, bz1[4] = {mxz.x, mxz.y, mxz.z, mxz.w};
-#pragma unroll
-    for(int j=0;j<4;j++)
+    while(!(current & MI_LEAF32))
     {
-      float lo = 0.0f, hi = hit.dist;
-      float t0 = (bx0[j] - o.x)*idx, t1 = (bx1[j] - o.x)*idx;
-      float mn = t0 < t1 ? t0 : t1, mx = t0 > t1 ? t0 : t1;
-      lo = lo > mn ? lo : mn; hi = hi < mx ? hi : mx;
-      t0 = (by0[j] - o.y)*idy; t1 = (by1[j] - o.y)*idy;
-      mn = t0 < t1 ? t0 : t1; mx = t0 > t1 ? t0 : t1;
-      lo = lo > mn ? lo : mn; hi = hi < mx ? hi : mx;
-      t0 = (bz0[j] - o.z)*idz; t1 = (bz1[j] - o.z)*idz;
-      mn = t0 < t1 ? t0 : t1; mx = t0 > t1 ? t0 : t1;
-      lo = lo > mn ? lo : mn; hi = hi < mx ? hi : mx;
-      tmin[j] = lo;
-      mask |= (lo <= hi ? 1u : 0u) << j;
-    }
-    bool have = false;
-    if(mask)
-    {
-      cnt[1]++;
-      cnt[2] += __popc(mask);
-      /* front-to-back order from split axes and ray signs, qbvhmp.c:1313-1320 */
-      const uint32_t ax = lds.axes[node];
-      const uint32_t axis0 = ax & 3u;
-      const uint32_t near0 = (nearbits >> axis0) & 1u, far0 = near0 ^ 1u;
-      const uint32_t axis1n = near0 ? ((ax >> 4) & 3u) : ((ax >> 2) & 3u);
-      const uint32_t axis1f = near0 ? ((ax >> 2) & 3u) : ((ax >> 4) & 3u);
-      const uint32_t near1f = (nearbits >> axis1f) & 1u, near1n = (nearbits >> axis1n) & 1u;
-      const uint32_t n11 = (far0 << 1) | (near1f ^ 1u);
-      const uint32_t n10 = (far0 << 1) | near1f;
-      const uint32_t n01 = (near0 << 1) | (near1n ^ 1u);
-      const uint32_t n00 = (near0 << 1) | near1n;
-      const uint32_t ch[4] = {child.x, child.y, child.z, child.w};
-      /* first hit child in order n00,n01,n10,n11 becomes current; the later ones are pushed far-first */
-      const uint32_t order[4] = {n00, n01, n10, n11};
-      int firstk = 4;
-#pragma unroll
-      for(int k=3;k>=0;k--) if((mask >> order[k]) & 1u) firstk = k;
-#pragma unroll
-      for(int k=3;k>=1;k--)
+      const uint32_t node = current;
+      /* 4 child slabs, qbvhmp.c:1188-1246; SSE min/max semantics (second operand on NaN) via ordered compares */
+      const float4 mnx = lds.nodes[0*N + node], mny = lds.nodes[1*N + node], mnz = lds.nodes[2*N + node];
+      const float4 mxx = lds.nodes[3*N + node], mxy = lds.nodes[4*N + node], mxz = lds.nodes[5*N + node];
+      const uint4 child = *(const uint4 *)&lds.nodes[6*N + node];
+      float tm0, tm1, tm2, tm3;
+      uint32_t mask = 0;
+#define SLAB(J, X0, X1, Y0, Y1, Z0, Z1, TM) { \
+        float lo = 0.0f, hi = hit.dist; \
+        float t0 = ((X0) - o.x)*idx, t1 = ((X1) - o.x)*idx; \
+        float mn = t0 < t1 ? t0 : t1, mx = t0 > t1 ? t0 : t1; \
+        lo = lo > mn ? lo : mn; hi = hi < mx ? hi : mx; \
+        t0 = ((Y0) - o.y)*idy; t1 = ((Y1) - o.y)*idy; \
+        mn = t0 < t1 ? t0 : t1; mx = t0 > t1 ? t0 : t1; \
+        lo = lo > mn ? lo : mn; hi = hi < mx ? hi : mx; \
+        t0 = ((Z0) - o.z)*idz; t1 = ((Z1) - o.z)*idz; \
+        mn = t0 < t1 ? t0 : t1; mx = t0 > t1 ? t0 : t1; \
+        lo = lo > mn ? lo : mn; hi = hi < mx ? hi : mx; \
+        TM = lo; mask |= (lo <= hi ? 1u : 0u) << (J); }
+      SLAB(0, mnx.x, mxx.x, mny.x, mxy.x, mnz.x, mxz.x, tm0)
+      SLAB(1, mnx.y, mxx.y, mny.y, mxy.y, mnz.y, mxz.y, tm1)
+      SLAB(2, mnx.z, mxx.z, mny.z, mxy.z, mnz.z, mxz.z, tm2)
+      SLAB(3, mnx.w, mxx.w, mny.w, mxy.w, mnz.w, mxz.w, tm3)
+#undef SLAB
+      if(mask)
       {
-        const uint32_t n = order[k];
-        if(k > firstk && ((mask >> n) & 1u))
+        cnt[1]++;
+        cnt[2] += __popc(mask);
+        /* front-to-back order from split axes and ray signs, qbvhmp.c:1313-1320 */
+        const uint32_t ax = lds.axes[node];
+        const uint32_t axis0 = ax & 3u;
+        const uint32_t near0 = (nearbits >> axis0) & 1u, far0 = near0 ^ 1u;
+        const uint32_t axis1n = near0 ? ((ax >> 4) & 3u) : ((ax >> 2) & 3u);
+        const uint32_t axis1f = near0 ? ((ax >> 2) & 3u) : ((ax >> 4) & 3u);
+        const uint32_t near1f = (nearbits >> axis1f) & 1u, near1n = (nearbits >> axis1n) & 1u;
+        const uint32_t n11 = (far0 << 1) | (near1f ^ 1u);
+        const uint32_t n10 = (far0 << 1) | near1f;
+        const uint32_t n01 = (near0 << 1) | (near1n ^ 1u);
+        const uint32_t n00 = (near0 << 1) | near1n;
+        const bool h00 = (mask >> n00) & 1u, h01 = (mask >> n01) & 1u, h10 = (mask >> n10) & 1u, h11 = (mask >> n11) & 1u;
+        /* the first hit child in order n00,n01,n10,n11 becomes current; later ones are pushed far-first (qbvhmp.c:1336-1354) */
+        const uint32_t firstn = h00 ? n00 : h01 ? n01 : h10 ? n10 : n11;
+        const bool p11 = h11 && (h00 || h01 || h10);
+        const bool p10 = h10 && (h00 || h01);
+        const bool p01 = h01 && h00;
+        if(p11) { stack_push<BLOCK, STACK>(lds, sp, make_uint2(SEL4(n11, child.x, child.y, child.z, child.w), __float_as_uint(SEL4(n11, tm0, tm1, tm2, tm3)))); sp++; }
+        if(p10) { stack_push<BLOCK, STACK>(lds, sp, make_uint2(SEL4(n10, child.x, child.y, child.z, child.w), __float_as_uint(SEL4(n10, tm0, tm1, tm2, tm3)))); sp++; }
+        if(p01) { stack_push<BLOCK, STACK>(lds, sp, make_uint2(SEL4(n01, child.x, child.y, child.z, child.w), __float_as_uint(SEL4(n01, tm0, tm1, tm2, tm3)))); sp++; }
+        current = SEL4(firstn, child.x, child.y, child.z, child.w);
+        cnt[7] = cnt[7] > (uint32_t)sp ? cnt[7] : (uint32_t)sp;
+      }
+      else
+      { /* pop, skipping entries that start behind the current hit (qbvhmp.c:1357-1364) */
+        current = MI_LEAF32;          /* empty leaf: falls out of this loop; `done` if the stack runs dry */
+        done = true;
+        while(sp > 0)
         {
-          lds.stack[sp*BLOCK] = make_uint2(ch[n], __float_as_uint(tmin[n]));
-          sp++;
+          sp--;
+          const uint2 e = stack_pop<BLOCK, STACK>(lds, sp);
+          if(!(__uint_as_float(e.y) > hit.dist)) { current = e.x; done = false; break; }
         }
       }
-      current = ch[order[firstk & 3]];
-      have = true;
     }
-    if(!have)
-    {
-      bool found = false;
-      while(sp > 0)
-      {
-        sp--;
-        const uint2 e = lds.stack[sp*BLOCK];
-        if(!(__uint_as_float(e.y) > hit.dist)) { current = e.x; found = true; break; }
-      }
-      if(!found) return;
-    }
-    while(current & MI_LEAF32)
-    {
+    if(!done)
+    { /* leaf: intersect its primitives (qbvhmp.c:1366-1379), then pop */
       uint32_t idxp = (current ^ MI_LEAF32) >> 5;
       const uint32_t num = current & 31u;
       for(uint32_t i=0;i<num;i++)
@@ -380,16 +420,15 @@ __device__ __forceinline__ void accel_intersect(const Lds &lds, const DPrim *pri
         prim_intersect(prims, idxp, o, d, ignore, hit);
         idxp++;
       }
-      bool found = false;
+      current = MI_LEAF32;
+      done = true;
       while(sp > 0)
       {
         sp--;
-        const uint2 e = lds.stack[sp*BLOCK];
-        if(!(__uint_as_float(e.y) > hit.dist)) { current = e.x; found = true; break; }
+        const uint2 e = stack_pop<BLOCK, STACK>(lds, sp);
+        if(!(__uint_as_float(e.y) > hit.dist)) { current = e.x; done = false; break; }
       }
-      if(!found) return;
     }
-    node = current;
   }
 }
 
@@ -1207,36 +1246,44 @@ __device__ __forceinline__ void spectrum_to_xyz(const DScene &sc, float lambda, 
   for(int k=0;k<3;k++) col[k] = ((1-f)*sc.cie_xyz[3*i+k] + f*sc.cie_xyz[3*(i+1)+k])*value;
 }
 
-__device__ __noinline__ void splat_bh(const DScene &sc, float pi, float pj, const float *col)
-{ /* filter_blackmanharris_splat, include/filter/blackmanharris.h:43-77 + box.h:23-36 */
+/* filter_blackmanharris_splat (include/blackmanharris.h:43-77) + filter_box_splat (box.h:23-36), executed by the whole
+ * wave for every lane that has a splat pending: sixteen lanes take one of the 4x4 taps each (3 cosf per tap instead of
+ * 96 per lane), the normalisation sum is formed in the reference's tap order, then each tap lane issues its three
+ * hardware float atomics. */
+__device__ __forceinline__ void splat_wave(const DScene &sc, bool pending, float pi, float pj, float c0, float c1, float c2)
+{
+  unsigned long long m = __ballot(pending);
+  const unsigned lane = __lane_id();
   const int wd = (int)sc.width, ht = (int)sc.height;
-  const int x0 = (int)(pi - 1.5f), y0 = (int)(pj - 1.5f);
-  const int u0 = -x0 < 0 ? 0 : -x0, v0 = -y0 < 0 ? 0 : -y0;
-  const int u4 = x0 + 4 > wd ? wd - x0 : 4, v4 = y0 + 4 > ht ? ht - y0 : 4;
-  float w[16];
-  float weight = 0.0f;
-  for(int v=0;v<4;v++) for(int u=0;u<4;u++)
+  while(m)
   {
+    const int src = __ffsll((long long)m) - 1;
+    m &= m - 1;
+    const float spi = __shfl(pi, src), spj = __shfl(pj, src);
+    const float s0 = __shfl(c0, src), s1 = __shfl(c1, src), s2 = __shfl(c2, src);
+    const int x0 = (int)(spi - 1.5f), y0 = (int)(spj - 1.5f);
+    const int u0 = -x0 < 0 ? 0 : -x0, v0 = -y0 < 0 ? 0 : -y0;
+    const int u4 = x0 + 4 > wd ? wd - x0 : 4, v4 = y0 + 4 > ht ? ht - y0 : 4;
+    const int u = lane & 3, v = (lane >> 2) & 3;
+    const bool inside = lane < 16 && v >= v0 && v < v4 && u >= u0 && u < u4;
     float f = 0.0f;
-    if(v >= v0 && v < v4 && u >= u0 && u < u4)
+    if(inside)
     {
-      const float uu = (x0 + u + .5f) - pi, vv = (y0 + v + .5f) - pj;
+      const float uu = (x0 + u + .5f) - spi, vv = (y0 + v + .5f) - spj;
       f = bh_w(sqrtf(uu*uu + vv*vv) + 1.5f);
-      weight += f;
     }
-    w[4*v+u] = f;
-  }
-  if(weight <= 0) return;
-  weight = 1.0f/weight;
-  for(int v=0;v<4;v++) for(int u=0;u<4;u++)
-  {
-    if(v >= v0 && v < v4 && u >= u0 && u < u4)
+    float weight = 0.0f;
+#pragma unroll
+    for(int k=0;k<16;k++) weight += __shfl(f, k);     /* taps outside the image contribute exactly 0, as if skipped */
+    if(weight <= 0) continue;
+    weight = 1.0f/weight;
+    if(inside)
     {
-      const float f = weight*w[4*v+u];
+      const float g = weight*f;
       float *px = sc.fb + 3*((size_t)(x0+u) + (size_t)wd*(y0+v));
-      atomicAdd(px+0, col[0]*f);
-      atomicAdd(px+1, col[1]*f);
-      atomicAdd(px+2, col[2]*f);
+      atomicAdd(px+0, s0*g);
+      atomicAdd(px+1, s1*g);
+      atomicAdd(px+2, s2*g);
     }
   }
 }
