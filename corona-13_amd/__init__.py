@@ -121,6 +121,15 @@ def record_dtype():
     return rec
 
 
+def shard_range(first, count, rank, world):
+    """Contiguous block of path indices [first, first+count) owned by `rank` of `world` (paths are independent;
+    SURVEY 8(e): partition by sample index range). Remainder indices go to the lowest ranks."""
+    base, rem = divmod(count, world)
+    my = base + (1 if rank < rem else 0)
+    start = first + rank * base + min(rank, rem)
+    return start, my
+
+
 # ---------------------------------------------------------------- host library
 _host = None
 

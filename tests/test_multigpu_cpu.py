@@ -1,0 +1,57 @@
+"""N > 1 path on CPU: world_size-2 gloo processes shard the path indices exactly like bench.py does and all-reduce
+the framebuffer; the result must equal the single-process render of the union of the indices. The per-rank renderer
+here is the oracle (test infrastructure) -- the sharding/reduce logic is what is under test, no GPU needed."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import REPO, SCENE_0010, load_pkg, make_scene, oracle_render
+
+
+def _worker(rank, world, port, outdir):
+    sys.path.insert(0, str(REPO / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = load_pkg()
+    scene = make_scene(SCENE_0010, width=64, height=64, max_verts=4)
+    per_frame = 2 * scene.width * scene.height
+    total = np.zeros((scene.height, scene.width, 3), dtype=np.float32)
+    for k in range(2):                                              # two "frames", as bench.py's step(k)
+        first, count = pkg.shard_range(k * world * per_frame, world * per_frame, rank, world)
+        fb, _, _ = oracle_render(scene, first, count, threads=1)
+        t = torch.from_numpy(fb)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)                    # the framebuffer reduce (RCCL on the GPU box)
+        total += t.numpy()
+    if rank == 0:
+        np.save(os.path.join(outdir, "reduced.npy"), total)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_range_partitions_exactly():
+    pkg = load_pkg()
+    for first, count, world in ((0, 10, 3), (7, 1, 4), (1 << 40, 942080 * 64, 8), (5, 0, 2)):
+        parts = [pkg.shard_range(first, count, r, world) for r in range(world)]
+        assert parts[0][0] == first and sum(c for _, c in parts) == count
+        for (f0, c0), (f1, _) in zip(parts, parts[1:]):
+            assert f0 + c0 == f1
+        assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
+
+
+def test_two_ranks_equal_single_process():
+    world = 2
+    port = 29500 + (os.getpid() % 2000)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, port, d), nprocs=world, join=True)
+        reduced = np.load(os.path.join(d, "reduced.npy"))
+    scene = make_scene(SCENE_0010, width=64, height=64, max_verts=4)
+    per_frame = 2 * scene.width * scene.height
+    single, _, _ = oracle_render(scene, 0, 2 * world * per_frame, threads=1)
+    assert np.allclose(reduced, single, rtol=1e-5, atol=1e-4)
+    assert reduced.sum() > 0

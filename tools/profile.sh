@@ -1,0 +1,36 @@
+#!/bin/bash
+# GPU box: collect the rocprofv3 evidence behind bench.py's roofline object.
+#   tools/profile.sh <tag>   -> gpurun_out/<tag>/{kernel_stats.csv, pmc_*.csv, bench.json}
+# PMC counters are collected in their own passes (never combined with tracing), as the guide prescribes.
+TAG=${1:-prof}
+R=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+python3 $R/bench.py --steps 5 > $OUT/bench.json 2> $OUT/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 5 --no-cpu-baseline > $OUT/trace.log 2>&1
+cp $OUT/trace/*/*_kernel_stats.csv $OUT/kernel_stats.csv
+pmc() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_$name -- python3 $R/bench.py --steps 2 --warmup 0 --no-cpu-baseline > $OUT/pmc_$name.log 2>&1; cp $OUT/pmc_$name/*/*_counter_collection.csv $OUT/pmc_$name.csv; }
+pmc fetch FETCH_SIZE
+pmc write WRITE_SIZE
+pmc sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_ANY
+pmc mem SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS
+pmc l2 TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum
+rm -rf $OUT/trace $OUT/pmc_*/ $OUT/*.log
+python3 - <<PY
+import csv, glob, json, collections
+out = "$OUT"
+res = {}
+for f in glob.glob(out + "/pmc_*.csv"):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if "mi_path_kernel" in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            res["VGPR_Count"] = r.get("VGPR_Count"); res["LDS_Block_Size"] = r.get("LDS_Block_Size"); res["Scratch_Size"] = r.get("Scratch_Size")
+            res["Grid_Size"] = r.get("Grid_Size"); res["Workgroup_Size"] = r.get("Workgroup_Size")
+    for k, v in agg.items():
+        res[k] = sum(v) / len(v)
+json.dump(res, open(out + "/pmc_summary.json", "w"), indent=1)
+print(json.dumps(res))
+PY
+cat $OUT/bench.json; head -3 $OUT/kernel_stats.csv
