@@ -240,6 +240,7 @@ def mi_lib():
         m.mi_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         m.mi_trace_paths.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
         m.mi_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        m.mi_last_kernel_launches.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         m.mi_scene_destroy.argtypes = [C.c_void_p]
         m.mi_scene_destroy.restype = None
         m.mi_shutdown.restype = None
@@ -250,7 +251,7 @@ def mi_lib():
 
 MI_SYMBOLS = ["mi_init", "mi_scene_create", "mi_scene_set_framebuffer", "mi_scene_set_stream", "mi_render",
               "mi_sync", "mi_fb_read", "mi_fb_clear", "mi_fb_device_ptr", "mi_counters", "mi_trace_paths",
-              "mi_last_kernel_ms", "mi_scene_destroy", "mi_shutdown", "mi_last_error"]
+              "mi_last_kernel_ms", "mi_last_kernel_launches", "mi_scene_destroy", "mi_shutdown", "mi_last_error"]
 
 
 class Backend:
@@ -307,6 +308,11 @@ class Backend:
         ms = C.c_float()
         self._check(self.m.mi_last_kernel_ms(self._ptr, C.byref(ms)), "mi_last_kernel_ms")
         return ms.value
+
+    def last_kernel_launches(self):
+        n = C.c_uint64()
+        self._check(self.m.mi_last_kernel_launches(self._ptr, C.byref(n)), "mi_last_kernel_launches")
+        return n.value
 
     def close(self):
         if self._ptr:

@@ -4,7 +4,7 @@
  * Replaces everything the reference reaches from work_sample() (src/view.c:618-628): one launch
  * traces path indices [first, first+count) and splats them into the device framebuffer.
  */
-#include "mi_path.h"
+#include "mi_wavefront.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -13,6 +13,7 @@
 #ifndef MI_BLOCK
 #define MI_BLOCK 1024    /* threads per workgroup: 16 waves/CU = 4 per SIMD (128 VGPRs each) */
 #endif
+#define MI_WORK_SHARDS 262144   /* upper bound on workgroups of one launch (path pool / 256) */
 #ifndef MI_STACK
 #define MI_STACK 12      /* LDS traversal stack entries per lane; deeper entries overflow to HBM (mi_device.h) */
 #endif
@@ -40,6 +41,15 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
   lds.overflow_stride = gridDim.x*MI_BLOCK;
   lds.overflow = stack_overflow + (size_t)blockIdx.x*MI_BLOCK + threadIdx.x;
 
+  /* every workgroup owns a contiguous part of the path index range and hands it out through an LDS counter: the
+     wave-level refill below then needs no global atomic at all (one shared counter costs ~11 ns per wave refill) */
+  __shared__ unsigned int blk_next;
+  if(threadIdx.x == 0) blk_next = 0;
+  __syncthreads();
+  const unsigned long long nb = gridDim.x;
+  const unsigned long long blk_lo = count/nb*blockIdx.x + (blockIdx.x < count%nb ? blockIdx.x : count%nb);
+  const unsigned long long blk_hi = blk_lo + count/nb + (blockIdx.x < count%nb ? 1 : 0);
+
   uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   PathState ps;
   ps.active = 0;
@@ -57,14 +67,14 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
       if(m)
       {
         const unsigned n = __popcll(m);
-        unsigned long long base = 0;
-        if(lane == (unsigned)(__ffsll((long long)m) - 1)) base = atomicAdd(sc.work, (unsigned long long)n);
+        unsigned int base = 0;
+        if(lane == (unsigned)(__ffsll((long long)m) - 1)) base = atomicAdd(&blk_next, n);     /* LDS atomic: this block's own range */
         base = __shfl(base, __ffsll((long long)m) - 1);
         if(want)
         {
           const unsigned rank = __popcll(m & ((1ull << lane) - 1ull));
-          const unsigned long long i = base + rank;
-          if(i < count) path_generate<RECORD>(sc, ps, first + i, RECORD ? records + i : nullptr, cnt);
+          const unsigned long long i = blk_lo + base + rank;
+          if(i < blk_hi) path_generate<RECORD>(sc, ps, first + i, RECORD ? records + i : nullptr, cnt);
           else exhausted = true;
         }
       }
@@ -88,7 +98,8 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
     if(!RECORD) splat_wave(sc, splat.pending, ps.pixel_i, ps.pixel_j, splat.c0, splat.c1, splat.c2);
   }
 
-  atomicMax(sc.counters + 7, (unsigned long long)cnt[7]);     /* deepest traversal stack use */
+  unsigned long long *shard = sc.counters + (size_t)(blockIdx.x % MI_COUNTER_SHARDS)*8;
+  atomicMax(shard + 7, (unsigned long long)cnt[7]);     /* deepest traversal stack use */
   /* ------------------------------------------------------------ flush work counters: wave reduction, one atomic per wave */
 #pragma unroll
   for(int k=0;k<8;k++)
@@ -96,7 +107,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
     unsigned long long c = cnt[k];
     for(int off=32;off>0;off>>=1) c += __shfl_down(c, off);
     if(k == 7) continue;                    /* slot 7 is a maximum, flushed above */
-    if(lane == 0 && c) atomicAdd(sc.counters + k, c);
+    if(lane == 0 && c) atomicAdd(shard + k, c);
   }
 }
 
@@ -128,6 +139,16 @@ struct mi_scene
   size_t lds_bytes;
   int grid;
   uint64_t launches;
+  /* wavefront pipeline (mi_wavefront.h) */
+  int wavefront;                    /* 1: wf_logic/wf_trace, 0: persistent megakernel */
+  WFPool pool;
+  void *d_pool, *d_wfcnt;           /* d_wfcnt: [0] trace_head, [1] live */
+  unsigned long long *h_live;       /* pinned ring of `live` read-backs */
+  hipEvent_t ev_live[8];
+  hipEvent_t ev_trace[2];           /* timing of one representative wf_trace launch */
+  float trace_ms_sum; int trace_ms_n;
+  double kernel_ms_total;           /* sum of dominant-kernel durations of the last mi_render */
+  uint64_t kernel_launches_last;
 };
 
 extern "C" const char *mi_last_error(void) { return g_err; }
@@ -155,6 +176,46 @@ template<typename T> static int upload(void **dst, const T *src, size_t count)
   if(src) HIPCHK(hipMemcpy(*dst, src, count*sizeof(T), hipMemcpyHostToDevice));
   else HIPCHK(hipMemset(*dst, 0, count*sizeof(T)));
   return MI_OK;
+}
+
+/* per-primitive constants of a line (truncated cone) primitive, computed once with the same float operations the
+ * reference performs inside every intersection test (include/geo/line.h:313-335,401-416, include/corona_common.h:178-198);
+ * layout documented at line_intersect (mi_kernels.h) */
+static void pack_line(DPrim &p, DPrimShade &q, const mi_vtx &a0, const mi_vtx &a1)
+{
+  float *f = &p.v[0][0];
+  uint32_t *fu = (uint32_t *)f;
+  const uint32_t type = p.type;
+  float r0, r1;
+  memcpy(&r0, &a0.n, 4); memcpy(&r1, &a1.n, 4);
+  const float v0[3] = {a0.v[0], a0.v[1], a0.v[2]}, v1[3] = {a1.v[0], a1.v[1], a1.v[2]};
+  float d[3] = {v1[0]-v0[0], v1[1]-v0[1], v1[2]-v0[2]};
+  const float dlen = sqrtf(d[0]*d[0] + d[1]*d[1] + d[2]*d[2]);
+  memset(f, 0, 64);
+  f[0] = v0[0]; f[1] = v0[1]; f[2] = v0[2]; f[3] = r0; f[4] = r1; f[5] = dlen;
+  if(fabsf(r1-r0) < 1e-3)
+  { /* cylinder: d *= 1.0f/dlen; get_onb(d, a, b) */
+    const float inv = 1.0f/dlen;
+    for(int k=0;k<3;k++) d[k] *= inv;
+    float a[3], b[3];
+    if(fabsf(d[1]) < 0.5) { a[0] = d[1]*0.0f - 1.0f*d[2]; a[1] = d[2]*0.0f - 0.0f*d[0]; a[2] = d[0]*1.0f - 0.0f*d[1]; }   /* d x (0,1,0) */
+    else                  { a[0] = d[1]*0.0f - 0.0f*d[2]; a[1] = d[2]*1.0f - 0.0f*d[0]; a[2] = d[0]*0.0f - 1.0f*d[1]; }   /* d x (1,0,0) */
+    const float il = 1.0f/sqrtf(a[0]*a[0] + a[1]*a[1] + a[2]*a[2]);
+    for(int k=0;k<3;k++) a[k] *= il;
+    b[0] = d[1]*a[2] - a[1]*d[2]; b[1] = d[2]*a[0] - a[2]*d[0]; b[2] = d[0]*a[1] - a[0]*d[1];
+    f[6] = d[0]; f[7] = d[1]; f[8] = d[2];
+    f[9] = a[0]; f[10] = a[1]; f[11] = a[2];
+    f[13] = b[0]; f[14] = b[1]; f[15] = b[2];
+  }
+  else
+  { /* cone: d *= 1.0/d_len (double), cos_a2 */
+    for(int k=0;k<3;k++) d[k] = (float)(d[k]*(1.0/dlen));
+    f[6] = d[0]; f[7] = d[1]; f[8] = d[2];
+    f[9] = v1[0]; f[10] = v1[1]; f[11] = v1[2];
+    f[13] = dlen*dlen/((r1-r0)*(r1-r0) + dlen*dlen);
+  }
+  fu[12] = type;
+  memcpy(&q.n[2], &v1[0], 4); memcpy(&q.n[3], &v1[1], 4); memcpy(&q.uv[2], &v1[2], 4);
 }
 
 static int tree_depth(const mi_scene_desc *h, uint32_t node, int depth)
@@ -248,13 +309,7 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
       memcpy(p.v[0], vtx[vi[0].v].v, 12);
       memcpy(&p.v[1][0], &vtx[vi[0].v].n, 4);
     }
-    else if(vc == MI_PRIM_LINE)
-    {
-      memcpy(p.v[0], vtx[vi[0].v].v, 12);
-      memcpy(p.v[1], vtx[vi[1].v].v, 12);
-      memcpy(&p.v[2][0], &vtx[vi[0].v].n, 4);
-      memcpy(&p.v[2][1], &vtx[vi[1].v].n, 4);
-    }
+    else if(vc == MI_PRIM_LINE) pack_line(p, q, vtx[vi[0].v], vtx[vi[1].v]);
     else for(uint32_t k=0;k<vc;k++) memcpy(p.v[k], vtx[vi[k].v].v, 12);
   }
   std::vector<DMaterial> mats(h->num_materials ? h->num_materials : 1);
@@ -297,8 +352,8 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   UP(d_cie, h->cie_xyz, (size_t)96*3);
   UP(d_checker, h->checker, h->checker ? (size_t)140*36 : 0);
   UP(d_metal, h->metal_ior, h->metal_ior ? (size_t)5*95*2 : 0);
-  UP(d_counters, (const unsigned long long *)nullptr, (size_t)8);
-  UP(d_work, (const unsigned long long *)nullptr, (size_t)1);
+  UP(d_counters, (const unsigned long long *)nullptr, (size_t)8*MI_COUNTER_SHARDS);
+  UP(d_work, (const unsigned long long *)nullptr, (size_t)MI_WORK_SHARDS);
 #undef UP
   if(!e)
   {
@@ -344,6 +399,34 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
     if(hipMalloc(&s->d_overflow, extra*(size_t)s->grid*MI_BLOCK*sizeof(uint2)) != hipSuccess)
     { mi_scene_destroy(s); return fail(MI_ERR_NOMEM, "cannot allocate the traversal stack overflow area"); }
   }
+  {
+    /* wavefront pool: CORONA_MI_MODE=mega selects the persistent megakernel, CORONA_MI_POOL the number of path slots */
+    const char *mode = getenv("CORONA_MI_MODE");
+    s->wavefront = !(mode && !strcmp(mode, "mega"));
+    const char *pe = getenv("CORONA_MI_POOL");
+    uint64_t P = pe ? strtoull(pe, 0, 10) : (1ull << 21);
+    if(P < 65536) P = 65536;
+    if(P > (size_t)MI_WORK_SHARDS*256) P = (size_t)MI_WORK_SHARDS*256;
+    P = (P + 4095) & ~4095ull;
+    s->pool.P = (uint32_t)P;
+    if(s->wavefront)
+    {
+      if(hipMalloc(&s->d_pool, (size_t)F_COUNT*P*sizeof(uint32_t)) != hipSuccess ||
+         hipMalloc(&s->d_wfcnt, (1 + WF_LIVE_SHARDS)*sizeof(unsigned long long)) != hipSuccess ||
+         hipHostMalloc((void **)&s->h_live, 8*WF_LIVE_SHARDS*sizeof(unsigned long long)) != hipSuccess)
+      { mi_scene_destroy(s); return fail(MI_ERR_NOMEM, "cannot allocate the path pool"); }
+      s->pool.s = (uint32_t *)s->d_pool;
+      s->pool.trace_head = (unsigned long long *)s->d_wfcnt;
+      s->pool.live = (unsigned long long *)s->d_wfcnt + 1;
+      for(int k=0;k<8;k++) if(hipEventCreateWithFlags(&s->ev_live[k], hipEventDisableTiming) != hipSuccess)
+      { mi_scene_destroy(s); return fail(MI_ERR_DEVICE, "cannot create events"); }
+      for(int k=0;k<2;k++) if(hipEventCreate(&s->ev_trace[k]) != hipSuccess)
+      { mi_scene_destroy(s); return fail(MI_ERR_DEVICE, "cannot create events"); }
+      if(hipFuncSetAttribute((const void *)wf_trace<MI_BLOCK, MI_STACK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess ||
+         hipFuncSetAttribute((const void *)wf_trace<MI_BLOCK, MI_STACK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess)
+      { mi_scene_destroy(s); return fail(MI_ERR_DEVICE, "cannot raise the dynamic LDS limit"); }
+    }
+  }
   *out = s;
   return MI_OK;
 }
@@ -363,10 +446,60 @@ extern "C" int mi_scene_set_stream(mi_scene *s, void *hip_stream)
   return MI_OK;
 }
 
+static int render_wavefront(mi_scene *s, uint64_t first_index, uint64_t count)
+{ /* host loop of the wavefront pipeline: [wf_logic, wf_trace]* until a logic pass leaves no ray pending.
+     The `live` counter is read back asynchronously, two iterations behind, so the queue never drains. */
+  const uint32_t P = s->pool.P;
+  const bool ptdl = s->d.sampler == MI_SAMPLER_PTDL;
+  HIPCHK(hipMemsetAsync(s->d_work, 0, (size_t)MI_WORK_SHARDS*sizeof(unsigned long long), s->stream));
+  HIPCHK(hipMemsetAsync(s->d_pool, 0, (size_t)F_COUNT*P*sizeof(uint32_t), s->stream));   /* all slots idle */
+  const int lgrid = (int)(P/WF_LOGIC_BLOCK);
+  const int ablate = getenv("CORONA_MI_ABLATE") ? atoi(getenv("CORONA_MI_ABLATE")) : 0;   /* development only */
+  s->kernel_ms_total = 0.0; s->kernel_launches_last = 0; s->trace_ms_sum = 0.0f; s->trace_ms_n = 0;
+  int timed_it = -1;
+  for(int it=0;;it++)
+  {
+    HIPCHK(hipMemsetAsync(s->d_wfcnt, 0, (1 + WF_LIVE_SHARDS)*sizeof(unsigned long long), s->stream));
+    if(ptdl) hipLaunchKernelGGL((wf_logic<true>), dim3(lgrid), dim3(WF_LOGIC_BLOCK), 0, s->stream, s->d, s->pool, (unsigned long long)first_index,
+                                (unsigned long long)count, (const uint32_t *)s->d_shape_material, (const float *)s->d_shape_L, ablate);
+    else     hipLaunchKernelGGL((wf_logic<false>), dim3(lgrid), dim3(WF_LOGIC_BLOCK), 0, s->stream, s->d, s->pool, (unsigned long long)first_index,
+                                (unsigned long long)count, (const uint32_t *)s->d_shape_material, (const float *)s->d_shape_L, ablate);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(s->h_live + (size_t)(it & 7)*WF_LIVE_SHARDS, s->pool.live, WF_LIVE_SHARDS*sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipEventRecord(s->ev_live[it & 7], s->stream));
+    /* time every 8th trace launch with HIP events on the launch stream */
+    const bool timed = (it & 7) == 2 && timed_it < 0;
+    if(timed) { HIPCHK(hipEventRecord(s->ev_trace[0], s->stream)); }
+    if(ptdl) hipLaunchKernelGGL((wf_trace<MI_BLOCK, MI_STACK, true>), dim3(s->grid), dim3(MI_BLOCK), s->lds_bytes, s->stream, s->d, s->pool, (uint2 *)s->d_overflow);
+    else     hipLaunchKernelGGL((wf_trace<MI_BLOCK, MI_STACK, false>), dim3(s->grid), dim3(MI_BLOCK), s->lds_bytes, s->stream, s->d, s->pool, (uint2 *)s->d_overflow);
+    HIPCHK(hipGetLastError());
+    if(timed) { HIPCHK(hipEventRecord(s->ev_trace[1], s->stream)); timed_it = it; }
+    s->kernel_launches_last++;
+    if(timed_it >= 0 && it >= timed_it + 2)
+    {
+      float ms = 0.0f;
+      if(hipEventElapsedTime(&ms, s->ev_trace[0], s->ev_trace[1]) == hipSuccess) { s->trace_ms_sum += ms; s->trace_ms_n++; }
+      timed_it = -1;
+    }
+    if(it >= 2)
+    { /* look at the pass two iterations back (it has certainly been submitted; wait for it to bound the queue depth) */
+      HIPCHK(hipEventSynchronize(s->ev_live[(it - 2) & 7]));
+      unsigned long long any = 0;
+      for(int k=0;k<WF_LIVE_SHARDS;k++) any |= s->h_live[(size_t)((it - 2) & 7)*WF_LIVE_SHARDS + k];
+      if(!any) break;
+    }
+    if(it > (1 << 24)) return fail(MI_ERR_DEVICE, "wavefront pipeline did not terminate");
+  }
+  s->have_timing = 1;
+  s->launches += s->kernel_launches_last;
+  return MI_OK;
+}
+
 extern "C" int mi_render(mi_scene *s, uint64_t first_index, uint64_t count)
 {
   if(!s) return fail(MI_ERR_ARG, "null scene");
   if(!count) return MI_OK;
+  if(s->wavefront) return render_wavefront(s, first_index, count);
   HIPCHK(hipMemsetAsync(s->d_work, 0, sizeof(unsigned long long), s->stream));
   int grid = s->grid;
   const uint64_t need = (count + MI_BLOCK - 1)/MI_BLOCK;
@@ -384,6 +517,7 @@ extern "C" int mi_render(mi_scene *s, uint64_t first_index, uint64_t count)
   HIPCHK(hipEventRecord(s->ev1, s->stream));
   s->have_timing = 1;
   s->launches++;
+  s->kernel_launches_last = 1;
   return MI_OK;
 }
 
@@ -419,9 +553,14 @@ extern "C" int mi_counters(mi_scene *s, uint64_t out[8])
 {
   if(!s || !out) return fail(MI_ERR_ARG, "null argument");
   HIPCHK(hipStreamSynchronize(s->stream));
-  unsigned long long tmp[8];
-  HIPCHK(hipMemcpy(tmp, s->d_counters, sizeof(tmp), hipMemcpyDeviceToHost));
-  for(int k=0;k<8;k++) out[k] = tmp[k];
+  std::vector<unsigned long long> tmp((size_t)8*MI_COUNTER_SHARDS);
+  HIPCHK(hipMemcpy(tmp.data(), s->d_counters, tmp.size()*sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  for(int k=0;k<8;k++) out[k] = 0;
+  for(int sh=0;sh<MI_COUNTER_SHARDS;sh++)
+  {
+    for(int k=0;k<7;k++) out[k] += tmp[(size_t)sh*8 + k];
+    if(tmp[(size_t)sh*8 + 7] > out[7]) out[7] = tmp[(size_t)sh*8 + 7];
+  }
   return MI_OK;
 }
 
@@ -459,14 +598,32 @@ extern "C" int mi_last_kernel_ms(mi_scene *s, float *ms)
 {
   if(!s || !ms) return fail(MI_ERR_ARG, "null argument");
   if(!s->have_timing) { *ms = 0.0f; return MI_OK; }
+  if(s->wavefront)
+  { /* average duration of the sampled wf_trace launches of the last mi_render (HIP events on the launch stream) */
+    HIPCHK(hipStreamSynchronize(s->stream));
+    *ms = s->trace_ms_n ? s->trace_ms_sum/(float)s->trace_ms_n : 0.0f;
+    return MI_OK;
+  }
   HIPCHK(hipEventSynchronize(s->ev1));
   HIPCHK(hipEventElapsedTime(ms, s->ev0, s->ev1));
+  return MI_OK;
+}
+
+extern "C" int mi_last_kernel_launches(mi_scene *s, uint64_t *launches)
+{
+  if(!s || !launches) return fail(MI_ERR_ARG, "null argument");
+  *launches = s->kernel_launches_last;
   return MI_OK;
 }
 
 extern "C" void mi_scene_destroy(mi_scene *s)
 {
   if(!s) return;
+  if(s->d_pool) hipFree(s->d_pool);
+  if(s->d_wfcnt) hipFree(s->d_wfcnt);
+  if(s->h_live) hipHostFree(s->h_live);
+  for(int k=0;k<8;k++) if(s->ev_live[k]) hipEventDestroy(s->ev_live[k]);
+  for(int k=0;k<2;k++) if(s->ev_trace[k]) hipEventDestroy(s->ev_trace[k]);
   void *bufs[] = { s->d_nodes, s->d_axes, s->d_prims, s->d_primshade, s->d_materials, s->d_light_prim, s->d_light_cdf, s->d_light_L,
                    s->d_cie, s->d_checker, s->d_metal, s->d_counters, s->d_work, s->d_shape_material, s->d_shape_L, s->d_overflow, s->d_fb_own };
   for(void *b : bufs) if(b) hipFree(b);

@@ -18,6 +18,7 @@
 
 #define MI_LEAF32 0x80000000u
 #define MI_NODE_FIELDS 7
+#define MI_COUNTER_SHARDS 256
 
 struct DPrim                       /* 64 B */
 {
@@ -65,8 +66,11 @@ struct DScene
   const float *cie_xyz, *checker, *metal_ior;
   /* output */
   float *fb;
-  unsigned long long *counters;    /* [8] */
-  unsigned long long *work;        /* next path index */
+  unsigned long long *counters;    /* [MI_COUNTER_SHARDS][8]: same-address atomics serialise at ~11 ns each, so every
+                                      workgroup adds into its own shard; mi_counters() sums them */
+  unsigned long long *work;        /* [work_shards] consumed-path counters: every workgroup owns a contiguous part of the
+                                      index range and its own counter (no same-address atomics between workgroups) */
+  uint32_t work_shards;
 };
 
 #endif

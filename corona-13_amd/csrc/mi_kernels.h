@@ -148,18 +148,23 @@ __device__ __forceinline__ float sphere_t(const V3 c, float radius, const V3 ro,
   else return fminf(x0, x1);
 }
 
-__device__ __noinline__ void line_intersect(const DPrim &p, const V3 ro, const V3 rd, Hit &hit, uint32_t prim, uint32_t ignore)
+/* Line primitives (truncated cones with radii r0, r1) carry their per-primitive constants precomputed at upload, with
+ * the very float operations the reference performs per test (mi_abi.hip: pack_line):
+ *   dword 0-2 v0 | 3 r0 | 4 r1 | 5 |v1-v0| | 6-8 unit axis d | 9-11 cylinder: onb a, cone: v1 | 12 type | 13-15 cylinder: onb b, cone: cos_a2,-,-
+ * For a cylinder hit.u / hit.v transport the raw cross-section coordinates (out[1], out[2]); the angle
+ * hit->v = atan2f(out[1], out[2])/2pi (include/geo/line.h:486) is evaluated once at shading time, not per candidate. */
+__device__ __forceinline__ void line_intersect(const DPrim &p, const V3 ro, const V3 rd, Hit &hit, uint32_t prim, uint32_t ignore)
 { /* geo_line_intersect + _geo_line_intersect_{cylinder,cone}, include/geo/line.h:313-505 (hair strips out of scope) */
-  const V3 v0 = ld3(p.v[0]), v1 = ld3(p.v[1]);
-  const float r0 = p.v[2][0], r1 = p.v[2][1];
+  const float *f = &p.v[0][0];
+  const V3 v0 = mk3(f[0], f[1], f[2]);
+  const float r0 = f[3], r1 = f[4];
   const bool linestrip = DMAX(r0, r1) <= 1e-2f;
   if(linestrip && ignore == prim) return;
-  V3 d = sub3(v1, v0);
+  const V3 d = mk3(f[6], f[7], f[8]);
   if(fabsf(r1-r0) < 1e-3)
   {
-    const float dlen = sqrtf(dot3(d, d));
-    d = scale3(d, 1.0f/dlen);
-    V3 a, b; get_onb(d, a, b);
+    const float dlen = f[5];
+    const V3 a = mk3(f[9], f[10], f[11]), b = mk3(f[13], f[14], f[15]);
     float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f, w0 = 0.0f, w1 = 0.0f, w2 = 0.0f;
     const float px[3] = {ro.x - v0.x, ro.y - v0.y, ro.z - v0.z}, dx[3] = {rd.x, rd.y, rd.z};
     const float dd[3] = {d.x, d.y, d.z}, aa[3] = {a.x, a.y, a.z}, bb[3] = {b.x, b.y, b.z};
@@ -201,16 +206,13 @@ __device__ __noinline__ void line_intersect(const DPrim &p, const V3 ro, const V
     if(t > 0.0f && t < hit.dist)
     {
       hit.dist = t; hit.prim = prim;
-      hit.u = out0/dlen;
-      hit.v = (float)((double)atan2f(out1, out2)/(2.0f*MI_PI_D));
+      hit.u = out1; hit.v = out2;                 /* raw; angle taken at shading time */
     }
   }
   else
   {
-    const float d_len = sqrtf(dot3(d, d));
-    d = mk3((float)(d.x*(1.0/d_len)), (float)(d.y*(1.0/d_len)), (float)(d.z*(1.0/d_len)));
+    const float d_len = f[5], cos_a2 = f[13];
     const float cos_dr = dot3(d, rd);
-    const float cos_a2 = d_len*d_len/((r1-r0)*(r1-r0) + d_len*d_len);
     const float tt = -r0*d_len/(r1-r0);
     const V3 tip = mk3(v0.x + tt*d.x, v0.y + tt*d.y, v0.z + tt*d.z);
     const V3 o = sub3(ro, tip);
@@ -220,12 +222,13 @@ __device__ __noinline__ void line_intersect(const DPrim &p, const V3 ro, const V
     const float c2 = cos_dr*cos_dr - cos_a2;
     const float c1 = cos_dr*cos_do - cos_a2*cos_ro;
     const float c0 = cos_do*cos_do - cos_a2*cos_oo;
-    float tmin = -1.0f, dist = hit.dist, hu = hit.u, hv = hit.v;
+    float tmin = -1.0f, dist = hit.dist, hu = hit.u;
     if(fabsf(c2) > 0.0)
     {
       const float discr = c1*c1 - c0*c2;
       if(discr < 0.0f) return;
       const float root = sqrtf(discr);
+#pragma unroll
       for(int i=-1;i<2;i+=2)
       {
         const float t = (-c1 + i*root)/c2;
@@ -235,28 +238,32 @@ __device__ __noinline__ void line_intersect(const DPrim &p, const V3 ro, const V
           const float dt = dot3(x, d);
           if(dt >= 0.0f && dt <= d_len)
           {
-            hu = dt/d_len;
-            V3 a, b; get_onb(d, a, b);
-            hv = (float)((double)atan2f(dot3(a, x), dot3(b, x))/(2.0f*MI_PI_D));
+            hu = dt/d_len;                          /* hit->v (angle around the axis) is recomputed from the hit point at shading time */
             tmin = dist = t;
           }
         }
       }
     }
-    /* the reference writes u/v as soon as a root is accepted, then commits dist/prim if t > min_dist */
-    hit.u = hu; hit.v = hv;
     if((linestrip && tmin > 1e-3f) || (!linestrip && tmin > 0.0f))
     {
-      hit.dist = tmin; hit.prim = prim;
+      hit.dist = tmin; hit.prim = prim; hit.u = hu; hit.v = 0.0f;
     }
   }
 }
 
-__device__ __forceinline__ void triquad_intersect(const DPrim &p, uint32_t type, const V3 o, const V3 d, Hit &hit, uint32_t prim)
+struct PrimRegs { float4 q0, q1, q2, q3; };   /* one DPrim as four 16-byte loads: v0.xyz v1.x | v1.yz v2.xy | v2.z v3.xyz | type pad */
+__device__ __forceinline__ PrimRegs prim_load(const DPrim *prims, uint32_t prim)
+{
+  const float4 *q = (const float4 *)(prims + prim);
+  PrimRegs r; r.q0 = q[0]; r.q1 = q[1]; r.q2 = q[2]; r.q3 = q[3];
+  return r;
+}
+
+__device__ __forceinline__ void triquad_intersect(const PrimRegs &r, uint32_t type, const V3 o, const V3 d, Hit &hit, uint32_t prim)
 { /* prims_intersect for tris and quads, src/prims.c:645-663: quad = tri(v0,v1,v2), and only if that misses tri(v0,v2,v3).
      Both triangles are evaluated without branches (same arithmetic as geo_tri_intersect, include/geo/triangle.h:263-305)
      and the reference's priority is applied afterwards, so a wave does not diverge on which half was hit. */
-  const V3 v0 = ld3(p.v[0]), v1 = ld3(p.v[1]), v2 = ld3(p.v[2]), v3 = ld3(p.v[3]);
+  const V3 v0 = mk3(r.q0.x, r.q0.y, r.q0.z), v1 = mk3(r.q0.w, r.q1.x, r.q1.y), v2 = mk3(r.q1.z, r.q1.w, r.q2.x), v3 = mk3(r.q2.y, r.q2.z, r.q2.w);
   const V3 tv = sub3(o, v0);
   const V3 e02 = sub3(v2, v0);
   /* triangle A: edge1 = v1-v0, edge2 = v2-v0 */
@@ -288,20 +295,15 @@ __device__ __forceinline__ void triquad_intersect(const DPrim &p, uint32_t type,
   }
 }
 
-__device__ __forceinline__ void prim_intersect(const DPrim *prims, uint32_t prim, const V3 o, const V3 d, uint32_t ignore, Hit &hit)
-{ /* prims_intersect, src/prims.c:638-672 */
+__device__ __forceinline__ void analytic_intersect(const DPrim *prims, uint32_t prim, const V3 o, const V3 d, uint32_t ignore, Hit &hit)
+{ /* prims_intersect for spheres and lines, src/prims.c:665-668 */
   const DPrim &p = prims[prim];
-  const uint32_t type = p.type;
-  if(type >= MI_PRIM_TRI)
-  {
-    if(prim != ignore) triquad_intersect(p, type, o, d, hit, prim);   /* triangle.h:271 */
-  }
-  else if(type == MI_PRIM_SPHERE)
+  if(p.type == MI_PRIM_SPHERE)
   { /* geo_sphere_intersect, include/geo/sphere.h:146-166; u,v are recomputed at shading time */
     const float t = sphere_t(ld3(p.v[0]), p.v[1][0], o, d);
     if(t > 0.0f && t < hit.dist) { hit.dist = t; hit.prim = prim; }
   }
-  else if(type == MI_PRIM_LINE) line_intersect(p, o, d, hit, prim, ignore);
+  else if(p.type == MI_PRIM_LINE) line_intersect(p, o, d, hit, prim, ignore);
 }
 
 /* ------------------------------------------------------------------------------------------ traversal */
@@ -330,23 +332,42 @@ __device__ __forceinline__ uint2 stack_pop(const Lds &lds, int sp)
 
 #define SEL4(n, a0, a1, a2, a3) ((n) == 0 ? (a0) : (n) == 1 ? (a1) : (n) == 2 ? (a2) : (a3))
 
-template<int BLOCK, int STACK>
-__device__ __forceinline__ void accel_intersect(const Lds &lds, const DPrim *prims, const V3 o, const V3 d, uint32_t ignore,
-                                                Hit &hit, uint32_t *cnt)
-{ /* accel_intersect, src/accel.d/qbvhmp.c:1262-1390 (static boxes), as a "while-while" loop: every lane first
-     descends inner nodes until it holds a leaf, then all lanes intersect their leaves together */
+struct TraceState
+{ /* resumable traversal of one ray: survives between rounds so that a wave can re-fill idle lanes in between */
+  int sp;
+  uint32_t current;
+  bool done;
+  float idx, idy, idz;   /* 1/dir, computed once per ray (qbvhmp.c:1291-1295) */
+};
+
+__device__ __forceinline__ void trace_begin(TraceState &ts, const V3 d, uint32_t *cnt)
+{
   cnt[0]++;
+  ts.idx = 1.0f/d.x; ts.idy = 1.0f/d.y; ts.idz = 1.0f/d.z;
+  ts.sp = 0;
+  ts.current = 0;      /* node 0 = root */
+  ts.done = false;
+}
+
+/* one "while-while" round of accel_intersect (src/accel.d/qbvhmp.c:1262-1390, static boxes): descend inner nodes until this
+ * lane holds a leaf (or runs out of work), then intersect that leaf and pop the next subtree */
+template<int BLOCK, int STACK>
+__device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, const V3 o, const V3 d, uint32_t ignore,
+                                            Hit &hit, TraceState &ts, uint32_t *cnt)
+{
   const uint32_t near_x = __float_as_uint(d.x) >> 31, near_y = __float_as_uint(d.y) >> 31, near_z = __float_as_uint(d.z) >> 31;
   const uint32_t nearbits = near_x | (near_y << 1) | (near_z << 2);
-  const float idx = 1.0f/d.x, idy = 1.0f/d.y, idz = 1.0f/d.z;
+  const float idx = ts.idx, idy = ts.idy, idz = ts.idz;
   const uint32_t N = lds.num_nodes;
-  int sp = 0;
-  uint32_t current = 0;       /* node 0 = root */
-  bool done = false;
-  while(!done)
+  int sp = ts.sp;
+  uint32_t current = ts.done ? MI_LEAF32 : ts.current;
+  bool done = ts.done;
   {
     while(!(current & MI_LEAF32))
     {
+#ifdef MI_PROFILE_LOOPS
+      if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) cnt[4]++;   /* wave-level inner iterations */
+#endif
       const uint32_t node = current;
       /* 4 child slabs, qbvhmp.c:1188-1246; SSE min/max semantics (second operand on NaN) via ordered compares */
       const float4 mnx = lds.nodes[0*N + node], mny = lds.nodes[1*N + node], mnz = lds.nodes[2*N + node];
@@ -414,11 +435,36 @@ __device__ __forceinline__ void accel_intersect(const Lds &lds, const DPrim *pri
     { /* leaf: intersect its primitives (qbvhmp.c:1366-1379), then pop */
       uint32_t idxp = (current ^ MI_LEAF32) >> 5;
       const uint32_t num = current & 31u;
+      /* triangles and quads first (software pipelined: the next primitive's 64 B are in flight while this one is
+         intersected); spheres / cones / cylinders of this leaf are remembered and intersected afterwards, so that the
+         wave runs that rare, long code once per leaf round instead of once per primitive slot. Every primitive of the
+         leaf is still tested exactly once against the running closest hit (prims_intersect, src/prims.c:638-672). */
+      uint32_t analytic = 0;
+      PrimRegs cur = prim_load(prims, num ? idxp : 0);
       for(uint32_t i=0;i<num;i++)
       {
+#ifdef MI_PROFILE_LOOPS
+        if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) cnt[5]++;   /* wave-level leaf slots */
+#endif
+        PrimRegs nxt = cur;
+        if(i + 1 < num) nxt = prim_load(prims, idxp + i + 1);
         cnt[3]++;
-        prim_intersect(prims, idxp, o, d, ignore, hit);
-        idxp++;
+        const uint32_t type = __float_as_uint(cur.q3.x);
+        if(type >= MI_PRIM_TRI)
+        {
+          if(idxp + i != ignore) triquad_intersect(cur, type, o, d, hit, idxp + i);   /* triangle.h:271 */
+        }
+        else analytic |= 1u << i;
+        cur = nxt;
+      }
+      while(analytic)
+      {
+#ifdef MI_PROFILE_LOOPS
+        if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) cnt[6]++;   /* wave-level analytic passes */
+#endif
+        const uint32_t i = __ffs(analytic) - 1;
+        analytic &= analytic - 1;
+        analytic_intersect(prims, idxp + i, o, d, ignore, hit);
       }
       current = MI_LEAF32;
       done = true;
@@ -430,6 +476,16 @@ __device__ __forceinline__ void accel_intersect(const Lds &lds, const DPrim *pri
       }
     }
   }
+  ts.sp = sp; ts.current = current; ts.done = done;
+}
+
+template<int BLOCK, int STACK>
+__device__ __forceinline__ void accel_intersect(const Lds &lds, const DPrim *prims, const V3 o, const V3 d, uint32_t ignore,
+                                                Hit &hit, uint32_t *cnt)
+{ /* closest hit for one ray per lane; the wave iterates rounds until every lane is done */
+  TraceState ts;
+  trace_begin(ts, d, cnt);
+  while(!ts.done) trace_round<BLOCK, STACK>(lds, prims, o, d, ignore, hit, ts, cnt);
 }
 
 /* ------------------------------------------------------------------------------------------ geometry at the hit */
@@ -496,16 +552,31 @@ __device__ __forceinline__ void surface_setup(const DScene &sc, uint32_t prim, c
     sf.n = sf.gn;
   }
   else if(type == MI_PRIM_LINE)
-  { /* line.h:123-161 */
-    const V3 v0 = ld3(p.v[0]), v1 = ld3(p.v[1]);
-    const float r0 = p.v[2][0], r1 = p.v[2][1];
+  { /* line.h:123-161; layout of the record: see line_intersect */
+    const float *f = &p.v[0][0];
+    const V3 v0 = mk3(f[0], f[1], f[2]);
+    const float r0 = f[3], r1 = f[4];
+    const V3 v1 = mk3(__uint_as_float(ps.n[2]), __uint_as_float(ps.n[3]), __uint_as_float(ps.uv[2]));
+    V3 d = sub3(v1, v0);
+    const float ilen_d = 1.0f/sqrtf(dot3(d, d));
+    d = scale3(d, ilen_d);
+    V3 a, b; get_onb(d, a, b);
+    if(fabsf(r1-r0) < 1e-3)
+    { /* cylinder: hit.u/hit.v carry out[1], out[2] of the intersection (line.h:484-486) */
+      const float out1 = sf.u, out2 = sf.v;
+      sf.v = (float)((double)atan2f(out1, out2)/(2.0f*MI_PI_D));
+      sf.u = dot3(sub3(sf.x, v0), d)*ilen_d;
+    }
+    else
+    { /* cone: line.h:445-449 with x = ray.pos + t*ray.dir - v0 == sf.x - v0 */
+      const V3 dc = mk3(f[6], f[7], f[8]);
+      V3 ac, bc; get_onb(dc, ac, bc);
+      const V3 x = sub3(sf.x, v0);
+      sf.v = (float)((double)atan2f(dot3(ac, x), dot3(bc, x))/(2.0f*MI_PI_D));
+    }
     if(fabsf(r0-r1) < 1e-3f && r0 < 0.01f) { sf.n = sf.gn = mk3(0, 0, 0); }
     else
     {
-      V3 d = sub3(v1, v0);
-      const float ilen_d = 1.0f/sqrtf(dot3(d, d));
-      d = scale3(d, ilen_d);
-      V3 a, b; get_onb(d, a, b);
       const float phi = (float)(2.0*MI_PI_D*(double)sf.v);
       float sinphi, cosphi;
       sincosf(phi, &sinphi, &cosphi);
@@ -1180,7 +1251,7 @@ __device__ __forceinline__ V3 tri_retime(const V3 v0, const V3 v1, const V3 v2, 
   return mk3(w*v0.x + v*v1.x + u*v2.x, w*v0.y + v*v1.y + u*v2.y, w*v0.z + v*v1.z + u*v2.z);
 }
 
-__device__ __forceinline__ V3 prim_sample(const DPrim &p, float r0, float r1, float &hu, float &hv)
+__device__ __forceinline__ V3 prim_sample(const DPrim &p, const DPrimShade &psh, float r0, float r1, float &hu, float &hv)
 { /* prims_sample + prims_retime, src/prims.c:178-252 */
   const uint32_t type = p.type;
   if(type == MI_PRIM_QUAD)
@@ -1206,8 +1277,9 @@ __device__ __forceinline__ V3 prim_sample(const DPrim &p, float r0, float r1, fl
   }
   /* line: geo_line_retime, include/geo/line.h:88-121 */
   hu = r0; hv = r1;
-  const V3 v0 = ld3(p.v[0]), v1 = ld3(p.v[1]);
-  const float lr0 = p.v[2][0], lr1 = p.v[2][1];
+  const float *f = &p.v[0][0];
+  const V3 v0 = mk3(f[0], f[1], f[2]), v1 = mk3(__uint_as_float(psh.n[2]), __uint_as_float(psh.n[3]), __uint_as_float(psh.uv[2]));
+  const float lr0 = f[3], lr1 = f[4];
   float y;
   if(fabsf(lr1-lr0) < 1e-3f) y = hu;
   else y = (sqrtf((lr1*lr1 - lr0*lr0)*hu + lr0*lr0) - lr0)/(lr1-lr0);

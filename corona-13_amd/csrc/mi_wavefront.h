@@ -27,25 +27,37 @@ enum
   F_HITPRIM, F_HITDIST, F_HITU, F_HITV, F_SHHITPRIM, F_SHHITDIST,
   F_COUNT
 };
+#define WF_LIVE_SHARDS 256
 #define WF_ACTIVE 1u
 #define WF_SHADOW 2u
 
 struct WFPool
 {
-  uint32_t *s;                      /* [F_COUNT][P] */
+  uint32_t *s;                      /* [P/64][F_COUNT][64] */
   uint32_t P;
   unsigned long long *trace_head;   /* next ray job */
-  unsigned long long *live;         /* rays pending after wf_logic */
+  unsigned long long *live;         /* [WF_LIVE_SHARDS] set to 1 by workgroups that leave rays pending after wf_logic */
 };
 
-#define WF(f) pool.s[(size_t)(f)*pool.P + slot]
+/* AoSoA: tiles of 64 slots, [tile][field][lane]. A wave's 64 slots are one contiguous 11 KB block (one or two pages)
+ * while every field access is still a coalesced 256-B row. A plain [field][P] layout touches F_COUNT pages 8 MB
+ * apart per wave and is TLB-bound (measured: wf_logic 2.4x slower, and slower the larger the pool). */
+#define WF(f) pool.s[((size_t)(slot >> 6)*F_COUNT + (f))*64 + (slot & 63u)]
 #define WFF(f) __uint_as_float(WF(f))
 
+#define WF_LOGIC_BLOCK 256
+#ifndef WF_REFILL_AT
+#define WF_REFILL_AT 48            /* re-fill a wave's idle lanes once fewer than this many rays are still in flight */
+#endif
+#define WF_CHUNK 512              /* ray jobs a wave claims with one global atomic */
+
 template<bool PTDL>
-__global__ __launch_bounds__(256) void wf_logic(DScene sc, WFPool pool, unsigned long long first, unsigned long long count,
-                                                const uint32_t *shape_material, const float *shape_L)
+__global__ __launch_bounds__(WF_LOGIC_BLOCK) void wf_logic(DScene sc, WFPool pool, unsigned long long first, unsigned long long count,
+                                                const uint32_t *shape_material, const float *shape_L, int ablate)
 {
-  const uint32_t slot = blockIdx.x*256 + threadIdx.x;
+  __shared__ unsigned int blk_want;
+  __shared__ unsigned long long blk_base;
+  const uint32_t slot = blockIdx.x*WF_LOGIC_BLOCK + threadIdx.x;
   const bool inrange = slot < pool.P;
   const unsigned lane = __lane_id();
   uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -93,38 +105,51 @@ __global__ __launch_bounds__(256) void wf_logic(DScene sc, WFPool pool, unsigned
     ps.prev_mode = 0; ps.prev_x = mk3(0, 0, 0);
     Hit hit;
     hit.prim = WF(F_HITPRIM); hit.dist = WFF(F_HITDIST); hit.u = WFF(F_HITU); hit.v = WFF(F_HITV);
-    path_shade<false, PTDL>(sc, ps, hit, shape_material, shape_L, nullptr, cnt, splat);
+    if(ablate & 1) ps.active = 0;
+    else path_shade<false, PTDL>(sc, ps, hit, shape_material, shape_L, nullptr, cnt, splat);
   }
   splat_wave(sc, splat.pending, ps.pixel_i, ps.pixel_j, splat.c0, splat.c1, splat.c2);
 
-  /* ---- re-fill dead slots (wave-level compaction of the work queue, as in the megakernel) */
+  /* ---- re-fill dead slots: ONE global atomic per workgroup (same-address atomics serialise), ranks via LDS + ballot */
   {
+    if(threadIdx.x == 0) blk_want = 0;
+    __syncthreads();
     const bool want = inrange && !ps.active && !ps.sh_pending;
     const unsigned long long m = __ballot(want);
-    if(m)
+    const int leader = m ? __ffsll((long long)m) - 1 : 0;
+    unsigned int wave_off = 0;
+    if(m && (int)lane == leader) wave_off = atomicAdd(&blk_want, (unsigned int)__popcll(m));
+    wave_off = __shfl(wave_off, leader);
+    __syncthreads();
+    /* this workgroup's own part of the index range and its own progress counter: an uncontended atomic */
+    const unsigned long long nb = gridDim.x;
+    const unsigned long long lo = count/nb*blockIdx.x + (blockIdx.x < count%nb ? blockIdx.x : count%nb);
+    const unsigned long long hi = lo + count/nb + (blockIdx.x < count%nb ? 1 : 0);
+    if(threadIdx.x == 0)
     {
-      const unsigned n = __popcll(m);
-      unsigned long long base = 0;
-      const int leader = __ffsll((long long)m) - 1;
-      if((int)lane == leader)
+      unsigned long long base = hi;
+      if(blk_want)
       {
-        /* do not touch the counter once it is past the end: keeps it from wrapping over many idle passes */
-        base = *(volatile unsigned long long *)sc.work;
-        if(base < count) base = atomicAdd(sc.work, (unsigned long long)n);
+        base = lo + *(volatile unsigned long long *)(sc.work + blockIdx.x);
+        if(base < hi) base = lo + atomicAdd(sc.work + blockIdx.x, (unsigned long long)blk_want);
       }
-      base = __shfl(base, leader);
-      if(want)
+      blk_base = base;
+    }
+    __syncthreads();
+    if(want)
+    {
+      const unsigned long long i = blk_base + wave_off + __popcll(m & ((1ull << lane) - 1ull));
+      if(i < hi)
       {
-        const unsigned rank = __popcll(m & ((1ull << lane) - 1ull));
-        const unsigned long long i = base + rank;
-        if(i < count) path_generate<false>(sc, ps, first + i, nullptr, cnt);
+        if(ablate & 2) { ps.active = 1; ps.org = mk3(16.7f, 0.25f, 6.35f); ps.dir = mk3(-0.95f, -0.01f, -0.29f); ps.ignore = MI_NOPRIM; ps.length = 1; ps.throughput = 1.0f; ps.pdf = 1.0f; ps.pdfprod = 1.0; ps.lambda = 500.0f; ps.scramble = 0.5f; ps.rng.s0 = i; ps.rng.s1 = 7; ps.prev_cos = 1.0f; ps.prev_throughput = 1.0f; ps.cur_ior = 1.0f; ps.media.ids = 0; ps.media.count = 0; ps.media.broken = 0; ps.prev_material_modes = 0; }
+        else path_generate<false>(sc, ps, first + i, nullptr, cnt);
       }
     }
   }
 
   /* ---- store the slot */
   const uint32_t nflags = (ps.active ? WF_ACTIVE : 0u) | (ps.sh_pending ? WF_SHADOW : 0u);
-  if(inrange && (flags | nflags))
+  if(inrange && (flags | nflags) && !((ablate & 4) && slot > 64))
   {
     WF(F_FLAGS) = nflags;
     if(nflags)
@@ -155,17 +180,15 @@ __global__ __launch_bounds__(256) void wf_logic(DScene sc, WFPool pool, unsigned
       WF(F_SHLIGHT) = ps.sh_light; WF(F_SHIGNORE) = ps.sh_ignore;
     }
   }
-  /* ---- rays pending for wf_trace + work counters */
-  {
-    const unsigned long long pend = __popcll(__ballot(nflags != 0));
-    if(lane == 0 && pend) atomicAdd(pool.live, pend);
-  }
+  /* ---- rays pending for wf_trace: a flag per workgroup shard (same-address stores serialise like atomics) + work counters */
+  if(__syncthreads_or(nflags != 0) && threadIdx.x == 0) *(volatile unsigned long long *)(pool.live + (blockIdx.x % WF_LIVE_SHARDS)) = 1ull;
+  unsigned long long *shard = sc.counters + (size_t)(blockIdx.x % MI_COUNTER_SHARDS)*8;
 #pragma unroll
   for(int k=4;k<7;k++)
   {
     unsigned long long c = cnt[k];
     for(int off=32;off>0;off>>=1) c += __shfl_down(c, off);
-    if(lane == 0 && c) atomicAdd(sc.counters + k, c);
+    if(lane == 0 && c) atomicAdd(shard + k, c);
   }
 }
 
@@ -191,9 +214,10 @@ __global__ __launch_bounds__(BLOCK) void wf_trace(DScene sc, WFPool pool, uint2 
   const unsigned long long njobs = PTDL ? 2ull*pool.P : pool.P;
   uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   bool busy = false, exhausted = false;
+  unsigned long long next = 0, chunk_end = 0;        /* wave-uniform: this wave's claimed part of the job range */
   uint32_t slot = 0, is_shadow = 0;
   TraceState ts;
-  ts.done = true; ts.sp = 0; ts.current = MI_LEAF32;
+  ts.done = true; ts.sp = 0; ts.current = MI_LEAF32; ts.idx = ts.idy = ts.idz = 1.0f;
   V3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
   uint32_t ignore = MI_NOPRIM;
   Hit hit;
@@ -208,60 +232,71 @@ __global__ __launch_bounds__(BLOCK) void wf_trace(DScene sc, WFPool pool, uint2 
       else { WF(F_HITPRIM) = hit.prim; WF(F_HITDIST) = __float_as_uint(hit.dist); WF(F_HITU) = __float_as_uint(hit.u); WF(F_HITV) = __float_as_uint(hit.v); }
       busy = false;
     }
-    /* re-fill idle lanes: up to four pulls so that empty slots (dead paths) do not starve the wave */
+    /* re-fill idle lanes from this wave's chunk of the job range; a new chunk costs one global atomic per WF_CHUNK jobs.
+       Up to four pulls so that empty slots (dead paths) do not starve the wave. */
     for(int pull=0;pull<4 && !exhausted;pull++)
     {
       const unsigned long long m = __ballot(!busy);
       if(!m) break;
-      unsigned long long base = 0;
-      const int leader = __ffsll((long long)m) - 1;
-      if((int)lane == leader) base = atomicAdd(pool.trace_head, (unsigned long long)__popcll(m));
-      base = __shfl(base, leader);
-      if(base >= njobs) { exhausted = true; break; }
-      if(!busy)
+      if(next >= chunk_end)
       {
-        const unsigned long long j = base + __popcll(m & ((1ull << lane) - 1ull));
-        if(j < njobs)
+        unsigned long long base = 0;
+        if(lane == 0) base = atomicAdd(pool.trace_head, (unsigned long long)WF_CHUNK);
+        base = __shfl(base, 0);
+        if(base >= njobs) { exhausted = true; break; }
+        next = base; chunk_end = base + WF_CHUNK < njobs ? base + WF_CHUNK : njobs;
+      }
+      const unsigned long long avail = chunk_end - next;
+      const unsigned rank = __popcll(m & ((1ull << lane) - 1ull));
+      const unsigned take = (unsigned)(__popcll(m) < avail ? __popcll(m) : avail);
+      if(!busy && rank < take)
+      {
+        const unsigned long long j = next + rank;
+        is_shadow = (PTDL && j >= pool.P) ? 1u : 0u;
+        slot = (uint32_t)(is_shadow ? j - pool.P : j);
+        const uint32_t flags = WF(F_FLAGS);
+        if(flags & (is_shadow ? WF_SHADOW : WF_ACTIVE))
         {
-          is_shadow = (PTDL && j >= pool.P) ? 1u : 0u;
-          slot = (uint32_t)(is_shadow ? j - pool.P : j);
-          const uint32_t flags = WF(F_FLAGS);
-          if(flags & (is_shadow ? WF_SHADOW : WF_ACTIVE))
+          if(is_shadow)
           {
-            if(is_shadow)
-            {
-              o = mk3(WFF(F_SHOX), WFF(F_SHOY), WFF(F_SHOZ)); d = mk3(WFF(F_SHDX), WFF(F_SHDY), WFF(F_SHDZ));
-              ignore = WF(F_SHIGNORE); hit.dist = WFF(F_SHDIST);
-            }
-            else
-            {
-              o = mk3(WFF(F_ORGX), WFF(F_ORGY), WFF(F_ORGZ)); d = mk3(WFF(F_DIRX), WFF(F_DIRY), WFF(F_DIRZ));
-              ignore = WF(F_IGNORE); hit.dist = FLT_MAX;
-            }
-            hit.prim = MI_NOPRIM; hit.u = hit.v = 0.0f;
-            trace_begin(ts, cnt);
-            busy = true;
+            o = mk3(WFF(F_SHOX), WFF(F_SHOY), WFF(F_SHOZ)); d = mk3(WFF(F_SHDX), WFF(F_SHDY), WFF(F_SHDZ));
+            ignore = WF(F_SHIGNORE); hit.dist = WFF(F_SHDIST);
           }
+          else
+          {
+            o = mk3(WFF(F_ORGX), WFF(F_ORGY), WFF(F_ORGZ)); d = mk3(WFF(F_DIRX), WFF(F_DIRY), WFF(F_DIRZ));
+            ignore = WF(F_IGNORE); hit.dist = FLT_MAX;
+          }
+          hit.prim = MI_NOPRIM; hit.u = hit.v = 0.0f;
+          trace_begin(ts, d, cnt);
+          busy = true;
         }
       }
+      next += take;
     }
     const unsigned long long bm = __ballot(busy);
     if(!bm) { if(exhausted) break; else continue; }
     /* traverse until a quarter of the wave is idle again (or, once the queue is dry, until everybody is done) */
-    const int refill_at = exhausted ? 0 : 48;
+    const int refill_at = exhausted ? 0 : WF_REFILL_AT;
     do
     {
       trace_round<BLOCK, STACK>(lds, sc.prims, o, d, ignore, hit, ts, cnt);
     }
     while(__popcll(__ballot(busy && !ts.done)) > refill_at);
   }
-  atomicMax(sc.counters + 7, (unsigned long long)cnt[7]);
+  unsigned long long *shard = sc.counters + (size_t)(blockIdx.x % MI_COUNTER_SHARDS)*8;
+  atomicMax(shard + 7, (unsigned long long)cnt[7]);
+#ifdef MI_PROFILE_LOOPS
+  const int nflush = 7;
+#else
+  const int nflush = 4;
+#endif
 #pragma unroll
-  for(int k=0;k<4;k++)
+  for(int k=0;k<nflush;k++)
   {
     unsigned long long c = cnt[k];
     for(int off=32;off>0;off>>=1) c += __shfl_down(c, off);
-    if(lane == 0 && c) atomicAdd(sc.counters + k, c);
+    if(lane == 0 && c) atomicAdd(shard + k, c);
   }
 }
 

@@ -194,7 +194,8 @@ int  mi_scene_set_framebuffer(mi_scene *s, float *device_fb);
 int  mi_scene_set_stream(mi_scene *s, void *hip_stream);
 
 /* Trace path indices [first, first+count) and splat them into the device framebuffer.
- * Asynchronous on the scene's stream.  replaces: src/view.c:643-645 (pool dispatch + barrier). */
+ * Stream ordered: returns once all work is queued on the scene's stream (the wavefront pipeline polls its own
+ * queue counter while doing so); use mi_sync() or stream order to wait.  replaces: src/view.c:643-645. */
 int  mi_render(mi_scene *s, uint64_t first_index, uint64_t count);
 
 /* Block until all queued work of this scene has finished. */
@@ -245,6 +246,9 @@ int  mi_trace_paths(mi_scene *s, uint64_t first_index, uint64_t count, mi_path_r
 /* Time of the last mi_render launch on the device in milliseconds (HIP events on the scene's
  * stream), and kernel launches since creation. For bench.py's roofline figure. */
 int  mi_last_kernel_ms(mi_scene *s, float *ms);
+/* number of launches of that kernel the last mi_render needed (1 for the megakernel, one per bounce batch for the
+ * wavefront pipeline, whose mi_last_kernel_ms is the average duration of its traversal kernel) */
+int  mi_last_kernel_launches(mi_scene *s, uint64_t *launches);
 
 void mi_scene_destroy(mi_scene *s);
 void mi_shutdown(void);
