@@ -400,9 +400,10 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
     { mi_scene_destroy(s); return fail(MI_ERR_NOMEM, "cannot allocate the traversal stack overflow area"); }
   }
   {
-    /* wavefront pool: CORONA_MI_MODE=mega selects the persistent megakernel, CORONA_MI_POOL the number of path slots */
+    /* kernel organisation: the persistent megakernel (default, faster) or the wavefront pipeline (CORONA_MI_MODE=wave,
+       CORONA_MI_POOL = number of path slots) */
     const char *mode = getenv("CORONA_MI_MODE");
-    s->wavefront = !(mode && !strcmp(mode, "mega"));
+    s->wavefront = (mode && !strcmp(mode, "wave"));
     const char *pe = getenv("CORONA_MI_POOL");
     uint64_t P = pe ? strtoull(pe, 0, 10) : (1ull << 21);
     if(P < 65536) P = 65536;
@@ -454,16 +455,15 @@ static int render_wavefront(mi_scene *s, uint64_t first_index, uint64_t count)
   HIPCHK(hipMemsetAsync(s->d_work, 0, (size_t)MI_WORK_SHARDS*sizeof(unsigned long long), s->stream));
   HIPCHK(hipMemsetAsync(s->d_pool, 0, (size_t)F_COUNT*P*sizeof(uint32_t), s->stream));   /* all slots idle */
   const int lgrid = (int)(P/WF_LOGIC_BLOCK);
-  const int ablate = getenv("CORONA_MI_ABLATE") ? atoi(getenv("CORONA_MI_ABLATE")) : 0;   /* development only */
   s->kernel_ms_total = 0.0; s->kernel_launches_last = 0; s->trace_ms_sum = 0.0f; s->trace_ms_n = 0;
   int timed_it = -1;
   for(int it=0;;it++)
   {
     HIPCHK(hipMemsetAsync(s->d_wfcnt, 0, (1 + WF_LIVE_SHARDS)*sizeof(unsigned long long), s->stream));
     if(ptdl) hipLaunchKernelGGL((wf_logic<true>), dim3(lgrid), dim3(WF_LOGIC_BLOCK), 0, s->stream, s->d, s->pool, (unsigned long long)first_index,
-                                (unsigned long long)count, (const uint32_t *)s->d_shape_material, (const float *)s->d_shape_L, ablate);
+                                (unsigned long long)count, (const uint32_t *)s->d_shape_material, (const float *)s->d_shape_L);
     else     hipLaunchKernelGGL((wf_logic<false>), dim3(lgrid), dim3(WF_LOGIC_BLOCK), 0, s->stream, s->d, s->pool, (unsigned long long)first_index,
-                                (unsigned long long)count, (const uint32_t *)s->d_shape_material, (const float *)s->d_shape_L, ablate);
+                                (unsigned long long)count, (const uint32_t *)s->d_shape_material, (const float *)s->d_shape_L);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(s->h_live + (size_t)(it & 7)*WF_LIVE_SHARDS, s->pool.live, WF_LIVE_SHARDS*sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipEventRecord(s->ev_live[it & 7], s->stream));

@@ -482,7 +482,7 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
 template<int BLOCK, int STACK>
 __device__ __forceinline__ void accel_intersect(const Lds &lds, const DPrim *prims, const V3 o, const V3 d, uint32_t ignore,
                                                 Hit &hit, uint32_t *cnt)
-{ /* closest hit for one ray per lane; the wave iterates rounds until every lane is done */
+{ /* closest hit for one ray per lane; the wave iterates until every lane is done */
   TraceState ts;
   trace_begin(ts, d, cnt);
   while(!ts.done) trace_round<BLOCK, STACK>(lds, prims, o, d, ignore, hit, ts, cnt);

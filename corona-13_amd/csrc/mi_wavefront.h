@@ -12,6 +12,11 @@
  * (profiles/r01_pmc_summary.json: 21 % lane utilisation) because every lane carries exactly one ray through
  * traversal AND shading. Splitting the two removes the coupling; the price is path state traffic
  * (~45 dwords read + written per ray, coalesced).
+ *
+ * Status (round 1, measured on MI355X, cfg 2): 1029 Msamples/s against 1213 for the megakernel -- wf_trace alone costs
+ * what the whole megakernel iteration costs (traversal is ~56 % VALU-issue bound in both), so the split only adds the
+ * state traffic. It is kept as an alternative organisation (CORONA_MI_MODE=wave) with identical results (same parity
+ * tests), and as the vehicle for per-material shading queues / ray sorting in later rounds.
  */
 #ifndef MI_WAVEFRONT_H
 #define MI_WAVEFRONT_H
@@ -53,7 +58,7 @@ struct WFPool
 
 template<bool PTDL>
 __global__ __launch_bounds__(WF_LOGIC_BLOCK) void wf_logic(DScene sc, WFPool pool, unsigned long long first, unsigned long long count,
-                                                const uint32_t *shape_material, const float *shape_L, int ablate)
+                                                const uint32_t *shape_material, const float *shape_L)
 {
   __shared__ unsigned int blk_want;
   __shared__ unsigned long long blk_base;
@@ -105,8 +110,7 @@ __global__ __launch_bounds__(WF_LOGIC_BLOCK) void wf_logic(DScene sc, WFPool poo
     ps.prev_mode = 0; ps.prev_x = mk3(0, 0, 0);
     Hit hit;
     hit.prim = WF(F_HITPRIM); hit.dist = WFF(F_HITDIST); hit.u = WFF(F_HITU); hit.v = WFF(F_HITV);
-    if(ablate & 1) ps.active = 0;
-    else path_shade<false, PTDL>(sc, ps, hit, shape_material, shape_L, nullptr, cnt, splat);
+    path_shade<false, PTDL>(sc, ps, hit, shape_material, shape_L, nullptr, cnt, splat);
   }
   splat_wave(sc, splat.pending, ps.pixel_i, ps.pixel_j, splat.c0, splat.c1, splat.c2);
 
@@ -141,15 +145,14 @@ __global__ __launch_bounds__(WF_LOGIC_BLOCK) void wf_logic(DScene sc, WFPool poo
       const unsigned long long i = blk_base + wave_off + __popcll(m & ((1ull << lane) - 1ull));
       if(i < hi)
       {
-        if(ablate & 2) { ps.active = 1; ps.org = mk3(16.7f, 0.25f, 6.35f); ps.dir = mk3(-0.95f, -0.01f, -0.29f); ps.ignore = MI_NOPRIM; ps.length = 1; ps.throughput = 1.0f; ps.pdf = 1.0f; ps.pdfprod = 1.0; ps.lambda = 500.0f; ps.scramble = 0.5f; ps.rng.s0 = i; ps.rng.s1 = 7; ps.prev_cos = 1.0f; ps.prev_throughput = 1.0f; ps.cur_ior = 1.0f; ps.media.ids = 0; ps.media.count = 0; ps.media.broken = 0; ps.prev_material_modes = 0; }
-        else path_generate<false>(sc, ps, first + i, nullptr, cnt);
+        path_generate<false>(sc, ps, first + i, nullptr, cnt);
       }
     }
   }
 
   /* ---- store the slot */
   const uint32_t nflags = (ps.active ? WF_ACTIVE : 0u) | (ps.sh_pending ? WF_SHADOW : 0u);
-  if(inrange && (flags | nflags) && !((ablate & 4) && slot > 64))
+  if(inrange && (flags | nflags))
   {
     WF(F_FLAGS) = nflags;
     if(nflags)
