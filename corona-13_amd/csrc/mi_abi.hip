@@ -271,7 +271,15 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   for(uint32_t n=0;n<N;n++)
   {
     const mi_node &nd = h->nodes[n];
-    for(int k=0;k<6;k++) for(int c=0;c<4;c++) nodes[((size_t)k*N + n)*4 + c] = nd.aabb[k][c];
+    /* fields 0..2 hold the lower, 3..5 the upper plane per axis. The reference marks empty children by an inverted box
+       (min = FLT_MAX, max = -FLT_MAX, qbvhmp.c:1095-1112) and evaluates min(t0,t1)/max(t0,t1), which is symmetric in the two
+       planes; the kernel picks entry/exit planes by ray sign instead, so inverted slabs are stored in ascending order */
+    for(int k=0;k<3;k++) for(int c=0;c<4;c++)
+    {
+      const float b0 = nd.aabb[k][c], b1 = nd.aabb[k+3][c];
+      nodes[((size_t)k*N + n)*4 + c]     = b0 > b1 ? b1 : b0;
+      nodes[((size_t)(k+3)*N + n)*4 + c] = b0 > b1 ? b0 : b1;
+    }
     for(int c=0;c<4;c++)
     {
       uint32_t link;

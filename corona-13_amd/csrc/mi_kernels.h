@@ -330,7 +330,14 @@ __device__ __forceinline__ uint2 stack_pop(const Lds &lds, int sp)
   return lds.overflow[(size_t)(sp - STACK)*lds.overflow_stride];
 }
 
-#define SEL4(n, a0, a1, a2, a3) ((n) == 0 ? (a0) : (n) == 1 ? (a1) : (n) == 2 ? (a2) : (a3))
+typedef unsigned int mi_u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) mi_u32x2 lds_uint2;   /* typed LDS pointer: ds_read/ds_write instead of flat */
+template<int BLOCK, int STACK>
+__device__ __forceinline__ uint2 stack_top(const Lds &lds, const lds_uint2 *lstack, int sp)
+{
+  if(sp < STACK) { const mi_u32x2 v = lstack[sp*BLOCK]; return make_uint2(v.x, v.y); }
+  return lds.overflow[(size_t)(sp - STACK)*lds.overflow_stride];
+}
 
 struct TraceState
 { /* resumable traversal of one ray: survives between rounds so that a wave can re-fill idle lanes in between */
@@ -362,6 +369,10 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
   int sp = ts.sp;
   uint32_t current = ts.done ? MI_LEAF32 : ts.current;
   bool done = ts.done;
+  lds_uint2 *lstack = (lds_uint2 *)lds.stack;
+  /* near-plane field of each axis: max planes (fields 3..5) for negative directions */
+  const uint32_t offx = near_x ? 3u*N : 0u, offy = near_y ? 3u*N : 0u, offz = near_z ? 3u*N : 0u;
+  const bool slow = __any(isinf(idx) || isinf(idy) || isinf(idz));
   {
     while(!(current & MI_LEAF32))
     {
@@ -369,12 +380,29 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
       if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) cnt[4]++;   /* wave-level inner iterations */
 #endif
       const uint32_t node = current;
-      /* 4 child slabs, qbvhmp.c:1188-1246; SSE min/max semantics (second operand on NaN) via ordered compares */
-      const float4 mnx = lds.nodes[0*N + node], mny = lds.nodes[1*N + node], mnz = lds.nodes[2*N + node];
-      const float4 mxx = lds.nodes[3*N + node], mxy = lds.nodes[4*N + node], mxz = lds.nodes[5*N + node];
       const uint4 child = *(const uint4 *)&lds.nodes[6*N + node];
       float tm0, tm1, tm2, tm3;
       uint32_t mask = 0;
+      if(!slow)
+      { /* 4 child slabs, qbvhmp.c:1188-1246. The ray's sign bits pick the entry / exit plane of every slab, which is what
+           the reference's min(t0,t1) / max(t0,t1) evaluate to for finite 1/dir and b_min <= b_max (rounding is monotonic;
+           empty children are uploaded as [-FLT_MAX, FLT_MAX], see upload_nodes). That leaves v_max3/v_min3 chains
+           instead of 48 compare+select pairs (each pair costs a VCC hazard nop on gfx950). */
+        const float4 nx = lds.nodes[offx + node],       fx = lds.nodes[3*N - offx + node];
+        const float4 ny = lds.nodes[N + offy + node],   fy = lds.nodes[4*N - offy + node];
+        const float4 nz = lds.nodes[2*N + offz + node], fz = lds.nodes[5*N - offz + node];
+#define SLAB(J, C, TM) { \
+        const float lo = fmaxf(fmaxf(fmaxf((nx.C - o.x)*idx, (ny.C - o.y)*idy), (nz.C - o.z)*idz), 0.0f); \
+        const float hi = fminf(fminf(fminf((fx.C - o.x)*idx, (fy.C - o.y)*idy), (fz.C - o.z)*idz), hit.dist); \
+        TM = lo; mask |= (lo <= hi ? 1u : 0u) << (J); }
+        SLAB(0, x, tm0) SLAB(1, y, tm1) SLAB(2, z, tm2) SLAB(3, w, tm3)
+#undef SLAB
+      }
+      else
+      { /* a lane of this wave has a zero direction component (1/dir infinite): 0*inf NaNs are possible and the reference's
+           SSE min/max semantics (second operand on NaN) decide; evaluate them literally with ordered compares */
+        const float4 mnx = lds.nodes[0*N + node], mny = lds.nodes[1*N + node], mnz = lds.nodes[2*N + node];
+        const float4 mxx = lds.nodes[3*N + node], mxy = lds.nodes[4*N + node], mxz = lds.nodes[5*N + node];
 #define SLAB(J, X0, X1, Y0, Y1, Z0, Z1, TM) { \
         float lo = 0.0f, hi = hit.dist; \
         float t0 = ((X0) - o.x)*idx, t1 = ((X1) - o.x)*idx; \
@@ -387,36 +415,52 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
         mn = t0 < t1 ? t0 : t1; mx = t0 > t1 ? t0 : t1; \
         lo = lo > mn ? lo : mn; hi = hi < mx ? hi : mx; \
         TM = lo; mask |= (lo <= hi ? 1u : 0u) << (J); }
-      SLAB(0, mnx.x, mxx.x, mny.x, mxy.x, mnz.x, mxz.x, tm0)
-      SLAB(1, mnx.y, mxx.y, mny.y, mxy.y, mnz.y, mxz.y, tm1)
-      SLAB(2, mnx.z, mxx.z, mny.z, mxy.z, mnz.z, mxz.z, tm2)
-      SLAB(3, mnx.w, mxx.w, mny.w, mxy.w, mnz.w, mxz.w, tm3)
+        SLAB(0, mnx.x, mxx.x, mny.x, mxy.x, mnz.x, mxz.x, tm0)
+        SLAB(1, mnx.y, mxx.y, mny.y, mxy.y, mnz.y, mxz.y, tm1)
+        SLAB(2, mnx.z, mxx.z, mny.z, mxy.z, mnz.z, mxz.z, tm2)
+        SLAB(3, mnx.w, mxx.w, mny.w, mxy.w, mnz.w, mxz.w, tm3)
 #undef SLAB
+      }
       if(mask)
       {
         cnt[1]++;
         cnt[2] += __popc(mask);
-        /* front-to-back order from split axes and ray signs, qbvhmp.c:1313-1320 */
+        /* front-to-back order from split axes and ray signs, qbvhmp.c:1313-1320: the near half is children
+           {2*near0, 2*near0+1}, ordered by the sign along its own split axis; likewise the far half */
         const uint32_t ax = lds.axes[node];
         const uint32_t axis0 = ax & 3u;
-        const uint32_t near0 = (nearbits >> axis0) & 1u, far0 = near0 ^ 1u;
+        const bool near0 = (nearbits >> axis0) & 1u;
         const uint32_t axis1n = near0 ? ((ax >> 4) & 3u) : ((ax >> 2) & 3u);
         const uint32_t axis1f = near0 ? ((ax >> 2) & 3u) : ((ax >> 4) & 3u);
-        const uint32_t near1f = (nearbits >> axis1f) & 1u, near1n = (nearbits >> axis1n) & 1u;
-        const uint32_t n11 = (far0 << 1) | (near1f ^ 1u);
-        const uint32_t n10 = (far0 << 1) | near1f;
-        const uint32_t n01 = (near0 << 1) | (near1n ^ 1u);
-        const uint32_t n00 = (near0 << 1) | near1n;
-        const bool h00 = (mask >> n00) & 1u, h01 = (mask >> n01) & 1u, h10 = (mask >> n10) & 1u, h11 = (mask >> n11) & 1u;
+        const bool near1n = (nearbits >> axis1n) & 1u, near1f = (nearbits >> axis1f) & 1u;
+        const uint32_t mh = near0 ? ((mask >> 2) | (mask << 2)) : mask;   /* bits 0,1 near half; 2,3 far half */
+        const uint32_t ca0 = near0 ? child.z : child.x, ca1 = near0 ? child.w : child.y;
+        const uint32_t cb0 = near0 ? child.x : child.z, cb1 = near0 ? child.y : child.w;
+        const float ta0 = near0 ? tm2 : tm0, ta1 = near0 ? tm3 : tm1;
+        const float tb0 = near0 ? tm0 : tm2, tb1 = near0 ? tm1 : tm3;
+        const uint32_t c00 = near1n ? ca1 : ca0, c01 = near1n ? ca0 : ca1;
+        const uint32_t c10 = near1f ? cb1 : cb0, c11 = near1f ? cb0 : cb1;
+        const float t01 = near1n ? ta0 : ta1;
+        const float t10 = near1f ? tb1 : tb0, t11 = near1f ? tb0 : tb1;
+        const bool h00 = (mh >> (near1n ? 1 : 0)) & 1u, h01 = (mh >> (near1n ? 0 : 1)) & 1u;
+        const bool h10 = (mh >> (near1f ? 3 : 2)) & 1u, h11 = (mh >> (near1f ? 2 : 3)) & 1u;
         /* the first hit child in order n00,n01,n10,n11 becomes current; later ones are pushed far-first (qbvhmp.c:1336-1354) */
-        const uint32_t firstn = h00 ? n00 : h01 ? n01 : h10 ? n10 : n11;
         const bool p11 = h11 && (h00 || h01 || h10);
         const bool p10 = h10 && (h00 || h01);
         const bool p01 = h01 && h00;
-        if(p11) { stack_push<BLOCK, STACK>(lds, sp, make_uint2(SEL4(n11, child.x, child.y, child.z, child.w), __float_as_uint(SEL4(n11, tm0, tm1, tm2, tm3)))); sp++; }
-        if(p10) { stack_push<BLOCK, STACK>(lds, sp, make_uint2(SEL4(n10, child.x, child.y, child.z, child.w), __float_as_uint(SEL4(n10, tm0, tm1, tm2, tm3)))); sp++; }
-        if(p01) { stack_push<BLOCK, STACK>(lds, sp, make_uint2(SEL4(n01, child.x, child.y, child.z, child.w), __float_as_uint(SEL4(n01, tm0, tm1, tm2, tm3)))); sp++; }
-        current = SEL4(firstn, child.x, child.y, child.z, child.w);
+        if(sp + 3 <= STACK)
+        { /* all three slots are in LDS */
+          if(p11) { lstack[sp*BLOCK] = mi_u32x2{c11, __float_as_uint(t11)}; sp++; }
+          if(p10) { lstack[sp*BLOCK] = mi_u32x2{c10, __float_as_uint(t10)}; sp++; }
+          if(p01) { lstack[sp*BLOCK] = mi_u32x2{c01, __float_as_uint(t01)}; sp++; }
+        }
+        else
+        {
+          if(p11) { stack_push<BLOCK, STACK>(lds, sp, make_uint2(c11, __float_as_uint(t11))); sp++; }
+          if(p10) { stack_push<BLOCK, STACK>(lds, sp, make_uint2(c10, __float_as_uint(t10))); sp++; }
+          if(p01) { stack_push<BLOCK, STACK>(lds, sp, make_uint2(c01, __float_as_uint(t01))); sp++; }
+        }
+        current = h00 ? c00 : h01 ? c01 : h10 ? c10 : c11;
         cnt[7] = cnt[7] > (uint32_t)sp ? cnt[7] : (uint32_t)sp;
       }
       else
@@ -426,7 +470,7 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
         while(sp > 0)
         {
           sp--;
-          const uint2 e = stack_pop<BLOCK, STACK>(lds, sp);
+          const uint2 e = stack_top<BLOCK, STACK>(lds, lstack, sp);
           if(!(__uint_as_float(e.y) > hit.dist)) { current = e.x; done = false; break; }
         }
       }
@@ -471,7 +515,7 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
       while(sp > 0)
       {
         sp--;
-        const uint2 e = stack_pop<BLOCK, STACK>(lds, sp);
+        const uint2 e = stack_top<BLOCK, STACK>(lds, lstack, sp);
         if(!(__uint_as_float(e.y) > hit.dist)) { current = e.x; done = false; break; }
       }
     }
