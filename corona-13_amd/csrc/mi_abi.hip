@@ -145,9 +145,6 @@ struct mi_scene
   void *d_pool, *d_wfcnt;           /* d_wfcnt: [0] trace_head, [1] live */
   unsigned long long *h_live;       /* pinned ring of `live` read-backs */
   hipEvent_t ev_live[8];
-  hipEvent_t ev_trace[2];           /* timing of one representative wf_trace launch */
-  float trace_ms_sum; int trace_ms_n;
-  double kernel_ms_total;           /* sum of dominant-kernel durations of the last mi_render */
   uint64_t kernel_launches_last;
 };
 
@@ -429,8 +426,6 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
       s->pool.live = (unsigned long long *)s->d_wfcnt + 1;
       for(int k=0;k<8;k++) if(hipEventCreateWithFlags(&s->ev_live[k], hipEventDisableTiming) != hipSuccess)
       { mi_scene_destroy(s); return fail(MI_ERR_DEVICE, "cannot create events"); }
-      for(int k=0;k<2;k++) if(hipEventCreate(&s->ev_trace[k]) != hipSuccess)
-      { mi_scene_destroy(s); return fail(MI_ERR_DEVICE, "cannot create events"); }
       if(hipFuncSetAttribute((const void *)wf_trace<MI_BLOCK, MI_STACK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess ||
          hipFuncSetAttribute((const void *)wf_trace<MI_BLOCK, MI_STACK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess)
       { mi_scene_destroy(s); return fail(MI_ERR_DEVICE, "cannot raise the dynamic LDS limit"); }
@@ -463,8 +458,8 @@ static int render_wavefront(mi_scene *s, uint64_t first_index, uint64_t count)
   HIPCHK(hipMemsetAsync(s->d_work, 0, (size_t)MI_WORK_SHARDS*sizeof(unsigned long long), s->stream));
   HIPCHK(hipMemsetAsync(s->d_pool, 0, (size_t)F_COUNT*P*sizeof(uint32_t), s->stream));   /* all slots idle */
   const int lgrid = (int)(P/WF_LOGIC_BLOCK);
-  s->kernel_ms_total = 0.0; s->kernel_launches_last = 0; s->trace_ms_sum = 0.0f; s->trace_ms_n = 0;
-  int timed_it = -1;
+  s->kernel_launches_last = 0;
+  HIPCHK(hipEventRecord(s->ev0, s->stream));
   for(int it=0;;it++)
   {
     HIPCHK(hipMemsetAsync(s->d_wfcnt, 0, (1 + WF_LIVE_SHARDS)*sizeof(unsigned long long), s->stream));
@@ -475,20 +470,10 @@ static int render_wavefront(mi_scene *s, uint64_t first_index, uint64_t count)
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(s->h_live + (size_t)(it & 7)*WF_LIVE_SHARDS, s->pool.live, WF_LIVE_SHARDS*sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipEventRecord(s->ev_live[it & 7], s->stream));
-    /* time every 8th trace launch with HIP events on the launch stream */
-    const bool timed = (it & 7) == 2 && timed_it < 0;
-    if(timed) { HIPCHK(hipEventRecord(s->ev_trace[0], s->stream)); }
     if(ptdl) hipLaunchKernelGGL((wf_trace<MI_BLOCK, MI_STACK, true>), dim3(s->grid), dim3(MI_BLOCK), s->lds_bytes, s->stream, s->d, s->pool, (uint2 *)s->d_overflow);
     else     hipLaunchKernelGGL((wf_trace<MI_BLOCK, MI_STACK, false>), dim3(s->grid), dim3(MI_BLOCK), s->lds_bytes, s->stream, s->d, s->pool, (uint2 *)s->d_overflow);
     HIPCHK(hipGetLastError());
-    if(timed) { HIPCHK(hipEventRecord(s->ev_trace[1], s->stream)); timed_it = it; }
     s->kernel_launches_last++;
-    if(timed_it >= 0 && it >= timed_it + 2)
-    {
-      float ms = 0.0f;
-      if(hipEventElapsedTime(&ms, s->ev_trace[0], s->ev_trace[1]) == hipSuccess) { s->trace_ms_sum += ms; s->trace_ms_n++; }
-      timed_it = -1;
-    }
     if(it >= 2)
     { /* look at the pass two iterations back (it has certainly been submitted; wait for it to bound the queue depth) */
       HIPCHK(hipEventSynchronize(s->ev_live[(it - 2) & 7]));
@@ -498,6 +483,7 @@ static int render_wavefront(mi_scene *s, uint64_t first_index, uint64_t count)
     }
     if(it > (1 << 24)) return fail(MI_ERR_DEVICE, "wavefront pipeline did not terminate");
   }
+  HIPCHK(hipEventRecord(s->ev1, s->stream));
   s->have_timing = 1;
   s->launches += s->kernel_launches_last;
   return MI_OK;
@@ -606,12 +592,6 @@ extern "C" int mi_last_kernel_ms(mi_scene *s, float *ms)
 {
   if(!s || !ms) return fail(MI_ERR_ARG, "null argument");
   if(!s->have_timing) { *ms = 0.0f; return MI_OK; }
-  if(s->wavefront)
-  { /* average duration of the sampled wf_trace launches of the last mi_render (HIP events on the launch stream) */
-    HIPCHK(hipStreamSynchronize(s->stream));
-    *ms = s->trace_ms_n ? s->trace_ms_sum/(float)s->trace_ms_n : 0.0f;
-    return MI_OK;
-  }
   HIPCHK(hipEventSynchronize(s->ev1));
   HIPCHK(hipEventElapsedTime(ms, s->ev0, s->ev1));
   return MI_OK;
@@ -631,7 +611,6 @@ extern "C" void mi_scene_destroy(mi_scene *s)
   if(s->d_wfcnt) hipFree(s->d_wfcnt);
   if(s->h_live) hipHostFree(s->h_live);
   for(int k=0;k<8;k++) if(s->ev_live[k]) hipEventDestroy(s->ev_live[k]);
-  for(int k=0;k<2;k++) if(s->ev_trace[k]) hipEventDestroy(s->ev_trace[k]);
   void *bufs[] = { s->d_nodes, s->d_axes, s->d_prims, s->d_primshade, s->d_materials, s->d_light_prim, s->d_light_cdf, s->d_light_L,
                    s->d_cie, s->d_checker, s->d_metal, s->d_counters, s->d_work, s->d_shape_material, s->d_shape_L, s->d_overflow, s->d_fb_own };
   for(void *b : bufs) if(b) hipFree(b);

@@ -246,8 +246,8 @@ int  mi_trace_paths(mi_scene *s, uint64_t first_index, uint64_t count, mi_path_r
 /* Time of the last mi_render launch on the device in milliseconds (HIP events on the scene's
  * stream), and kernel launches since creation. For bench.py's roofline figure. */
 int  mi_last_kernel_ms(mi_scene *s, float *ms);
-/* number of launches of that kernel the last mi_render needed (1 for the megakernel, one per bounce batch for the
- * wavefront pipeline, whose mi_last_kernel_ms is the average duration of its traversal kernel) */
+/* number of traversal-kernel launches the last mi_render needed: 1 for the megakernel; one per bounce batch for the
+ * wavefront pipeline, whose mi_last_kernel_ms spans the whole launch sequence */
 int  mi_last_kernel_launches(mi_scene *s, uint64_t *launches);
 
 void mi_scene_destroy(mi_scene *s);

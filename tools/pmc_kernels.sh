@@ -7,6 +7,8 @@ run() { rocprofv3 --pmc "$@" --output-format csv -d /tmp/pk/$1 -- python3 $R/$SC
 SCRIPT=$1
 run SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_ANY
 run SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM
+run SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS SQ_INST_LEVEL_LDS SQ_IFETCH_LEVEL
+run SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_ACTIVE_INST_VALU2 SQ_INST_LEVEL_VMEM
 run FETCH_SIZE
 run WRITE_SIZE
 python3 - <<PY
