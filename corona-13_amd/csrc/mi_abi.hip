@@ -13,6 +13,9 @@
 #ifndef MI_BLOCK
 #define MI_BLOCK 1024    /* threads per workgroup: 16 waves/CU = 4 per SIMD (128 VGPRs each) */
 #endif
+#ifndef MI_TAIL_LANES
+#define MI_TAIL_LANES 16       /* a traversal slice ends when fewer rays than this are still under way */
+#endif
 #define MI_WORK_SHARDS 262144   /* upper bound on workgroups of one launch (path pool / 256) */
 #ifndef MI_STACK
 #define MI_STACK 12      /* LDS traversal stack entries per lane; deeper entries overflow to HBM (mi_device.h) */
@@ -56,7 +59,19 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
   ps.sh_pending = 0;
   bool exhausted = false;
   const unsigned lane = __lane_id();
+  TraceState ts;
+  ts.done = true;
+  Hit hit;
+  hit.prim = MI_NOPRIM; hit.dist = FLT_MAX; hit.u = hit.v = 0.0f;
+  bool tracing = false, tr_shadow = false;
 
+#ifdef MI_PROFILE_PHASES   /* development build: counters 1,2,3,5 become wave clock ticks in refill / traversal / shading / splat */
+#define MI_PHASE(k) { const unsigned long long t_ = clock64(); ph[k] += (uint32_t)(t_ - t_phase); t_phase = t_; }
+  unsigned long long t_phase = clock64();
+  uint32_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#else
+#define MI_PHASE(k)
+#endif
   while(true)
   {
     /* ------------------------------------------------------------ refill idle lanes (wave-level compaction of the work queue) */
@@ -80,24 +95,53 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
       }
     }
     if(!__any(ps.active || ps.sh_pending)) break;
+    const bool exhausted_wave = __any(exhausted);   /* this block's index range has run dry */
+    MI_PHASE(1)
 
     /* ------------------------------------------------------------ one ray per busy lane: a pending shadow ray first, else the extension ray */
+    if(!tracing && (ps.active || ps.sh_pending))
+    {
+      tr_shadow = PTDL && ps.sh_pending;
+      hit.prim = MI_NOPRIM; hit.dist = tr_shadow ? ps.sh_dist : FLT_MAX; hit.u = hit.v = 0.0f;
+      trace_begin(ts, tr_shadow ? ps.sh_dir : ps.dir, cnt);
+      tracing = true;
+    }
+    /* ------------------------------------------------------------ a slice of traversal: while-while rounds until only a tail of
+       MI_TAIL_LANES rays is still under way. Those lanes keep their traversal state (registers + LDS stack) and go on in the
+       next iteration next to the fresh rays of the lanes that shade now, so one long ray does not hold 63 lanes idle. */
+    {
+      const V3 o = tr_shadow ? ps.sh_org : ps.org, d = tr_shadow ? ps.sh_dir : ps.dir;
+      const uint32_t ignore = tr_shadow ? ps.sh_ignore : ps.ignore;
+      const unsigned tail = exhausted_wave ? 1u : (unsigned)MI_TAIL_LANES;
+      while(true)
+      {
+        const bool busy = tracing && !ts.done;
+        const unsigned nbusy = __popcll(__ballot(busy));
+        if(!nbusy) break;
+        if(nbusy < tail && __any(tracing && ts.done)) break;
+        if(busy) trace_round<MI_BLOCK, MI_STACK>(lds, sc.prims, o, d, ignore, hit, ts, cnt);
+      }
+    }
+    MI_PHASE(2)
     SplatReq splat;
     splat.pending = false; splat.c0 = splat.c1 = splat.c2 = 0.0f;
-    const bool do_shadow = PTDL && ps.sh_pending;
-    Hit hit;
-    hit.prim = MI_NOPRIM; hit.dist = do_shadow ? ps.sh_dist : FLT_MAX; hit.u = hit.v = 0.0f;
-    if(do_shadow || ps.active)
-      accel_intersect<MI_BLOCK, MI_STACK>(lds, sc.prims, do_shadow ? ps.sh_org : ps.org, do_shadow ? ps.sh_dir : ps.dir,
-                                          do_shadow ? ps.sh_ignore : ps.ignore, hit, cnt);
-    mi_path_record *rec = RECORD ? records + (ps.index - first) : nullptr;
-    if(do_shadow) shadow_resolve<RECORD>(sc, ps, hit, rec, cnt, splat);
-    else if(ps.active) path_shade<RECORD, PTDL>(sc, ps, hit, shape_material, shape_L, rec, cnt, splat);
+    if(tracing && ts.done)
+    {
+      tracing = false;
+      mi_path_record *rec = RECORD ? records + (ps.index - first) : nullptr;
+      if(tr_shadow) shadow_resolve<RECORD>(sc, ps, hit, rec, cnt, splat);
+      else path_shade<RECORD, PTDL>(sc, ps, hit, shape_material, shape_L, rec, cnt, splat);
+    }
 
     /* ------------------------------------------------------------ splats of this iteration, cooperatively */
+    MI_PHASE(3)
     if(!RECORD) splat_wave(sc, splat.pending, ps.pixel_i, ps.pixel_j, splat.c0, splat.c1, splat.c2);
+    MI_PHASE(5)
   }
 
+#ifdef MI_PROFILE_PHASES
+  cnt[1] = lane ? 0 : ph[1]; cnt[2] = lane ? 0 : ph[2]; cnt[3] = lane ? 0 : ph[3]; cnt[5] = lane ? 0 : ph[5];
+#endif
   unsigned long long *shard = sc.counters + (size_t)(blockIdx.x % MI_COUNTER_SHARDS)*8;
   atomicMax(shard + 7, (unsigned long long)cnt[7]);     /* deepest traversal stack use */
   /* ------------------------------------------------------------ flush work counters: wave reduction, one atomic per wave */
