@@ -339,6 +339,9 @@ __device__ __forceinline__ uint2 stack_top(const Lds &lds, const lds_uint2 *lsta
   return lds.overflow[(size_t)(sp - STACK)*lds.overflow_stride];
 }
 
+#ifndef MI_TAIL_INNER
+#define MI_TAIL_INNER 4
+#endif
 struct TraceState
 { /* resumable traversal of one ray: survives between rounds so that a wave can re-fill idle lanes in between */
   int sp;
@@ -374,8 +377,14 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
   const uint32_t offx = near_x ? 3u*N : 0u, offy = near_y ? 3u*N : 0u, offz = near_z ? 3u*N : 0u;
   const bool slow = __any(isinf(idx) || isinf(idy) || isinf(idz));
   {
-    while(!(current & MI_LEAF32))
-    {
+    while(true)
+    { /* descend until every lane holds a leaf -- or only a tail of MI_TAIL_INNER lanes is still descending while others
+         wait with a leaf: those go on descending in the next round (their `current` stays an inner node) */
+      const bool inner = !(current & MI_LEAF32);
+      const unsigned ninner = __popcll(__ballot(inner));
+      if(!ninner) break;
+      if(ninner < MI_TAIL_INNER && __any((current & MI_LEAF32) && !done)) break;
+      if(!inner) continue;
 #ifdef MI_PROFILE_LOOPS
       if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) cnt[4]++;   /* wave-level inner iterations */
 #endif
@@ -475,7 +484,7 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
         }
       }
     }
-    if(!done)
+    if(!done && (current & MI_LEAF32))
     { /* leaf: intersect its primitives (qbvhmp.c:1366-1379), then pop */
       uint32_t idxp = (current ^ MI_LEAF32) >> 5;
       const uint32_t num = current & 31u;
