@@ -53,7 +53,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
   const unsigned long long blk_lo = count/nb*blockIdx.x + (blockIdx.x < count%nb ? blockIdx.x : count%nb);
   const unsigned long long blk_hi = blk_lo + count/nb + (blockIdx.x < count%nb ? 1 : 0);
 
-  uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t cnt[MI_CNT] = {0};
   PathState ps;
   ps.active = 0;
   ps.sh_pending = 0;
@@ -65,13 +65,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
   hit.prim = MI_NOPRIM; hit.dist = FLT_MAX; hit.u = hit.v = 0.0f;
   bool tracing = false, tr_shadow = false;
 
-#ifdef MI_PROFILE_PHASES   /* development build: counters 1,2,3,5 become wave clock ticks in refill / traversal / shading / splat */
-#define MI_PHASE(k) { const unsigned long long t_ = clock64(); ph[k] += (uint32_t)(t_ - t_phase); t_phase = t_; }
-  unsigned long long t_phase = clock64();
-  uint32_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#else
-#define MI_PHASE(k)
-#endif
+  MI_PHASE_INIT(cnt)
   while(true)
   {
     /* ------------------------------------------------------------ refill idle lanes (wave-level compaction of the work queue) */
@@ -96,7 +90,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
     }
     if(!__any(ps.active || ps.sh_pending)) break;
     const bool exhausted_wave = __any(exhausted);   /* this block's index range has run dry */
-    MI_PHASE(1)
+    MI_PHASE(cnt, 0)
 
     /* ------------------------------------------------------------ one ray per busy lane: a pending shadow ray first, else the extension ray */
     if(!tracing && (ps.active || ps.sh_pending))
@@ -122,7 +116,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
         if(busy) trace_round<MI_BLOCK, MI_STACK>(lds, sc.prims, o, d, ignore, hit, ts, cnt);
       }
     }
-    MI_PHASE(2)
+    MI_PHASE(cnt, 1)
     SplatReq splat;
     splat.pending = false; splat.c0 = splat.c1 = splat.c2 = 0.0f;
     if(tracing && ts.done)
@@ -134,21 +128,31 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
     }
 
     /* ------------------------------------------------------------ splats of this iteration, cooperatively */
-    MI_PHASE(3)
+    MI_PHASE(cnt, 5)
     if(!RECORD) splat_wave(sc, splat.pending, ps.pixel_i, ps.pixel_j, splat.c0, splat.c1, splat.c2);
-    MI_PHASE(5)
+    MI_PHASE(cnt, 6)
   }
 
-#ifdef MI_PROFILE_PHASES
-  cnt[1] = lane ? 0 : ph[1]; cnt[2] = lane ? 0 : ph[2]; cnt[3] = lane ? 0 : ph[3]; cnt[5] = lane ? 0 : ph[5];
+#ifdef MI_PROFILE_LOOPS    /* development build: box hits / splats / vertices become wave-level inner iterations / leaf slots / analytic passes */
+  cnt[2] = cnt[8]; cnt[5] = cnt[9]; cnt[6] = cnt[10];
+#endif
+#ifdef MI_PROFILE_PHASES   /* development build: the 8 counters become lane 0's phase ticks | occurrences << 36 (tools/phase_probe.py) */
+  unsigned long long phase_out[8];
+  for(int k=0;k<8;k++) phase_out[k] = lane ? 0ull : ((unsigned long long)cnt[8 + k] | ((unsigned long long)cnt[16 + k] << 36));
 #endif
   unsigned long long *shard = sc.counters + (size_t)(blockIdx.x % MI_COUNTER_SHARDS)*8;
+#ifndef MI_PROFILE_PHASES
   atomicMax(shard + 7, (unsigned long long)cnt[7]);     /* deepest traversal stack use */
+#endif
   /* ------------------------------------------------------------ flush work counters: wave reduction, one atomic per wave */
 #pragma unroll
   for(int k=0;k<8;k++)
   {
     unsigned long long c = cnt[k];
+#ifdef MI_PROFILE_PHASES
+    c = phase_out[k];
+    if(k == 7) { if(lane == 0 && c) atomicAdd(shard + 7, c); continue; }
+#endif
     for(int off=32;off>0;off>>=1) c += __shfl_down(c, off);
     if(k == 7) continue;                    /* slot 7 is a maximum, flushed above */
     if(lane == 0 && c) atomicAdd(shard + k, c);
@@ -597,7 +601,11 @@ extern "C" int mi_counters(mi_scene *s, uint64_t out[8])
   for(int sh=0;sh<MI_COUNTER_SHARDS;sh++)
   {
     for(int k=0;k<7;k++) out[k] += tmp[(size_t)sh*8 + k];
+#ifdef MI_PROFILE_PHASES
+    out[7] += tmp[(size_t)sh*8 + 7];
+#else
     if(tmp[(size_t)sh*8 + 7] > out[7]) out[7] = tmp[(size_t)sh*8 + 7];
+#endif
   }
   return MI_OK;
 }

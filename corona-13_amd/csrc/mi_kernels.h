@@ -97,6 +97,27 @@ __device__ __forceinline__ void rng_seed(Rng &r, unsigned long long index, unsig
   for(int k=0;k<10;k++) (void)rng_next(r);
 }
 
+/* ------------------------------------------------------------------------------------------ work counters
+ * cnt[0..7]: rays, node visits, box hits, primitive tests, paths, splats, vertices, deepest stack. Development builds
+ * append more: -DMI_PROFILE_LOOPS wave-level loop iterations (cnt[8..10]), -DMI_PROFILE_PHASES lane-0 clock ticks per
+ * phase (cnt[8+k]), their occurrences (cnt[16+k]), the last marker (cnt[30]) and time stamp (cnt[31]). */
+#if defined(MI_PROFILE_PHASES) || defined(MI_PROFILE_LOOPS)
+#define MI_CNT 32
+#else
+#define MI_CNT 8
+#endif
+#ifdef MI_PROFILE_PHASES
+#define MI_PHASE_INIT(cnt) { (cnt)[31] = (uint32_t)clock64(); (cnt)[30] = 6; }
+/* markers run 0 1 [2 3 4 7] 5 6 per iteration; an interval counts only if this lane also passed the marker before it */
+#define MI_PHASE(cnt, k) { const uint32_t t_ = (uint32_t)clock64(); \
+  const uint32_t pred_ = (k) == 0 ? 6 : (k) == 5 ? 7 : (k) == 7 ? 4 : (k) - 1; \
+  if((cnt)[30] == pred_) { (cnt)[8 + (k)] += t_ - (cnt)[31]; (cnt)[16 + (k)]++; } \
+  (cnt)[31] = t_; (cnt)[30] = (k); }
+#else
+#define MI_PHASE_INIT(cnt)
+#define MI_PHASE(cnt, k)
+#endif
+
 /* ------------------------------------------------------------------------------------------ hit */
 struct Hit
 {
@@ -386,7 +407,7 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
       if(ninner < MI_TAIL_INNER && __any((current & MI_LEAF32) && !done)) break;
       if(!inner) continue;
 #ifdef MI_PROFILE_LOOPS
-      if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) cnt[4]++;   /* wave-level inner iterations */
+      if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) cnt[8]++;   /* wave-level inner iterations */
 #endif
       const uint32_t node = current;
       const uint4 child = *(const uint4 *)&lds.nodes[6*N + node];
@@ -497,7 +518,7 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
       for(uint32_t i=0;i<num;i++)
       {
 #ifdef MI_PROFILE_LOOPS
-        if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) cnt[5]++;   /* wave-level leaf slots */
+        if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) cnt[9]++;   /* wave-level leaf slots */
 #endif
         PrimRegs nxt = cur;
         if(i + 1 < num) nxt = prim_load(prims, idxp + i + 1);
@@ -513,7 +534,7 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
       while(analytic)
       {
 #ifdef MI_PROFILE_LOOPS
-        if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) cnt[6]++;   /* wave-level analytic passes */
+        if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) cnt[10]++;   /* wave-level analytic passes */
 #endif
         const uint32_t i = __ffs(analytic) - 1;
         analytic &= analytic - 1;

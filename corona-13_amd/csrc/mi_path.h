@@ -196,6 +196,7 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
     sf.x = mk3(ps.org.x + hit.dist*ps.dir.x, ps.org.y + hit.dist*ps.dir.y, ps.org.z + hit.dist*ps.dir.z);
     sf.u = hit.u; sf.v = hit.v;
     surface_setup(sc, hit.prim, omega, ps.scramble, sf);
+    MI_PHASE(cnt, 2)
     const DPrimShade &pshade = sc.primshade[hit.prim];
     const DMaterial &mat = sc.materials[pshade.material];
     const uint32_t shape = MI_PRIMID_SHAPE(pshade.primid);
@@ -229,6 +230,7 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
       if(sh.roughness > 1e-4f) material_modes |= s_glossy; else material_modes |= s_specular;
     }
 
+    MI_PHASE(cnt, 3)
     /* self-intersection, src/pathspace.c:807-820 */
     const uint32_t type = sc.prims[hit.prim].type;
     if((type > 2 || hit.dist < 1e-4f) && hit.prim == ps.ignore)
@@ -401,6 +403,7 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
           }
         }
       }
+      MI_PHASE(cnt, 4)
       /* next path_extend, src/pathspace.c:167-259 */
       if(alive && ps.length >= (int)sc.max_verts) alive = false;
       if(alive && !(vthr > 0.0f))
@@ -414,6 +417,7 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
         if(mat.bsdf == MI_BSDF_DIFFUSE) sample_diffuse(ps.rng, sf, sh, mode, bs);
         else if(mat.bsdf == MI_BSDF_DIELECTRIC) sample_dielectric(ps.rng, sf, sh, omega, eta_ratio, mode, bs);
         else sample_metal(sc, ps.rng, sf, sh, omega, ps.cur_ior, (int)mat.param[0], ps.lambda, mode, bs);
+        MI_PHASE(cnt, 7)
         /* shader_sample tail, src/shader.c:582-589 */
         bs.omega = normalise3(bs.omega);
         const float dts = ((sf.flags & s_inside) ? -1 : 1)*dot3(sf.gn, bs.omega);

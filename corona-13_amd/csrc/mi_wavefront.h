@@ -65,7 +65,7 @@ __global__ __launch_bounds__(WF_LOGIC_BLOCK) void wf_logic(DScene sc, WFPool poo
   const uint32_t slot = blockIdx.x*WF_LOGIC_BLOCK + threadIdx.x;
   const bool inrange = slot < pool.P;
   const unsigned lane = __lane_id();
-  uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t cnt[MI_CNT] = {0};
   PathState ps;
   ps.active = 0; ps.sh_pending = 0;
   ps.pixel_i = ps.pixel_j = 0.0f; ps.lambda = 400.0f;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(BLOCK) void wf_trace(DScene sc, WFPool pool, uint2 
 
   const unsigned lane = __lane_id();
   const unsigned long long njobs = PTDL ? 2ull*pool.P : pool.P;
-  uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t cnt[MI_CNT] = {0};
   bool busy = false, exhausted = false;
   unsigned long long next = 0, chunk_end = 0;        /* wave-uniform: this wave's claimed part of the job range */
   uint32_t slot = 0, is_shadow = 0;

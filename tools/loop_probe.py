@@ -1,3 +1,5 @@
+"""development helper (GPU box): wave-level iteration counts of the traversal loops, from a -DMI_PROFILE_LOOPS build
+(CORONA_MI_LIB=.../libcorona_mi_loops.so python3 tools/loop_probe.py)"""
 import sys, time, os
 sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parent.parent / "tests"))
 from helpers import *
@@ -9,9 +11,6 @@ c0 = be.counters()
 be.render(0, 16 * per); be.sync()
 c = [b - a for a, b in zip(c0, be.counters())]
 rays = c[0]
-# cnt[4..6] are polluted by wf_logic's paths/splats/verts; logic adds paths (c4), splats (c5), verts (c6): subtract known values
-paths = 16 * per
-print("rays", rays, "nodes/ray", c[1] / rays, "prims/ray", c[3] / rays)
-print("wave-level inner iterations per ray x64:", (c[4] - paths) * 64 / rays)
-print("wave-level leaf slots per ray x64:", (c[5]) * 64 / rays, "(minus splats ~0)")
-print("wave-level analytic passes per ray x64:", (c[6] - (c0[6] * 0)) * 64 / rays, "(polluted by verts)")
+print("rays/path %.3f  node visits/ray %.2f  prim tests/ray %.2f" % (rays / c[4], c[1] / rays, c[3] / rays))
+print("lane slots per ray (wave-level iterations x 64 / rays):  inner %.2f (useful %.2f)   leaf %.2f (useful %.2f)   analytic %.2f" %
+      (c[2] * 64 / rays, c[1] / rays, c[5] * 64 / rays, c[3] / rays, c[6] * 64 / rays))

@@ -11,7 +11,11 @@ for name, mv, sampler in (("pt mv8", 8, 0), ("ptdl mv8", 8, 1)):
     be.render(0, per); be.sync()
     c0 = be.counters(); be.render(per, 8 * per); be.sync(); c1 = be.counters()
     d = [b - a for a, b in zip(c0, c1)]
-    tot = d[1] + d[2] + d[3] + d[5]
-    print(name, "kernel ms %.2f" % be.last_kernel_ms(), " refill/generate %.1f%%  traversal %.1f%%  shading %.1f%%  splat %.1f%%" %
-          (100 * d[1] / tot, 100 * d[2] / tot, 100 * d[3] / tot, 100 * d[5] / tot), " rays/path %.2f" % (d[0] / d[4]))
+    names = ["refill/generate", "traversal", "surface_setup", "prepare+media", "emit/RR/NEE", "sample tail", "splat", "bsdf sample"]
+    ticks = [x & ((1 << 36) - 1) for x in d]; occ = [x >> 36 for x in d]
+    iters = occ[1]
+    # wave time of a phase ~ average ticks per occurrence (lane 0) x wave iterations
+    est = [t / max(o, 1) * iters for t, o in zip(ticks, occ)]
+    tot = sum(est)
+    print(name, "kernel ms %.2f" % be.last_kernel_ms(), " | ".join("%s %.1f%% (%.0f ticks)" % (n, 100 * e / tot, t / max(o, 1)) for n, e, t, o in zip(names, est, ticks, occ)))
     be.close()
