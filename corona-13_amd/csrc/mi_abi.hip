@@ -178,7 +178,7 @@ struct mi_scene
 {
   DScene d;
   uint32_t width, height;
-  void *d_nodes, *d_axes, *d_prims, *d_primshade, *d_materials, *d_light_prim, *d_light_cdf, *d_light_L;
+  void *d_nodes, *d_axes, *d_prims, *d_primshade, *d_primgeo, *d_materials, *d_light_prim, *d_light_cdf, *d_light_L;
   void *d_cie, *d_checker, *d_metal, *d_counters, *d_work, *d_shape_material, *d_shape_L, *d_overflow;
   float *d_fb_own, *d_fb;
   hipStream_t stream_own, stream;
@@ -341,6 +341,8 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   /* primitives: resolve primid -> vtxidx -> vtx once */
   std::vector<DPrim> prims(h->num_prims ? h->num_prims : 1);
   std::vector<DPrimShade> pshade(h->num_prims ? h->num_prims : 1);
+  std::vector<DPrimGeo> pgeo(h->num_prims ? h->num_prims : 1);
+  memset(pgeo.data(), 0, pgeo.size()*sizeof(DPrimGeo));
   memset(prims.data(), 0, prims.size()*sizeof(DPrim));
   memset(pshade.data(), 0, pshade.size()*sizeof(DPrimShade));
   for(uint64_t i=0;i<h->num_prims;i++)
@@ -362,8 +364,34 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
       memcpy(p.v[0], vtx[vi[0].v].v, 12);
       memcpy(&p.v[1][0], &vtx[vi[0].v].n, 4);
     }
-    else if(vc == MI_PRIM_LINE) pack_line(p, q, vtx[vi[0].v], vtx[vi[1].v]);
-    else for(uint32_t k=0;k<vc;k++) memcpy(p.v[k], vtx[vi[k].v].v, 12);
+    else if(vc == MI_PRIM_LINE)
+    {
+      pack_line(p, q, vtx[vi[0].v], vtx[vi[1].v]);
+      /* shading-side frame of the line (line.h:123-161), with the functions the kernel would run per vertex */
+      float *g = pgeo[i].f;
+      const V3 v0 = ld3(vtx[vi[0].v].v), v1 = ld3(vtx[vi[1].v].v);
+      V3 d = sub3(v1, v0);
+      const float ilen_d = 1.0f/sqrtf(dot3(d, d));
+      d = scale3(d, ilen_d);
+      V3 a, b; get_onb(d, a, b);
+      V3 ac, bc; get_onb(mk3(p.v[2][0], p.v[2][1], p.v[2][2]), ac, bc);    /* dwords 6..8: the intersection's unit axis */
+      g[0] = d.x; g[1] = d.y; g[2] = d.z; g[3] = ilen_d;
+      g[4] = a.x; g[5] = a.y; g[6] = a.z; g[7] = b.x; g[8] = b.y; g[9] = b.z;
+      g[10] = ac.x; g[11] = ac.y; g[12] = ac.z; g[13] = bc.x; g[14] = bc.y; g[15] = bc.z;
+    }
+    else
+    {
+      for(uint32_t k=0;k<vc;k++) memcpy(p.v[k], vtx[vi[k].v].v, 12);
+      float *g = pgeo[i].f;
+      for(uint32_t k=0;k<vc;k++) { const V3 n = decode_normal(q.n[k]); g[3*k] = n.x; g[3*k+1] = n.y; g[3*k+2] = n.z; }
+      const V3 ga = tri_geo_normal(ld3(p.v[0]), ld3(p.v[1]), ld3(p.v[2]));
+      g[12] = ga.x; g[13] = ga.y; g[14] = ga.z;
+      if(vc == MI_PRIM_QUAD)
+      {
+        const V3 gb = tri_geo_normal(ld3(p.v[0]), ld3(p.v[2]), ld3(p.v[3]));
+        g[15] = gb.x; g[16] = gb.y; g[17] = gb.z;
+      }
+    }
   }
   std::vector<DMaterial> mats(h->num_materials ? h->num_materials : 1);
   for(uint32_t i=0;i<h->num_materials;i++)
@@ -396,6 +424,7 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   UP(d_axes, axes.data(), axes.size());
   UP(d_prims, prims.data(), prims.size());
   UP(d_primshade, pshade.data(), pshade.size());
+  UP(d_primgeo, pgeo.data(), pgeo.size());
   UP(d_materials, mats.data(), mats.size());
   UP(d_shape_material, shape_mat.data(), shape_mat.size());
   UP(d_shape_L, shape_L.data(), shape_L.size());
@@ -422,7 +451,7 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   s->stream = s->stream_own;
 
   d.nodes = (const float4 *)s->d_nodes; d.node_axes = (const uint32_t *)s->d_axes;
-  d.prims = (const DPrim *)s->d_prims; d.primshade = (const DPrimShade *)s->d_primshade;
+  d.prims = (const DPrim *)s->d_prims; d.primshade = (const DPrimShade *)s->d_primshade; d.primgeo = (const DPrimGeo *)s->d_primgeo;
   d.materials = (const DMaterial *)s->d_materials;
   d.num_lights = h->lights.num_prims;
   d.light_prim = (const uint32_t *)s->d_light_prim; d.light_cdf = (const float *)s->d_light_cdf; d.light_L = (const float *)s->d_light_L;
@@ -663,7 +692,7 @@ extern "C" void mi_scene_destroy(mi_scene *s)
   if(s->d_wfcnt) hipFree(s->d_wfcnt);
   if(s->h_live) hipHostFree(s->h_live);
   for(int k=0;k<8;k++) if(s->ev_live[k]) hipEventDestroy(s->ev_live[k]);
-  void *bufs[] = { s->d_nodes, s->d_axes, s->d_prims, s->d_primshade, s->d_materials, s->d_light_prim, s->d_light_cdf, s->d_light_L,
+  void *bufs[] = { s->d_nodes, s->d_axes, s->d_prims, s->d_primshade, s->d_primgeo, s->d_materials, s->d_light_prim, s->d_light_cdf, s->d_light_L,
                    s->d_cie, s->d_checker, s->d_metal, s->d_counters, s->d_work, s->d_shape_material, s->d_shape_L, s->d_overflow, s->d_fb_own };
   for(void *b : bufs) if(b) hipFree(b);
   if(s->stream_own) hipStreamDestroy(s->stream_own);

@@ -10,6 +10,7 @@
  *             intersection test is ONE aligned fetch instead of primid -> vtxidx -> vtx
  *             (src/prims.c:638-672, include/geo.h:120-138)
  *  primshade  one 48-B record per primitive, touched once per path vertex (normals, uv, material)
+ *  primgeo    one 80-B record per primitive, touched once per path vertex (decoded normals / line frames)
  */
 #ifndef MI_DEVICE_H
 #define MI_DEVICE_H
@@ -36,6 +37,14 @@ struct DPrimShade                  /* 48 B */
   uint32_t pad;
 };
 
+struct DPrimGeo                    /* 80 B of per-primitive constants of the shading side, precomputed at upload with the
+                                      kernel's own (host+device) functions */
+{
+  float f[20];                     /* tri/quad: decoded vertex normals n0..n3 [0..11], geometric normal of (v0 v1 v2) [12..14] and of
+                                      (v0 v2 v3) [15..17]. line: unit axis d [0..2], 1/|v1-v0| [3], onb a [4..6], b [7..9] of d;
+                                      cone: onb of the intersection-side axis [10..12], [13..15] */
+};
+
 struct DMaterial
 {
   uint32_t bsdf, num_ops;
@@ -54,6 +63,7 @@ struct DScene
   const uint32_t *node_axes;       /* [num_nodes] */
   const DPrim  *prims;
   const DPrimShade *primshade;
+  const DPrimGeo *primgeo;
   float aabb[6];
   float far_dist;                  /* 2 * largest box extent, src/pathspace.c:867-870 */
   /* materials / lights / camera / tables */

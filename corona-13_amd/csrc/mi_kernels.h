@@ -44,23 +44,24 @@ enum { s_tech_extend = 1, s_tech_nee = 2 };
 #define DCLAMP(a, m, M) DMIN(DMAX(a, m), M)
 
 struct V3 { float x, y, z; };
-__device__ __forceinline__ V3 mk3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
-__device__ __forceinline__ float dot3(const V3 a, const V3 b) { return a.x*b.x + a.y*b.y + a.z*b.z; }
-__device__ __forceinline__ V3 cross3(const V3 a, const V3 b)
+#define MI_HD __host__ __device__ __forceinline__   /* per-primitive constants are precomputed on the host with the very same code */
+MI_HD V3 mk3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+MI_HD float dot3(const V3 a, const V3 b) { return a.x*b.x + a.y*b.y + a.z*b.z; }
+MI_HD V3 cross3(const V3 a, const V3 b)
 { /* crossproduct macro, include/corona_common.h:161-164 */
   return mk3(a.y*b.z - b.y*a.z, a.z*b.x - b.z*a.x, a.x*b.y - b.x*a.y);
 }
-__device__ __forceinline__ V3 sub3(const V3 a, const V3 b) { return mk3(a.x-b.x, a.y-b.y, a.z-b.z); }
-__device__ __forceinline__ V3 scale3(const V3 a, float s) { return mk3(a.x*s, a.y*s, a.z*s); }
-__device__ __forceinline__ V3 neg3(const V3 a) { return mk3(-a.x, -a.y, -a.z); }
-__device__ __forceinline__ V3 normalise3(const V3 a)
+MI_HD V3 sub3(const V3 a, const V3 b) { return mk3(a.x-b.x, a.y-b.y, a.z-b.z); }
+MI_HD V3 scale3(const V3 a, float s) { return mk3(a.x*s, a.y*s, a.z*s); }
+MI_HD V3 neg3(const V3 a) { return mk3(-a.x, -a.y, -a.z); }
+MI_HD V3 normalise3(const V3 a)
 { /* normalise, include/corona_common.h:172-176 */
   const float len = 1.0f/sqrtf(dot3(a, a));
   return scale3(a, len);
 }
-__device__ __forceinline__ V3 ld3(const float *p) { return mk3(p[0], p[1], p[2]); }
+MI_HD V3 ld3(const float *p) { return mk3(p[0], p[1], p[2]); }
 
-__device__ __forceinline__ void get_onb(const V3 n, V3 &u, V3 &v)
+MI_HD void get_onb(const V3 n, V3 &u, V3 &v)
 { /* get_onb, include/corona_common.h:178-198 */
   if(fabsf(n.y) < 0.5) u = cross3(n, mk3(0, 1, 0));
   else                 u = cross3(n, mk3(1, 0, 0));
@@ -563,13 +564,13 @@ __device__ __forceinline__ void accel_intersect(const Lds &lds, const DPrim *pri
 }
 
 /* ------------------------------------------------------------------------------------------ geometry at the hit */
-__device__ __forceinline__ V3 decode_normal(uint32_t enc)
+MI_HD V3 decode_normal(uint32_t enc)
 { /* geo_decode_normal, include/geo.h:24-44 */
   const uint32_t p0 = enc & 0xffffu, p1 = enc >> 16;
   const uint32_t v0 = 0x3f800000u | ((p0 & 0x7fffu) << 8);
   const uint32_t v1 = 0x3f800000u | ((p1 & 0x7fffu) << 8);
-  float x = __uint_as_float(__float_as_uint(2.0f*__uint_as_float(v0) - 2.0f) | ((p0 & 0x8000u) << 16));
-  float y = __uint_as_float(__float_as_uint(2.0f*__uint_as_float(v1) - 2.0f) | ((p1 & 0x8000u) << 16));
+  float x = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, 2.0f*__builtin_bit_cast(float, v0) - 2.0f) | ((p0 & 0x8000u) << 16));
+  float y = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, 2.0f*__builtin_bit_cast(float, v1) - 2.0f) | ((p1 & 0x8000u) << 16));
   const float z = 1.0f - (fabsf(x) + fabsf(y));
   if(z < 0.0f)
   {
@@ -602,75 +603,69 @@ struct Surf
   uint32_t flags;
 };
 
-__device__ __forceinline__ void tri_normal(const V3 v0, const V3 v1, const V3 v2, const V3 n0, const V3 n1, const V3 n2, float u, float v, Surf &sf)
-{ /* geo_tri_get_normal, include/geo/triangle.h:63-82 */
-  sf.gn = normalise3(mk3((v1.y-v0.y)*(v2.z-v0.z) - (v1.z-v0.z)*(v2.y-v0.y),
-                         (v1.z-v0.z)*(v2.x-v0.x) - (v1.x-v0.x)*(v2.z-v0.z),
-                         (v1.x-v0.x)*(v2.y-v0.y) - (v1.y-v0.y)*(v2.x-v0.x)));
-  const float w = 1.0f - u - v;
-  sf.n = normalise3(mk3(u*n2.x + v*n1.x + w*n0.x, u*n2.y + v*n1.y + w*n0.y, u*n2.z + v*n1.z + w*n0.z));
+MI_HD V3 tri_geo_normal(const V3 v0, const V3 v1, const V3 v2)
+{ /* geo_tri_get_normal, include/geo/triangle.h:63-70 */
+  return normalise3(mk3((v1.y-v0.y)*(v2.z-v0.z) - (v1.z-v0.z)*(v2.y-v0.y),
+                        (v1.z-v0.z)*(v2.x-v0.x) - (v1.x-v0.x)*(v2.z-v0.z),
+                        (v1.x-v0.x)*(v2.y-v0.y) - (v1.y-v0.y)*(v2.x-v0.x)));
 }
 
 __device__ __forceinline__ void surface_setup(const DScene &sc, uint32_t prim, const V3 omega, float scramble, Surf &sf)
 { /* prims_get_normal_time (src/prims.c:254-366) + manifold_init (include/pathspace/manifold.h:215-232) */
   const DPrim &p = sc.prims[prim];
   const DPrimShade &ps = sc.primshade[prim];
+  const float *g = sc.primgeo[prim].f;      /* per-primitive constants, see DPrimGeo */
   const uint32_t type = p.type;
-  if(type == MI_PRIM_SPHERE)
-  { /* sphere.h:51-62,160-161 */
-    const V3 c = ld3(p.v[0]);
-    const float radius = p.v[1][0];
-    sf.u = (float)((double)atan2f((sf.x.y-c.y)/radius, (sf.x.x-c.x)/radius)/(2.0f*MI_PI_D));
-    sf.v = (float)((double)acosf(DCLAMP((sf.x.z-c.z)/radius, -1.0f, 1.0f))/MI_PI_D);
-    sf.gn = normalise3(sub3(sf.x, c));
-    sf.n = sf.gn;
-  }
-  else if(type == MI_PRIM_LINE)
-  { /* line.h:123-161; layout of the record: see line_intersect */
+  if(type < MI_PRIM_TRI)
+  { /* sphere (sphere.h:51-62,160-161) and line (line.h:123-161; record layout: see line_intersect). The two share one
+       atan2f site: a wave that holds hits of both kinds runs the long libm sequence once. */
     const float *f = &p.v[0][0];
-    const V3 v0 = mk3(f[0], f[1], f[2]);
-    const float r0 = f[3], r1 = f[4];
-    const V3 v1 = mk3(__uint_as_float(ps.n[2]), __uint_as_float(ps.n[3]), __uint_as_float(ps.uv[2]));
-    V3 d = sub3(v1, v0);
-    const float ilen_d = 1.0f/sqrtf(dot3(d, d));
-    d = scale3(d, ilen_d);
-    V3 a, b; get_onb(d, a, b);
-    if(fabsf(r1-r0) < 1e-3)
-    { /* cylinder: hit.u/hit.v carry out[1], out[2] of the intersection (line.h:484-486) */
-      const float out1 = sf.u, out2 = sf.v;
-      sf.v = (float)((double)atan2f(out1, out2)/(2.0f*MI_PI_D));
-      sf.u = dot3(sub3(sf.x, v0), d)*ilen_d;
+    const V3 v0 = mk3(f[0], f[1], f[2]);           /* sphere: centre */
+    const float r0 = f[3], r1 = f[4];              /* sphere: f[3] = radius */
+    const bool sphere = type == MI_PRIM_SPHERE;
+    const bool cylinder = !sphere && fabsf(r1-r0) < 1e-3;
+    const V3 x = sub3(sf.x, v0);
+    float ay, ax;
+    if(sphere) { ay = x.y/r0; ax = x.x/r0; }
+    else if(cylinder) { ay = sf.u; ax = sf.v; }    /* hit.u/hit.v carry out[1], out[2] of the intersection (line.h:484-486) */
+    else { ay = dot3(mk3(g[10], g[11], g[12]), x); ax = dot3(mk3(g[13], g[14], g[15]), x); }   /* cone: line.h:445-449 */
+    const float ang = (float)((double)atan2f(ay, ax)/(2.0f*MI_PI_D));
+    if(sphere)
+    {
+      sf.u = ang;
+      sf.v = (float)((double)acosf(DCLAMP(x.z/r0, -1.0f, 1.0f))/MI_PI_D);
+      sf.gn = normalise3(x);
+      sf.n = sf.gn;
     }
-    else
-    { /* cone: line.h:445-449 with x = ray.pos + t*ray.dir - v0 == sf.x - v0 */
-      const V3 dc = mk3(f[6], f[7], f[8]);
-      V3 ac, bc; get_onb(dc, ac, bc);
-      const V3 x = sub3(sf.x, v0);
-      sf.v = (float)((double)atan2f(dot3(ac, x), dot3(bc, x))/(2.0f*MI_PI_D));
-    }
-    if(fabsf(r0-r1) < 1e-3f && r0 < 0.01f) { sf.n = sf.gn = mk3(0, 0, 0); }
     else
     {
-      const float phi = (float)(2.0*MI_PI_D*(double)sf.v);
-      float sinphi, cosphi;
-      sincosf(phi, &sinphi, &cosphi);
-      const V3 n = mk3(a.x*sinphi + b.x*cosphi, a.y*sinphi + b.y*cosphi, a.z*sinphi + b.z*cosphi);
-      const float rr = r1 - r0;
-      if(fabsf(rr) < 1e-3) sf.n = n;
-      else sf.n = normalise3(mk3(n.x - d.x*(r1-r0)*ilen_d, n.y - d.y*(r1-r0)*ilen_d, n.z - d.z*(r1-r0)*ilen_d));
-      sf.gn = sf.n;
+      const V3 d = mk3(g[0], g[1], g[2]), a = mk3(g[4], g[5], g[6]), b = mk3(g[7], g[8], g[9]);
+      const float ilen_d = g[3];
+      sf.v = ang;
+      if(cylinder) sf.u = dot3(x, d)*ilen_d;
+      if(fabsf(r0-r1) < 1e-3f && r0 < 0.01f) { sf.n = sf.gn = mk3(0, 0, 0); }
+      else
+      {
+        const float phi = (float)(2.0*MI_PI_D*(double)sf.v);
+        float sinphi, cosphi;
+        sincosf(phi, &sinphi, &cosphi);
+        const V3 n = mk3(a.x*sinphi + b.x*cosphi, a.y*sinphi + b.y*cosphi, a.z*sinphi + b.z*cosphi);
+        const float rr = r1 - r0;
+        if(fabsf(rr) < 1e-3) sf.n = n;
+        else sf.n = normalise3(mk3(n.x - d.x*(r1-r0)*ilen_d, n.y - d.y*(r1-r0)*ilen_d, n.z - d.z*(r1-r0)*ilen_d));
+        sf.gn = sf.n;
+      }
     }
   }
   else
-  {
-    const V3 v0 = ld3(p.v[0]), v2 = ld3(p.v[2]);
-    const V3 n0 = decode_normal(ps.n[0]), n2 = decode_normal(ps.n[2]);
-    if(type == MI_PRIM_TRI)
-      tri_normal(v0, ld3(p.v[1]), v2, n0, decode_normal(ps.n[1]), n2, sf.u, sf.v, sf);
-    else if(sf.v >= sf.u)
-      tri_normal(v0, ld3(p.v[1]), v2, n0, decode_normal(ps.n[1]), n2, sf.u, sf.v - sf.u, sf);
-    else
-      tri_normal(v0, v2, ld3(p.v[3]), n0, n2, decode_normal(ps.n[3]), sf.u - sf.v, sf.v, sf);
+  { /* triangle / quad halves (v0 v1 v2) and (v0 v2 v3): decoded vertex normals and both geometric normals come from DPrimGeo */
+    const bool second = type == MI_PRIM_QUAD && !(sf.v >= sf.u);
+    const float u = second ? sf.u - sf.v : sf.u;
+    const float v = type == MI_PRIM_TRI ? sf.v : second ? sf.v : sf.v - sf.u;
+    const float *n1 = g + (second ? 6 : 3), *n2 = g + (second ? 9 : 6);
+    sf.gn = ld3(g + (second ? 15 : 12));
+    const float w = 1.0f - u - v;
+    sf.n = normalise3(mk3(u*n2[0] + v*n1[0] + w*g[0], u*n2[1] + v*n1[1] + w*g[1], u*n2[2] + v*n1[2] + w*g[2]));
   }
   /* texture coordinates, src/prims.c:300-365 */
   if(ps.uv[0] == 0) { sf.s = sf.u; sf.t = sf.v; }
