@@ -359,6 +359,8 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
     if((uint32_t)sh.material >= h->num_materials || h->materials[sh.material].bsdf > MI_BSDF_METAL)
     { free(s); return fail(MI_ERR_UNSUPPORTED, "shape uses a material outside the scope"); }
     for(uint32_t k=0;k<vc;k++) { q.n[k] = vtx[vi[k].v].n; q.uv[k] = vi[k].uv; }
+    if(vc == MI_PRIM_LINE) { pgeo[i].f[18] = (vi[0].uv >> 21)/2048.0f; pgeo[i].f[19] = ((vi[0].uv & 0x1ffc00u) >> 10)/2048.0f; }
+    else for(uint32_t k=0;k<vc;k++) { pgeo[i].f[18+2*k] = half2float(vi[k].uv & 0xffffu); pgeo[i].f[19+2*k] = half2float(vi[k].uv >> 16); }
     if(vc == MI_PRIM_SPHERE)
     {
       memcpy(p.v[0], vtx[vi[0].v].v, 12);

@@ -581,7 +581,7 @@ MI_HD V3 decode_normal(uint32_t enc)
   return normalise3(mk3(x, y, z));
 }
 
-__device__ __forceinline__ float half2float(uint32_t h)
+MI_HD float half2float(uint32_t h)
 { /* half_to_float, include/half.h:57-80 */
   const uint32_t sign = (h & 0x8000u) << 16;
   uint32_t o = (h & 0x7fffu) << 13;
@@ -591,9 +591,9 @@ __device__ __forceinline__ float half2float(uint32_t h)
   else if(ex == 0)
   {
     o += 1 << 23;
-    o = __float_as_uint(__uint_as_float(o) - __uint_as_float(113u << 23));
+    o = __builtin_bit_cast(uint32_t, __builtin_bit_cast(float, o) - __builtin_bit_cast(float, 113u << 23));
   }
-  return __uint_as_float(o | sign);
+  return __builtin_bit_cast(float, o | sign);
 }
 
 struct Surf
@@ -667,42 +667,18 @@ __device__ __forceinline__ void surface_setup(const DScene &sc, uint32_t prim, c
     const float w = 1.0f - u - v;
     sf.n = normalise3(mk3(u*n2[0] + v*n1[0] + w*g[0], u*n2[1] + v*n1[1] + w*g[1], u*n2[2] + v*n1[2] + w*g[2]));
   }
-  /* texture coordinates, src/prims.c:300-365 */
+  /* texture coordinates, src/prims.c:300-365; the half / fixed-point uv of the record are decoded at upload (g[18..25]) */
   if(ps.uv[0] == 0) { sf.s = sf.u; sf.t = sf.v; }
-  else if(type == MI_PRIM_SPHERE)
-  {
-    sf.s = sf.u + half2float(ps.uv[0] & 0xffffu);
-    sf.t = sf.v + half2float(ps.uv[0] >> 16);
-  }
-  else if(type == MI_PRIM_LINE)
-  {
-    sf.s = (ps.uv[0] >> 21)/2048.0f;
-    sf.t = ((ps.uv[0] & 0x1ffc00u) >> 10)/2048.0f;
-  }
+  else if(type == MI_PRIM_SPHERE) { sf.s = sf.u + g[18]; sf.t = sf.v + g[19]; }
+  else if(type == MI_PRIM_LINE) { sf.s = g[18]; sf.t = g[19]; }
   else
   {
-    const float u0s = half2float(ps.uv[0] & 0xffffu), u0t = half2float(ps.uv[0] >> 16);
-    const float u2s = half2float(ps.uv[2] & 0xffffu), u2t = half2float(ps.uv[2] >> 16);
-    if(type == MI_PRIM_TRI)
-    {
-      const float u1s = half2float(ps.uv[1] & 0xffffu), u1t = half2float(ps.uv[1] >> 16);
-      sf.s = (1.0f-sf.u-sf.v)*u0s + sf.v*u1s + sf.u*u2s;
-      sf.t = (1.0f-sf.u-sf.v)*u0t + sf.v*u1t + sf.u*u2t;
-    }
-    else if(sf.v >= sf.u)
-    {
-      const float u1s = half2float(ps.uv[1] & 0xffffu), u1t = half2float(ps.uv[1] >> 16);
-      const float u = sf.u, v = sf.v - sf.u;
-      sf.s = (1.0f-u-v)*u0s + v*u1s + u*u2s;
-      sf.t = (1.0f-u-v)*u0t + v*u1t + u*u2t;
-    }
-    else
-    {
-      const float u3s = half2float(ps.uv[3] & 0xffffu), u3t = half2float(ps.uv[3] >> 16);
-      const float u = sf.u - sf.v, v = sf.v;
-      sf.s = (1.0f-u-v)*u0s + v*u2s + u*u3s;
-      sf.t = (1.0f-u-v)*u0t + v*u2t + u*u3t;
-    }
+    const bool second = type == MI_PRIM_QUAD && !(sf.v >= sf.u);
+    const float u = second ? sf.u - sf.v : sf.u;
+    const float v = type == MI_PRIM_TRI ? sf.v : second ? sf.v : sf.v - sf.u;
+    const float *t1 = g + (second ? 22 : 20), *t2 = g + (second ? 24 : 22);
+    sf.s = (1.0f-u-v)*g[18] + v*t1[0] + u*t2[0];
+    sf.t = (1.0f-u-v)*g[19] + v*t1[1] + u*t2[1];
   }
   /* flip towards the ray, tangent frame */
   sf.flags = s_none;
@@ -849,8 +825,10 @@ __device__ __forceinline__ void ggx_sample11(float tan_theta_i, float U1, float 
   {
     const float r = sqrtf(U1/fmaxf(1e-8f, 1-U1));
     const float phi = (float)(2.0f*MI_PI_D*(double)U2);
-    slope_x = r*cosf(phi);
-    slope_y = r*sinf(phi);
+    float sn, cs;
+    sincosf(phi, &sn, &cs);
+    slope_x = r*cs;
+    slope_y = r*sn;
     return;
   }
   const float a = 1.0f/tan_theta_i;
@@ -969,7 +947,9 @@ __device__ __forceinline__ void sample_diffuse(Rng &rng, const Surf &sf, const S
   const float sq = sqrtf(x1);
   const float c0 = sqrtf((float)(1.0 - (double)x1));
   const float ang = (float)(2*MI_PI_D*(double)x2);
-  const float c1 = sq*cosf(ang), c2 = sq*sinf(ang);
+  float sn, cs;
+  sincosf(ang, &sn, &cs);                 /* one range reduction for both (same values as sinf/cosf) */
+  const float c1 = sq*cs, c2 = sq*sn;
   bs.omega = mk3(c0*sf.n.x + c1*sf.a.x + c2*sf.b.x, c0*sf.n.y + c1*sf.a.y + c2*sf.b.y, c0*sf.n.z + c1*sf.a.z + c2*sf.b.z);
   bs.pdf = (float)(1.0f/MI_PI_D);
   bs.mode = mode_in;

@@ -71,7 +71,8 @@ __device__ __forceinline__ void path_generate(const DScene &sc, PathState &ps, u
   ps.index = index;
   rng_seed(ps.rng, ps.index, sc.frame);
   ps.scramble = 0.1f + rng_next(ps.rng)*(0.9f-0.1f);
-  const float lf = fmodf(rng_next(ps.rng) + 0/(float)1, 1.0f);
+  const float lf0 = rng_next(ps.rng) + 0/(float)1;
+  const float lf = lf0 < 1.0f ? lf0 : fmodf(lf0, 1.0f);     /* fmodf(x, 1) == x for 0 <= x < 1; the libm loop only runs otherwise */
   ps.lambda = 360 + (830 - 360)*lf;
   const float time = rng_next(ps.rng)*sc.cam.time_scale;
   (void)rng_next(ps.rng);
@@ -85,8 +86,10 @@ __device__ __forceinline__ void path_generate(const DScene &sc, PathState &ps, u
   const float r2 = rng_next(ps.rng);
   const float lens_radius = (.5f/cam.f_stop)*cam.focal_length;
   const float ang = (float)(2*MI_PI_D*(double)r1);
-  const float lu = cosf(ang)*sqrtf(r2)*lens_radius;
-  const float lv = sinf(ang)*sqrtf(r2)*lens_radius;
+  float sn, cs;
+  sincosf(ang, &sn, &cs);                 /* one range reduction for both (same values as sinf/cosf) */
+  const float lu = cs*sqrtf(r2)*lens_radius;
+  const float lv = sn*sqrtf(r2)*lens_radius;
   const V3 ca = ld3(cam.a), cb = ld3(cam.b), cn = ld3(cam.n);
   const float f = cam.focus/cam.focal_length;
   const float f_dir = cam.focus;
