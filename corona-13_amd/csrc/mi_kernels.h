@@ -1368,25 +1368,30 @@ __device__ __forceinline__ void spectrum_to_xyz(const DScene &sc, float lambda, 
 }
 
 /* filter_blackmanharris_splat (include/blackmanharris.h:43-77) + filter_box_splat (box.h:23-36), executed by the whole
- * wave for every lane that has a splat pending: sixteen lanes take one of the 4x4 taps each (3 cosf per tap instead of
- * 96 per lane), the normalisation sum is formed in the reference's tap order, then each tap lane issues its three
- * hardware float atomics. */
+ * wave for the lanes that have a splat pending, four splats per pass: each group of sixteen lanes takes one splat and
+ * each of its lanes one of the 4x4 taps (3 cosf per tap instead of 96 per lane); the normalisation sum is formed in the
+ * reference's tap order, then each tap lane issues its three hardware float atomics. */
 __device__ __forceinline__ void splat_wave(const DScene &sc, bool pending, float pi, float pj, float c0, float c1, float c2)
 {
   unsigned long long m = __ballot(pending);
   const unsigned lane = __lane_id();
+  const unsigned grp = lane >> 4, base = lane & 48u;
   const int wd = (int)sc.width, ht = (int)sc.height;
   while(m)
   {
-    const int src = __ffsll((long long)m) - 1;
-    m &= m - 1;
+    /* group g serves the g-th pending lane of this pass */
+    const unsigned long long m1 = m & (m - 1), m2 = m1 & (m1 - 1), m3 = m2 & (m2 - 1);
+    const unsigned long long mine = grp == 0 ? m : grp == 1 ? m1 : grp == 2 ? m2 : m3;
+    m = m3 & (m3 - 1);
+    const bool have = mine != 0;
+    const int src = have ? __ffsll((long long)mine) - 1 : 0;
     const float spi = __shfl(pi, src), spj = __shfl(pj, src);
     const float s0 = __shfl(c0, src), s1 = __shfl(c1, src), s2 = __shfl(c2, src);
     const int x0 = (int)(spi - 1.5f), y0 = (int)(spj - 1.5f);
     const int u0 = -x0 < 0 ? 0 : -x0, v0 = -y0 < 0 ? 0 : -y0;
     const int u4 = x0 + 4 > wd ? wd - x0 : 4, v4 = y0 + 4 > ht ? ht - y0 : 4;
     const int u = lane & 3, v = (lane >> 2) & 3;
-    const bool inside = lane < 16 && v >= v0 && v < v4 && u >= u0 && u < u4;
+    const bool inside = have && v >= v0 && v < v4 && u >= u0 && u < u4;
     float f = 0.0f;
     if(inside)
     {
@@ -1395,12 +1400,10 @@ __device__ __forceinline__ void splat_wave(const DScene &sc, bool pending, float
     }
     float weight = 0.0f;
 #pragma unroll
-    for(int k=0;k<16;k++) weight += __shfl(f, k);     /* taps outside the image contribute exactly 0, as if skipped */
-    if(weight <= 0) continue;
-    weight = 1.0f/weight;
-    if(inside)
+    for(int k=0;k<16;k++) weight += __shfl(f, base + k);     /* taps outside the image contribute exactly 0, as if skipped */
+    if(inside && weight > 0)
     {
-      const float g = weight*f;
+      const float g = (1.0f/weight)*f;
       float *px = sc.fb + 3*((size_t)(x0+u) + (size_t)wd*(y0+v));
       atomicAdd(px+0, s0*g);
       atomicAdd(px+1, s1*g);
