@@ -12,7 +12,7 @@ import json
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, SCENE_0010, SCENE_ROUGH, load_pkg, make_scene, oracle_records, oracle_render
+from helpers import GOLDEN, SCENE_0010, SCENE_METAL, SCENE_ROUGH, load_pkg, make_scene, oracle_records, oracle_render
 
 pkg = load_pkg()
 pytestmark = pytest.mark.gpu
@@ -27,6 +27,8 @@ CASES = [
     ("cfg1 pt 256x256 mv4", SCENE_0010, pkg.MI_SAMPLER_PT, 256, 256, 4, 8000),
     ("cfg3 ptdl 1280x720 mv8", SCENE_0010, pkg.MI_SAMPLER_PTDL, 1280, 720, 8, 20000),
     ("cfg4 rough dielectric mv32", SCENE_ROUGH, pkg.MI_SAMPLER_PT, 1280, 720, 32, 8000),
+    ("metal pt mv8", SCENE_METAL, pkg.MI_SAMPLER_PT, 1280, 720, 8, 8000),
+    ("metal ptdl mv8", SCENE_METAL, pkg.MI_SAMPLER_PTDL, 1280, 720, 8, 8000),
 ]
 
 

