@@ -239,6 +239,7 @@ def mi_lib():
         m.mi_fb_device_ptr.restype = C.c_void_p
         m.mi_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         m.mi_trace_paths.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+        m.mi_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         m.mi_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         m.mi_last_kernel_launches.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         m.mi_scene_destroy.argtypes = [C.c_void_p]
@@ -250,8 +251,16 @@ def mi_lib():
 
 
 MI_SYMBOLS = ["mi_init", "mi_scene_create", "mi_scene_set_framebuffer", "mi_scene_set_stream", "mi_render",
-              "mi_sync", "mi_fb_read", "mi_fb_clear", "mi_fb_device_ptr", "mi_counters", "mi_trace_paths",
+              "mi_sync", "mi_fb_read", "mi_fb_clear", "mi_fb_device_ptr", "mi_counters", "mi_trace_paths", "mi_intersect",
               "mi_last_kernel_ms", "mi_last_kernel_launches", "mi_scene_destroy", "mi_shutdown", "mi_last_error"]
+
+
+def ray_dtypes():
+    """numpy dtypes of mi_ray and mi_hit (32 B each)."""
+    import numpy as np
+    ray = np.dtype([("pos", "<f4", 3), ("dir", "<f4", 3), ("ignore", "<u4"), ("max_dist", "<f4")])
+    hit = np.dtype([("primid", "<u8"), ("prim", "<u4"), ("dist", "<f4"), ("u", "<f4"), ("v", "<f4"), ("pad", "<u4", 2)])
+    return ray, hit
 
 
 class Backend:
@@ -302,6 +311,21 @@ class Backend:
         import numpy as np
         out = np.zeros(count, dtype=record_dtype())
         self._check(self.m.mi_trace_paths(self._ptr, first, count, out.ctypes.data), "mi_trace_paths")
+        return out
+
+    def intersect(self, pos, direction, ignore=None, max_dist=None):
+        """closest hits of caller-supplied rays (test hook, mi_intersect): returns a structured array (primid, prim, dist, u, v)"""
+        import numpy as np
+        RAY_DTYPE, HIT_DTYPE = ray_dtypes()
+        pos = np.ascontiguousarray(pos, dtype=np.float32).reshape(-1, 3)
+        direction = np.ascontiguousarray(direction, dtype=np.float32).reshape(-1, 3)
+        n = len(pos)
+        rays = np.zeros(n, dtype=RAY_DTYPE)
+        rays["pos"] = pos; rays["dir"] = direction
+        rays["ignore"] = 0xffffffff if ignore is None else ignore
+        rays["max_dist"] = np.float32(3.4028234663852886e38) if max_dist is None else max_dist
+        out = np.zeros(n, dtype=HIT_DTYPE)
+        self._check(self.m.mi_intersect(self._ptr, rays.ctypes.data, n, out.ctypes.data), "mi_intersect")
         return out
 
     def last_kernel_ms(self):

@@ -159,6 +159,44 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
   }
 }
 
+/* ======================================================================================= unit hook: rays in, hits out */
+__global__ __launch_bounds__(MI_BLOCK) void mi_intersect_kernel(DScene sc, const mi_ray *rays, unsigned long long n, mi_hit *out,
+                                                                uint2 *stack_overflow)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t N = sc.num_nodes;
+  float4 *lds_nodes = (float4 *)smem;
+  uint32_t *lds_axes = (uint32_t *)(smem + (size_t)MI_NODE_FIELDS*N*16);
+  const size_t stack_off = (((size_t)MI_NODE_FIELDS*N*16 + (size_t)N*4) + 15) & ~(size_t)15;
+  uint2 *lds_stack = (uint2 *)(smem + stack_off);
+  for(uint32_t i=threadIdx.x;i<MI_NODE_FIELDS*N;i+=MI_BLOCK) lds_nodes[i] = sc.nodes[i];
+  for(uint32_t i=threadIdx.x;i<N;i+=MI_BLOCK) lds_axes[i] = sc.node_axes[i];
+  __syncthreads();
+  Lds lds;
+  lds.nodes = lds_nodes; lds.axes = lds_axes; lds.stack = lds_stack + threadIdx.x; lds.num_nodes = N;
+  lds.overflow_stride = gridDim.x*MI_BLOCK;
+  lds.overflow = stack_overflow + (size_t)blockIdx.x*MI_BLOCK + threadIdx.x;
+  uint32_t cnt[MI_CNT] = {0};
+  for(unsigned long long base=(unsigned long long)blockIdx.x*MI_BLOCK; base<n; base+=(unsigned long long)gridDim.x*MI_BLOCK)
+  {
+    const unsigned long long i = base + threadIdx.x;
+    if(i < n)
+    {
+      const mi_ray r = rays[i];
+      Hit hit;
+      hit.prim = MI_NOPRIM; hit.dist = r.max_dist; hit.u = hit.v = 0.0f;
+      accel_intersect<MI_BLOCK, MI_STACK>(lds, sc.prims, mk3(r.pos[0], r.pos[1], r.pos[2]), mk3(r.dir[0], r.dir[1], r.dir[2]), r.ignore, hit, cnt);
+      mi_hit h;
+      h.prim = hit.prim; h.primid = hit.prim == MI_NOPRIM ? MI_PRIMID_INVALID : sc.primshade[hit.prim].primid;
+      h.dist = hit.dist; h.u = hit.u; h.v = hit.v; h.pad[0] = h.pad[1] = 0;
+      out[i] = h;
+    }
+  }
+  unsigned long long *shard = sc.counters + (size_t)(blockIdx.x % MI_COUNTER_SHARDS)*8;
+  atomicMax(shard + 7, (unsigned long long)cnt[7]);
+  for(int k=0;k<4;k++) if(cnt[k]) atomicAdd(shard + k, (unsigned long long)cnt[k]);
+}
+
 /* ======================================================================================= host side */
 static thread_local char g_err[512] = "";
 static int g_device = -1;
@@ -467,7 +505,8 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   const size_t node_bytes = (((size_t)MI_NODE_FIELDS*N*16 + (size_t)N*4) + 15) & ~(size_t)15;
   s->lds_bytes = node_bytes + (size_t)MI_STACK*MI_BLOCK*sizeof(uint2);
   if(s->lds_bytes > 160*1024) { mi_scene_destroy(s); return fail(MI_ERR_UNSUPPORTED, "BVH does not fit the LDS-resident traversal of this build"); }
-  if(hipFuncSetAttribute((const void *)mi_path_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess ||
+  if(hipFuncSetAttribute((const void *)mi_intersect_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess ||
+     hipFuncSetAttribute((const void *)mi_path_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess ||
      hipFuncSetAttribute((const void *)mi_path_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess ||
      hipFuncSetAttribute((const void *)mi_path_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess ||
      hipFuncSetAttribute((const void *)mi_path_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess)
@@ -668,6 +707,31 @@ extern "C" int mi_trace_paths(mi_scene *s, uint64_t first_index, uint64_t count,
   if(e == hipSuccess) e = hipMemcpy(host_out, d_rec, count*sizeof(mi_path_record), hipMemcpyDeviceToHost);
   hipFree(d_rec);
   if(e != hipSuccess) { snprintf(g_err, sizeof(g_err), "mi_trace_paths: %s", hipGetErrorString(e)); fprintf(stderr, "[mi] %s\n", g_err); return MI_ERR_DEVICE; }
+  return MI_OK;
+}
+
+extern "C" int mi_intersect(mi_scene *s, const mi_ray *rays, uint64_t n, mi_hit *host_out)
+{
+  if(!s || !rays || !host_out) return fail(MI_ERR_ARG, "null argument");
+  if(!n) return MI_OK;
+  void *d_rays = nullptr, *d_hits = nullptr;
+  hipError_t e = hipMalloc(&d_rays, n*sizeof(mi_ray));
+  if(e == hipSuccess) e = hipMalloc(&d_hits, n*sizeof(mi_hit));
+  if(e == hipSuccess) e = hipMemcpyAsync(d_rays, rays, n*sizeof(mi_ray), hipMemcpyHostToDevice, s->stream);
+  if(e == hipSuccess)
+  {
+    int grid = s->grid;
+    const uint64_t need = (n + MI_BLOCK - 1)/MI_BLOCK;
+    if((uint64_t)grid > need) grid = (int)need;
+    hipLaunchKernelGGL(mi_intersect_kernel, dim3(grid), dim3(MI_BLOCK), s->lds_bytes, s->stream, s->d, (const mi_ray *)d_rays,
+                       (unsigned long long)n, (mi_hit *)d_hits, (uint2 *)s->d_overflow);
+    e = hipGetLastError();
+  }
+  if(e == hipSuccess) e = hipStreamSynchronize(s->stream);
+  if(e == hipSuccess) e = hipMemcpy(host_out, d_hits, n*sizeof(mi_hit), hipMemcpyDeviceToHost);
+  if(d_rays) hipFree(d_rays);
+  if(d_hits) hipFree(d_hits);
+  if(e != hipSuccess) { snprintf(g_err, sizeof(g_err), "mi_intersect: %s", hipGetErrorString(e)); fprintf(stderr, "[mi] %s\n", g_err); return MI_ERR_DEVICE; }
   return MI_OK;
 }
 

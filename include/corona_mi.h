@@ -243,6 +243,16 @@ typedef struct mi_path_record
 } mi_path_record;
 int  mi_trace_paths(mi_scene *s, uint64_t first_index, uint64_t count, mi_path_record *host_out);
 
+/* Test hook: closest hit of n caller-supplied rays, i.e. accel_intersect (src/accel.d/qbvhmp.c:1262-1390)
+ * + prims_intersect (src/prims.c:638-672) on their own. `ignore` is the builder-order index of the primitive
+ * the ray starts on (ray_t.ignore, include/corona_common.h) or MI_RAY_NO_IGNORE; `max_dist` initialises hit.dist.
+ * u,v are the reference's hit.u / hit.v for triangles and quads; for spheres and lines they are evaluated at
+ * shading time in this backend and are not comparable here. Adds to mi_counters like a render. */
+#define MI_RAY_NO_IGNORE 0xffffffffu
+typedef struct mi_ray { float pos[3], dir[3]; uint32_t ignore; float max_dist; } mi_ray;
+typedef struct mi_hit { mi_primid primid; uint32_t prim; float dist, u, v; uint32_t pad[2]; } mi_hit;   /* 32 B */
+int  mi_intersect(mi_scene *s, const mi_ray *rays, uint64_t n, mi_hit *host_out);
+
 /* Time of the last mi_render launch on the device in milliseconds (HIP events on the scene's
  * stream), and kernel launches since creation. For bench.py's roofline figure. */
 int  mi_last_kernel_ms(mi_scene *s, float *ms);

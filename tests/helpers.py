@@ -60,6 +60,24 @@ def oracle_records(scene, first, count):
     return out
 
 
+def oracle_intersect(scene, pos, direction, ignore_primid=None, max_dist=None):
+    """closest hits of caller-supplied rays by the oracle's accel_intersect; returns (hits, counters)"""
+    ray_dt = np.dtype({"names": ["pos", "dir", "ignore", "max_dist"], "formats": [("<f4", 3), ("<f4", 3), "<u8", "<f4"],
+                       "offsets": [0, 12, 24, 32], "itemsize": 40})
+    hit_dt = np.dtype({"names": ["prim", "dist", "u", "v"], "formats": ["<u8", "<f4", "<f4", "<f4"], "offsets": [0, 8, 12, 16], "itemsize": 24})
+    pos = np.ascontiguousarray(pos, dtype=np.float32).reshape(-1, 3)
+    n = len(pos)
+    rays = np.zeros(n, dtype=ray_dt)
+    rays["pos"] = pos
+    rays["dir"] = np.asarray(direction, dtype=np.float32).reshape(-1, 3)
+    rays["ignore"] = 0xffffffffffffffff if ignore_primid is None else ignore_primid
+    rays["max_dist"] = np.float32(3.4028234663852886e38) if max_dist is None else max_dist
+    out = np.zeros(n, dtype=hit_dt)
+    cnt = (C.c_uint64 * 8)()
+    oracle_lib().oracle_intersect(scene.desc_ptr, rays.ctypes.data, n, out.ctypes.data, cnt)
+    return out, list(cnt)
+
+
 def oracle_render(scene, first, count, threads=1):
     fb = np.zeros((scene.height, scene.width, 3), dtype=np.float32)
     cnt = (C.c_uint64 * 8)()

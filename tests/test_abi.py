@@ -29,6 +29,8 @@ def test_struct_sizes_match_header():
     assert C.sizeof(pkg.MiCamera) == 80
     assert C.sizeof(pkg.MiPathVertex) == 112 and C.sizeof(pkg.MiPathSplat) == 24
     assert C.sizeof(pkg.MiPathRecord) == 40 + 8 * 24 + 8 * 112
+    ray, hit = pkg.ray_dtypes()
+    assert ray.itemsize == 32 and hit.itemsize == 32          # mi_ray, mi_hit
 
 
 def test_product_never_imports_oracle():

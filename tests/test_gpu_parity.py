@@ -12,7 +12,7 @@ import json
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, SCENE_0010, SCENE_METAL, SCENE_ROUGH, load_pkg, make_scene, oracle_records, oracle_render
+from helpers import GOLDEN, SCENE_0010, SCENE_METAL, SCENE_ROUGH, load_pkg, make_scene, oracle_intersect, oracle_records, oracle_render
 
 pkg = load_pkg()
 pytestmark = pytest.mark.gpu
@@ -206,3 +206,83 @@ def test_errors_are_reported():
     assert m.mi_scene_create(d, C.byref(out)) < 0
     d.contents.struct_size = C.sizeof(pkg.MiSceneDesc)
     assert m.mi_render(None, 0, 1) < 0
+
+
+def _compare_hits(scene, be, pos, direction, ignore=None, max_dist=None):
+    """mi_intersect vs the oracle's accel_intersect on the same rays: primitive and distance bit-exact, u/v bit-exact on
+    triangles and quads (spheres / lines get theirs at shading time), work counters equal"""
+    primid = np.ctypeslib.as_array(scene.desc.primid, shape=(scene.desc.num_prims,))
+    ign_id = None if ignore is None else np.where(ignore == 0xffffffff, np.uint64(0xffffffffffffffff), primid[np.minimum(ignore, len(primid) - 1)])
+    c0 = be.counters()
+    gpu = be.intersect(pos, direction, ignore=ignore, max_dist=max_dist)
+    c1 = be.counters()
+    ora, cnt = oracle_intersect(scene, pos, direction, ignore_primid=ign_id, max_dist=max_dist)
+    assert np.array_equal(gpu["primid"], ora["prim"])
+    assert np.array_equal(gpu["dist"].view(np.uint32), ora["dist"].view(np.uint32))
+    hit = gpu["primid"] != 0xffffffffffffffff
+    triquad = hit & ((gpu["primid"] >> np.uint64(61)) >= 3)
+    assert np.array_equal(gpu["u"][triquad].view(np.uint32), ora["u"][triquad].view(np.uint32))
+    assert np.array_equal(gpu["v"][triquad].view(np.uint32), ora["v"][triquad].view(np.uint32))
+    for k in range(4):                    # rays, node visits, box hits, primitive tests
+        assert c1[k] - c0[k] == cnt[k], (k, c1[k] - c0[k], cnt[k])
+    return gpu
+
+
+def test_intersect_random_rays_bit_exact():
+    scene = make_scene(SCENE_0010, width=256, height=256, max_verts=8)
+    be = pkg.Backend(scene)
+    rng = np.random.default_rng(7)
+    n = 200000
+    lo, hi = np.array(scene.desc.aabb[:3]), np.array(scene.desc.aabb[3:6])
+    # origins around the objects in the middle of the backdrop, directions uniform on the sphere
+    pos = rng.uniform(-4, 4, size=(n, 3)).astype(np.float32) + np.float32([0, 0, 2])
+    d = rng.normal(size=(n, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    gpu = _compare_hits(scene, be, pos, d)
+    assert (gpu["primid"] != 0xffffffffffffffff).mean() > 0.3
+    kinds = (gpu["primid"][gpu["primid"] != 0xffffffffffffffff] >> np.uint64(61))
+    assert set(np.unique(kinds)) >= {1, 2, 4}                     # spheres, lines and quads were all hit
+    # with an ignored primitive and a finite search distance
+    ignore = rng.integers(0, scene.desc.num_prims, size=n).astype(np.uint32)
+    ignore[::3] = 0xffffffff
+    _compare_hits(scene, be, pos, d, ignore=ignore, max_dist=rng.uniform(0.5, 30, size=n).astype(np.float32))
+    assert lo[0] < hi[0]
+    be.close()
+
+
+def test_intersect_degenerate_rays_follow_sse_nan_semantics():
+    """rays with zero direction components (1/dir = +-inf) whose origin lies exactly in box planes: 0*inf = NaN in the
+    slab test, resolved by the reference's SSE min/max operand order (qbvhmp.c:1188-1246). The kernel switches to its
+    literal compare/select slab test for such waves; hits, distances and counters must still equal the oracle's."""
+    scene = make_scene(SCENE_0010, width=256, height=256, max_verts=8)
+    be = pkg.Backend(scene)
+    rng = np.random.default_rng(11)
+    nodes = scene.desc.nodes
+    planes = [[], [], []]
+    for i in range(scene.desc.num_nodes):
+        for k in range(3):
+            for c in range(4):
+                for b in (nodes[i].aabb[k][c], nodes[i].aabb[k + 3][c]):
+                    if abs(b) < 1e30:
+                        planes[k].append(b)
+    planes = [np.unique(np.float32(p)) for p in planes]
+    n = 60000
+    pos = rng.uniform(-4, 4, size=(n, 3)).astype(np.float32) + np.float32([0, 0, 2])
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    for i in range(n):
+        zero = rng.integers(1, 7)                    # bit mask of axes with a zero direction component (not all three)
+        for k in range(3):
+            if zero & (1 << k):
+                d[i, k] = 0.0 if rng.random() < 0.5 else -0.0
+                if rng.random() < 0.7:
+                    pos[i, k] = rng.choice(planes[k])  # origin exactly in a box plane of that axis
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    assert ((d == 0).sum(axis=1) >= 1).all()
+    gpu = _compare_hits(scene, be, pos, d)
+    assert (gpu["primid"] != 0xffffffffffffffff).mean() > 0.2
+    # mixed waves: only every 64th ray degenerate
+    mixed = rng.normal(size=(n, 3)).astype(np.float32)
+    mixed[::64] = d[::64]
+    mixed = (mixed / np.linalg.norm(mixed, axis=1, keepdims=True)).astype(np.float32)
+    _compare_hits(scene, be, pos, mixed)
+    be.close()
