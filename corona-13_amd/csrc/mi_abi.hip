@@ -294,7 +294,8 @@ static void pack_line(DPrim &p, DPrimShade &q, const mi_vtx &a0, const mi_vtx &a
   { /* cone: d *= 1.0/d_len (double), cos_a2 */
     for(int k=0;k<3;k++) d[k] = (float)(d[k]*(1.0/dlen));
     f[6] = d[0]; f[7] = d[1]; f[8] = d[2];
-    f[9] = v1[0]; f[10] = v1[1]; f[11] = v1[2];
+    const float tt = -r0*dlen/(r1-r0);            /* apex of the cone, line.h:395-397 */
+    f[9] = v0[0] + tt*d[0]; f[10] = v0[1] + tt*d[1]; f[11] = v0[2] + tt*d[2];
     f[13] = dlen*dlen/((r1-r0)*(r1-r0) + dlen*dlen);
   }
   fu[12] = type;
@@ -421,14 +422,22 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
     }
     else
     {
-      for(uint32_t k=0;k<vc;k++) memcpy(p.v[k], vtx[vi[k].v].v, 12);
       float *g = pgeo[i].f;
+      V3 vv[4] = {};
+      for(uint32_t k=0;k<vc;k++) vv[k] = ld3(vtx[vi[k].v].v);
+      memcpy(p.v[0], vtx[vi[0].v].v, 12);
+      for(uint32_t k=1;k<vc;k++)
+      { /* the intersection test works on edges (triangle.h:271-283): the same float subtraction, once */
+        const V3 e = sub3(vv[k], vv[0]);
+        p.v[k][0] = e.x; p.v[k][1] = e.y; p.v[k][2] = e.z;
+        g[26 + 3*(k-1)] = vv[k].x; g[27 + 3*(k-1)] = vv[k].y; g[28 + 3*(k-1)] = vv[k].z;
+      }
       for(uint32_t k=0;k<vc;k++) { const V3 n = decode_normal(q.n[k]); g[3*k] = n.x; g[3*k+1] = n.y; g[3*k+2] = n.z; }
-      const V3 ga = tri_geo_normal(ld3(p.v[0]), ld3(p.v[1]), ld3(p.v[2]));
+      const V3 ga = tri_geo_normal(vv[0], vv[1], vv[2]);
       g[12] = ga.x; g[13] = ga.y; g[14] = ga.z;
       if(vc == MI_PRIM_QUAD)
       {
-        const V3 gb = tri_geo_normal(ld3(p.v[0]), ld3(p.v[2]), ld3(p.v[3]));
+        const V3 gb = tri_geo_normal(vv[0], vv[2], vv[3]);
         g[15] = gb.x; g[16] = gb.y; g[17] = gb.z;
       }
     }

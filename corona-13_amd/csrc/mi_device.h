@@ -10,7 +10,7 @@
  *             intersection test is ONE aligned fetch instead of primid -> vtxidx -> vtx
  *             (src/prims.c:638-672, include/geo.h:120-138)
  *  primshade  one 48-B record per primitive, touched once per path vertex (normals, uv, material)
- *  primgeo    one 128-B record per primitive, touched once per path vertex (decoded normals / line frames)
+ *  primgeo    one 144-B record per primitive, touched once per path vertex (decoded normals / line frames)
  */
 #ifndef MI_DEVICE_H
 #define MI_DEVICE_H
@@ -23,7 +23,8 @@
 
 struct DPrim                       /* 64 B */
 {
-  float v[4][3];                   /* tri/quad: vertices. sphere: v[0] centre, v[1][0] radius. line: v[0], v[1], v[2][0]=r0, v[2][1]=r1 */
+  float v[4][3];                   /* tri/quad: v[0] = v0, v[1..3] = edges v1-v0, v2-v0, v3-v0. sphere: v[0] centre, v[1][0] radius.
+                                      line: see line_intersect (mi_kernels.h) */
   uint32_t type;                   /* vcnt: 1 sphere, 2 line, 3 tri, 4 quad */
   uint32_t pad[3];
 };
@@ -37,13 +38,14 @@ struct DPrimShade                  /* 48 B */
   uint32_t pad;
 };
 
-struct DPrimGeo                    /* 128 B of per-primitive constants of the shading side, precomputed at upload with the
+struct DPrimGeo                    /* 144 B of per-primitive constants of the shading side, precomputed at upload with the
                                       kernel's own (host+device) functions */
 {
-  float f[32];                     /* tri/quad: decoded vertex normals n0..n3 [0..11], geometric normal of (v0 v1 v2) [12..14] and of
+  float f[36];                     /* tri/quad: decoded vertex normals n0..n3 [0..11], geometric normal of (v0 v1 v2) [12..14] and of
                                       (v0 v2 v3) [15..17]. line: unit axis d [0..2], 1/|v1-v0| [3], onb a [4..6], b [7..9] of d;
                                       cone: onb of the intersection-side axis [10..12], [13..15].
-                                      [18..25] texture coordinates: tri/quad (s,t) of v0..v3, sphere offset, line (s,t) */
+                                      [18..25] texture coordinates: tri/quad (s,t) of v0..v3, sphere offset, line (s,t).
+                                      [26..34] tri/quad: vertices v1, v2, v3 (DPrim holds v0 and the edges) */
 };
 
 struct DMaterial

@@ -172,7 +172,7 @@ __device__ __forceinline__ float sphere_t(const V3 c, float radius, const V3 ro,
 
 /* Line primitives (truncated cones with radii r0, r1) carry their per-primitive constants precomputed at upload, with
  * the very float operations the reference performs per test (mi_abi.hip: pack_line):
- *   dword 0-2 v0 | 3 r0 | 4 r1 | 5 |v1-v0| | 6-8 unit axis d | 9-11 cylinder: onb a, cone: v1 | 12 type | 13-15 cylinder: onb b, cone: cos_a2,-,-
+ *   dword 0-2 v0 | 3 r0 | 4 r1 | 5 |v1-v0| | 6-8 unit axis d | 9-11 cylinder: onb a, cone: tip | 12 type | 13-15 cylinder: onb b, cone: cos_a2,-,-
  * For a cylinder hit.u / hit.v transport the raw cross-section coordinates (out[1], out[2]); the angle
  * hit->v = atan2f(out[1], out[2])/2pi (include/geo/line.h:486) is evaluated once at shading time, not per candidate. */
 __device__ __forceinline__ void line_intersect(const DPrim &p, const V3 ro, const V3 rd, Hit &hit, uint32_t prim, uint32_t ignore)
@@ -235,8 +235,7 @@ __device__ __forceinline__ void line_intersect(const DPrim &p, const V3 ro, cons
   {
     const float d_len = f[5], cos_a2 = f[13];
     const float cos_dr = dot3(d, rd);
-    const float tt = -r0*d_len/(r1-r0);
-    const V3 tip = mk3(v0.x + tt*d.x, v0.y + tt*d.y, v0.z + tt*d.z);
+    const V3 tip = mk3(f[9], f[10], f[11]);      /* v0 + (-r0*d_len/(r1-r0))*d, formed at upload */
     const V3 o = sub3(ro, tip);
     const float cos_do = dot3(d, o);
     const float cos_ro = dot3(rd, o);
@@ -273,7 +272,7 @@ __device__ __forceinline__ void line_intersect(const DPrim &p, const V3 ro, cons
   }
 }
 
-struct PrimRegs { float4 q0, q1, q2, q3; };   /* one DPrim as four 16-byte loads: v0.xyz v1.x | v1.yz v2.xy | v2.z v3.xyz | type pad */
+struct PrimRegs { float4 q0, q1, q2, q3; };   /* one DPrim as four 16-byte loads: v0.xyz e1.x | e1.yz e2.xy | e2.z e3.xyz | type pad */
 __device__ __forceinline__ PrimRegs prim_load(const DPrim *prims, uint32_t prim)
 {
   const float4 *q = (const float4 *)(prims + prim);
@@ -285,11 +284,10 @@ __device__ __forceinline__ void triquad_intersect(const PrimRegs &r, uint32_t ty
 { /* prims_intersect for tris and quads, src/prims.c:645-663: quad = tri(v0,v1,v2), and only if that misses tri(v0,v2,v3).
      Both triangles are evaluated without branches (same arithmetic as geo_tri_intersect, include/geo/triangle.h:263-305)
      and the reference's priority is applied afterwards, so a wave does not diverge on which half was hit. */
-  const V3 v0 = mk3(r.q0.x, r.q0.y, r.q0.z), v1 = mk3(r.q0.w, r.q1.x, r.q1.y), v2 = mk3(r.q1.z, r.q1.w, r.q2.x), v3 = mk3(r.q2.y, r.q2.z, r.q2.w);
+  /* the record holds v0 and the three edges v1-v0, v2-v0, v3-v0 (formed at upload with the same float subtraction) */
+  const V3 v0 = mk3(r.q0.x, r.q0.y, r.q0.z), eA1 = mk3(r.q0.w, r.q1.x, r.q1.y), e02 = mk3(r.q1.z, r.q1.w, r.q2.x), eB2 = mk3(r.q2.y, r.q2.z, r.q2.w);
   const V3 tv = sub3(o, v0);
-  const V3 e02 = sub3(v2, v0);
   /* triangle A: edge1 = v1-v0, edge2 = v2-v0 */
-  const V3 eA1 = sub3(v1, v0);
   const V3 pA = cross3(d, e02);
   const float invA = 1.0f/dot3(eA1, pA);
   const float vA = dot3(tv, pA)*invA;
@@ -298,7 +296,6 @@ __device__ __forceinline__ void triquad_intersect(const PrimRegs &r, uint32_t ty
   const float tA = dot3(e02, qA)*invA;
   const bool hitA = !(vA < 0.0f || vA > 1.0f) && !(uA < 0.0f || uA + vA > 1.0f) && (tA > 0.0f && tA <= hit.dist);
   /* triangle B: edge1 = v2-v0, edge2 = v3-v0 */
-  const V3 eB2 = sub3(v3, v0);
   const V3 pB = cross3(d, eB2);
   const float invB = 1.0f/dot3(e02, pB);
   const float vB = dot3(tv, pB)*invB;
@@ -1300,20 +1297,21 @@ __device__ __forceinline__ V3 tri_retime(const V3 v0, const V3 v1, const V3 v2, 
   return mk3(w*v0.x + v*v1.x + u*v2.x, w*v0.y + v*v1.y + u*v2.y, w*v0.z + v*v1.z + u*v2.z);
 }
 
-__device__ __forceinline__ V3 prim_sample(const DPrim &p, const DPrimShade &psh, float r0, float r1, float &hu, float &hv)
+__device__ __forceinline__ V3 prim_sample(const DPrim &p, const DPrimShade &psh, const DPrimGeo &geo, float r0, float r1, float &hu, float &hv)
 { /* prims_sample + prims_retime, src/prims.c:178-252 */
   const uint32_t type = p.type;
+  const float *gv = geo.f + 26;             /* v1, v2, v3 of a triangle / quad (DPrim keeps v0 and the edges) */
   if(type == MI_PRIM_QUAD)
   {
     hu = r0; hv = r1;
-    if(hv >= hu) return tri_retime(ld3(p.v[0]), ld3(p.v[1]), ld3(p.v[2]), hu, hv - hu);
-    return tri_retime(ld3(p.v[0]), ld3(p.v[2]), ld3(p.v[3]), hu - hv, hv);
+    if(hv >= hu) return tri_retime(ld3(p.v[0]), ld3(gv), ld3(gv + 3), hu, hv - hu);
+    return tri_retime(ld3(p.v[0]), ld3(gv + 3), ld3(gv + 6), hu - hv, hv);
   }
   if(type == MI_PRIM_TRI)
   {
     const float a = sqrtf(r0);
     hu = r1*a; hv = (1.0f-r1)*a;
-    return tri_retime(ld3(p.v[0]), ld3(p.v[1]), ld3(p.v[2]), hu, hv);
+    return tri_retime(ld3(p.v[0]), ld3(gv), ld3(gv + 3), hu, hv);
   }
   if(type == MI_PRIM_SPHERE)
   { /* geo_sphere_retime, include/geo/sphere.h:38-49 */

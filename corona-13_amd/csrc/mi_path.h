@@ -335,7 +335,7 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
             const uint32_t t = sample_cdf(sc.light_cdf, (int)sc.num_lights, r1);
             const uint32_t lp = sc.light_prim[t];
             Surf ls;
-            ls.x = prim_sample(sc.prims[lp], sc.primshade[lp], r2, r3, ls.u, ls.v);
+            ls.x = prim_sample(sc.prims[lp], sc.primshade[lp], sc.primgeo[lp], r2, r3, ls.u, ls.v);
             V3 ol = sub3(ls.x, sf.x);
             const float ldist = sqrtf(dot3(ol, ol));
             const double il = 1./(double)ldist;
