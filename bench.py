@@ -129,6 +129,8 @@ def main():
     def step(k):
         # rank r renders its own contiguous block of path indices of "frame" k: no data-path collective
         first, count = pkg.shard_range(k * world * per_frame, world * per_frame, rank, world)
+        if world > 1:
+            fb.zero_()                                     # the reduce works on this step's partial sums only
         be.render(first, count)
         if world > 1:
             dist.all_reduce(fb, op=dist.ReduceOp.SUM)      # framebuffer reduce over xGMI (RCCL)
