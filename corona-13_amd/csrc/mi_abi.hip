@@ -621,24 +621,30 @@ extern "C" int mi_render(mi_scene *s, uint64_t first_index, uint64_t count)
   if(!s) return fail(MI_ERR_ARG, "null scene");
   if(!count) return MI_OK;
   if(s->wavefront) return render_wavefront(s, first_index, count);
-  HIPCHK(hipMemsetAsync(s->d_work, 0, sizeof(unsigned long long), s->stream));
-  int grid = s->grid;
-  const uint64_t need = (count + MI_BLOCK - 1)/MI_BLOCK;
-  if((uint64_t)grid > need) grid = (int)need;
   HIPCHK(hipEventRecord(s->ev0, s->stream));
-  if(s->d.sampler == MI_SAMPLER_PTDL)
-    hipLaunchKernelGGL((mi_path_kernel<false, true>), dim3(grid), dim3(MI_BLOCK), s->lds_bytes, s->stream,
-                       s->d, (unsigned long long)first_index, (unsigned long long)count, (const uint32_t *)s->d_shape_material,
-                       (const float *)s->d_shape_L, (mi_path_record *)nullptr, (uint2 *)s->d_overflow);
-  else
-    hipLaunchKernelGGL((mi_path_kernel<false, false>), dim3(grid), dim3(MI_BLOCK), s->lds_bytes, s->stream,
-                       s->d, (unsigned long long)first_index, (unsigned long long)count, (const uint32_t *)s->d_shape_material,
-                       (const float *)s->d_shape_L, (mi_path_record *)nullptr, (uint2 *)s->d_overflow);
-  HIPCHK(hipGetLastError());
+  s->kernel_launches_last = 0;
+  /* every workgroup hands out its share of the range through a 32-bit LDS counter: keep a share below 2^31 paths */
+  const uint64_t per_launch = (uint64_t)s->grid << 31;
+  for(uint64_t done = 0; done < count; done += per_launch)
+  {
+    const uint64_t n = count - done < per_launch ? count - done : per_launch;
+    int grid = s->grid;
+    const uint64_t need = (n + MI_BLOCK - 1)/MI_BLOCK;
+    if((uint64_t)grid > need) grid = (int)need;
+    if(s->d.sampler == MI_SAMPLER_PTDL)
+      hipLaunchKernelGGL((mi_path_kernel<false, true>), dim3(grid), dim3(MI_BLOCK), s->lds_bytes, s->stream,
+                         s->d, (unsigned long long)(first_index + done), (unsigned long long)n, (const uint32_t *)s->d_shape_material,
+                         (const float *)s->d_shape_L, (mi_path_record *)nullptr, (uint2 *)s->d_overflow);
+    else
+      hipLaunchKernelGGL((mi_path_kernel<false, false>), dim3(grid), dim3(MI_BLOCK), s->lds_bytes, s->stream,
+                         s->d, (unsigned long long)(first_index + done), (unsigned long long)n, (const uint32_t *)s->d_shape_material,
+                         (const float *)s->d_shape_L, (mi_path_record *)nullptr, (uint2 *)s->d_overflow);
+    HIPCHK(hipGetLastError());
+    s->kernel_launches_last++;
+  }
   HIPCHK(hipEventRecord(s->ev1, s->stream));
   s->have_timing = 1;
-  s->launches++;
-  s->kernel_launches_last = 1;
+  s->launches += s->kernel_launches_last;
   return MI_OK;
 }
 
