@@ -286,3 +286,26 @@ def test_intersect_degenerate_rays_follow_sse_nan_semantics():
     mixed = (mixed / np.linalg.norm(mixed, axis=1, keepdims=True)).astype(np.float32)
     _compare_hits(scene, be, pos, mixed)
     be.close()
+
+
+def test_cfg5_film_3840x2160():
+    """BASELINE config 5's film (3840x2160, padded to 3840x2176; 100 MB framebuffer): one sample per pixel, sharded over two
+    path-index ranges like two ranks would, against the oracle's image of the same indices"""
+    scene = make_scene(SCENE_0010, width=3840, height=2160, max_verts=8)
+    assert (scene.width, scene.height) == (3840, 2176)
+    be = pkg.Backend(scene)
+    n = scene.width * scene.height
+    for r in range(2):
+        first, count = pkg.shard_range(0, n, r, 2)
+        be.render(first, count)
+    fb = be.fb_read()
+    cnt = be.counters()
+    assert cnt[4] == n
+    ofb, ocnt, _ = oracle_render(scene, 0, n, threads=8)
+    gain = scene.gain(1)
+    rmse = np.sqrt((((fb - ofb) * gain) ** 2).sum() / n)
+    assert rmse < 0.05, rmse
+    assert np.allclose(fb.sum(axis=(0, 1)), ofb.sum(axis=(0, 1)), rtol=1e-3)
+    for k in range(4):
+        assert abs(cnt[k] - ocnt[k]) <= 1e-3 * ocnt[k], (k, cnt[k], ocnt[k])
+    be.close()
