@@ -506,6 +506,23 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   d.light_prim = (const uint32_t *)s->d_light_prim; d.light_cdf = (const float *)s->d_light_cdf; d.light_L = (const float *)s->d_light_L;
   d.p_sky = h->lights.p_sky; d.p_geo = h->lights.p_geo; d.p_vol = h->lights.p_vol;
   d.cam = h->cam;
+  { /* same expressions, same order as path_generate evaluated them per path before (thinlens.c:68-128) */
+    const mi_camera &cam = h->cam;
+    DCamConst &c = d.cc;
+    c.W = (float)h->width; c.H = (float)h->height;
+    c.lens_radius = (.5f/cam.f_stop)*cam.focal_length;
+    const float f = cam.focus/cam.focal_length;
+    c.f_dir = cam.focus;
+    c.f_rg = -cam.film_width*f/c.W;
+    c.f_up = -cam.film_height*f/c.H;
+    const float A = (float)(MI_PI_D*(double)cam.focal_length*(double)cam.focal_length/(double)(4.0f*cam.f_stop*cam.f_stop));
+    c.pdf_a = (float)(1./(double)A);
+    c.sensor = 106.86535f*100.0f*cam.exposure_time;
+    c.fl2 = cam.focal_length*cam.focal_length;
+    c.pdf_v = 1.0f/(cam.film_width*cam.film_height);
+    c.pdf_av = c.pdf_a*c.pdf_v;
+    c.Wc = c.W-1e-4f; c.Hc = c.H-1e-4f;
+  }
   d.cie_xyz = (const float *)s->d_cie; d.checker = (const float *)s->d_checker; d.metal_ior = (const float *)s->d_metal;
   d.fb = s->d_fb;
   d.counters = (unsigned long long *)s->d_counters;

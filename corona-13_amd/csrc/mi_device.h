@@ -55,6 +55,12 @@ struct DMaterial
   float param[4];
 };
 
+struct DCamConst                   /* per-launch camera constants of camera_sample (src/camera.d/thinlens.c:68-128), formed once at
+                                      upload with the float / double expressions the kernel would evaluate per path */
+{
+  float lens_radius, f_dir, f_rg, f_up, pdf_a, pdf_v, sensor, fl2, pdf_av, W, H, Wc, Hc;
+};
+
 struct DScene
 {
   /* film */
@@ -76,6 +82,7 @@ struct DScene
   const float *light_cdf, *light_L;
   float p_sky, p_geo, p_vol;
   mi_camera cam;
+  DCamConst cc;
   const float *cie_xyz, *checker, *metal_ior;
   /* output */
   float *fb;

@@ -77,42 +77,36 @@ __device__ __forceinline__ void path_generate(const DScene &sc, PathState &ps, u
   const float time = rng_next(ps.rng)*sc.cam.time_scale;
   (void)rng_next(ps.rng);
   (void)rng_next(ps.rng);
-  /* camera_sample, src/camera.d/thinlens.c:68-128 */
+  /* camera_sample, src/camera.d/thinlens.c:68-128; everything that does not depend on the random numbers is in sc.cc */
   const mi_camera &cam = sc.cam;
-  const float W = (float)sc.width, H = (float)sc.height;
+  const DCamConst &cc = sc.cc;
+  const float W = cc.W, H = cc.H;
   const float ci = rng_next(ps.rng)*W;
   const float cj = rng_next(ps.rng)*H;
   const float r1 = rng_next(ps.rng);
   const float r2 = rng_next(ps.rng);
-  const float lens_radius = (.5f/cam.f_stop)*cam.focal_length;
   const float ang = (float)(2*MI_PI_D*(double)r1);
   float sn, cs;
   sincosf(ang, &sn, &cs);                 /* one range reduction for both (same values as sinf/cosf) */
-  const float lu = cs*sqrtf(r2)*lens_radius;
-  const float lv = sn*sqrtf(r2)*lens_radius;
+  const float lu = cs*sqrtf(r2)*cc.lens_radius;
+  const float lv = sn*sqrtf(r2)*cc.lens_radius;
   const V3 ca = ld3(cam.a), cb = ld3(cam.b), cn = ld3(cam.n);
-  const float f = cam.focus/cam.focal_length;
-  const float f_dir = cam.focus;
-  const float f_rg = -cam.film_width*f/W;
-  const float f_up = -cam.film_height*f/H;
   const V3 aoff = mk3(lu*ca.x + lv*cb.x, lu*ca.y + lv*cb.y, lu*ca.z + lv*cb.z);
-  const float ki = (ci-.5f*W)*f_rg, kj = (cj-.5f*H)*f_up;
-  V3 om = mk3(f_dir*cn.x + (ki*ca.x + kj*cb.x) - aoff.x,
-              f_dir*cn.y + (ki*ca.y + kj*cb.y) - aoff.y,
-              f_dir*cn.z + (ki*ca.z + kj*cb.z) - aoff.z);
+  const float ki = (ci-.5f*W)*cc.f_rg, kj = (cj-.5f*H)*cc.f_up;
+  V3 om = mk3(cc.f_dir*cn.x + (ki*ca.x + kj*cb.x) - aoff.x,
+              cc.f_dir*cn.y + (ki*ca.y + kj*cb.y) - aoff.y,
+              cc.f_dir*cn.z + (ki*ca.z + kj*cb.z) - aoff.z);
   om = normalise3(om);
-  const float A = (float)(MI_PI_D*(double)cam.focal_length*(double)cam.focal_length/(double)(4.0f*cam.f_stop*cam.f_stop));
-  const float pdf_a = (float)(1./(double)A);
-  const float sensor = 106.86535f*100.0f*cam.exposure_time;
+  const float pdf_a = cc.pdf_a, sensor = cc.sensor;
   const float dt = dot3(om, cn);
   const float dot4 = dt*dt*dt*dt;
-  ps.pixel_i = (float)DCLAMP((double)ci, 0.0, (double)(W-1e-4f));
-  ps.pixel_j = (float)DCLAMP((double)cj, 0.0, (double)(H-1e-4f));
-  const float G = dot4/(cam.focal_length*cam.focal_length);
-  const float pdf_v = 1.0f/(cam.film_width*cam.film_height);
+  ps.pixel_i = (float)DCLAMP((double)ci, 0.0, (double)cc.Wc);
+  ps.pixel_j = (float)DCLAMP((double)cj, 0.0, (double)cc.Hc);
+  const float G = dot4/cc.fl2;
+  const float pdf_v = cc.pdf_v;
   ps.pdf = pdf_v*pdf_a/G;
   const V3 x0 = mk3(cam.pos[0] + aoff.x, cam.pos[1] + aoff.y, cam.pos[2] + aoff.z);
-  const float thr0 = sensor*G/(pdf_a*pdf_v);
+  const float thr0 = sensor*G/cc.pdf_av;
   ps.org = x0; ps.dir = om; ps.ignore = MI_NOPRIM;
   ps.prev_x = x0;
   ps.prev_cos = fabsf(dot3(cn, om));        /* path_lambert on the sensor vertex */
