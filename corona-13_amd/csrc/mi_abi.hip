@@ -22,27 +22,13 @@
 #endif
 
 /* ======================================================================================= persistent megakernel */
-template<bool RECORD, bool PTDL>
+template<bool RECORD, bool PTDL, bool NODES_LDS>
 __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned long long first, unsigned long long count,
                                                            const uint32_t *shape_material, const float *shape_L, mi_path_record *records,
                                                            uint2 *stack_overflow)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const uint32_t N = sc.num_nodes;
-  float4 *lds_nodes = (float4 *)smem;
-  uint32_t *lds_axes = (uint32_t *)(smem + (size_t)MI_NODE_FIELDS*N*16);
-  const size_t stack_off = (((size_t)MI_NODE_FIELDS*N*16 + (size_t)N*4) + 15) & ~(size_t)15;
-  uint2 *lds_stack = (uint2 *)(smem + stack_off);
-
-  /* stage the BVH into LDS once per workgroup (coalesced 16-B loads) */
-  for(uint32_t i=threadIdx.x;i<MI_NODE_FIELDS*N;i+=MI_BLOCK) lds_nodes[i] = sc.nodes[i];
-  for(uint32_t i=threadIdx.x;i<N;i+=MI_BLOCK) lds_axes[i] = sc.node_axes[i];
-  __syncthreads();
-
-  Lds lds;
-  lds.nodes = lds_nodes; lds.axes = lds_axes; lds.stack = lds_stack + threadIdx.x; lds.num_nodes = N;
-  lds.overflow_stride = gridDim.x*MI_BLOCK;
-  lds.overflow = stack_overflow + (size_t)blockIdx.x*MI_BLOCK + threadIdx.x;
+  const Lds lds = lds_setup<MI_BLOCK, NODES_LDS>(sc, smem, stack_overflow);
 
   /* every workgroup owns a contiguous part of the path index range and hands it out through an LDS counter: the
      wave-level refill below then needs no global atomic at all (one shared counter costs ~11 ns per wave refill) */
@@ -160,22 +146,12 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
 }
 
 /* ======================================================================================= unit hook: rays in, hits out */
+template<bool NODES_LDS>
 __global__ __launch_bounds__(MI_BLOCK) void mi_intersect_kernel(DScene sc, const mi_ray *rays, unsigned long long n, mi_hit *out,
                                                                 uint2 *stack_overflow)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const uint32_t N = sc.num_nodes;
-  float4 *lds_nodes = (float4 *)smem;
-  uint32_t *lds_axes = (uint32_t *)(smem + (size_t)MI_NODE_FIELDS*N*16);
-  const size_t stack_off = (((size_t)MI_NODE_FIELDS*N*16 + (size_t)N*4) + 15) & ~(size_t)15;
-  uint2 *lds_stack = (uint2 *)(smem + stack_off);
-  for(uint32_t i=threadIdx.x;i<MI_NODE_FIELDS*N;i+=MI_BLOCK) lds_nodes[i] = sc.nodes[i];
-  for(uint32_t i=threadIdx.x;i<N;i+=MI_BLOCK) lds_axes[i] = sc.node_axes[i];
-  __syncthreads();
-  Lds lds;
-  lds.nodes = lds_nodes; lds.axes = lds_axes; lds.stack = lds_stack + threadIdx.x; lds.num_nodes = N;
-  lds.overflow_stride = gridDim.x*MI_BLOCK;
-  lds.overflow = stack_overflow + (size_t)blockIdx.x*MI_BLOCK + threadIdx.x;
+  const Lds lds = lds_setup<MI_BLOCK, NODES_LDS>(sc, smem, stack_overflow);
   uint32_t cnt[MI_CNT] = {0};
   for(unsigned long long base=(unsigned long long)blockIdx.x*MI_BLOCK; base<n; base+=(unsigned long long)gridDim.x*MI_BLOCK)
   {
@@ -223,6 +199,7 @@ struct mi_scene
   hipEvent_t ev0, ev1;
   int have_timing;
   size_t lds_bytes;
+  bool nodes_lds;                   /* BVH staged in LDS (fits next to the stacks) or read from HBM */
   int grid;
   uint64_t launches;
   /* wavefront pipeline (mi_wavefront.h) */
@@ -529,14 +506,23 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   d.work = (unsigned long long *)s->d_work;
 
   const size_t node_bytes = (((size_t)MI_NODE_FIELDS*N*16 + (size_t)N*4) + 15) & ~(size_t)15;
-  s->lds_bytes = node_bytes + (size_t)MI_STACK*MI_BLOCK*sizeof(uint2);
-  if(s->lds_bytes > 160*1024) { mi_scene_destroy(s); return fail(MI_ERR_UNSUPPORTED, "BVH does not fit the LDS-resident traversal of this build"); }
-  if(hipFuncSetAttribute((const void *)mi_intersect_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess ||
-     hipFuncSetAttribute((const void *)mi_path_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess ||
-     hipFuncSetAttribute((const void *)mi_path_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess ||
-     hipFuncSetAttribute((const void *)mi_path_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess ||
-     hipFuncSetAttribute((const void *)mi_path_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess)
-  { mi_scene_destroy(s); return fail(MI_ERR_DEVICE, "cannot raise the dynamic LDS limit"); }
+  const size_t stack_bytes = (size_t)MI_STACK*MI_BLOCK*sizeof(uint2);
+  /* the tree lives in LDS next to the traversal stacks when it fits (0010_pt: 50 KB + 96 KB of 160 KB); larger trees are
+     read from HBM / L2 by the NODES_LDS = false instantiations (CORONA_MI_NODES=global forces that, for tests) */
+  const char *nodes_env = getenv("CORONA_MI_NODES");
+  s->nodes_lds = node_bytes + stack_bytes <= 160*1024 && !(nodes_env && !strcmp(nodes_env, "global"));
+  s->lds_bytes = (s->nodes_lds ? node_bytes : 0) + stack_bytes;
+  {
+    const void *kernels[] = {
+      (const void *)mi_intersect_kernel<true>, (const void *)mi_intersect_kernel<false>,
+      (const void *)mi_path_kernel<false, false, true>, (const void *)mi_path_kernel<true, false, true>,
+      (const void *)mi_path_kernel<false, true, true>, (const void *)mi_path_kernel<true, true, true>,
+      (const void *)mi_path_kernel<false, false, false>, (const void *)mi_path_kernel<true, false, false>,
+      (const void *)mi_path_kernel<false, true, false>, (const void *)mi_path_kernel<true, true, false> };
+    for(const void *k : kernels)
+      if(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess)
+      { mi_scene_destroy(s); return fail(MI_ERR_DEVICE, "cannot raise the dynamic LDS limit"); }
+  }
   hipDeviceProp_t prop;
   if(hipGetDeviceProperties(&prop, g_device) != hipSuccess) { mi_scene_destroy(s); return fail(MI_ERR_DEVICE, "hipGetDeviceProperties failed"); }
   int per_cu = (int)((160*1024)/s->lds_bytes);
@@ -570,8 +556,10 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
       s->pool.live = (unsigned long long *)s->d_wfcnt + 1;
       for(int k=0;k<8;k++) if(hipEventCreateWithFlags(&s->ev_live[k], hipEventDisableTiming) != hipSuccess)
       { mi_scene_destroy(s); return fail(MI_ERR_DEVICE, "cannot create events"); }
-      if(hipFuncSetAttribute((const void *)wf_trace<MI_BLOCK, MI_STACK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess ||
-         hipFuncSetAttribute((const void *)wf_trace<MI_BLOCK, MI_STACK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess)
+      if(hipFuncSetAttribute((const void *)wf_trace<MI_BLOCK, MI_STACK, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess ||
+         hipFuncSetAttribute((const void *)wf_trace<MI_BLOCK, MI_STACK, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess ||
+         hipFuncSetAttribute((const void *)wf_trace<MI_BLOCK, MI_STACK, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess ||
+         hipFuncSetAttribute((const void *)wf_trace<MI_BLOCK, MI_STACK, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess)
       { mi_scene_destroy(s); return fail(MI_ERR_DEVICE, "cannot raise the dynamic LDS limit"); }
     }
   }
@@ -614,8 +602,10 @@ static int render_wavefront(mi_scene *s, uint64_t first_index, uint64_t count)
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(s->h_live + (size_t)(it & 7)*WF_LIVE_SHARDS, s->pool.live, WF_LIVE_SHARDS*sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipEventRecord(s->ev_live[it & 7], s->stream));
-    if(ptdl) hipLaunchKernelGGL((wf_trace<MI_BLOCK, MI_STACK, true>), dim3(s->grid), dim3(MI_BLOCK), s->lds_bytes, s->stream, s->d, s->pool, (uint2 *)s->d_overflow);
-    else     hipLaunchKernelGGL((wf_trace<MI_BLOCK, MI_STACK, false>), dim3(s->grid), dim3(MI_BLOCK), s->lds_bytes, s->stream, s->d, s->pool, (uint2 *)s->d_overflow);
+#define MI_WF_TRACE(P, L) hipLaunchKernelGGL((wf_trace<MI_BLOCK, MI_STACK, P, L>), dim3(s->grid), dim3(MI_BLOCK), s->lds_bytes, s->stream, s->d, s->pool, (uint2 *)s->d_overflow)
+    if(s->nodes_lds) { if(ptdl) MI_WF_TRACE(true, true); else MI_WF_TRACE(false, true); }
+    else             { if(ptdl) MI_WF_TRACE(true, false); else MI_WF_TRACE(false, false); }
+#undef MI_WF_TRACE
     HIPCHK(hipGetLastError());
     s->kernel_launches_last++;
     if(it >= 2)
@@ -633,6 +623,24 @@ static int render_wavefront(mi_scene *s, uint64_t first_index, uint64_t count)
   return MI_OK;
 }
 
+static void launch_path_kernel(mi_scene *s, bool record, int grid, uint64_t first, uint64_t n, mi_path_record *rec)
+{ /* pick the instantiation: RECORD (test hook) x PTDL (sampler) x NODES_LDS (tree fits LDS) */
+  const bool ptdl = s->d.sampler == MI_SAMPLER_PTDL;
+#define MI_LAUNCH(R, P, L) hipLaunchKernelGGL((mi_path_kernel<R, P, L>), dim3(grid), dim3(MI_BLOCK), s->lds_bytes, s->stream, s->d, \
+    (unsigned long long)first, (unsigned long long)n, (const uint32_t *)s->d_shape_material, (const float *)s->d_shape_L, rec, (uint2 *)s->d_overflow)
+  if(s->nodes_lds)
+  {
+    if(record) { if(ptdl) MI_LAUNCH(true, true, true); else MI_LAUNCH(true, false, true); }
+    else       { if(ptdl) MI_LAUNCH(false, true, true); else MI_LAUNCH(false, false, true); }
+  }
+  else
+  {
+    if(record) { if(ptdl) MI_LAUNCH(true, true, false); else MI_LAUNCH(true, false, false); }
+    else       { if(ptdl) MI_LAUNCH(false, true, false); else MI_LAUNCH(false, false, false); }
+  }
+#undef MI_LAUNCH
+}
+
 extern "C" int mi_render(mi_scene *s, uint64_t first_index, uint64_t count)
 {
   if(!s) return fail(MI_ERR_ARG, "null scene");
@@ -648,14 +656,7 @@ extern "C" int mi_render(mi_scene *s, uint64_t first_index, uint64_t count)
     int grid = s->grid;
     const uint64_t need = (n + MI_BLOCK - 1)/MI_BLOCK;
     if((uint64_t)grid > need) grid = (int)need;
-    if(s->d.sampler == MI_SAMPLER_PTDL)
-      hipLaunchKernelGGL((mi_path_kernel<false, true>), dim3(grid), dim3(MI_BLOCK), s->lds_bytes, s->stream,
-                         s->d, (unsigned long long)(first_index + done), (unsigned long long)n, (const uint32_t *)s->d_shape_material,
-                         (const float *)s->d_shape_L, (mi_path_record *)nullptr, (uint2 *)s->d_overflow);
-    else
-      hipLaunchKernelGGL((mi_path_kernel<false, false>), dim3(grid), dim3(MI_BLOCK), s->lds_bytes, s->stream,
-                         s->d, (unsigned long long)(first_index + done), (unsigned long long)n, (const uint32_t *)s->d_shape_material,
-                         (const float *)s->d_shape_L, (mi_path_record *)nullptr, (uint2 *)s->d_overflow);
+    launch_path_kernel(s, false, grid, first_index + done, n, nullptr);
     HIPCHK(hipGetLastError());
     s->kernel_launches_last++;
   }
@@ -725,14 +726,7 @@ extern "C" int mi_trace_paths(mi_scene *s, uint64_t first_index, uint64_t count,
     int grid = s->grid;
     const uint64_t need = (count + MI_BLOCK - 1)/MI_BLOCK;
     if((uint64_t)grid > need) grid = (int)need;
-    if(s->d.sampler == MI_SAMPLER_PTDL)
-      hipLaunchKernelGGL((mi_path_kernel<true, true>), dim3(grid), dim3(MI_BLOCK), s->lds_bytes, s->stream,
-                         s->d, (unsigned long long)first_index, (unsigned long long)count, (const uint32_t *)s->d_shape_material,
-                         (const float *)s->d_shape_L, (mi_path_record *)d_rec, (uint2 *)s->d_overflow);
-    else
-      hipLaunchKernelGGL((mi_path_kernel<true, false>), dim3(grid), dim3(MI_BLOCK), s->lds_bytes, s->stream,
-                         s->d, (unsigned long long)first_index, (unsigned long long)count, (const uint32_t *)s->d_shape_material,
-                         (const float *)s->d_shape_L, (mi_path_record *)d_rec, (uint2 *)s->d_overflow);
+    launch_path_kernel(s, true, grid, first_index, count, (mi_path_record *)d_rec);
     e = hipGetLastError();
   }
   if(e == hipSuccess) e = hipStreamSynchronize(s->stream);
@@ -755,8 +749,10 @@ extern "C" int mi_intersect(mi_scene *s, const mi_ray *rays, uint64_t n, mi_hit 
     int grid = s->grid;
     const uint64_t need = (n + MI_BLOCK - 1)/MI_BLOCK;
     if((uint64_t)grid > need) grid = (int)need;
-    hipLaunchKernelGGL(mi_intersect_kernel, dim3(grid), dim3(MI_BLOCK), s->lds_bytes, s->stream, s->d, (const mi_ray *)d_rays,
-                       (unsigned long long)n, (mi_hit *)d_hits, (uint2 *)s->d_overflow);
+    if(s->nodes_lds) hipLaunchKernelGGL(mi_intersect_kernel<true>, dim3(grid), dim3(MI_BLOCK), s->lds_bytes, s->stream, s->d, (const mi_ray *)d_rays,
+                                        (unsigned long long)n, (mi_hit *)d_hits, (uint2 *)s->d_overflow);
+    else             hipLaunchKernelGGL(mi_intersect_kernel<false>, dim3(grid), dim3(MI_BLOCK), s->lds_bytes, s->stream, s->d, (const mi_ray *)d_rays,
+                                        (unsigned long long)n, (mi_hit *)d_hits, (uint2 *)s->d_overflow);
     e = hipGetLastError();
   }
   if(e == hipSuccess) e = hipStreamSynchronize(s->stream);

@@ -328,8 +328,8 @@ __device__ __forceinline__ void analytic_intersect(const DPrim *prims, uint32_t 
 /* ------------------------------------------------------------------------------------------ traversal */
 struct Lds
 {
-  const float4 *nodes;      /* [MI_NODE_FIELDS][num_nodes] in LDS */
-  const uint32_t *axes;     /* [num_nodes] in LDS */
+  const float4 *nodes;      /* [MI_NODE_FIELDS][num_nodes] in LDS (or in HBM when the tree does not fit, see lds_setup) */
+  const uint32_t *axes;     /* [num_nodes], same place */
   uint2 *stack;             /* [STACK][BLOCK] in LDS, this thread's column */
   uint2 *overflow;          /* [extra][total threads] in HBM, this thread's column: entries beyond STACK (rare) */
   uint32_t overflow_stride;
@@ -356,6 +356,37 @@ __device__ __forceinline__ uint2 stack_top(const Lds &lds, const lds_uint2 *lsta
 {
   if(sp < STACK) { const mi_u32x2 v = lstack[sp*BLOCK]; return make_uint2(v.x, v.y); }
   return lds.overflow[(size_t)(sp - STACK)*lds.overflow_stride];
+}
+
+/* Workgroup prologue shared by all traversal kernels. NODES_LDS: the BVH is staged into LDS once per workgroup
+ * (coalesced 16-B loads) in front of the traversal stacks; otherwise it does not fit next to the stacks and is read from
+ * HBM / L2 through the same SoA layout (mi_device.h), LDS holds the stacks only. Call from all threads (barrier inside). */
+template<int BLOCK, bool NODES_LDS>
+__device__ __forceinline__ Lds lds_setup(const DScene &sc, unsigned char *smem, uint2 *stack_overflow)
+{
+  const uint32_t N = sc.num_nodes;
+  Lds lds;
+  uint2 *lds_stack;
+  if(NODES_LDS)
+  {
+    float4 *lds_nodes = (float4 *)smem;
+    uint32_t *lds_axes = (uint32_t *)(smem + (size_t)MI_NODE_FIELDS*N*16);
+    const size_t stack_off = (((size_t)MI_NODE_FIELDS*N*16 + (size_t)N*4) + 15) & ~(size_t)15;
+    lds_stack = (uint2 *)(smem + stack_off);
+    for(uint32_t i=threadIdx.x;i<MI_NODE_FIELDS*N;i+=BLOCK) lds_nodes[i] = sc.nodes[i];
+    for(uint32_t i=threadIdx.x;i<N;i+=BLOCK) lds_axes[i] = sc.node_axes[i];
+    __syncthreads();
+    lds.nodes = lds_nodes; lds.axes = lds_axes;
+  }
+  else
+  {
+    lds_stack = (uint2 *)smem;
+    lds.nodes = sc.nodes; lds.axes = sc.node_axes;
+  }
+  lds.stack = lds_stack + threadIdx.x; lds.num_nodes = N;
+  lds.overflow_stride = gridDim.x*BLOCK;
+  lds.overflow = stack_overflow + (size_t)blockIdx.x*BLOCK + threadIdx.x;
+  return lds;
 }
 
 #ifndef MI_TAIL_INNER

@@ -196,22 +196,11 @@ __global__ __launch_bounds__(WF_LOGIC_BLOCK) void wf_logic(DScene sc, WFPool poo
 }
 
 /* ---------------------------------------------------------------------------------------------------- trace */
-template<int BLOCK, int STACK, bool PTDL>
+template<int BLOCK, int STACK, bool PTDL, bool NODES_LDS>
 __global__ __launch_bounds__(BLOCK) void wf_trace(DScene sc, WFPool pool, uint2 *stack_overflow)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const uint32_t N = sc.num_nodes;
-  float4 *lds_nodes = (float4 *)smem;
-  uint32_t *lds_axes = (uint32_t *)(smem + (size_t)MI_NODE_FIELDS*N*16);
-  const size_t stack_off = (((size_t)MI_NODE_FIELDS*N*16 + (size_t)N*4) + 15) & ~(size_t)15;
-  uint2 *lds_stack = (uint2 *)(smem + stack_off);
-  for(uint32_t i=threadIdx.x;i<MI_NODE_FIELDS*N;i+=BLOCK) lds_nodes[i] = sc.nodes[i];
-  for(uint32_t i=threadIdx.x;i<N;i+=BLOCK) lds_axes[i] = sc.node_axes[i];
-  __syncthreads();
-  Lds lds;
-  lds.nodes = lds_nodes; lds.axes = lds_axes; lds.stack = lds_stack + threadIdx.x; lds.num_nodes = N;
-  lds.overflow_stride = gridDim.x*BLOCK;
-  lds.overflow = stack_overflow + (size_t)blockIdx.x*BLOCK + threadIdx.x;
+  const Lds lds = lds_setup<BLOCK, NODES_LDS>(sc, smem, stack_overflow);
 
   const unsigned lane = __lane_id();
   const unsigned long long njobs = PTDL ? 2ull*pool.P : pool.P;

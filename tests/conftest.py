@@ -17,3 +17,11 @@ def pytest_configure(config):
         subprocess.check_call(["make", "-C", str(REPO / "corona-13_amd")])
     if not (REPO / "oracle" / "liboracle.so").exists():
         subprocess.check_call(["make", "-C", str(REPO / "oracle"), "liboracle.so"])
+    # generated scene data: the finer backdrop of scenes/0054_fine (deterministic, checked by hash)
+    fine = REPO / "scenes" / "geo" / "plane_fine.geo"
+    if not fine.exists():
+        subprocess.check_call([sys.executable, str(REPO / "tools" / "make_geo.py"), "subdivide",
+                               str(REPO / "scenes" / "geo" / "plane.geo"), str(fine), "2"])
+    import hashlib
+    digest = hashlib.sha256(fine.read_bytes()).hexdigest()
+    assert digest == "5ab97b31c13baef90daac0af6367b1fae8e764d591f5da9e895a698a19d6410f", "scenes/geo/plane_fine.geo differs from the file the goldens were made with"

@@ -114,6 +114,7 @@ def main():
         dump_paths("ptdl_mv8", "dump_ptdl_xs_mv8", 8, "0010_pt", 1280, 720, 3000)
         dump_paths("pt_mv4_256", "dump_pt_xs_mv4", 4, "0010_pt", 256, 256, 2000)
         dump_paths("rough_mv32", "dump_pt_xs_mv32", 32, "0052_rough", 1280, 720, 2000)
+        dump_paths("fine_mv8", "dump_pt_xs_mv8", 8, "0054_fine", 1280, 720, 3000)     # needs scenes/geo/plane_fine.geo (tools/make_geo.py)
         dump_paths("metal_mv8", "dump_pt_xs_mv8", 8, "0053_metal", 1280, 720, 3000)
         dump_paths("metal_ptdl_mv8", "dump_ptdl_xs_mv8", 8, "0053_metal", 1280, 720, 3000)
         counters()

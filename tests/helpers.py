@@ -17,6 +17,7 @@ REPO = Path(__file__).resolve().parent.parent
 GOLDEN = REPO / "tests" / "golden"
 SCENE_0010 = REPO / "scenes" / "0010_pt" / "test.nra2"
 SCENE_ROUGH = REPO / "scenes" / "0052_rough" / "test.nra2"
+SCENE_FINE = REPO / "scenes" / "0054_fine" / "test.nra2"       # 0010 with every backdrop quad split 2x2 (tools/make_geo.py): 1711 nodes, too big for LDS
 SCENE_METAL = REPO / "scenes" / "0053_metal" / "test.nra2"     # 0052 with `metal Au`, roughness 0.3 on cone/sphere/cylinder
 
 

@@ -12,7 +12,7 @@ import json
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, SCENE_0010, SCENE_METAL, SCENE_ROUGH, load_pkg, make_scene, oracle_intersect, oracle_records, oracle_render
+from helpers import GOLDEN, SCENE_0010, SCENE_FINE, SCENE_METAL, SCENE_ROUGH, load_pkg, make_scene, oracle_intersect, oracle_records, oracle_render
 
 pkg = load_pkg()
 pytestmark = pytest.mark.gpu
@@ -27,6 +27,8 @@ CASES = [
     ("cfg1 pt 256x256 mv4", SCENE_0010, pkg.MI_SAMPLER_PT, 256, 256, 4, 8000),
     ("cfg3 ptdl 1280x720 mv8", SCENE_0010, pkg.MI_SAMPLER_PTDL, 1280, 720, 8, 60000),
     ("cfg4 rough dielectric mv32", SCENE_ROUGH, pkg.MI_SAMPLER_PT, 1280, 720, 32, 30000),
+    ("fine backdrop (tree in HBM) pt mv8", SCENE_FINE, pkg.MI_SAMPLER_PT, 1280, 720, 8, 30000),
+    ("fine backdrop (tree in HBM) ptdl mv8", SCENE_FINE, pkg.MI_SAMPLER_PTDL, 1280, 720, 8, 10000),
     ("metal pt mv8", SCENE_METAL, pkg.MI_SAMPLER_PT, 1280, 720, 8, 8000),
     ("metal ptdl mv8", SCENE_METAL, pkg.MI_SAMPLER_PTDL, 1280, 720, 8, 8000),
 ]
@@ -329,3 +331,26 @@ def test_wavefront_pipeline_equals_megakernel(sampler, monkeypatch):
     a, b = out["mega"][0], out["wave"][0]
     assert np.abs(a - b).max() <= 1e-4 * np.abs(a).max()
     assert np.allclose(a.sum(axis=(0, 1)), b.sum(axis=(0, 1)), rtol=1e-5)
+
+
+def test_tree_larger_than_lds_is_read_from_hbm():
+    """the 1711-node tree of scenes/0054_fine (198 KB) does not fit next to the 96 KB of traversal stacks: the kernels
+    instantiated with the tree in HBM take over; ray-level results stay bit-exact and the image matches the oracle"""
+    scene = make_scene(SCENE_FINE, width=640, height=352, max_verts=8)
+    assert scene.desc.num_nodes * 116 > 64 * 1024
+    be = pkg.Backend(scene)
+    rng = np.random.default_rng(3)
+    n = 100000
+    pos = rng.uniform(-4, 4, size=(n, 3)).astype(np.float32) + np.float32([0, 0, 2])
+    d = rng.normal(size=(n, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    d[::50, 1] = 0.0                                       # some degenerate rays too
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    _compare_hits(scene, be, pos, d)
+    npx = scene.width * scene.height
+    be.render(0, npx)
+    fb = be.fb_read()
+    ofb, _, _ = oracle_render(scene, 0, npx, threads=8)
+    rmse = np.sqrt((((fb - ofb) * scene.gain(1)) ** 2).sum() / npx)
+    assert rmse < 0.05, rmse
+    be.close()
