@@ -720,7 +720,6 @@ extern "C" int mi_trace_paths(mi_scene *s, uint64_t first_index, uint64_t count,
   void *d_rec = nullptr;
   HIPCHK(hipMalloc(&d_rec, count*sizeof(mi_path_record)));
   hipError_t e = hipMemsetAsync(d_rec, 0, count*sizeof(mi_path_record), s->stream);
-  if(e == hipSuccess) e = hipMemsetAsync(s->d_work, 0, sizeof(unsigned long long), s->stream);
   if(e == hipSuccess)
   {
     int grid = s->grid;

@@ -88,7 +88,7 @@ struct DScene
   float *fb;
   unsigned long long *counters;    /* [MI_COUNTER_SHARDS][8]: same-address atomics serialise at ~11 ns each, so every
                                       workgroup adds into its own shard; mi_counters() sums them */
-  unsigned long long *work;        /* [work_shards] consumed-path counters: every workgroup owns a contiguous part of the
+  unsigned long long *work;        /* wavefront pipeline: [work_shards] consumed-path counters: every workgroup owns a contiguous part of the
                                       index range and its own counter (no same-address atomics between workgroups) */
   uint32_t work_shards;
 };

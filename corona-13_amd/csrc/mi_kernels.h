@@ -128,27 +128,6 @@ struct Hit
 #define MI_NOPRIM 0xffffffffu
 
 /* ------------------------------------------------------------------------------------------ primitives */
-__device__ __forceinline__ bool tri_intersect(const V3 v0, const V3 v1, const V3 v2, const V3 o, const V3 d, Hit &hit, uint32_t prim)
-{ /* geo_tri_intersect, include/geo/triangle.h:263-305 (min_dist == 0) */
-  const V3 e1 = sub3(v1, v0), e2 = sub3(v2, v0);
-  const V3 pv = cross3(d, e2);
-  const float det = dot3(e1, pv);
-  const float inv_det = 1.0f/det;
-  const V3 tv = sub3(o, v0);
-  const float v = dot3(tv, pv)*inv_det;
-  if(v < 0.0f || v > 1.0f) return false;
-  const V3 qv = cross3(tv, e1);
-  const float u = dot3(d, qv)*inv_det;
-  if(u < 0.0f || u + v > 1.0f) return false;
-  const float dist = dot3(e2, qv)*inv_det;
-  if(dist > 0.0f && dist <= hit.dist)
-  {
-    hit.dist = dist; hit.prim = prim; hit.u = u; hit.v = v;
-    return true;
-  }
-  return false;
-}
-
 __device__ __forceinline__ float sphere_t(const V3 c, float radius, const V3 ro, const V3 rd)
 { /* _geo_sphere_intersect, include/geo/sphere.h:112-144 */
   const float a = dot3(rd, rd);
@@ -342,13 +321,6 @@ __device__ __forceinline__ void stack_push(const Lds &lds, int sp, uint2 e)
   if(sp < STACK) lds.stack[sp*BLOCK] = e;
   else lds.overflow[(size_t)(sp - STACK)*lds.overflow_stride] = e;
 }
-template<int BLOCK, int STACK>
-__device__ __forceinline__ uint2 stack_pop(const Lds &lds, int sp)
-{
-  if(sp < STACK) return lds.stack[sp*BLOCK];
-  return lds.overflow[(size_t)(sp - STACK)*lds.overflow_stride];
-}
-
 typedef unsigned int mi_u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) mi_u32x2 lds_uint2;   /* typed LDS pointer: ds_read/ds_write instead of flat */
 template<int BLOCK, int STACK>
