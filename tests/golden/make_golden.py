@@ -106,6 +106,21 @@ def tilemeans(name, binary, mv, scene, w, h, spp, threads=8):
     shutil.rmtree(work, ignore_errors=True)
 
 
+def image_pair(name, binary, mv, scene, w, h, spp, threads=8):
+    """two independent high-spp renders of a tiny film (frames 1 and 2 seed the generators differently): per-pixel golden
+    image plus the reference's own per-pixel noise floor at that sample count"""
+    imgs = []
+    for frame in (1, 2):
+        work, log = run_ref(binary, mv, scene, ["-s", str(spp), "--batch", "1024", "-w", str(w), "-h", str(h), "-t", str(threads),
+                                                "--frame", str(frame), "-x", "_img"])
+        imgs.append(read_pfm(work / "scenes" / scene / "test_img_fb00.pfm").copy())
+        shutil.rmtree(work, ignore_errors=True)
+    np.savez_compressed(GOLD / f"image_{name}.npz", a=imgs[0].astype(np.float32), b=imgs[1].astype(np.float32), spp=spp, max_verts=mv)
+    a, b = imgs
+    print("wrote image pair", name, a.shape, "means", a.mean(axis=(0, 1)), b.mean(axis=(0, 1)),
+          "rmse(a,b)/mean", np.sqrt(((a - b) ** 2).mean()) / a.mean())
+
+
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "quick"
     if what in ("quick", "paths", "all"):
@@ -123,6 +138,7 @@ def main():
         tilemeans("ptdl_mv8", "corona_ptdl_sfmt_mv8", 8, "0010_pt", 1280, 720, 512)
         tilemeans("rough_mv32", "corona_pt_sfmt_mv32", 32, "0052_rough", 1280, 720, 512)
         tilemeans("pt_mv4_256", "corona_pt_sfmt_mv4", 4, "0010_pt", 256, 256, 4096)
+        image_pair("pt_mv8_64", "corona_pt_sfmt_mv8", 8, "0010_pt", 64, 64, 65536)
 
 
 if __name__ == "__main__":

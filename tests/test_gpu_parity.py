@@ -354,3 +354,24 @@ def test_tree_larger_than_lds_is_read_from_hbm():
     rmse = np.sqrt((((fb - ofb) * scene.gain(1)) ** 2).sum() / npx)
     assert rmse < 0.05, rmse
     be.close()
+
+
+def test_per_pixel_against_reference_render():
+    """per-pixel L2 against the REAL reference: 64x64 film, 65 536 spp (tests/golden/image_pt_mv8_64.npz holds two
+    independent reference renders a, b of that job). Pure pt finds the small emitter with 0.5 % of its paths, so even at
+    this sample count a pixel carries a few per cent of noise; the tolerance is the reference's own noise floor:
+    E|g - (a+b)/2|^2 = 0.75 E|a - b|^2 for an unbiased g, asserted with a 15 % margin, plus the image means."""
+    g = np.load(GOLDEN / "image_pt_mv8_64.npz")
+    a, b, spp = g["a"], g["b"], int(g["spp"])
+    scene = make_scene(SCENE_0010, width=64, height=64, max_verts=int(g["max_verts"]))
+    assert a.shape == (scene.height, scene.width, 3)
+    be = pkg.Backend(scene)
+    be.render(0, spp * scene.width * scene.height)
+    img = be.fb_read() * scene.gain(spp)
+    be.close()
+    ref = 0.5 * (a + b)
+    floor = np.sqrt(((a - b) ** 2).mean())
+    rmse = np.sqrt(((img - ref) ** 2).mean())
+    assert rmse <= floor, (rmse, floor)                       # expected 0.87 * floor for Gaussian noise; measured 0.68 (heavy-tailed)
+    assert rmse >= 0.5 * floor                                # and not suspiciously smooth either
+    assert np.all(np.abs(img.mean(axis=(0, 1)) / ref.mean(axis=(0, 1)) - 1) < 5e-3)
