@@ -185,7 +185,7 @@ def main():
             "config": {"workload": "configs[1]: regression/0010_pt test.nra2, pt sampler, 1280x720 (padded 1280x736), 64 spp, max depth 8",
                        "paths_per_step_per_gpu": per_frame, "sharding": f"path-index ranges x{world}, framebuffer all-reduce"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "mi_path_kernel<false,false>", "kernel_ms": kms,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "mi_path_kernel<false,false,true> (RECORD, PTDL, NODES_LDS)", "kernel_ms": kms,
                          "algorithmic_bytes_per_sample": bytes_per_sample,
                          "work_per_sample": {"rays": dc[0] / paths, "node_visits": dc[1] / paths, "prim_tests": dc[3] / paths, "splats": dc[5] / paths}},
         }
