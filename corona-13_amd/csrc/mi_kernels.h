@@ -737,7 +737,9 @@ __device__ __forceinline__ void run_prepare_ops(const DScene &sc, const DMateria
       const float u = sf.s, t = sf.t;
       const int i = (int)(14.0f*u) % 14, j = (int)(10.0f*t) % 10;
       float val;
-      const float fu = fmodf(14.0f*u, 1.0f), ft = fmodf(10.0f*t, 1.0f);
+      /* fmodf(x, 1.0f) == x - truncf(x) exactly (the fraction of a float is a float); the libm loop is not needed */
+      const float xu = 14.0f*u, xt = 10.0f*t;
+      const float fu = xu - truncf(xu), ft = xt - truncf(xt);
       if(fu < 0.1f || fu > 0.9f || ft < 0.1f || ft > 0.9f) val = 0.3f;
       else
       {
