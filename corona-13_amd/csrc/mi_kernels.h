@@ -1,16 +1,17 @@
 /* mi_kernels.h -- HIP device code of the pt/ptdl path tracing hot path for gfx950 (MI355X).
  *
- * One persistent kernel; every lane owns one path at a time and runs a small state machine
+ * This header holds the device functions shared by the kernel organisations (persistent megakernel in mi_abi.hip,
+ * wavefront pipeline in mi_wavefront.h): random numbers, primitive tests, resumable QBVH traversal (trace_round),
+ * surface set-up, materials and BSDFs, emitter sampling, splat. Every lane owns one path at a time,
  *      NEW -> [ EXTEND-ray -> traverse -> shade ( -> SHADOW-ray -> traverse -> connect ) ]* -> NEW
- * so a lane whose path ends re-fills itself immediately (wave64 ballot + prefix rank, one atomic per
- * wave) instead of idling until the longest path of the wave is done. There is exactly one traversal
- * site in the loop; extension and shadow rays of different lanes share it.
+ * and a lane whose path ends re-fills itself in place (wave64 ballot + prefix rank on a workgroup-local counter).
+ * There is exactly one traversal site; extension and shadow rays of different lanes share it.
  *
- * Memory placement (see mi_device.h): BVH nodes staged once per workgroup into LDS (SoA of 16-byte
- * lanes so that divergent lanes spread over all LDS slots), per-lane traversal stack in LDS
- * ([entry][thread] so a wave's accesses are conflict free), primitives as single 64-B records from
- * L2/HBM, framebuffer splats as hardware float atomics. MFMA is not used: there is no dense
- * contraction anywhere in this path.
+ * Memory placement (see mi_device.h): BVH nodes staged once per workgroup into LDS when they fit (SoA of 16-byte
+ * lanes so that divergent lanes spread over all LDS slots; otherwise read from HBM/L2, lds_setup), per-lane traversal
+ * stack in LDS ([entry][thread] so a wave's accesses are conflict free), primitives as single 64-B records from
+ * L2/HBM, per-primitive shading constants precomputed at upload (DPrimGeo), framebuffer splats as hardware float
+ * atomics. MFMA is not used: there is no dense contraction anywhere in this path.
  *
  * Arithmetic follows the reference operation by operation (fp contraction off) so that a path with
  * the same random numbers takes the same branches:
