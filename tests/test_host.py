@@ -8,7 +8,7 @@ import tempfile
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, SCENE_0010, SCENE_ROUGH, golden_coeffs, load_pkg, make_scene
+from helpers import GOLDEN, REPO, SCENE_0010, SCENE_ROUGH, golden_coeffs, load_pkg, make_scene
 
 pkg = load_pkg()
 
@@ -149,3 +149,28 @@ def test_bad_scenes_fail_loudly(tmp_path):
 def test_gain_formula():
     s = make_scene(SCENE_0010, inject=False, width=256, height=256, max_verts=4)
     assert abs(s.gain(64) - 400 / (100 * 64)) < 1e-9   # src/view.c:651-657: gain * iso / (100 * spp)
+
+
+def test_pfmdiff_tool_matches_reference_tool(tmp_path):
+    """host/pfmdiff-mi prints the reference's figure (tools/img/pfmdiff.c:75-86) for two PFM images; where the reference's
+    own tool has been built (oracle/_ref/pfmdiff, build container only) the two outputs are compared directly"""
+    import subprocess
+    rng = np.random.default_rng(5)
+    a = rng.random((24, 32, 3)).astype(np.float32)
+    b = (a + 0.01 * rng.standard_normal(a.shape)).astype(np.float32)
+
+    def write(fn, img):
+        with open(fn, "wb") as f:
+            f.write(b"PF\n%d %d\n-1.0\n" % (img.shape[1], img.shape[0]))
+            f.write(img[::-1].tobytes())
+    write(tmp_path / "a.pfm", a); write(tmp_path / "b.pfm", b)
+    tool = REPO / "corona-13_amd" / "host" / "pfmdiff-mi"
+    out = subprocess.run([str(tool), str(tmp_path / "a.pfm"), str(tmp_path / "b.pfm")], capture_output=True, text=True, check=True).stdout
+    rmse = float(out.split("rmse:")[1])
+    want = float(np.sqrt(((a.astype(np.float64) - b) ** 2).sum() / (a.shape[0] * a.shape[1])))
+    assert abs(rmse - want) < 1e-5 * want
+    ref = REPO / "oracle" / "_ref" / "pfmdiff"
+    if ref.exists():
+        rout = subprocess.run([str(ref), str(tmp_path / "a.pfm"), str(tmp_path / "b.pfm"), str(tmp_path / "d.pfm")], capture_output=True, text=True).stdout
+        if "rmse:" in rout:
+            assert abs(float(rout.split("rmse:")[1].split()[0]) - rmse) < 1e-5 * want
