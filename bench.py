@@ -108,9 +108,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # under torch.distributed.run (RANK/WORLD_SIZE/MASTER_* in the environment) a process group is always formed, also
+    # for a single rank, so that the RCCL path can be exercised on a one-GPU box
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
 
     pkg = load_package()
     scene = make_scene(SCENE_0010, width=W, height=H, max_verts=MAX_VERTS)
@@ -122,17 +125,17 @@ def main():
     be.set_stream(stream.cuda_stream)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     def step(k):
         # rank r renders its own contiguous block of path indices of "frame" k: no data-path collective
         first, count = pkg.shard_range(k * world * per_frame, world * per_frame, rank, world)
-        if world > 1:
+        if use_dist:
             fb.zero_()                                     # the reduce works on this step's partial sums only
         be.render(first, count)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(fb, op=dist.ReduceOp.SUM)      # framebuffer reduce over xGMI (RCCL)
 
     for k in range(args.warmup):
@@ -148,7 +151,7 @@ def main():
     t1 = time.perf_counter()
     c1 = be.counters()
     elapsed = t1 - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -192,10 +195,10 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(scene)
         print(json.dumps(out))
-    if world > 1:
+    be.close()
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-    be.close()
 
 
 if __name__ == "__main__":
