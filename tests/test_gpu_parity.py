@@ -375,3 +375,34 @@ def test_per_pixel_against_reference_render():
     assert rmse <= floor, (rmse, floor)                       # expected 0.87 * floor for Gaussian noise; measured 0.68 (heavy-tailed)
     assert rmse >= 0.5 * floor                                # and not suspiciously smooth either
     assert np.all(np.abs(img.mean(axis=(0, 1)) / ref.mean(axis=(0, 1)) - 1) < 5e-3)
+
+
+def test_command_line_renderer(tmp_path):
+    """the stand-alone C host (corona-13_amd/host/corona-mi: scene loaders, progression loop with --batch, PFM writer,
+    sidecar) drives the same ABI: its image equals the library render of the same path indices (float atomic order
+    aside), compared with host/pfmdiff-mi like the reference's regression scripts compare renders"""
+    import re
+    import shutil
+    import subprocess
+    from helpers import REPO
+    shutil.copytree(REPO / "scenes", tmp_path / "scenes")
+    cli = REPO / "corona-13_amd" / "host" / "corona-mi"
+    scene_file = tmp_path / "scenes" / "0010_pt" / "test.nra2"
+    out = subprocess.run([str(cli), str(scene_file), "-s", "24", "--batch", "10", "-w", "256", "-h", "256", "--max-verts", "8", "-x", "_cli"],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    pfm = tmp_path / "scenes" / "0010_pt" / "test_cli_fb00.pfm"
+    side = (tmp_path / "scenes" / "0010_pt" / "test_cli_fb00.pfm.txt").read_text()
+    assert re.search(r"samples per pixel: 24 ", side) and re.search(r"elapsed wallclock prog [\d.]+s", side) and "res 256x256" in side
+    # the same job through the Python view of the ABI, with the host's own colour fit (no injected reference coefficients)
+    scene = make_scene(SCENE_0010, inject=False, width=256, height=256, max_verts=8)
+    be = pkg.Backend(scene)
+    be.render(0, 24 * scene.width * scene.height)
+    img = be.fb_read() * scene.gain(24)
+    be.close()
+    with open(tmp_path / "lib.pfm", "wb") as f:
+        f.write(b"PF\n%d %d\n-1.0\n" % (img.shape[1], img.shape[0]))
+        f.write(np.ascontiguousarray(img, dtype=np.float32).tobytes())     # rows in framebuffer order, like view_write_images
+    d = subprocess.run([str(REPO / "corona-13_amd" / "host" / "pfmdiff-mi"), str(pfm), str(tmp_path / "lib.pfm")], capture_output=True, text=True)
+    assert d.returncode == 0, d.stdout + d.stderr
+    assert float(d.stdout.split("rmse:")[1]) < 1e-3, d.stdout
