@@ -516,23 +516,27 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
          wave runs that rare, long code once per leaf round instead of once per primitive slot. Every primitive of the
          leaf is still tested exactly once against the running closest hit (prims_intersect, src/prims.c:638-672). */
       uint32_t analytic = 0;
-      PrimRegs cur = prim_load(prims, num ? idxp : 0);
-      for(uint32_t i=0;i<num;i++)
+      /* two record buffers in ping-pong: the load of primitive i+1 is in flight while i is intersected, and no
+         16-register copy is needed per iteration */
+#define MI_LEAF_STEP(R, I) { cnt[3]++; \
+        const uint32_t type = __float_as_uint((R).q3.x); \
+        if(type >= MI_PRIM_TRI) { if(idxp + (I) != ignore) triquad_intersect((R), type, o, d, hit, idxp + (I)); }   /* triangle.h:271 */ \
+        else analytic |= 1u << (I); }
+      PrimRegs ra = prim_load(prims, num ? idxp : 0), rb = ra;
+      for(uint32_t i=0;i<num;i+=2)
       {
 #ifdef MI_PROFILE_LOOPS
-        if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) cnt[9]++;   /* wave-level leaf slots */
+        if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) cnt[9] += 2;   /* wave-level leaf slots */
 #endif
-        PrimRegs nxt = cur;
-        if(i + 1 < num) nxt = prim_load(prims, idxp + i + 1);
-        cnt[3]++;
-        const uint32_t type = __float_as_uint(cur.q3.x);
-        if(type >= MI_PRIM_TRI)
+        if(i + 1 < num) rb = prim_load(prims, idxp + i + 1);
+        MI_LEAF_STEP(ra, i)
+        if(i + 1 < num)
         {
-          if(idxp + i != ignore) triquad_intersect(cur, type, o, d, hit, idxp + i);   /* triangle.h:271 */
+          if(i + 2 < num) ra = prim_load(prims, idxp + i + 2);
+          MI_LEAF_STEP(rb, i + 1)
         }
-        else analytic |= 1u << i;
-        cur = nxt;
       }
+#undef MI_LEAF_STEP
       while(analytic)
       {
 #ifdef MI_PROFILE_LOOPS
