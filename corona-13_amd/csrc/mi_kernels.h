@@ -522,7 +522,7 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
         const uint32_t type = __float_as_uint((R).q3.x); \
         if(type >= MI_PRIM_TRI) { if(idxp + (I) != ignore) triquad_intersect((R), type, o, d, hit, idxp + (I)); }   /* triangle.h:271 */ \
         else analytic |= 1u << (I); }
-      PrimRegs ra = prim_load(prims, num ? idxp : 0), rb = ra;
+      PrimRegs ra = prim_load(prims, num ? idxp : 0), rb;      /* rb is loaded before each use (same condition) */
       for(uint32_t i=0;i<num;i+=2)
       {
 #ifdef MI_PROFILE_LOOPS
