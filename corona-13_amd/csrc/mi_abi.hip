@@ -163,7 +163,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_intersect_kernel(DScene sc, const
       hit.prim = MI_NOPRIM; hit.dist = r.max_dist; hit.u = hit.v = 0.0f;
       accel_intersect<MI_BLOCK, MI_STACK>(lds, sc.prims, mk3(r.pos[0], r.pos[1], r.pos[2]), mk3(r.dir[0], r.dir[1], r.dir[2]), r.ignore, hit, cnt);
       mi_hit h;
-      h.prim = hit.prim; h.primid = hit.prim == MI_NOPRIM ? MI_PRIMID_INVALID : sc.primshade[hit.prim].primid;
+      h.prim = hit.prim; h.primid = hit.prim == MI_NOPRIM ? MI_PRIMID_INVALID : MI_GEO_PRIMID(sc.primgeo[hit.prim]);
       h.dist = hit.dist; h.u = hit.u; h.v = hit.v; h.pad[0] = h.pad[1] = 0;
       out[i] = h;
     }
@@ -192,7 +192,7 @@ struct mi_scene
 {
   DScene d;
   uint32_t width, height;
-  void *d_nodes, *d_axes, *d_prims, *d_primshade, *d_primgeo, *d_materials, *d_light_prim, *d_light_cdf, *d_light_L;
+  void *d_nodes, *d_axes, *d_prims, *d_primgeo, *d_materials, *d_light_prim, *d_light_cdf, *d_light_L;
   void *d_cie, *d_checker, *d_metal, *d_counters, *d_work, *d_shape_material, *d_shape_L, *d_overflow;
   float *d_fb_own, *d_fb;
   hipStream_t stream_own, stream;
@@ -241,7 +241,7 @@ template<typename T> static int upload(void **dst, const T *src, size_t count)
 /* per-primitive constants of a line (truncated cone) primitive, computed once with the same float operations the
  * reference performs inside every intersection test (include/geo/line.h:313-335,401-416, include/corona_common.h:178-198);
  * layout documented at line_intersect (mi_kernels.h) */
-static void pack_line(DPrim &p, DPrimShade &q, const mi_vtx &a0, const mi_vtx &a1)
+static void pack_line(DPrim &p, const mi_vtx &a0, const mi_vtx &a1)
 {
   float *f = &p.v[0][0];
   uint32_t *fu = (uint32_t *)f;
@@ -276,7 +276,6 @@ static void pack_line(DPrim &p, DPrimShade &q, const mi_vtx &a0, const mi_vtx &a
     f[13] = dlen*dlen/((r1-r0)*(r1-r0) + dlen*dlen);
   }
   fu[12] = type;
-  memcpy(&q.n[2], &v1[0], 4); memcpy(&q.n[3], &v1[1], 4); memcpy(&q.uv[2], &v1[2], 4);
 }
 
 static int tree_depth(const mi_scene_desc *h, uint32_t node, int depth)
@@ -356,11 +355,9 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   }
   /* primitives: resolve primid -> vtxidx -> vtx once */
   std::vector<DPrim> prims(h->num_prims ? h->num_prims : 1);
-  std::vector<DPrimShade> pshade(h->num_prims ? h->num_prims : 1);
   std::vector<DPrimGeo> pgeo(h->num_prims ? h->num_prims : 1);
   memset(pgeo.data(), 0, pgeo.size()*sizeof(DPrimGeo));
   memset(prims.data(), 0, prims.size()*sizeof(DPrim));
-  memset(pshade.data(), 0, pshade.size()*sizeof(DPrimShade));
   for(uint64_t i=0;i<h->num_prims;i++)
   {
     const mi_primid pi = h->primid[i];
@@ -369,22 +366,24 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
     const mi_shape &sh = h->shapes[shape];
     const mi_vtxidx *vi = h->vtxidx + sh.vtxidx_base + MI_PRIMID_VI(pi);
     const mi_vtx *vtx = h->vtx + sh.vtx_base;
-    DPrim &p = prims[i]; DPrimShade &q = pshade[i];
+    DPrim &p = prims[i]; DPrimGeo &q = pgeo[i];
     p.type = vc;
-    q.primid = pi; q.material = (uint32_t)sh.material;
+    q.type = vc; q.material = (uint32_t)sh.material; q.uv0 = vi[0].uv;
+    q.primid_lo = (uint32_t)pi; q.primid_hi = (uint32_t)(pi >> 32);
     if((uint32_t)sh.material >= h->num_materials || h->materials[sh.material].bsdf > MI_BSDF_METAL)
     { free(s); return fail(MI_ERR_UNSUPPORTED, "shape uses a material outside the scope"); }
-    for(uint32_t k=0;k<vc;k++) { q.n[k] = vtx[vi[k].v].n; q.uv[k] = vi[k].uv; }
     if(vc == MI_PRIM_LINE) { pgeo[i].f[18] = (vi[0].uv >> 21)/2048.0f; pgeo[i].f[19] = ((vi[0].uv & 0x1ffc00u) >> 10)/2048.0f; }
     else for(uint32_t k=0;k<vc;k++) { pgeo[i].f[18+2*k] = half2float(vi[k].uv & 0xffffu); pgeo[i].f[19+2*k] = half2float(vi[k].uv >> 16); }
     if(vc == MI_PRIM_SPHERE)
     {
       memcpy(p.v[0], vtx[vi[0].v].v, 12);
       memcpy(&p.v[1][0], &vtx[vi[0].v].n, 4);
+      memcpy(&q.f[29], vtx[vi[0].v].v, 12);           /* centre and radius for the shading side */
+      memcpy(&q.f[32], &vtx[vi[0].v].n, 4);
     }
     else if(vc == MI_PRIM_LINE)
     {
-      pack_line(p, q, vtx[vi[0].v], vtx[vi[1].v]);
+      pack_line(p, vtx[vi[0].v], vtx[vi[1].v]);
       /* shading-side frame of the line (line.h:123-161), with the functions the kernel would run per vertex */
       float *g = pgeo[i].f;
       const V3 v0 = ld3(vtx[vi[0].v].v), v1 = ld3(vtx[vi[1].v].v);
@@ -396,6 +395,8 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
       g[0] = d.x; g[1] = d.y; g[2] = d.z; g[3] = ilen_d;
       g[4] = a.x; g[5] = a.y; g[6] = a.z; g[7] = b.x; g[8] = b.y; g[9] = b.z;
       g[10] = ac.x; g[11] = ac.y; g[12] = ac.z; g[13] = bc.x; g[14] = bc.y; g[15] = bc.z;
+      g[26] = v1.x; g[27] = v1.y; g[28] = v1.z; g[29] = v0.x; g[30] = v0.y; g[31] = v0.z;
+      g[32] = p.v[1][0]; g[33] = p.v[1][1];           /* r0, r1 (dwords 3, 4 of the line record) */
     }
     else
     {
@@ -409,7 +410,7 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
         p.v[k][0] = e.x; p.v[k][1] = e.y; p.v[k][2] = e.z;
         g[26 + 3*(k-1)] = vv[k].x; g[27 + 3*(k-1)] = vv[k].y; g[28 + 3*(k-1)] = vv[k].z;
       }
-      for(uint32_t k=0;k<vc;k++) { const V3 n = decode_normal(q.n[k]); g[3*k] = n.x; g[3*k+1] = n.y; g[3*k+2] = n.z; }
+      for(uint32_t k=0;k<vc;k++) { const V3 n = decode_normal(vtx[vi[k].v].n); g[3*k] = n.x; g[3*k+1] = n.y; g[3*k+2] = n.z; }
       const V3 ga = tri_geo_normal(vv[0], vv[1], vv[2]);
       g[12] = ga.x; g[13] = ga.y; g[14] = ga.z;
       if(vc == MI_PRIM_QUAD)
@@ -449,7 +450,6 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   UP(d_nodes, nodes.data(), nodes.size());
   UP(d_axes, axes.data(), axes.size());
   UP(d_prims, prims.data(), prims.size());
-  UP(d_primshade, pshade.data(), pshade.size());
   UP(d_primgeo, pgeo.data(), pgeo.size());
   UP(d_materials, mats.data(), mats.size());
   UP(d_shape_material, shape_mat.data(), shape_mat.size());
@@ -477,7 +477,7 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   s->stream = s->stream_own;
 
   d.nodes = (const float4 *)s->d_nodes; d.node_axes = (const uint32_t *)s->d_axes;
-  d.prims = (const DPrim *)s->d_prims; d.primshade = (const DPrimShade *)s->d_primshade; d.primgeo = (const DPrimGeo *)s->d_primgeo;
+  d.prims = (const DPrim *)s->d_prims; d.primgeo = (const DPrimGeo *)s->d_primgeo;
   d.materials = (const DMaterial *)s->d_materials;
   d.num_lights = h->lights.num_prims;
   d.light_prim = (const uint32_t *)s->d_light_prim; d.light_cdf = (const float *)s->d_light_cdf; d.light_L = (const float *)s->d_light_L;
@@ -785,7 +785,7 @@ extern "C" void mi_scene_destroy(mi_scene *s)
   if(s->d_wfcnt) hipFree(s->d_wfcnt);
   if(s->h_live) hipHostFree(s->h_live);
   for(int k=0;k<8;k++) if(s->ev_live[k]) hipEventDestroy(s->ev_live[k]);
-  void *bufs[] = { s->d_nodes, s->d_axes, s->d_prims, s->d_primshade, s->d_primgeo, s->d_materials, s->d_light_prim, s->d_light_cdf, s->d_light_L,
+  void *bufs[] = { s->d_nodes, s->d_axes, s->d_prims, s->d_primgeo, s->d_materials, s->d_light_prim, s->d_light_cdf, s->d_light_L,
                    s->d_cie, s->d_checker, s->d_metal, s->d_counters, s->d_work, s->d_shape_material, s->d_shape_L, s->d_overflow, s->d_fb_own };
   for(void *b : bufs) if(b) hipFree(b);
   if(s->stream_own) hipStreamDestroy(s->stream_own);

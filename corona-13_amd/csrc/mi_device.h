@@ -9,8 +9,7 @@
  *  prims      one 64-B record per primitive in builder (leaf) order, pre-resolved at upload so an
  *             intersection test is ONE aligned fetch instead of primid -> vtxidx -> vtx
  *             (src/prims.c:638-672, include/geo.h:120-138)
- *  primshade  one 48-B record per primitive, touched once per path vertex (normals, uv, material)
- *  primgeo    one 144-B record per primitive, touched once per path vertex (decoded normals / line frames)
+ *  primgeo    one 160-B record per primitive, touched once per path vertex (decoded normals, line frames, uv, material, primid)
  */
 #ifndef MI_DEVICE_H
 #define MI_DEVICE_H
@@ -29,24 +28,22 @@ struct DPrim                       /* 64 B */
   uint32_t pad[3];
 };
 
-struct DPrimShade                  /* 48 B */
+struct DPrimGeo                    /* 160 B: everything the shading side needs about one primitive, in one record (one
+                                      dependent fetch per path vertex); the float constants are precomputed at upload with
+                                      the kernel's own (host+device) functions */
 {
-  uint32_t n[4];                   /* oct-encoded vertex normals */
-  uint32_t uv[4];                  /* half2 uv per vertex (11/11/10 for lines) */
-  uint64_t primid;                 /* the reference's packed primid (records, medium stack shape id) */
-  uint32_t material;
-  uint32_t pad;
-};
-
-struct DPrimGeo                    /* 144 B of per-primitive constants of the shading side, precomputed at upload with the
-                                      kernel's own (host+device) functions */
-{
-  float f[36];                     /* tri/quad: decoded vertex normals n0..n3 [0..11], geometric normal of (v0 v1 v2) [12..14] and of
+  float f[35];                     /* tri/quad: decoded vertex normals n0..n3 [0..11], geometric normal of (v0 v1 v2) [12..14] and of
                                       (v0 v2 v3) [15..17]. line: unit axis d [0..2], 1/|v1-v0| [3], onb a [4..6], b [7..9] of d;
                                       cone: onb of the intersection-side axis [10..12], [13..15].
                                       [18..25] texture coordinates: tri/quad (s,t) of v0..v3, sphere offset, line (s,t).
-                                      [26..34] tri/quad: vertices v1, v2, v3 (DPrim holds v0 and the edges) */
+                                      [26..34] tri/quad: vertices v1, v2, v3 (DPrim holds v0 and the edges);
+                                               line: v1 [26..28], v0 [29..31], r0 [32], r1 [33]; sphere: centre [29..31], radius [32] */
+  uint32_t type;                   /* vcnt: 1 sphere, 2 line, 3 tri, 4 quad */
+  uint32_t material;
+  uint32_t uv0;                    /* raw uv word of vertex 0: 0 = the primitive has no texture coordinates (src/prims.c:300) */
+  uint32_t primid_lo, primid_hi;   /* the reference's packed primid (records, medium stack shape id) */
 };
+#define MI_GEO_PRIMID(g) ((uint64_t)(g).primid_lo | ((uint64_t)(g).primid_hi << 32))
 
 struct DMaterial
 {
@@ -71,7 +68,6 @@ struct DScene
   const float4  *nodes;            /* [MI_NODE_FIELDS][num_nodes] */
   const uint32_t *node_axes;       /* [num_nodes] */
   const DPrim  *prims;
-  const DPrimShade *primshade;
   const DPrimGeo *primgeo;
   float aabb[6];
   float far_dist;                  /* 2 * largest box extent, src/pathspace.c:867-870 */

@@ -617,16 +617,14 @@ MI_HD V3 tri_geo_normal(const V3 v0, const V3 v1, const V3 v2)
 
 __device__ __forceinline__ void surface_setup(const DScene &sc, uint32_t prim, const V3 omega, float scramble, Surf &sf)
 { /* prims_get_normal_time (src/prims.c:254-366) + manifold_init (include/pathspace/manifold.h:215-232) */
-  const DPrim &p = sc.prims[prim];
-  const DPrimShade &ps = sc.primshade[prim];
-  const float *g = sc.primgeo[prim].f;      /* per-primitive constants, see DPrimGeo */
-  const uint32_t type = p.type;
+  const DPrimGeo &geo = sc.primgeo[prim];
+  const float *g = geo.f;                   /* per-primitive constants, see DPrimGeo */
+  const uint32_t type = geo.type;
   if(type < MI_PRIM_TRI)
-  { /* sphere (sphere.h:51-62,160-161) and line (line.h:123-161; record layout: see line_intersect). The two share one
-       atan2f site: a wave that holds hits of both kinds runs the long libm sequence once. */
-    const float *f = &p.v[0][0];
-    const V3 v0 = mk3(f[0], f[1], f[2]);           /* sphere: centre */
-    const float r0 = f[3], r1 = f[4];              /* sphere: f[3] = radius */
+  { /* sphere (sphere.h:51-62,160-161) and line (line.h:123-161). The two share one atan2f site: a wave that holds hits
+       of both kinds runs the long libm sequence once. */
+    const V3 v0 = mk3(g[29], g[30], g[31]);        /* sphere: centre */
+    const float r0 = g[32], r1 = g[33];            /* sphere: g[32] = radius */
     const bool sphere = type == MI_PRIM_SPHERE;
     const bool cylinder = !sphere && fabsf(r1-r0) < 1e-3;
     const V3 x = sub3(sf.x, v0);
@@ -673,7 +671,7 @@ __device__ __forceinline__ void surface_setup(const DScene &sc, uint32_t prim, c
     sf.n = normalise3(mk3(u*n2[0] + v*n1[0] + w*g[0], u*n2[1] + v*n1[1] + w*g[1], u*n2[2] + v*n1[2] + w*g[2]));
   }
   /* texture coordinates, src/prims.c:300-365; the half / fixed-point uv of the record are decoded at upload (g[18..25]) */
-  if(ps.uv[0] == 0) { sf.s = sf.u; sf.t = sf.v; }
+  if(geo.uv0 == 0) { sf.s = sf.u; sf.t = sf.v; }
   else if(type == MI_PRIM_SPHERE) { sf.s = sf.u + g[18]; sf.t = sf.v + g[19]; }
   else if(type == MI_PRIM_LINE) { sf.s = g[18]; sf.t = g[19]; }
   else
@@ -1307,7 +1305,7 @@ __device__ __forceinline__ V3 tri_retime(const V3 v0, const V3 v1, const V3 v2, 
   return mk3(w*v0.x + v*v1.x + u*v2.x, w*v0.y + v*v1.y + u*v2.y, w*v0.z + v*v1.z + u*v2.z);
 }
 
-__device__ __forceinline__ V3 prim_sample(const DPrim &p, const DPrimShade &psh, const DPrimGeo &geo, float r0, float r1, float &hu, float &hv)
+__device__ __forceinline__ V3 prim_sample(const DPrim &p, const DPrimGeo &geo, float r0, float r1, float &hu, float &hv)
 { /* prims_sample + prims_retime, src/prims.c:178-252 */
   const uint32_t type = p.type;
   const float *gv = geo.f + 26;             /* v1, v2, v3 of a triangle / quad (DPrim keeps v0 and the edges) */
@@ -1335,7 +1333,7 @@ __device__ __forceinline__ V3 prim_sample(const DPrim &p, const DPrimShade &psh,
   /* line: geo_line_retime, include/geo/line.h:88-121 */
   hu = r0; hv = r1;
   const float *f = &p.v[0][0];
-  const V3 v0 = mk3(f[0], f[1], f[2]), v1 = mk3(__uint_as_float(psh.n[2]), __uint_as_float(psh.n[3]), __uint_as_float(psh.uv[2]));
+  const V3 v0 = mk3(f[0], f[1], f[2]), v1 = mk3(geo.f[26], geo.f[27], geo.f[28]);
   const float lr0 = f[3], lr1 = f[4];
   float y;
   if(fabsf(lr1-lr0) < 1e-3f) y = hu;

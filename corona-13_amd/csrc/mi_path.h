@@ -194,9 +194,9 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
     sf.u = hit.u; sf.v = hit.v;
     surface_setup(sc, hit.prim, omega, ps.scramble, sf);
     MI_PHASE(cnt, 2)
-    const DPrimShade &pshade = sc.primshade[hit.prim];
+    const DPrimGeo &pshade = sc.primgeo[hit.prim];
     const DMaterial &mat = sc.materials[pshade.material];
-    const uint32_t shape = MI_PRIMID_SHAPE(pshade.primid);
+    const uint32_t shape = (pshade.primid_lo >> 3) & 0x1fffffffu;          /* MI_PRIMID_SHAPE */
     Shading sh;
     run_prepare_ops(sc, mat, sf, ps.lambda, sh);
     uint32_t material_modes = 0;
@@ -229,7 +229,7 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
 
     MI_PHASE(cnt, 3)
     /* self-intersection, src/pathspace.c:807-820 */
-    const uint32_t type = sc.prims[hit.prim].type;
+    const uint32_t type = pshade.type;
     if((type > 2 || hit.dist < 1e-4f) && hit.prim == ps.ignore)
     {
       alive = false;
@@ -266,7 +266,7 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
       float vthr = ps.throughput;
       if(RECORD)
       {
-        rec_vertex<RECORD>(rec, v, pshade.primid, hit.dist, sf.x, sf.n, sf.gn, omega, mode, sf.flags, vthr, vpdf, sf.u, sf.v, sh,
+        rec_vertex<RECORD>(rec, v, MI_GEO_PRIMID(pshade), hit.dist, sf.x, sf.n, sf.gn, omega, mode, sf.flags, vthr, vpdf, sf.u, sf.v, sh,
                            eta_ratio, (int)pshade.material);
         rec->length = ps.length; rec->throughput = path_throughput;
       }
@@ -329,13 +329,13 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
             const uint32_t t = sample_cdf(sc.light_cdf, (int)sc.num_lights, r1);
             const uint32_t lp = sc.light_prim[t];
             Surf ls;
-            ls.x = prim_sample(sc.prims[lp], sc.primshade[lp], sc.primgeo[lp], r2, r3, ls.u, ls.v);
+            ls.x = prim_sample(sc.prims[lp], sc.primgeo[lp], r2, r3, ls.u, ls.v);
             V3 ol = sub3(ls.x, sf.x);
             const float ldist = sqrtf(dot3(ol, ol));
             const double il = 1./(double)ldist;
             ol = mk3((float)((double)ol.x*il), (float)((double)ol.y*il), (float)((double)ol.z*il));
             surface_setup(sc, lp, ol, ps.scramble, ls);
-            const DPrimShade &lshade = sc.primshade[lp];
+            const DPrimGeo &lshade = sc.primgeo[lp];
             Shading lsh;
             run_prepare_ops(sc, sc.materials[lshade.material], ls, ps.lambda, lsh);
             float lpdf = sc.light_L[t];
