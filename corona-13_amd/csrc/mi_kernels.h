@@ -296,7 +296,14 @@ __device__ __forceinline__ void triquad_intersect(const PrimRegs &r, uint32_t ty
 
 __device__ __forceinline__ void analytic_intersect(const DPrim *prims, uint32_t prim, const V3 o, const V3 d, uint32_t ignore, Hit &hit)
 { /* prims_intersect for spheres and lines, src/prims.c:665-668 */
-  const DPrim &p = prims[prim];
+  /* the whole 64-B record in four 16-B loads up front (one memory round trip), then registers only */
+  const float4 *q = (const float4 *)(prims + prim);
+  const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+  DPrim p;
+  p.v[0][0] = q0.x; p.v[0][1] = q0.y; p.v[0][2] = q0.z; p.v[1][0] = q0.w;
+  p.v[1][1] = q1.x; p.v[1][2] = q1.y; p.v[2][0] = q1.z; p.v[2][1] = q1.w;
+  p.v[2][2] = q2.x; p.v[3][0] = q2.y; p.v[3][1] = q2.z; p.v[3][2] = q2.w;
+  p.type = __float_as_uint(q3.x); p.pad[0] = __float_as_uint(q3.y); p.pad[1] = __float_as_uint(q3.z); p.pad[2] = __float_as_uint(q3.w);
   if(p.type == MI_PRIM_SPHERE)
   { /* geo_sphere_intersect, include/geo/sphere.h:146-166; u,v are recomputed at shading time */
     const float t = sphere_t(ld3(p.v[0]), p.v[1][0], o, d);
