@@ -9,7 +9,7 @@
  *  prims      one 64-B record per primitive in builder (leaf) order, pre-resolved at upload so an
  *             intersection test is ONE aligned fetch instead of primid -> vtxidx -> vtx
  *             (src/prims.c:638-672, include/geo.h:120-138)
- *  primgeo    one 160-B record per primitive, touched once per path vertex (decoded normals, line frames, uv, material, primid)
+ *  primgeo    one 176-B record per primitive, touched once per path vertex (decoded normals, line frames, uv, material, primid)
  */
 #ifndef MI_DEVICE_H
 #define MI_DEVICE_H
@@ -28,20 +28,22 @@ struct DPrim                       /* 64 B */
   uint32_t pad[3];
 };
 
-struct DPrimGeo                    /* 160 B: everything the shading side needs about one primitive, in one record (one
-                                      dependent fetch per path vertex); the float constants are precomputed at upload with
-                                      the kernel's own (host+device) functions */
+struct DPrimGeo                    /* 176 B: everything the shading side needs about one primitive, in one record; the float
+                                      constants are precomputed at upload with the kernel's own (host+device) functions */
 {
+  /* header, fetched first as one 16-B load: it decides the branches and starts the material fetch */
+  uint32_t type;                   /* vcnt: 1 sphere, 2 line, 3 tri, 4 quad */
+  uint32_t material;
+  uint32_t uv0;                    /* raw uv word of vertex 0: 0 = the primitive has no texture coordinates (src/prims.c:300) */
+  uint32_t primid_lo;              /* the reference's packed primid (records, medium stack shape id) */
+  uint32_t primid_hi, pad[3];
   float f[35];                     /* tri/quad: decoded vertex normals n0..n3 [0..11], geometric normal of (v0 v1 v2) [12..14] and of
                                       (v0 v2 v3) [15..17]. line: unit axis d [0..2], 1/|v1-v0| [3], onb a [4..6], b [7..9] of d;
                                       cone: onb of the intersection-side axis [10..12], [13..15].
                                       [18..25] texture coordinates: tri/quad (s,t) of v0..v3, sphere offset, line (s,t).
                                       [26..34] tri/quad: vertices v1, v2, v3 (DPrim holds v0 and the edges);
                                                line: v1 [26..28], v0 [29..31], r0 [32], r1 [33]; sphere: centre [29..31], radius [32] */
-  uint32_t type;                   /* vcnt: 1 sphere, 2 line, 3 tri, 4 quad */
-  uint32_t material;
-  uint32_t uv0;                    /* raw uv word of vertex 0: 0 = the primitive has no texture coordinates (src/prims.c:300) */
-  uint32_t primid_lo, primid_hi;   /* the reference's packed primid (records, medium stack shape id) */
+  float pad2;
 };
 #define MI_GEO_PRIMID(g) ((uint64_t)(g).primid_lo | ((uint64_t)(g).primid_hi << 32))
 

@@ -622,11 +622,11 @@ MI_HD V3 tri_geo_normal(const V3 v0, const V3 v1, const V3 v2)
                         (v1.x-v0.x)*(v2.y-v0.y) - (v1.y-v0.y)*(v2.x-v0.x)));
 }
 
-__device__ __forceinline__ void surface_setup(const DScene &sc, uint32_t prim, const V3 omega, float scramble, Surf &sf)
+__device__ __forceinline__ void surface_setup(const DScene &sc, uint32_t prim, const uint4 head, const V3 omega, float scramble, Surf &sf)
 { /* prims_get_normal_time (src/prims.c:254-366) + manifold_init (include/pathspace/manifold.h:215-232) */
   const DPrimGeo &geo = sc.primgeo[prim];
   const float *g = geo.f;                   /* per-primitive constants, see DPrimGeo */
-  const uint32_t type = geo.type;
+  const uint32_t type = head.x;             /* head = the record's first 16 bytes: type, material, uv0, primid_lo */
   if(type < MI_PRIM_TRI)
   { /* sphere (sphere.h:51-62,160-161) and line (line.h:123-161). The two share one atan2f site: a wave that holds hits
        of both kinds runs the long libm sequence once. */
@@ -678,7 +678,7 @@ __device__ __forceinline__ void surface_setup(const DScene &sc, uint32_t prim, c
     sf.n = normalise3(mk3(u*n2[0] + v*n1[0] + w*g[0], u*n2[1] + v*n1[1] + w*g[1], u*n2[2] + v*n1[2] + w*g[2]));
   }
   /* texture coordinates, src/prims.c:300-365; the half / fixed-point uv of the record are decoded at upload (g[18..25]) */
-  if(geo.uv0 == 0) { sf.s = sf.u; sf.t = sf.v; }
+  if(head.z == 0) { sf.s = sf.u; sf.t = sf.v; }
   else if(type == MI_PRIM_SPHERE) { sf.s = sf.u + g[18]; sf.t = sf.v + g[19]; }
   else if(type == MI_PRIM_LINE) { sf.s = g[18]; sf.t = g[19]; }
   else

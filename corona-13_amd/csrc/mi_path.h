@@ -192,11 +192,15 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
     Surf sf;
     sf.x = mk3(ps.org.x + hit.dist*ps.dir.x, ps.org.y + hit.dist*ps.dir.y, ps.org.z + hit.dist*ps.dir.z);
     sf.u = hit.u; sf.v = hit.v;
-    surface_setup(sc, hit.prim, omega, ps.scramble, sf);
-    MI_PHASE(cnt, 2)
+    /* the record's header first (one 16-B load): it names the material, whose fetch is then under way while the
+       surface is set up */
     const DPrimGeo &pshade = sc.primgeo[hit.prim];
-    const DMaterial &mat = sc.materials[pshade.material];
-    const uint32_t shape = (pshade.primid_lo >> 3) & 0x1fffffffu;          /* MI_PRIMID_SHAPE */
+    const uint4 head = *(const uint4 *)&pshade;                     /* type, material, uv0, primid_lo */
+    const DMaterial &mat = sc.materials[head.y];
+    const uint32_t mat_bsdf = mat.bsdf;
+    surface_setup(sc, hit.prim, head, omega, ps.scramble, sf);
+    MI_PHASE(cnt, 2)
+    const uint32_t shape = (head.w >> 3) & 0x1fffffffu;             /* MI_PRIMID_SHAPE */
     Shading sh;
     run_prepare_ops(sc, mat, sf, ps.lambda, sh);
     uint32_t material_modes = 0;
@@ -205,7 +209,7 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
       Media hyp = ps.media;
       media_apply(hyp, shape, (sf.flags & s_inside) != 0);
       float interior_self = 1.0f;
-      if(mat.bsdf == MI_BSDF_DIELECTRIC) interior_self = eta_from_abbe(mat.param[0], mat.param[1], ps.lambda);
+      if(mat_bsdf == MI_BSDF_DIELECTRIC) interior_self = eta_from_abbe(mat.param[0], mat.param[1], ps.lambda);
       if(hyp.broken) eta_ratio = -1.0f;
       else
       {
@@ -214,14 +218,14 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
         eta_ratio = ps.cur_ior/ior2;
       }
     }
-    if(mat.bsdf == MI_BSDF_DIFFUSE) { if(sh.rd > 0.0f) material_modes = s_reflect | s_diffuse; }
-    else if(mat.bsdf == MI_BSDF_DIELECTRIC)
+    if(mat_bsdf == MI_BSDF_DIFFUSE) { if(sh.rd > 0.0f) material_modes = s_reflect | s_diffuse; }
+    else if(mat_bsdf == MI_BSDF_DIELECTRIC)
     {
       material_modes = s_reflect | s_transmit;
       if(fabsf(1.0f - eta_ratio/1.0f) < 1e-3f) sh.roughness = 0.0f;
       if(sh.roughness > GLOSSY_THR) material_modes |= s_glossy; else material_modes |= s_specular;
     }
-    else if(mat.bsdf == MI_BSDF_METAL)
+    else if(mat_bsdf == MI_BSDF_METAL)
     {
       material_modes = s_reflect;
       if(sh.roughness > 1e-4f) material_modes |= s_glossy; else material_modes |= s_specular;
@@ -229,7 +233,7 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
 
     MI_PHASE(cnt, 3)
     /* self-intersection, src/pathspace.c:807-820 */
-    const uint32_t type = pshade.type;
+    const uint32_t type = head.x;
     if((type > 2 || hit.dist < 1e-4f) && hit.prim == ps.ignore)
     {
       alive = false;
@@ -267,7 +271,7 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
       if(RECORD)
       {
         rec_vertex<RECORD>(rec, v, MI_GEO_PRIMID(pshade), hit.dist, sf.x, sf.n, sf.gn, omega, mode, sf.flags, vthr, vpdf, sf.u, sf.v, sh,
-                           eta_ratio, (int)pshade.material);
+                           eta_ratio, (int)head.y);
         rec->length = ps.length; rec->throughput = path_throughput;
       }
       if(mode & s_emit)
@@ -334,10 +338,10 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
             const float ldist = sqrtf(dot3(ol, ol));
             const double il = 1./(double)ldist;
             ol = mk3((float)((double)ol.x*il), (float)((double)ol.y*il), (float)((double)ol.z*il));
-            surface_setup(sc, lp, ol, ps.scramble, ls);
-            const DPrimGeo &lshade = sc.primgeo[lp];
+            const uint4 lhead = *(const uint4 *)&sc.primgeo[lp];
+            surface_setup(sc, lp, lhead, ol, ps.scramble, ls);
             Shading lsh;
-            run_prepare_ops(sc, sc.materials[lshade.material], ls, ps.lambda, lsh);
+            run_prepare_ops(sc, sc.materials[lhead.y], ls, ps.lambda, lsh);
             float lpdf = sc.light_L[t];
             float edf = lsh.em/lpdf;
             if(lsh.roughness > 1.0f-1e-4f) edf = (float)((double)edf*((double)1.0f/MI_PI_D));
@@ -352,8 +356,8 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
             if(edf > 0.0f)
             {
               BsdfEval be;
-              if(mat.bsdf == MI_BSDF_DIFFUSE) be = brdf_diffuse(sf, sh, ol);
-              else if(mat.bsdf == MI_BSDF_DIELECTRIC) be = brdf_dielectric(sf, sh, omega, ol, eta_ratio);
+              if(mat_bsdf == MI_BSDF_DIFFUSE) be = brdf_diffuse(sf, sh, ol);
+              else if(mat_bsdf == MI_BSDF_DIELECTRIC) be = brdf_dielectric(sf, sh, omega, ol, eta_ratio);
               else be = brdf_metal(sc, sf, sh, omega, ol, ps.cur_ior, (int)mat.param[0], ps.lambda);
               bool okn = be.value > 0.0f;
               if(okn && (be.mode & s_transmit))
@@ -379,8 +383,8 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
                   tn = tn*wn;
                   /* sampler_mis(path, rr*pdf_nee, path_pdf_extend(path, v+1)), ptdl.c:143-146 */
                   float pb;
-                  if(mat.bsdf == MI_BSDF_DIFFUSE) pb = (float)(1.0f/MI_PI_D);
-                  else if(mat.bsdf == MI_BSDF_DIELECTRIC) pb = pdf_dielectric(sf, sh, omega, ol, eta_ratio, be.mode);
+                  if(mat_bsdf == MI_BSDF_DIFFUSE) pb = (float)(1.0f/MI_PI_D);
+                  else if(mat_bsdf == MI_BSDF_DIELECTRIC) pb = pdf_dielectric(sf, sh, omega, ol, eta_ratio, be.mode);
                   else pb = pdf_metal(sf, sh, omega, ol, be.mode);
                   const float pe = (1.0f*pb)*Gn;
                   const double pp = ps.pdfprod;
@@ -411,8 +415,8 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
       if(alive)
       {
         BsdfSample bs;
-        if(mat.bsdf == MI_BSDF_DIFFUSE) sample_diffuse(ps.rng, sf, sh, mode, bs);
-        else if(mat.bsdf == MI_BSDF_DIELECTRIC) sample_dielectric(ps.rng, sf, sh, omega, eta_ratio, mode, bs);
+        if(mat_bsdf == MI_BSDF_DIFFUSE) sample_diffuse(ps.rng, sf, sh, mode, bs);
+        else if(mat_bsdf == MI_BSDF_DIELECTRIC) sample_dielectric(ps.rng, sf, sh, omega, eta_ratio, mode, bs);
         else sample_metal(sc, ps.rng, sf, sh, omega, ps.cur_ior, (int)mat.param[0], ps.lambda, mode, bs);
         MI_PHASE(cnt, 7)
         /* shader_sample tail, src/shader.c:582-589 */
