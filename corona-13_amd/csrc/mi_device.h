@@ -47,11 +47,11 @@ struct DPrimGeo                    /* 176 B: everything the shading side needs a
 };
 #define MI_GEO_PRIMID(g) ((uint64_t)(g).primid_lo | ((uint64_t)(g).primid_hi << 32))
 
-struct DMaterial
+struct DMaterial                   /* 144 B; the header (one 16-B load) and each 32-B op (two 16-B loads) are fetched whole */
 {
   uint32_t bsdf, num_ops;
+  float param[2];                  /* dielectric: n_d, abbe; metal: table id */
   mi_shade_op op[MI_MAX_OPS];
-  float param[4];
 };
 
 struct DCamConst                   /* per-launch camera constants of camera_sample (src/camera.d/thinlens.c:68-128), formed once at

@@ -729,12 +729,17 @@ __device__ __forceinline__ void set_slot(Shading &sh, uint32_t slot, float val)
   else if(slot == MI_SLOT_EMISSION) sh.em = val;
 }
 
-__device__ __forceinline__ void run_prepare_ops(const DScene &sc, const DMaterial &m, const Surf &sf, float lambda, Shading &sh)
+__device__ __forceinline__ void run_prepare_ops(const DScene &sc, const DMaterial &m, uint32_t num_ops, const Surf &sf, float lambda, Shading &sh)
 { /* mult.c:154-167 -> color.c:75-82 / colorcheckersg.c:244-262 */
   sh.roughness = 1.0f; sh.rs = sh.rd = sh.rg = sh.em = 0.0f;
-  for(uint32_t k=0;k<m.num_ops;k++)
+  for(uint32_t k=0;k<num_ops;k++)
   {
-    const mi_shade_op &op = m.op[k];
+    /* one op = two 16-B loads issued together: kind, slot, coeff[0..1] | coeff[2], mul, roughness, pad */
+    const uint4 oa = *(const uint4 *)&m.op[k];
+    const float4 ob = *(const float4 *)((const char *)&m.op[k] + 16);
+    mi_shade_op op;
+    op.kind = oa.x; op.slot = oa.y; op.coeff[0] = __uint_as_float(oa.z); op.coeff[1] = __uint_as_float(oa.w);
+    op.coeff[2] = ob.x; op.mul = ob.y; op.roughness = ob.z;
     if(op.kind == MI_OP_COLOR)
     {
       sh.roughness = op.roughness;

@@ -197,19 +197,21 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
     const DPrimGeo &pshade = sc.primgeo[hit.prim];
     const uint4 head = *(const uint4 *)&pshade;                     /* type, material, uv0, primid_lo */
     const DMaterial &mat = sc.materials[head.y];
-    const uint32_t mat_bsdf = mat.bsdf;
+    const uint4 mhead = *(const uint4 *)&mat;                       /* bsdf, num_ops, param[0..1] */
+    const uint32_t mat_bsdf = mhead.x;
+    const float mat_p0 = __uint_as_float(mhead.z), mat_p1 = __uint_as_float(mhead.w);
     surface_setup(sc, hit.prim, head, omega, ps.scramble, sf);
     MI_PHASE(cnt, 2)
     const uint32_t shape = (head.w >> 3) & 0x1fffffffu;             /* MI_PRIMID_SHAPE */
     Shading sh;
-    run_prepare_ops(sc, mat, sf, ps.lambda, sh);
+    run_prepare_ops(sc, mat, mhead.y, sf, ps.lambda, sh);
     uint32_t material_modes = 0;
     float eta_ratio = 1.0f;      /* path_eta_ratio(v): e[v].vol.ior / ior behind the interface, src/pathspace.c:117-124 */
     {
       Media hyp = ps.media;
       media_apply(hyp, shape, (sf.flags & s_inside) != 0);
       float interior_self = 1.0f;
-      if(mat_bsdf == MI_BSDF_DIELECTRIC) interior_self = eta_from_abbe(mat.param[0], mat.param[1], ps.lambda);
+      if(mat_bsdf == MI_BSDF_DIELECTRIC) interior_self = eta_from_abbe(mat_p0, mat_p1, ps.lambda);
       if(hyp.broken) eta_ratio = -1.0f;
       else
       {
@@ -341,7 +343,7 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
             const uint4 lhead = *(const uint4 *)&sc.primgeo[lp];
             surface_setup(sc, lp, lhead, ol, ps.scramble, ls);
             Shading lsh;
-            run_prepare_ops(sc, sc.materials[lhead.y], ls, ps.lambda, lsh);
+            run_prepare_ops(sc, sc.materials[lhead.y], sc.materials[lhead.y].num_ops, ls, ps.lambda, lsh);
             float lpdf = sc.light_L[t];
             float edf = lsh.em/lpdf;
             if(lsh.roughness > 1.0f-1e-4f) edf = (float)((double)edf*((double)1.0f/MI_PI_D));
@@ -358,7 +360,7 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
               BsdfEval be;
               if(mat_bsdf == MI_BSDF_DIFFUSE) be = brdf_diffuse(sf, sh, ol);
               else if(mat_bsdf == MI_BSDF_DIELECTRIC) be = brdf_dielectric(sf, sh, omega, ol, eta_ratio);
-              else be = brdf_metal(sc, sf, sh, omega, ol, ps.cur_ior, (int)mat.param[0], ps.lambda);
+              else be = brdf_metal(sc, sf, sh, omega, ol, ps.cur_ior, (int)mat_p0, ps.lambda);
               bool okn = be.value > 0.0f;
               if(okn && (be.mode & s_transmit))
               { /* path_edge_init_volume on the connection edge */
@@ -417,7 +419,7 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
         BsdfSample bs;
         if(mat_bsdf == MI_BSDF_DIFFUSE) sample_diffuse(ps.rng, sf, sh, mode, bs);
         else if(mat_bsdf == MI_BSDF_DIELECTRIC) sample_dielectric(ps.rng, sf, sh, omega, eta_ratio, mode, bs);
-        else sample_metal(sc, ps.rng, sf, sh, omega, ps.cur_ior, (int)mat.param[0], ps.lambda, mode, bs);
+        else sample_metal(sc, ps.rng, sf, sh, omega, ps.cur_ior, (int)mat_p0, ps.lambda, mode, bs);
         MI_PHASE(cnt, 7)
         /* shader_sample tail, src/shader.c:582-589 */
         bs.omega = normalise3(bs.omega);
