@@ -427,8 +427,13 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
     memcpy(mats[i].op, h->materials[i].op, sizeof(mats[i].op));
     memcpy(mats[i].param, h->materials[i].param, sizeof(mats[i].param));
   }
-  std::vector<uint32_t> shape_mat(h->num_shapes ? h->num_shapes : 1);
-  for(uint32_t i=0;i<h->num_shapes;i++) shape_mat[i] = (uint32_t)h->shapes[i].material;
+  std::vector<uint32_t> shape_mat(4*(size_t)(h->num_shapes ? h->num_shapes : 1), 0u);   /* per shape: bsdf, material, param[0], param[1] */
+  for(uint32_t i=0;i<h->num_shapes;i++)
+  {
+    const mi_material &m = h->materials[h->shapes[i].material];
+    shape_mat[4*i+0] = m.bsdf; shape_mat[4*i+1] = (uint32_t)h->shapes[i].material;
+    memcpy(&shape_mat[4*i+2], &m.param[0], 4); memcpy(&shape_mat[4*i+3], &m.param[1], 4);
+  }
   std::vector<float> shape_L(h->num_shapes ? h->num_shapes : 1, 0.0f);
   for(uint32_t k=0;k<h->lights.num_prims;k++)
   {

@@ -815,8 +815,9 @@ __device__ __forceinline__ int media_top_shape(const Media &m)
 __device__ __forceinline__ float shape_interior_ior(const DScene &sc, const uint32_t *shape_material, int shape, float lambda)
 {
   if(shape < 0) return 1.0f;
-  const DMaterial &m = sc.materials[shape_material[shape]];
-  if(m.bsdf == MI_BSDF_DIELECTRIC) return eta_from_abbe(m.param[0], m.param[1], lambda);
+  /* per shape: bsdf, material id, n_d, abbe of its material in one 16-B entry (instead of shape -> material -> bsdf -> params) */
+  const uint4 e = ((const uint4 *)shape_material)[shape];
+  if(e.x == MI_BSDF_DIELECTRIC) return eta_from_abbe(__uint_as_float(e.z), __uint_as_float(e.w), lambda);
   return 1.0f;
 }
 
