@@ -420,6 +420,7 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
 #endif
       const uint32_t node = current;
       const uint4 child = *(const uint4 *)&lds.nodes[6*N + node];
+      const uint32_t ax = lds.axes[node];       /* with the other loads of this node, not after the slab test */
       float tm0, tm1, tm2, tm3;
       uint32_t mask = 0;
       if(!slow)
@@ -466,7 +467,6 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
         cnt[2] += __popc(mask);
         /* front-to-back order from split axes and ray signs, qbvhmp.c:1313-1320: the near half is children
            {2*near0, 2*near0+1}, ordered by the sign along its own split axis; likewise the far half */
-        const uint32_t ax = lds.axes[node];
         const uint32_t axis0 = ax & 3u;
         const bool near0 = (nearbits >> axis0) & 1u;
         const uint32_t axis1n = near0 ? ((ax >> 4) & 3u) : ((ax >> 2) & 3u);
