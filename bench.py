@@ -31,6 +31,16 @@ sys.path.insert(0, str(REPO))
 sys.path.insert(0, str(REPO / "tests"))
 
 W, H, SPP, MAX_VERTS = 1280, 720, 64, 8
+# BASELINE.json configs; the metric is quoted on configs[1], which is what the driver's plain `bench.py` run measures.
+# The others can be timed with --config (development / DESIGN.md table); their CPU baseline leg is not run.
+CONFIGS = {
+    "cfg1": dict(scene="0010_pt", sampler="pt", w=256, h=256, spp=4, mv=4, name="configs[0]: regression/0010_pt, pt, 256x256, 4 spp, max depth 4"),
+    "cfg2": dict(scene="0010_pt", sampler="pt", w=W, h=H, spp=SPP, mv=MAX_VERTS,
+                 name="configs[1]: regression/0010_pt test.nra2, pt sampler, 1280x720 (padded 1280x736), 64 spp, max depth 8"),
+    "cfg3": dict(scene="0010_pt", sampler="ptdl", w=1280, h=720, spp=64, mv=8, name="configs[2]: regression/0011_ptdl (0010 scene, ptdl sampler), 1280x720, 64 spp"),
+    "cfg4": dict(scene="0052_rough", sampler="pt", w=1280, h=720, spp=256, mv=32, name="configs[3]: regression/0052 parameters (rough dielectric), max depth 32, 1280x720, 256 spp"),
+    "cfg5": dict(scene="0010_pt", sampler="pt", w=3840, h=2160, spp=128, mv=8, name="configs[4]: regression/0010_pt at 3840x2160, 1024 spp over 8 GPUs = 128 spp per GPU"),
+}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
@@ -95,12 +105,13 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from __graft_entry__ import load_package
-    from helpers import SCENE_0010, make_scene
+    from helpers import make_scene
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -116,9 +127,11 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
 
     pkg = load_package()
-    scene = make_scene(SCENE_0010, width=W, height=H, max_verts=MAX_VERTS)
+    cfg = CONFIGS[args.config]
+    scene = make_scene(REPO / "scenes" / cfg["scene"] / "test.nra2", width=cfg["w"], height=cfg["h"], max_verts=cfg["mv"],
+                       sampler=pkg.MI_SAMPLER_PTDL if cfg["sampler"] == "ptdl" else pkg.MI_SAMPLER_PT)
     be = pkg.Backend(scene, device=local_rank)
-    per_frame = SPP * scene.width * scene.height
+    per_frame = cfg["spp"] * scene.width * scene.height
     fb = torch.zeros((scene.height, scene.width, 3), dtype=torch.float32, device=f"cuda:{local_rank}")
     stream = torch.cuda.current_stream()
     be.set_framebuffer(fb.data_ptr())
@@ -173,7 +186,7 @@ def main():
         traffic, traffic_src = profiled_traffic()
         total = args.steps * per_frame * world
         out = {
-            "metric": "Msamples/sec (and ms/frame) at 1280x720, 64 spp, regression/0010_pt",
+            "metric": "Msamples/sec (and ms/frame) at 1280x720, 64 spp, regression/0010_pt" if args.config == "cfg2" else "Msamples/sec (and ms/frame), " + args.config,
             "value": total / elapsed / 1e6,
             "unit": "Msamples/s",
             "n_gpus": world,
@@ -185,14 +198,15 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic: regression/0010_pt scene (6 of 7 shapes, scenes/0010_pt), per-path xorshift128+ seeds",
-            "config": {"workload": "configs[1]: regression/0010_pt test.nra2, pt sampler, 1280x720 (padded 1280x736), 64 spp, max depth 8",
+            "config": {"workload": cfg["name"],
                        "paths_per_step_per_gpu": per_frame, "sharding": f"path-index ranges x{world}, framebuffer all-reduce"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "mi_path_kernel<false,false,true> (RECORD, PTDL, NODES_LDS)", "kernel_ms": kms,
+                         "traffic": traffic if args.config == "cfg2" else None, "traffic_source": traffic_src if args.config == "cfg2" else None,
+                         "kernel": "mi_path_kernel<false,%s,true> (RECORD, PTDL, NODES_LDS)" % ("true" if cfg["sampler"] == "ptdl" else "false"), "kernel_ms": kms,
                          "algorithmic_bytes_per_sample": bytes_per_sample,
                          "work_per_sample": {"rays": dc[0] / paths, "node_visits": dc[1] / paths, "prim_tests": dc[3] / paths, "splats": dc[5] / paths}},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.config == "cfg2":
             out["cpu_baseline"] = cpu_baseline(scene)
         print(json.dumps(out))
     be.close()
