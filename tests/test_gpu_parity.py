@@ -406,3 +406,23 @@ def test_command_line_renderer(tmp_path):
     d = subprocess.run([str(REPO / "corona-13_amd" / "host" / "pfmdiff-mi"), str(pfm), str(tmp_path / "lib.pfm")], capture_output=True, text=True)
     assert d.returncode == 0, d.stdout + d.stderr
     assert float(d.stdout.split("rmse:")[1]) < 1e-3, d.stdout
+
+
+def test_other_frame_seed_and_large_indices():
+    """the per-path generator is keyed by (path index, frame) (src/points.d/xorshift128p.c:53-59): another frame number and
+    path indices beyond 2^32 (a long progressive render) still give the oracle's paths"""
+    scene = make_scene(SCENE_0010, width=640, height=352, max_verts=8, frame=7)
+    be = pkg.Backend(scene)
+    for first in (0, (1 << 33) + 12345):
+        gpu = be.trace_paths(first, 4000)
+        ora = oracle_records(scene, first, 4000)
+        assert np.array_equal(gpu["index"], ora["index"])
+        assert np.abs(gpu["pixel_i"] - ora["pixel_i"]).max() <= 1e-5 and np.abs(gpu["lambda"] - ora["lambda"]).max() <= 1e-5
+        assert (gpu["length"] == ora["length"]).mean() >= 0.999
+        m = (gpu["length"] == ora["length"]) & (ora["length"] > 2)
+        assert (gpu["v"]["prim"][m, 2] == ora["v"]["prim"][m, 2]).mean() >= 0.999
+    # and the frame does change the samples
+    other = pkg.Backend(make_scene(SCENE_0010, width=640, height=352, max_verts=8, frame=8))
+    assert np.abs(other.trace_paths(0, 64)["pixel_i"] - be.trace_paths(0, 64)["pixel_i"]).max() > 1.0
+    other.close()
+    be.close()
