@@ -266,11 +266,20 @@ def ray_dtypes():
 class Backend:
     """Device-resident scene on one MI355X, driven through the C ABI."""
 
-    def __init__(self, scene: Scene, device: int = -1):
+    def __init__(self, scene: Scene, device: int = -1, device_build: bool = False):
+        """device_build: hand the scene over WITHOUT the host-built tree (mi_scene_desc.nodes = NULL); the backend then
+        builds its own 4-wide BVH on the GPU (csrc/mi_build.h)"""
         self.m = mi_lib()
         self._check(self.m.mi_init(device), "mi_init")
         self._ptr = C.c_void_p()
-        self._check(self.m.mi_scene_create(scene.desc_ptr, C.byref(self._ptr)), "mi_scene_create")
+        desc_ptr = scene.desc_ptr
+        if device_build:
+            self._desc = MiSceneDesc()
+            C.memmove(C.byref(self._desc), scene.desc_ptr, C.sizeof(MiSceneDesc))
+            self._desc.nodes = None
+            self._desc.num_nodes = 0
+            desc_ptr = C.pointer(self._desc)
+        self._check(self.m.mi_scene_create(desc_ptr, C.byref(self._ptr)), "mi_scene_create")
         self.scene = scene
 
     def _check(self, err, what):

@@ -5,6 +5,10 @@
  * traces path indices [first, first+count) and splats them into the device framebuffer.
  */
 #include "mi_wavefront.h"
+#include "mi_build.h"
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -294,6 +298,104 @@ static int tree_depth(const mi_scene_desc *h, uint32_t node, int depth)
   return best;
 }
 
+/* ---------------------------------------------------------------------------------------- device build (mi_build.h) */
+static int build_on_device(mi_scene *s, const mi_scene_desc *h, uint32_t *num_nodes, int *stack_need)
+{
+  const uint32_t n = (uint32_t)h->num_prims;
+  BuildBufs b;
+  memset(&b, 0, sizeof(b));
+  b.n = n;
+  std::vector<void *> tmp;
+  auto dev = [&](size_t bytes) -> void * { void *p = nullptr; if(hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr; tmp.push_back(p); return p; };
+  auto release = [&]() { for(void *p : tmp) hipFree(p); };
+#define BALLOC(field, type, count) if(!(b.field = (type *)dev(sizeof(type)*(size_t)(count)))) { release(); return fail(MI_ERR_NOMEM, "device build: out of memory"); }
+  BALLOC(box, float, 8*(size_t)n) BALLOC(key_in, uint32_t, n) BALLOC(key, uint32_t, n) BALLOC(val_in, uint32_t, n) BALLOC(perm, uint32_t, n)
+  BALLOC(left, int, n) BALLOC(right, int, n) BALLOC(parent, int, n) BALLOC(leaf_parent, int, n) BALLOC(first, int, n) BALLOC(last, int, n)
+  BALLOC(ibox, float, 8*(size_t)n) BALLOC(visits, unsigned int, n) BALLOC(qflag, unsigned int, n) BALLOC(qindex, unsigned int, n) BALLOC(stats, unsigned int, 4)
+#undef BALLOC
+  hipError_t e = hipMemset(b.visits, 0, sizeof(unsigned int)*n);
+  if(e == hipSuccess) e = hipMemset(b.stats, 0, sizeof(unsigned int)*4);
+  if(e == hipSuccess) e = hipMemset(b.qflag, 0, sizeof(unsigned int)*n);
+  const int grid = (int)((n + BL_BLOCK - 1)/BL_BLOCK);
+  const float ext[3] = { h->aabb[3]-h->aabb[0], h->aabb[4]-h->aabb[1], h->aabb[5]-h->aabb[2] };
+  const float3 slo = make_float3(h->aabb[0], h->aabb[1], h->aabb[2]);
+  const float3 sinv = make_float3(ext[0] > 0 ? 1.0f/ext[0] : 0.0f, ext[1] > 0 ? 1.0f/ext[1] : 0.0f, ext[2] > 0 ? 1.0f/ext[2] : 0.0f);
+  if(e == hipSuccess)
+  {
+    hipLaunchKernelGGL(bl_boxes, dim3(grid), dim3(BL_BLOCK), 0, 0, b, (const DPrim *)s->d_prims, (const DPrimGeo *)s->d_primgeo, slo, sinv);
+    e = hipGetLastError();
+  }
+  if(e == hipSuccess)
+  { /* sort (Morton code, primitive) pairs */
+    size_t bytes = 0;
+    e = rocprim::radix_sort_pairs(nullptr, bytes, b.key_in, b.key, b.val_in, b.perm, (size_t)n, 0, 30, 0);
+    void *scratch = e == hipSuccess ? dev(bytes) : nullptr;
+    if(e == hipSuccess && !scratch) e = hipErrorOutOfMemory;
+    if(e == hipSuccess) e = rocprim::radix_sort_pairs(scratch, bytes, b.key_in, b.key, b.val_in, b.perm, (size_t)n, 0, 30, 0);
+  }
+  if(e == hipSuccess)
+  {
+    hipLaunchKernelGGL(bl_hierarchy, dim3(grid), dim3(BL_BLOCK), 0, 0, b);
+    hipLaunchKernelGGL(bl_refit, dim3(grid), dim3(BL_BLOCK), 0, 0, b);
+    hipLaunchKernelGGL(bl_mark, dim3(grid), dim3(BL_BLOCK), 0, 0, b);
+    e = hipGetLastError();
+  }
+  if(e == hipSuccess)
+  { /* 4-wide node indices: exclusive scan of the flags */
+    size_t bytes = 0;
+    e = rocprim::exclusive_scan(nullptr, bytes, b.qflag, b.qindex, 0u, (size_t)(n - 1), rocprim::plus<unsigned int>(), 0);
+    void *scratch = e == hipSuccess ? dev(bytes) : nullptr;
+    if(e == hipSuccess && !scratch) e = hipErrorOutOfMemory;
+    if(e == hipSuccess) e = rocprim::exclusive_scan(scratch, bytes, b.qflag, b.qindex, 0u, (size_t)(n - 1), rocprim::plus<unsigned int>(), 0);
+  }
+  uint32_t N = 0;
+  unsigned int stats[4] = {0, 0, 0, 0};
+  if(e == hipSuccess)
+  {
+    unsigned int last_idx = 0, last_flag = 0;
+    e = hipMemcpy(&last_idx, b.qindex + (n - 2), sizeof(unsigned int), hipMemcpyDeviceToHost);
+    if(e == hipSuccess) e = hipMemcpy(&last_flag, b.qflag + (n - 2), sizeof(unsigned int), hipMemcpyDeviceToHost);
+    if(e == hipSuccess) e = hipMemcpy(stats, b.stats, sizeof(stats), hipMemcpyDeviceToHost);
+    N = last_idx + last_flag;
+  }
+  if(e == hipSuccess && (!N || N >= MI_LEAF32)) e = hipErrorInvalidValue;
+  if(e == hipSuccess)
+  {
+    if(hipMalloc(&s->d_nodes, (size_t)MI_NODE_FIELDS*N*16) != hipSuccess || hipMalloc(&s->d_axes, (size_t)N*4) != hipSuccess) e = hipErrorOutOfMemory;
+  }
+  if(e == hipSuccess)
+  {
+    hipLaunchKernelGGL(bl_emit, dim3(grid), dim3(BL_BLOCK), 0, 0, b, (float4 *)s->d_nodes, (uint32_t *)s->d_axes, N);
+    e = hipGetLastError();
+  }
+  if(e == hipSuccess)
+  { /* primitive records into sorted order; emitter indices follow */
+    void *np = nullptr, *ng = nullptr;
+    uint32_t *inv = (uint32_t *)dev(sizeof(uint32_t)*(size_t)n);
+    if(!inv || hipMalloc(&np, sizeof(DPrim)*(size_t)n) != hipSuccess || hipMalloc(&ng, sizeof(DPrimGeo)*(size_t)n) != hipSuccess) e = hipErrorOutOfMemory;
+    if(e == hipSuccess)
+    {
+      hipLaunchKernelGGL(bl_gather<DPrim>, dim3(grid), dim3(BL_BLOCK), 0, 0, (DPrim *)np, (const DPrim *)s->d_prims, (const uint32_t *)b.perm, n);
+      hipLaunchKernelGGL(bl_gather<DPrimGeo>, dim3(grid), dim3(BL_BLOCK), 0, 0, (DPrimGeo *)ng, (const DPrimGeo *)s->d_primgeo, (const uint32_t *)b.perm, n);
+      hipLaunchKernelGGL(bl_invert, dim3(grid), dim3(BL_BLOCK), 0, 0, inv, (const uint32_t *)b.perm, n);
+      if(h->lights.num_prims)
+        hipLaunchKernelGGL(bl_remap, dim3((h->lights.num_prims + BL_BLOCK - 1)/BL_BLOCK), dim3(BL_BLOCK), 0, 0, (uint32_t *)s->d_light_prim, (const uint32_t *)inv,
+                           h->lights.num_prims);
+      e = hipGetLastError();
+      if(e == hipSuccess) e = hipDeviceSynchronize();
+      if(e == hipSuccess) { hipFree(s->d_prims); hipFree(s->d_primgeo); s->d_prims = np; s->d_primgeo = ng; np = ng = nullptr; }
+    }
+    if(np) hipFree(np);
+    if(ng) hipFree(ng);
+  }
+  if(e == hipSuccess) e = hipDeviceSynchronize();
+  release();
+  if(e != hipSuccess) { snprintf(g_err, sizeof(g_err), "device build: %s", hipGetErrorString(e)); fprintf(stderr, "[mi] %s\n", g_err); return MI_ERR_DEVICE; }
+  *num_nodes = N;
+  *stack_need = 3*((int)stats[0] + 1);
+  return MI_OK;
+}
+
 extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
 {
   if(!h || !out) return fail(MI_ERR_ARG, "mi_scene_create: null argument");
@@ -303,13 +405,16 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   if(!h->width || !h->height || (h->width & 31) || (h->height & 31)) return fail(MI_ERR_ARG, "film size must be a non-zero multiple of 32");
   if(h->max_verts < 2 || h->max_verts > 32) return fail(MI_ERR_ARG, "max_verts must be in [2,32]");
   if(h->sampler != MI_SAMPLER_PT && h->sampler != MI_SAMPLER_PTDL) return fail(MI_ERR_ARG, "unknown sampler");
-  if(!h->num_nodes || !h->nodes || !h->cie_xyz) return fail(MI_ERR_ARG, "scene has no nodes / tables");
+  if(!h->cie_xyz) return fail(MI_ERR_ARG, "scene has no tables");
+  const bool device_build = !h->nodes;                      /* no tree handed over: build it on the device (mi_build.h) */
+  if(!device_build && !h->num_nodes) return fail(MI_ERR_ARG, "scene has no nodes");
+  if(device_build && h->num_prims < 2) return fail(MI_ERR_UNSUPPORTED, "the device build needs at least two primitives");
   if(h->num_shapes > 255) return fail(MI_ERR_UNSUPPORTED, "more than 255 shapes");
   if(h->num_prims >= (1u << 26)) return fail(MI_ERR_UNSUPPORTED, "more than 2^26 primitives");
 
-  const int depth = tree_depth(h, 0, 0);
+  const int depth = device_build ? 0 : tree_depth(h, 0, 0);
   if(depth > 200) return fail(MI_ERR_ARG, "BVH deeper than 200 levels or cyclic");
-  const int stack_need = 3*(depth+1);                       /* at most 3 pushes per inner node on the way down */
+  int stack_need = 3*(depth+1);                             /* at most 3 pushes per inner node on the way down */
 
   mi_scene *s = (mi_scene *)calloc(1, sizeof(mi_scene));
   if(!s) return fail(MI_ERR_NOMEM, "out of host memory");
@@ -325,7 +430,7 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   }
 
   /* nodes: SoA of 16-byte lanes, children as 32-bit links */
-  const uint32_t N = h->num_nodes;
+  uint32_t N = device_build ? 0 : h->num_nodes;
   std::vector<float> nodes((size_t)MI_NODE_FIELDS*N*4);
   std::vector<uint32_t> axes(N);
   for(uint32_t n=0;n<N;n++)
@@ -452,8 +557,11 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
 
   int e = MI_OK;
 #define UP(dst, src, cnt) if(!e) e = upload(&s->dst, src, cnt)
-  UP(d_nodes, nodes.data(), nodes.size());
-  UP(d_axes, axes.data(), axes.size());
+  if(!device_build)
+  {
+    UP(d_nodes, nodes.data(), nodes.size());
+    UP(d_axes, axes.data(), axes.size());
+  }
   UP(d_prims, prims.data(), prims.size());
   UP(d_primgeo, pgeo.data(), pgeo.size());
   UP(d_materials, mats.data(), mats.size());
@@ -468,6 +576,11 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   UP(d_counters, (const unsigned long long *)nullptr, (size_t)8*MI_COUNTER_SHARDS);
   UP(d_work, (const unsigned long long *)nullptr, (size_t)MI_WORK_SHARDS);
 #undef UP
+  if(!e && device_build)
+  {
+    e = build_on_device(s, h, &N, &stack_need);
+    d.num_nodes = N;
+  }
   if(!e)
   {
     void *fb = nullptr;

@@ -1,0 +1,245 @@
+/* mi_build.h -- 4-wide BVH construction on the device (replaces the host build
+ * src/accel.d/qbvhmp.c:425-1144 when the caller hands over no tree, mi_scene_desc.nodes == NULL).
+ *
+ * LBVH (Karras 2012) + collapse: primitive boxes -> 30-bit Morton codes of the box centres -> radix sort (rocPRIM) ->
+ * binary radix tree, one thread per internal node -> bottom-up box refit -> every second level of the binary tree
+ * becomes one 4-wide node; binary subtrees of at most MI_BUILD_LEAF primitives become leaves (their primitives are
+ * contiguous in sorted order, so a leaf is "first << 5 | count" like the reference's). The output is written straight
+ * into the traversal's SoA node layout (mi_device.h), with the split axes and the lower/upper child order the ordered
+ * traversal expects (children {0,1} = lower half along axis0, {2,3} = upper half). Primitive records are then gathered
+ * into sorted order.
+ *
+ * The tree differs from the reference builder's (binned SAH sweep), so node-visit counters differ; closest hits do not
+ * depend on the tree (tests/test_gpu_parity.py: same primitive and distance as the oracle on the host-built tree, bit
+ * for bit, apart from exact ties).
+ */
+#ifndef MI_BUILD_H
+#define MI_BUILD_H
+
+#include "mi_kernels.h"
+
+#define MI_BUILD_LEAF 4           /* most primitives in a leaf */
+#define BL_BLOCK 256
+
+struct BuildBufs
+{
+  uint32_t n;                     /* primitives */
+  float *box;                     /* [n][8]: lo xyz, pad, hi xyz, pad -- in ORIGINAL order */
+  uint32_t *key_in, *key, *val_in, *perm;        /* Morton codes and primitive ids, unsorted / sorted */
+  int *left, *right, *parent;     /* binary radix tree: children of internal node i (>= 0: internal, < 0: ~leaf position), parents */
+  int *leaf_parent;               /* parent of sorted leaf i */
+  int *first, *last;              /* sorted range of internal node i */
+  float *ibox;                    /* [n-1][8] boxes of the internal nodes */
+  unsigned int *visits;           /* refit arrival counters */
+  unsigned int *qflag, *qindex;   /* 1 if internal node i becomes a 4-wide node; its index */
+  unsigned int *stats;            /* [0] deepest 4-wide level */
+};
+
+__device__ __forceinline__ uint32_t bl_expand(uint32_t v)
+{ /* 10 bits -> every third bit */
+  v = (v*0x00010001u) & 0xFF0000FFu;
+  v = (v*0x00000101u) & 0x0F00F00Fu;
+  v = (v*0x00000011u) & 0xC30C30C3u;
+  v = (v*0x00000005u) & 0x49249249u;
+  return v;
+}
+
+__global__ __launch_bounds__(BL_BLOCK) void bl_boxes(BuildBufs b, const DPrim *prims, const DPrimGeo *geo, float3 slo, float3 sinv)
+{
+  const uint32_t i = blockIdx.x*BL_BLOCK + threadIdx.x;
+  if(i >= b.n) return;
+  const DPrim &p = prims[i];
+  const float *g = geo[i].f;
+  float lo[3], hi[3];
+  if(p.type >= MI_PRIM_TRI)
+  {
+    for(int k=0;k<3;k++) lo[k] = hi[k] = p.v[0][k];
+    for(uint32_t v=1;v<p.type;v++) for(int k=0;k<3;k++)
+    { const float x = g[26 + 3*(v-1) + k]; lo[k] = fminf(lo[k], x); hi[k] = fmaxf(hi[k], x); }
+  }
+  else if(p.type == MI_PRIM_SPHERE)
+  {
+    const float r = p.v[1][0]*1.0001f + 1e-6f;
+    for(int k=0;k<3;k++) { lo[k] = p.v[0][k] - r; hi[k] = p.v[0][k] + r; }
+  }
+  else
+  { /* line: both end points, padded by the larger radius */
+    const float *f = &p.v[0][0];
+    const float r = fmaxf(f[3], f[4])*1.0001f + 1e-6f;
+    for(int k=0;k<3;k++) { lo[k] = fminf(f[k], g[26+k]) - r; hi[k] = fmaxf(f[k], g[26+k]) + r; }
+  }
+  float *o = b.box + 8*(size_t)i;
+  o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = 0.0f; o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = 0.0f;
+  const float cx = ((lo[0] + hi[0])*0.5f - slo.x)*sinv.x, cy = ((lo[1] + hi[1])*0.5f - slo.y)*sinv.y, cz = ((lo[2] + hi[2])*0.5f - slo.z)*sinv.z;
+  const uint32_t qx = (uint32_t)fminf(fmaxf(cx*1024.0f, 0.0f), 1023.0f), qy = (uint32_t)fminf(fmaxf(cy*1024.0f, 0.0f), 1023.0f),
+                 qz = (uint32_t)fminf(fmaxf(cz*1024.0f, 0.0f), 1023.0f);
+  b.key_in[i] = (bl_expand(qx) << 2) | (bl_expand(qy) << 1) | bl_expand(qz);
+  b.val_in[i] = i;
+}
+
+__device__ __forceinline__ int bl_delta(const uint32_t *key, int n, int i, int j)
+{ /* length of the common prefix of the (key, index) pairs i and j; -1 outside the array */
+  if(j < 0 || j >= n) return -1;
+  const uint32_t a = key[i], c = key[j];
+  if(a != c) return __clz(a ^ c);
+  return 32 + __clz((uint32_t)i ^ (uint32_t)j);
+}
+
+__global__ __launch_bounds__(BL_BLOCK) void bl_hierarchy(BuildBufs b)
+{ /* Karras, "Maximizing parallelism in the construction of BVHs, octrees and k-d trees", one thread per internal node */
+  const int n = (int)b.n;
+  const int i = blockIdx.x*BL_BLOCK + threadIdx.x;
+  if(i >= n - 1) return;
+  const uint32_t *key = b.key;
+  const int d = bl_delta(key, n, i, i+1) - bl_delta(key, n, i, i-1) >= 0 ? 1 : -1;
+  const int dmin = bl_delta(key, n, i, i-d);
+  int lmax = 2;
+  while(bl_delta(key, n, i, i + lmax*d) > dmin) lmax *= 2;
+  int l = 0;
+  for(int t=lmax/2;t>=1;t/=2) if(bl_delta(key, n, i, i + (l+t)*d) > dmin) l += t;
+  const int j = i + l*d;
+  const int dnode = bl_delta(key, n, i, j);
+  int s = 0;
+  for(int t=(l+1)/2;;t=(t+1)/2)
+  {
+    if(bl_delta(key, n, i, i + (s+t)*d) > dnode) s += t;
+    if(t == 1) break;
+  }
+  const int gamma = i + s*d + (d < 0 ? -1 : 0);
+  const int lo = i < j ? i : j, hi = i < j ? j : i;
+  const int lc = lo == gamma ? ~gamma : gamma;
+  const int rc = hi == gamma + 1 ? ~(gamma + 1) : gamma + 1;
+  b.left[i] = lc; b.right[i] = rc; b.first[i] = lo; b.last[i] = hi;
+  if(lc >= 0) b.parent[lc] = i; else b.leaf_parent[~lc] = i;
+  if(rc >= 0) b.parent[rc] = i; else b.leaf_parent[~rc] = i;
+  if(i == 0) b.parent[0] = -1;
+}
+
+__device__ __forceinline__ void bl_load_box(const BuildBufs &b, int child, float *lo, float *hi)
+{
+  /* volatile: internal boxes may have been written by another CU moments ago (bl_refit); bypass the incoherent L1 */
+  const volatile float *p = child >= 0 ? b.ibox + 8*(size_t)child : b.box + 8*(size_t)b.perm[~child];
+  lo[0] = p[0]; lo[1] = p[1]; lo[2] = p[2]; hi[0] = p[4]; hi[1] = p[5]; hi[2] = p[6];
+}
+
+__global__ __launch_bounds__(BL_BLOCK) void bl_refit(BuildBufs b)
+{ /* one thread per leaf walks up; the second thread to arrive at a node forms its box */
+  const int i = blockIdx.x*BL_BLOCK + threadIdx.x;
+  if(i >= (int)b.n) return;
+  int node = b.leaf_parent[i];
+  while(node >= 0)
+  {
+    __threadfence();
+    if(atomicAdd(&b.visits[node], 1u) == 0) return;
+    __threadfence();
+    float l0[3], h0[3], l1[3], h1[3];
+    bl_load_box(b, b.left[node], l0, h0);
+    bl_load_box(b, b.right[node], l1, h1);
+    volatile float *o = b.ibox + 8*(size_t)node;
+    for(int k=0;k<3;k++) { o[k] = fminf(l0[k], l1[k]); o[4+k] = fmaxf(h0[k], h1[k]); }
+    node = b.parent[node];
+  }
+}
+
+__device__ __forceinline__ bool bl_large(const BuildBufs &b, int child)
+{ /* internal node with more primitives than a leaf may hold */
+  return child >= 0 && b.last[child] - b.first[child] + 1 > MI_BUILD_LEAF;
+}
+
+__global__ __launch_bounds__(BL_BLOCK) void bl_mark(BuildBufs b)
+{ /* 4-wide nodes: the large internal nodes at even depth (every second level is folded into its parent) */
+  const int i = blockIdx.x*BL_BLOCK + threadIdx.x;
+  if(i >= (int)b.n - 1) return;
+  int depth = 0;
+  for(int p=b.parent[i];p>=0;p=b.parent[p]) depth++;
+  const bool q = (i == 0) || (bl_large(b, i) && !(depth & 1));
+  b.qflag[i] = q ? 1u : 0u;
+  if(q) atomicMax(&b.stats[0], (unsigned int)(depth/2 + 1));
+}
+
+__device__ __forceinline__ uint32_t bl_link(const BuildBufs &b, int child)
+{
+  if(child < 0) return MI_LEAF32 | ((uint32_t)(~child) << 5) | 1u;
+  if(!bl_large(b, child)) return MI_LEAF32 | ((uint32_t)b.first[child] << 5) | (uint32_t)(b.last[child] - b.first[child] + 1);
+  return b.qindex[child];
+}
+
+__device__ __forceinline__ int bl_split_axis(const float *l0, const float *h0, const float *l1, const float *h1, bool &swap)
+{ /* axis along which the two boxes' centres are farthest apart; swap = the first box is the upper one */
+  float best = -1.0f; int axis = 0; swap = false;
+  for(int k=0;k<3;k++)
+  {
+    const float dlt = (l1[k] + h1[k]) - (l0[k] + h0[k]);
+    if(fabsf(dlt) > best) { best = fabsf(dlt); axis = k; swap = dlt < 0.0f; }
+  }
+  return axis;
+}
+
+__global__ __launch_bounds__(BL_BLOCK) void bl_emit(BuildBufs b, float4 *nodes, uint32_t *axes, uint32_t N)
+{
+  const int i = blockIdx.x*BL_BLOCK + threadIdx.x;
+  if(i >= (int)b.n - 1 || !b.qflag[i]) return;
+  const uint32_t q = b.qindex[i];
+  int half[2] = { b.left[i], b.right[i] };
+  float hl[2][3], hh[2][3];
+  bl_load_box(b, half[0], hl[0], hh[0]);
+  bl_load_box(b, half[1], hl[1], hh[1]);
+  bool sw;
+  const int axis0 = bl_split_axis(hl[0], hh[0], hl[1], hh[1], sw);
+  if(sw) { const int t = half[0]; half[0] = half[1]; half[1] = t; }
+  uint32_t link[4];
+  float lo[4][3], hi[4][3];
+  int axis1[2] = {0, 0};
+  for(int h=0;h<2;h++)
+  {
+    int c0 = half[h], c1 = 0;
+    bool two = false;
+    if(bl_large(b, c0)) { c1 = b.right[c0]; c0 = b.left[c0]; two = true; }
+    if(two)
+    {
+      float l0[3], h0[3], l1[3], h1[3];
+      bl_load_box(b, c0, l0, h0); bl_load_box(b, c1, l1, h1);
+      bool s2;
+      axis1[h] = bl_split_axis(l0, h0, l1, h1, s2);
+      if(s2) { const int t = c0; c0 = c1; c1 = t; }
+      bl_load_box(b, c0, lo[2*h], hi[2*h]); bl_load_box(b, c1, lo[2*h+1], hi[2*h+1]);
+      link[2*h] = bl_link(b, c0); link[2*h+1] = bl_link(b, c1);
+    }
+    else
+    { /* a leaf fills one slot; the other one is empty: inverted box (never entered), empty leaf link */
+      bl_load_box(b, c0, lo[2*h], hi[2*h]);
+      link[2*h] = bl_link(b, c0);
+      for(int k=0;k<3;k++) { lo[2*h+1][k] = FLT_MAX; hi[2*h+1][k] = -FLT_MAX; }
+      link[2*h+1] = MI_LEAF32;
+    }
+  }
+  for(int k=0;k<3;k++)
+  {
+    nodes[(size_t)k*N + q] = make_float4(lo[0][k], lo[1][k], lo[2][k], lo[3][k]);
+    nodes[(size_t)(k+3)*N + q] = make_float4(hi[0][k], hi[1][k], hi[2][k], hi[3][k]);
+  }
+  uint4 lk = make_uint4(link[0], link[1], link[2], link[3]);
+  nodes[(size_t)6*N + q] = *(float4 *)&lk;
+  axes[q] = (uint32_t)axis0 | ((uint32_t)axis1[0] << 2) | ((uint32_t)axis1[1] << 4);
+}
+
+template<class T>
+__global__ __launch_bounds__(BL_BLOCK) void bl_gather(T *out, const T *in, const uint32_t *perm, uint32_t n)
+{
+  const uint32_t i = blockIdx.x*BL_BLOCK + threadIdx.x;
+  if(i < n) out[i] = in[perm[i]];
+}
+
+__global__ __launch_bounds__(BL_BLOCK) void bl_invert(uint32_t *inv, const uint32_t *perm, uint32_t n)
+{
+  const uint32_t i = blockIdx.x*BL_BLOCK + threadIdx.x;
+  if(i < n) inv[perm[i]] = i;
+}
+
+__global__ __launch_bounds__(BL_BLOCK) void bl_remap(uint32_t *idx, const uint32_t *inv, uint32_t n)
+{
+  const uint32_t i = blockIdx.x*BL_BLOCK + threadIdx.x;
+  if(i < n) idx[i] = inv[idx[i]];
+}
+
+#endif
