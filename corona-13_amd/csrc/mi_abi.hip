@@ -305,6 +305,9 @@ static int build_on_device(mi_scene *s, const mi_scene_desc *h, uint32_t *num_no
   BuildBufs b;
   memset(&b, 0, sizeof(b));
   b.n = n;
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  const bool verbose = getenv("CORONA_MI_VERBOSE") != nullptr;
+  if(verbose) { hipEventCreate(&t0); hipEventCreate(&t1); }
   std::vector<void *> tmp;
   auto dev = [&](size_t bytes) -> void * { void *p = nullptr; if(hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr; tmp.push_back(p); return p; };
   auto release = [&]() { for(void *p : tmp) hipFree(p); };
@@ -313,6 +316,7 @@ static int build_on_device(mi_scene *s, const mi_scene_desc *h, uint32_t *num_no
   BALLOC(left, int, n) BALLOC(right, int, n) BALLOC(parent, int, n) BALLOC(leaf_parent, int, n) BALLOC(first, int, n) BALLOC(last, int, n)
   BALLOC(ibox, float, 8*(size_t)n) BALLOC(visits, unsigned int, n) BALLOC(qflag, unsigned int, n) BALLOC(qindex, unsigned int, n) BALLOC(stats, unsigned int, 4)
 #undef BALLOC
+  if(verbose) hipEventRecord(t0, 0);
   hipError_t e = hipMemset(b.visits, 0, sizeof(unsigned int)*n);
   if(e == hipSuccess) e = hipMemset(b.stats, 0, sizeof(unsigned int)*4);
   if(e == hipSuccess) e = hipMemset(b.qflag, 0, sizeof(unsigned int)*n);
@@ -388,7 +392,15 @@ static int build_on_device(mi_scene *s, const mi_scene_desc *h, uint32_t *num_no
     if(np) hipFree(np);
     if(ng) hipFree(ng);
   }
+  if(verbose) hipEventRecord(t1, 0);
   if(e == hipSuccess) e = hipDeviceSynchronize();
+  if(verbose)
+  {
+    float ms = 0.0f;
+    if(e == hipSuccess && hipEventElapsedTime(&ms, t0, t1) == hipSuccess)
+      fprintf(stderr, "[mi] device build: %u primitives -> %u 4-wide nodes, %u levels, %.3f ms on the device\n", n, N, stats[0], ms);
+    hipEventDestroy(t0); hipEventDestroy(t1);
+  }
   release();
   if(e != hipSuccess) { snprintf(g_err, sizeof(g_err), "device build: %s", hipGetErrorString(e)); fprintf(stderr, "[mi] %s\n", g_err); return MI_ERR_DEVICE; }
   *num_nodes = N;

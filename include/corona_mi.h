@@ -153,7 +153,9 @@ typedef struct mi_scene_desc
   uint64_t frame;             /* rt.anim_frame, seeds the per-path generator      */
 
   uint32_t         num_nodes;
-  const mi_node   *nodes;     /* node 0 = root                                    */
+  const mi_node   *nodes;     /* node 0 = root. NULL (with num_nodes 0): no tree is handed over and the backend builds its own
+                                 4-wide BVH on the device (replaces accel_build, src/accel.d/qbvhmp.c:425-1144); primid may
+                                 then be in any order, hits report the same primids, traversal counters differ */
   float            aabb[6];   /* scene box (accel_aabb)                           */
   uint64_t         num_prims;
   const mi_primid *primid;    /* in builder order (leaves index into this)        */
