@@ -2,7 +2,10 @@
  * (src/main.c:415-437, usage 420-428; src/view.c:275-292; src/display.d/null.c:50-75):
  *
  *   corona-mi <scene.nra2> [-s spp] [-w width] [-h height] [-x postfix] [--frame n] [--batch n]
- *             [--sampler pt|ptdl] [--max-verts n] [--rgb2spec lut] [--iso v] [-c cam]
+ *             [--sampler pt|ptdl] [--max-verts n] [--rgb2spec lut] [--iso v] [-c cam] [--info]
+ *
+ * --info validates the scene files (.nra2, .geo, .cam) on the host and prints what the backend would get, without
+ * touching a GPU (validators for the on-disk formats).
  *
  * Progression loop of view_render() (src/view.c:630-695) with the pthread pool dispatch (643-645)
  * replaced by one mi_render() per batch; writes <basename><postfix>_fb00.pfm like view_write_images
@@ -25,7 +28,7 @@ int main(int argc, char *argv[])
   if(argc < 2)
   {
     fprintf(stderr, "usage: %s <scene.nra2> [-s spp] [-w w] [-h h] [-x postfix] [--frame n] [--batch n]\n"
-                    "          [--sampler pt|ptdl] [--max-verts n] [--rgb2spec ergb2spec.coeff] [--iso v] [-c file.cam]\n", argv[0]);
+                    "          [--sampler pt|ptdl] [--max-verts n] [--rgb2spec ergb2spec.coeff] [--iso v] [-c file.cam] [--info]\n", argv[0]);
     return 1;
   }
   ch_options opt;
@@ -33,6 +36,7 @@ int main(int argc, char *argv[])
   opt.verbose = 1;
   uint64_t spp = 10, batch = 1;              /* display_open default: 10 progressions */
   const char *postfix = "render";
+  int info_only = 0;
   for(int i=2;i<argc;i++)
   {
     if(!strcmp(argv[i], "-s") && i+1 < argc) spp = strtoull(argv[++i], 0, 10);
@@ -46,12 +50,38 @@ int main(int argc, char *argv[])
     else if(!strcmp(argv[i], "--iso") && i+1 < argc) opt.iso = atof(argv[++i]);
     else if(!strcmp(argv[i], "--max-verts") && i+1 < argc) opt.max_verts = atoi(argv[++i]);
     else if(!strcmp(argv[i], "--rgb2spec") && i+1 < argc) opt.rgb2spec_lut = argv[++i];
+    else if(!strcmp(argv[i], "--info")) info_only = 1;
     else if(!strcmp(argv[i], "--sampler") && i+1 < argc) opt.sampler = !strcmp(argv[++i], "ptdl") ? MI_SAMPLER_PTDL : MI_SAMPLER_PT;
   }
   if(!batch) batch = 1;
   ch_scene *scene = 0;
   if(ch_scene_load(argv[1], &opt, &scene)) return 2;
   const mi_scene_desc *d = ch_scene_desc(scene);
+  if(info_only)
+  {
+    uint64_t kinds[5] = {0, 0, 0, 0, 0}, leaves = 0, leaf_prims = 0;
+    uint32_t leaf_max = 0;
+    for(uint64_t i=0;i<d->num_prims;i++) kinds[MI_PRIMID_VCNT(d->primid[i]) <= 4 ? MI_PRIMID_VCNT(d->primid[i]) : 0]++;
+    for(uint32_t n=0;n<d->num_nodes;n++) for(int c=0;c<4;c++) if(d->nodes[n].child[c] & MI_NODE_LEAF)
+    {
+      const uint32_t cnt = (uint32_t)(d->nodes[n].child[c] & 31);
+      if(cnt) { leaves++; leaf_prims += cnt; if(cnt > leaf_max) leaf_max = cnt; }
+    }
+    printf("scene    : %s\n", argv[1]);
+    printf("film     : %ux%u (padded to multiples of 32), max path vertices %u, sampler %s, frame %lu\n", d->width, d->height, d->max_verts,
+        d->sampler == MI_SAMPLER_PTDL ? "ptdl" : "pt", (unsigned long)d->frame);
+    printf("shapes   : %u, materials %u\n", d->num_shapes, d->num_materials);
+    printf("prims    : %lu (spheres %lu, lines %lu, triangles %lu, quads %lu)\n", (unsigned long)d->num_prims, (unsigned long)kinds[1],
+        (unsigned long)kinds[2], (unsigned long)kinds[3], (unsigned long)kinds[4]);
+    printf("accel    : qbvh, %u nodes, %lu leaves, %.2f prims per leaf (max %u)\n", d->num_nodes, (unsigned long)leaves,
+        leaves ? (double)leaf_prims/leaves : 0.0, leaf_max);
+    printf("aabb     : (%.3f, %.3f)x(%.3f, %.3f)x(%.3f, %.3f) dm^3\n", d->aabb[0], d->aabb[3], d->aabb[1], d->aabb[4], d->aabb[2], d->aabb[5]);
+    printf("emitters : %u primitives, p_geo %.3f\n", d->lights.num_prims, d->lights.p_geo);
+    printf("camera   : pos (%.3f %.3f %.3f) focus %.3f focal length %.4f f/%.2f film %.4fx%.4f\n", d->cam.pos[0], d->cam.pos[1], d->cam.pos[2],
+        d->cam.focus, d->cam.focal_length, d->cam.f_stop, d->cam.film_width, d->cam.film_height);
+    ch_scene_free(scene);
+    return 0;
+  }
   mi_scene *dev = 0;
   if(mi_init(-1) || mi_scene_create(d, &dev)) { fprintf(stderr, "[main] %s\n", mi_last_error()); return 2; }
 

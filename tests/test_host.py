@@ -174,3 +174,22 @@ def test_pfmdiff_tool_matches_reference_tool(tmp_path):
         rout = subprocess.run([str(ref), str(tmp_path / "a.pfm"), str(tmp_path / "b.pfm"), str(tmp_path / "d.pfm")], capture_output=True, text=True).stdout
         if "rmse:" in rout:
             assert abs(float(rout.split("rmse:")[1].split()[0]) - rmse) < 1e-5 * want
+
+
+def test_cli_info_validates_scene_files(tmp_path):
+    """corona-mi --info: the host loaders as a validator of .nra2 / .geo / .cam (no GPU involved)"""
+    import shutil
+    import subprocess
+    cli = REPO / "corona-13_amd" / "host" / "corona-mi"
+    out = subprocess.run([str(cli), str(SCENE_0010), "-w", "1280", "-h", "720", "--max-verts", "8", "--info"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "film     : 1280x736" in out.stdout and "4108 (spheres 1, lines 2, triangles 0, quads 4105)" in out.stdout
+    assert "qbvh, 428 nodes, 1283 leaves" in out.stdout and "(max 6)" in out.stdout and "emitters : 3 primitives" in out.stdout
+    # a truncated geometry file is reported, the shape is skipped like the reference does (src/prims.c:783-788)
+    shutil.copytree(REPO / "scenes", tmp_path / "scenes")
+    geo = tmp_path / "scenes" / "geo" / "sphere.geo"
+    geo.write_bytes(geo.read_bytes()[:40])
+    bad = subprocess.run([str(cli), str(tmp_path / "scenes" / "0010_pt" / "test.nra2"), "--info"], capture_output=True, text=True)
+    assert "sphere" in bad.stderr and ("spheres 0" in bad.stdout or bad.returncode != 0)
+    # a missing scene file is an error
+    assert subprocess.run([str(cli), str(tmp_path / "nothing.nra2"), "--info"], capture_output=True, text=True).returncode != 0
