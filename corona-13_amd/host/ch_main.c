@@ -2,7 +2,7 @@
  * (src/main.c:415-437, usage 420-428; src/view.c:275-292; src/display.d/null.c:50-75):
  *
  *   corona-mi <scene.nra2> [-s spp] [-w width] [-h height] [-x postfix] [--frame n] [--batch n]
- *             [--sampler pt|ptdl] [--max-verts n] [--rgb2spec lut] [--iso v] [-c cam] [--info]
+ *             [--sampler pt|ptdl] [--max-verts n] [--rgb2spec lut]  [--iso v] [-c cam] [--info] [--device-build]
  *
  * --info validates the scene files (.nra2, .geo, .cam) on the host and prints what the backend would get, without
  * touching a GPU (validators for the on-disk formats).
@@ -36,7 +36,7 @@ int main(int argc, char *argv[])
   opt.verbose = 1;
   uint64_t spp = 10, batch = 1;              /* display_open default: 10 progressions */
   const char *postfix = "render";
-  int info_only = 0;
+  int info_only = 0, device_build = 0;
   for(int i=2;i<argc;i++)
   {
     if(!strcmp(argv[i], "-s") && i+1 < argc) spp = strtoull(argv[++i], 0, 10);
@@ -51,6 +51,7 @@ int main(int argc, char *argv[])
     else if(!strcmp(argv[i], "--max-verts") && i+1 < argc) opt.max_verts = atoi(argv[++i]);
     else if(!strcmp(argv[i], "--rgb2spec") && i+1 < argc) opt.rgb2spec_lut = argv[++i];
     else if(!strcmp(argv[i], "--info")) info_only = 1;
+    else if(!strcmp(argv[i], "--device-build")) device_build = 1;     /* hand the scene over without the host-built tree */
     else if(!strcmp(argv[i], "--sampler") && i+1 < argc) opt.sampler = !strcmp(argv[++i], "ptdl") ? MI_SAMPLER_PTDL : MI_SAMPLER_PT;
   }
   if(!batch) batch = 1;
@@ -83,6 +84,8 @@ int main(int argc, char *argv[])
     return 0;
   }
   mi_scene *dev = 0;
+  mi_scene_desc without_tree = *d;
+  if(device_build) { without_tree.nodes = 0; without_tree.num_nodes = 0; d = &without_tree; }
   if(mi_init(-1) || mi_scene_create(d, &dev)) { fprintf(stderr, "[main] %s\n", mi_last_error()); return 2; }
 
   const uint64_t per = (uint64_t)d->width*d->height;

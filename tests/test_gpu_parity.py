@@ -406,6 +406,13 @@ def test_command_line_renderer(tmp_path):
     d = subprocess.run([str(REPO / "corona-13_amd" / "host" / "pfmdiff-mi"), str(pfm), str(tmp_path / "lib.pfm")], capture_output=True, text=True)
     assert d.returncode == 0, d.stdout + d.stderr
     assert float(d.stdout.split("rmse:")[1]) < 1e-3, d.stdout
+    # --device-build: same image from the tree built on the GPU
+    out = subprocess.run([str(cli), str(scene_file), "-s", "24", "--batch", "24", "-w", "256", "-h", "256", "--max-verts", "8", "-x", "_dev", "--device-build"],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    d = subprocess.run([str(REPO / "corona-13_amd" / "host" / "pfmdiff-mi"), str(tmp_path / "scenes" / "0010_pt" / "test_dev_fb00.pfm"), str(tmp_path / "lib.pfm")],
+                       capture_output=True, text=True)
+    assert d.returncode == 0 and float(d.stdout.split("rmse:")[1]) < 1e-3, d.stdout + d.stderr
 
 
 def test_other_frame_seed_and_large_indices():
