@@ -483,3 +483,28 @@ def test_device_built_tree_renders_the_same_paths(sampler):
     cnt = [b - a for a, b in zip(c0, be.counters())]
     assert abs(cnt[0] - ocnt[0]) <= 1e-4 * ocnt[0] and cnt[4] == npx     # same rays; node / primitive counts belong to the other tree
     be.close()
+
+
+def test_device_build_tiny_scene(tmp_path):
+    """three quads (the emitter alone): the smallest trees the device build produces (two internal binary nodes)"""
+    import shutil
+    from helpers import REPO
+    shutil.copytree(REPO / "scenes", tmp_path / "scenes")
+    nra = tmp_path / "scenes" / "0010_pt" / "test.nra2"
+    lines = nra.read_text().splitlines()
+    k = lines.index("6")                                   # the shape count line
+    nra.write_text("\n".join(lines[:k] + ["1", "5 ../geo/emitter"]) + "\n")
+    scene = make_scene(nra, inject=False, width=64, height=64, max_verts=4)
+    assert scene.desc.num_prims == 3
+    host, devb = pkg.Backend(scene), pkg.Backend(scene, device_build=True)
+    rng = np.random.default_rng(2)
+    lo, hi = np.array(scene.desc.aabb[:3]), np.array(scene.desc.aabb[3:6])
+    n = 20000
+    target = rng.uniform(lo, hi, size=(n, 3))
+    pos = (target + rng.normal(size=(n, 3)) * 3).astype(np.float32)
+    d = target - pos
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    a, b = host.intersect(pos, d), devb.intersect(pos, d)
+    assert (a["primid"] != 0xffffffffffffffff).mean() > 0.05
+    assert np.array_equal(a["primid"], b["primid"]) and np.array_equal(a["dist"].view(np.uint32), b["dist"].view(np.uint32))
+    host.close(); devb.close()
