@@ -1,0 +1,32 @@
+"""development helper (GPU box): GPU path records against the oracle on millions of paths, in chunks
+(python3 tools/parity_soak.py [paths per configuration])"""
+import sys, time
+sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parent.parent / "tests"))
+import numpy as np
+from helpers import *
+pkg = load_pkg()
+total = int(sys.argv[1]) if len(sys.argv) > 1 else 2000000
+chunk = 250000
+for name, path, sampler, mv in (("cfg2 pt mv8", SCENE_0010, pkg.MI_SAMPLER_PT, 8), ("cfg3 ptdl mv8", SCENE_0010, pkg.MI_SAMPLER_PTDL, 8),
+                                ("cfg4 rough mv32", SCENE_ROUGH, pkg.MI_SAMPLER_PT, 32), ("metal ptdl mv8", SCENE_METAL, pkg.MI_SAMPLER_PTDL, 8)):
+    scene = make_scene(path, width=1280, height=720, max_verts=mv, sampler=sampler)
+    be = pkg.Backend(scene)
+    n = same_len = same_prims = same_splats = 0
+    worst_thr = 0.0
+    t0 = time.time()
+    for first in range(777, 777 + total, chunk):
+        g = be.trace_paths(first, chunk)
+        o = oracle_records(scene, first, chunk)
+        sl = g["length"] == o["length"]
+        k = np.arange(8)[None, :]
+        valid = k < np.minimum(o["length"], 8)[:, None]
+        sp = sl & ((g["v"]["prim"] == o["v"]["prim"]) | ~valid).all(axis=1)
+        ss = sp & (g["num_splats"] == o["num_splats"])
+        n += chunk; same_len += int(sl.sum()); same_prims += int(sp.sum()); same_splats += int(ss.sum())
+        m = sp[:, None] & valid & (k >= 1)
+        thr_g, thr_o = g["v"]["throughput"][m], o["v"]["throughput"][m]
+        rel = np.abs(thr_g - thr_o) / np.maximum(1e-20, np.maximum(np.abs(thr_g), np.abs(thr_o)))
+        worst_thr = max(worst_thr, float(np.quantile(rel, 0.9999)) if len(rel) else 0.0)
+    be.close()
+    print("%-16s %d paths: same length %d (%.5f %%), same primitive sequence %d (%.5f %%), and same splat count %d; 99.99th pct throughput deviation %.2e; %.0f s" %
+          (name, n, same_len, 100.0 * same_len / n, same_prims, 100.0 * same_prims / n, same_splats, worst_thr, time.time() - t0), flush=True)
