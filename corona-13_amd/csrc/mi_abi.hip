@@ -307,16 +307,16 @@ static int build_on_device(mi_scene *s, const mi_scene_desc *h, uint32_t *num_no
   b.n = n;
   hipEvent_t t0 = nullptr, t1 = nullptr;
   const bool verbose = getenv("CORONA_MI_VERBOSE") != nullptr;
-  if(verbose) { hipEventCreate(&t0); hipEventCreate(&t1); }
+  if(verbose) { (void)hipEventCreate(&t0); (void)hipEventCreate(&t1); }
   std::vector<void *> tmp;
   auto dev = [&](size_t bytes) -> void * { void *p = nullptr; if(hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr; tmp.push_back(p); return p; };
-  auto release = [&]() { for(void *p : tmp) hipFree(p); };
+  auto release = [&]() { for(void *p : tmp) (void)hipFree(p); };
 #define BALLOC(field, type, count) if(!(b.field = (type *)dev(sizeof(type)*(size_t)(count)))) { release(); return fail(MI_ERR_NOMEM, "device build: out of memory"); }
   BALLOC(box, float, 8*(size_t)n) BALLOC(key_in, uint32_t, n) BALLOC(key, uint32_t, n) BALLOC(val_in, uint32_t, n) BALLOC(perm, uint32_t, n)
   BALLOC(left, int, n) BALLOC(right, int, n) BALLOC(parent, int, n) BALLOC(leaf_parent, int, n) BALLOC(first, int, n) BALLOC(last, int, n)
   BALLOC(ibox, float, 8*(size_t)n) BALLOC(visits, unsigned int, n) BALLOC(qflag, unsigned int, n) BALLOC(qindex, unsigned int, n) BALLOC(stats, unsigned int, 4)
 #undef BALLOC
-  if(verbose) hipEventRecord(t0, 0);
+  if(verbose) (void)hipEventRecord(t0, 0);
   hipError_t e = hipMemset(b.visits, 0, sizeof(unsigned int)*n);
   if(e == hipSuccess) e = hipMemset(b.stats, 0, sizeof(unsigned int)*4);
   if(e == hipSuccess) e = hipMemset(b.qflag, 0, sizeof(unsigned int)*n);
@@ -387,19 +387,19 @@ static int build_on_device(mi_scene *s, const mi_scene_desc *h, uint32_t *num_no
                            h->lights.num_prims);
       e = hipGetLastError();
       if(e == hipSuccess) e = hipDeviceSynchronize();
-      if(e == hipSuccess) { hipFree(s->d_prims); hipFree(s->d_primgeo); s->d_prims = np; s->d_primgeo = ng; np = ng = nullptr; }
+      if(e == hipSuccess) { (void)hipFree(s->d_prims); (void)hipFree(s->d_primgeo); s->d_prims = np; s->d_primgeo = ng; np = ng = nullptr; }
     }
-    if(np) hipFree(np);
-    if(ng) hipFree(ng);
+    if(np) (void)hipFree(np);
+    if(ng) (void)hipFree(ng);
   }
-  if(verbose) hipEventRecord(t1, 0);
+  if(verbose) (void)hipEventRecord(t1, 0);
   if(e == hipSuccess) e = hipDeviceSynchronize();
   if(verbose)
   {
     float ms = 0.0f;
     if(e == hipSuccess && hipEventElapsedTime(&ms, t0, t1) == hipSuccess)
       fprintf(stderr, "[mi] device build: %u primitives -> %u 4-wide nodes, %u levels, %.3f ms on the device\n", n, N, stats[0], ms);
-    hipEventDestroy(t0); hipEventDestroy(t1);
+    (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
   }
   release();
   if(e != hipSuccess) { snprintf(g_err, sizeof(g_err), "device build: %s", hipGetErrorString(e)); fprintf(stderr, "[mi] %s\n", g_err); return MI_ERR_DEVICE; }
@@ -597,7 +597,8 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   {
     void *fb = nullptr;
     if(hipMalloc(&fb, sizeof(float)*3*(size_t)h->width*h->height) != hipSuccess) e = fail(MI_ERR_NOMEM, "cannot allocate the device framebuffer");
-    else { s->d_fb_own = (float *)fb; hipMemset(fb, 0, sizeof(float)*3*(size_t)h->width*h->height); }
+    else if(hipMemset(fb, 0, sizeof(float)*3*(size_t)h->width*h->height) != hipSuccess) { (void)hipFree(fb); e = fail(MI_ERR_DEVICE, "cannot clear the device framebuffer"); }
+    else s->d_fb_own = (float *)fb;
   }
   if(e) { mi_scene_destroy(s); return e; }
   s->d_fb = s->d_fb_own;
@@ -860,7 +861,7 @@ extern "C" int mi_trace_paths(mi_scene *s, uint64_t first_index, uint64_t count,
   }
   if(e == hipSuccess) e = hipStreamSynchronize(s->stream);
   if(e == hipSuccess) e = hipMemcpy(host_out, d_rec, count*sizeof(mi_path_record), hipMemcpyDeviceToHost);
-  hipFree(d_rec);
+  (void)hipFree(d_rec);
   if(e != hipSuccess) { snprintf(g_err, sizeof(g_err), "mi_trace_paths: %s", hipGetErrorString(e)); fprintf(stderr, "[mi] %s\n", g_err); return MI_ERR_DEVICE; }
   return MI_OK;
 }
@@ -886,8 +887,8 @@ extern "C" int mi_intersect(mi_scene *s, const mi_ray *rays, uint64_t n, mi_hit 
   }
   if(e == hipSuccess) e = hipStreamSynchronize(s->stream);
   if(e == hipSuccess) e = hipMemcpy(host_out, d_hits, n*sizeof(mi_hit), hipMemcpyDeviceToHost);
-  if(d_rays) hipFree(d_rays);
-  if(d_hits) hipFree(d_hits);
+  if(d_rays) (void)hipFree(d_rays);
+  if(d_hits) (void)hipFree(d_hits);
   if(e != hipSuccess) { snprintf(g_err, sizeof(g_err), "mi_intersect: %s", hipGetErrorString(e)); fprintf(stderr, "[mi] %s\n", g_err); return MI_ERR_DEVICE; }
   return MI_OK;
 }
@@ -911,16 +912,16 @@ extern "C" int mi_last_kernel_launches(mi_scene *s, uint64_t *launches)
 extern "C" void mi_scene_destroy(mi_scene *s)
 {
   if(!s) return;
-  if(s->d_pool) hipFree(s->d_pool);
-  if(s->d_wfcnt) hipFree(s->d_wfcnt);
-  if(s->h_live) hipHostFree(s->h_live);
-  for(int k=0;k<8;k++) if(s->ev_live[k]) hipEventDestroy(s->ev_live[k]);
+  if(s->d_pool) (void)hipFree(s->d_pool);
+  if(s->d_wfcnt) (void)hipFree(s->d_wfcnt);
+  if(s->h_live) (void)hipHostFree(s->h_live);
+  for(int k=0;k<8;k++) if(s->ev_live[k]) (void)hipEventDestroy(s->ev_live[k]);
   void *bufs[] = { s->d_nodes, s->d_axes, s->d_prims, s->d_primgeo, s->d_materials, s->d_light_prim, s->d_light_cdf, s->d_light_L,
                    s->d_cie, s->d_checker, s->d_metal, s->d_counters, s->d_work, s->d_shape_material, s->d_shape_L, s->d_overflow, s->d_fb_own };
-  for(void *b : bufs) if(b) hipFree(b);
-  if(s->stream_own) hipStreamDestroy(s->stream_own);
-  if(s->ev0) hipEventDestroy(s->ev0);
-  if(s->ev1) hipEventDestroy(s->ev1);
+  for(void *b : bufs) if(b) (void)hipFree(b);
+  if(s->stream_own) (void)hipStreamDestroy(s->stream_own);
+  if(s->ev0) (void)hipEventDestroy(s->ev0);
+  if(s->ev1) (void)hipEventDestroy(s->ev1);
   free(s);
 }
 
