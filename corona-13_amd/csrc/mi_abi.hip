@@ -314,12 +314,10 @@ static int build_on_device(mi_scene *s, const mi_scene_desc *h, uint32_t *num_no
 #define BALLOC(field, type, count) if(!(b.field = (type *)dev(sizeof(type)*(size_t)(count)))) { release(); return fail(MI_ERR_NOMEM, "device build: out of memory"); }
   BALLOC(box, float, 8*(size_t)n) BALLOC(key_in, uint32_t, n) BALLOC(key, uint32_t, n) BALLOC(val_in, uint32_t, n) BALLOC(perm, uint32_t, n)
   BALLOC(left, int, n) BALLOC(right, int, n) BALLOC(parent, int, n) BALLOC(leaf_parent, int, n) BALLOC(first, int, n) BALLOC(last, int, n)
-  BALLOC(ibox, float, 8*(size_t)n) BALLOC(visits, unsigned int, n) BALLOC(qflag, unsigned int, n) BALLOC(qindex, unsigned int, n) BALLOC(stats, unsigned int, 4)
+  BALLOC(ibox, float, 8*(size_t)n) BALLOC(visits, unsigned int, n)
 #undef BALLOC
   if(verbose) (void)hipEventRecord(t0, 0);
   hipError_t e = hipMemset(b.visits, 0, sizeof(unsigned int)*n);
-  if(e == hipSuccess) e = hipMemset(b.stats, 0, sizeof(unsigned int)*4);
-  if(e == hipSuccess) e = hipMemset(b.qflag, 0, sizeof(unsigned int)*n);
   const int grid = (int)((n + BL_BLOCK - 1)/BL_BLOCK);
   const float ext[3] = { h->aabb[3]-h->aabb[0], h->aabb[4]-h->aabb[1], h->aabb[5]-h->aabb[2] };
   const float3 slo = make_float3(h->aabb[0], h->aabb[1], h->aabb[2]);
@@ -341,36 +339,46 @@ static int build_on_device(mi_scene *s, const mi_scene_desc *h, uint32_t *num_no
   {
     hipLaunchKernelGGL(bl_hierarchy, dim3(grid), dim3(BL_BLOCK), 0, 0, b);
     hipLaunchKernelGGL(bl_refit, dim3(grid), dim3(BL_BLOCK), 0, 0, b);
-    hipLaunchKernelGGL(bl_mark, dim3(grid), dim3(BL_BLOCK), 0, 0, b);
     e = hipGetLastError();
-  }
-  if(e == hipSuccess)
-  { /* 4-wide node indices: exclusive scan of the flags */
-    size_t bytes = 0;
-    e = rocprim::exclusive_scan(nullptr, bytes, b.qflag, b.qindex, 0u, (size_t)(n - 1), rocprim::plus<unsigned int>(), 0);
-    void *scratch = e == hipSuccess ? dev(bytes) : nullptr;
-    if(e == hipSuccess && !scratch) e = hipErrorOutOfMemory;
-    if(e == hipSuccess) e = rocprim::exclusive_scan(scratch, bytes, b.qflag, b.qindex, 0u, (size_t)(n - 1), rocprim::plus<unsigned int>(), 0);
   }
   uint32_t N = 0;
   unsigned int stats[4] = {0, 0, 0, 0};
   if(e == hipSuccess)
-  {
-    unsigned int last_idx = 0, last_flag = 0;
-    e = hipMemcpy(&last_idx, b.qindex + (n - 2), sizeof(unsigned int), hipMemcpyDeviceToHost);
-    if(e == hipSuccess) e = hipMemcpy(&last_flag, b.qflag + (n - 2), sizeof(unsigned int), hipMemcpyDeviceToHost);
-    if(e == hipSuccess) e = hipMemcpy(stats, b.stats, sizeof(stats), hipMemcpyDeviceToHost);
-    N = last_idx + last_flag;
-  }
-  if(e == hipSuccess && (!N || N >= MI_LEAF32)) e = hipErrorInvalidValue;
-  if(e == hipSuccess)
-  {
-    if(hipMalloc(&s->d_nodes, (size_t)MI_NODE_FIELDS*N*16) != hipSuccess || hipMalloc(&s->d_axes, (size_t)N*4) != hipSuccess) e = hipErrorOutOfMemory;
-  }
-  if(e == hipSuccess)
-  {
-    hipLaunchKernelGGL(bl_emit, dim3(grid), dim3(BL_BLOCK), 0, 0, b, (float4 *)s->d_nodes, (uint32_t *)s->d_axes, N);
-    e = hipGetLastError();
+  { /* top-down collapse, one launch per level of the 4-wide tree */
+    const uint32_t cap = n - 1;
+    float4 *tnodes = (float4 *)dev((size_t)MI_NODE_FIELDS*cap*16);
+    uint32_t *taxes = (uint32_t *)dev((size_t)cap*4);
+    int *la = (int *)dev(sizeof(int)*(size_t)n), *lb = (int *)dev(sizeof(int)*(size_t)n);
+    unsigned int *qa = (unsigned int *)dev(sizeof(int)*(size_t)n), *qb = (unsigned int *)dev(sizeof(int)*(size_t)n);
+    unsigned int *cnt = (unsigned int *)dev(8);
+    if(!tnodes || !taxes || !la || !lb || !qa || !qb || !cnt) e = hipErrorOutOfMemory;
+    unsigned int hc[2] = {1, 0};
+    const int zero = 0;
+    if(e == hipSuccess) e = hipMemcpy(la, &zero, 4, hipMemcpyHostToDevice);
+    if(e == hipSuccess) e = hipMemcpy(qa, &zero, 4, hipMemcpyHostToDevice);
+    unsigned int n_in = 1, levels = 0;
+    while(e == hipSuccess && n_in)
+    {
+      hc[1] = 0;
+      e = hipMemcpy(cnt, hc, 8, hipMemcpyHostToDevice);
+      if(e != hipSuccess) break;
+      CollapseLists L = { la, qa, lb, qb, cnt, n_in };
+      hipLaunchKernelGGL(bl_collapse, dim3((n_in + BL_BLOCK - 1)/BL_BLOCK), dim3(BL_BLOCK), 0, 0, b, L, tnodes, taxes, cap);
+      e = hipGetLastError();
+      if(e == hipSuccess) e = hipMemcpy(hc, cnt, 8, hipMemcpyDeviceToHost);
+      n_in = hc[1];
+      std::swap(la, lb); std::swap(qa, qb);
+      levels++;
+    }
+    N = hc[0]; stats[0] = levels;
+    if(e == hipSuccess && (!N || N >= MI_LEAF32 || N > cap)) e = hipErrorInvalidValue;
+    if(e == hipSuccess && (hipMalloc(&s->d_nodes, (size_t)MI_NODE_FIELDS*N*16) != hipSuccess || hipMalloc(&s->d_axes, (size_t)N*4) != hipSuccess)) e = hipErrorOutOfMemory;
+    if(e == hipSuccess)
+    {
+      hipLaunchKernelGGL(bl_repack, dim3((MI_NODE_FIELDS*N + BL_BLOCK - 1)/BL_BLOCK), dim3(BL_BLOCK), 0, 0, (float4 *)s->d_nodes, (const float4 *)tnodes, N, cap);
+      e = hipGetLastError();
+      if(e == hipSuccess) e = hipMemcpy(s->d_axes, taxes, (size_t)N*4, hipMemcpyDeviceToDevice);
+    }
   }
   if(e == hipSuccess)
   { /* primitive records into sorted order; emitter indices follow */
