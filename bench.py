@@ -106,6 +106,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--tree", default="reference", choices=["reference", "device"],
+                    help="reference: the QBVH the reference's builder makes, handed over through the ABI (default, the drop-in contract); "
+                         "device: no tree handed over, the backend builds its own (csrc/mi_build.h)")
     args = ap.parse_args()
 
     import torch
@@ -142,7 +145,7 @@ def main():
     cfg = CONFIGS[args.config]
     scene = make_scene(REPO / "scenes" / cfg["scene"] / "test.nra2", width=cfg["w"], height=cfg["h"], max_verts=cfg["mv"],
                        sampler=pkg.MI_SAMPLER_PTDL if cfg["sampler"] == "ptdl" else pkg.MI_SAMPLER_PT)
-    be = pkg.Backend(scene, device=local_rank)
+    be = pkg.Backend(scene, device=local_rank, device_build=args.tree == "device")
     per_frame = cfg["spp"] * scene.width * scene.height
     fb = torch.zeros((scene.height, scene.width, 3), dtype=torch.float32, device=f"cuda:{local_rank}")
     stream = torch.cuda.current_stream()
@@ -210,11 +213,11 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic: regression/0010_pt scene (6 of 7 shapes, scenes/0010_pt), per-path xorshift128+ seeds",
-            "config": {"workload": cfg["name"],
+            "config": {"workload": cfg["name"], "tree": args.tree,
                        "paths_per_step_per_gpu": per_frame, "sharding": f"path-index ranges x{world}, framebuffer all-reduce"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic if args.config == "cfg2" else None, "traffic_source": traffic_src if args.config == "cfg2" else None,
-                         "kernel": "mi_path_kernel<false,%s,true> (RECORD, PTDL, NODES_LDS)" % ("true" if cfg["sampler"] == "ptdl" else "false"), "kernel_ms": kms,
+                         "kernel": "mi_path_kernel<false,%s,%s> (RECORD, PTDL, NODES_LDS)" % ("true" if cfg["sampler"] == "ptdl" else "false", "true" if be.nodes_in_lds() else "false"), "kernel_ms": kms,
                          "algorithmic_bytes_per_sample": bytes_per_sample,
                          "work_per_sample": {"rays": dc[0] / paths, "node_visits": dc[1] / paths, "prim_tests": dc[3] / paths, "splats": dc[5] / paths}},
         }

@@ -242,6 +242,7 @@ def mi_lib():
         m.mi_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         m.mi_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         m.mi_last_kernel_launches.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        m.mi_scene_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         m.mi_scene_destroy.argtypes = [C.c_void_p]
         m.mi_scene_destroy.restype = None
         m.mi_shutdown.restype = None
@@ -252,7 +253,7 @@ def mi_lib():
 
 MI_SYMBOLS = ["mi_init", "mi_scene_create", "mi_scene_set_framebuffer", "mi_scene_set_stream", "mi_render",
               "mi_sync", "mi_fb_read", "mi_fb_clear", "mi_fb_device_ptr", "mi_counters", "mi_trace_paths", "mi_intersect",
-              "mi_last_kernel_ms", "mi_last_kernel_launches", "mi_scene_destroy", "mi_shutdown", "mi_last_error"]
+              "mi_last_kernel_ms", "mi_last_kernel_launches", "mi_scene_stats", "mi_scene_destroy", "mi_shutdown", "mi_last_error"]
 
 
 def ray_dtypes():
@@ -346,6 +347,15 @@ class Backend:
         n = C.c_uint64()
         self._check(self.m.mi_last_kernel_launches(self._ptr, C.byref(n)), "mi_last_kernel_launches")
         return n.value
+
+    def stats(self):
+        """dict: 4-wide nodes, tree staged in LDS, stack entries needed, tree built on the device"""
+        out = (C.c_uint32 * 4)()
+        self._check(self.m.mi_scene_stats(self._ptr, out), "mi_scene_stats")
+        return {"nodes": out[0], "nodes_in_lds": bool(out[1]), "stack_need": out[2], "device_built": bool(out[3])}
+
+    def nodes_in_lds(self):
+        return self.stats()["nodes_in_lds"]
 
     def close(self):
         if self._ptr:

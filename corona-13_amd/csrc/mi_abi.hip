@@ -204,6 +204,8 @@ struct mi_scene
   int have_timing;
   size_t lds_bytes;
   bool nodes_lds;                   /* BVH staged in LDS (fits next to the stacks) or read from HBM */
+  bool device_built;                /* tree made by mi_build.h */
+  int stack_need;                   /* stack entries a ray may need */
   int grid;
   uint64_t launches;
   /* wavefront pipeline (mi_wavefront.h) */
@@ -651,6 +653,7 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   const char *nodes_env = getenv("CORONA_MI_NODES");
   s->nodes_lds = node_bytes + stack_bytes <= 160*1024 && !(nodes_env && !strcmp(nodes_env, "global"));
   s->lds_bytes = (s->nodes_lds ? node_bytes : 0) + stack_bytes;
+  s->device_built = device_build; s->stack_need = stack_need;
   {
     const void *kernels[] = {
       (const void *)mi_intersect_kernel<true>, (const void *)mi_intersect_kernel<false>,
@@ -914,6 +917,13 @@ extern "C" int mi_last_kernel_launches(mi_scene *s, uint64_t *launches)
 {
   if(!s || !launches) return fail(MI_ERR_ARG, "null argument");
   *launches = s->kernel_launches_last;
+  return MI_OK;
+}
+
+extern "C" int mi_scene_stats(mi_scene *s, uint32_t out[4])
+{
+  if(!s || !out) return fail(MI_ERR_ARG, "null argument");
+  out[0] = s->d.num_nodes; out[1] = s->nodes_lds ? 1u : 0u; out[2] = (uint32_t)s->stack_need; out[3] = s->device_built ? 1u : 0u;
   return MI_OK;
 }
 

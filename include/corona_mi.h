@@ -262,6 +262,11 @@ int  mi_last_kernel_ms(mi_scene *s, float *ms);
  * wavefront pipeline, whose mi_last_kernel_ms spans the whole launch sequence */
 int  mi_last_kernel_launches(mi_scene *s, uint64_t *launches);
 
+/* what the backend made of the scene: out[0] 4-wide nodes, out[1] 1 if the tree is staged in LDS (0: traversed from HBM),
+ * out[2] traversal stack entries a ray may need, out[3] 1 if the tree was built on the device (mi_scene_desc.nodes == NULL).
+ * No reference counterpart (the reference prints accel statistics to its log, src/accel.d/qbvhmp.c:1121-1144). */
+int  mi_scene_stats(mi_scene *s, uint32_t out[4]);
+
 void mi_scene_destroy(mi_scene *s);
 void mi_shutdown(void);
 

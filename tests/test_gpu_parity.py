@@ -508,3 +508,21 @@ def test_device_build_tiny_scene(tmp_path):
     assert (a["primid"] != 0xffffffffffffffff).mean() > 0.05
     assert np.array_equal(a["primid"], b["primid"]) and np.array_equal(a["dist"].view(np.uint32), b["dist"].view(np.uint32))
     host.close(); devb.close()
+
+
+def test_scene_stats():
+    """mi_scene_stats: node count, where the tree lives, stack need, who built it"""
+    scene = make_scene(width=64, height=64, max_verts=4)
+    be = pkg.Backend(scene)
+    st = be.stats()
+    assert st["nodes"] == scene.desc.num_nodes and st["nodes_in_lds"] and not st["device_built"] and 3 <= st["stack_need"] <= 64
+    be.close()
+    fine = make_scene(SCENE_FINE, width=64, height=64, max_verts=4)
+    be = pkg.Backend(fine)
+    st = be.stats()
+    assert st["nodes"] == fine.desc.num_nodes and not st["nodes_in_lds"]
+    be.close()
+    be = pkg.Backend(scene, device_build=True)
+    st = be.stats()
+    assert st["device_built"] and scene.desc.num_prims // 8 <= st["nodes"] < scene.desc.num_prims
+    be.close()
