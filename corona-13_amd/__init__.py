@@ -24,6 +24,7 @@ HOST_LIB = PKG_DIR / "host" / "libcorona_host.so"
 MI_LIB = Path(os.environ.get("CORONA_MI_LIB", PKG_DIR / "csrc" / "libcorona_mi.so"))   # override: kernel-variant experiments only
 
 MI_SAMPLER_PT, MI_SAMPLER_PTDL = 0, 1
+MI_POINTS_RAND, MI_POINTS_HALTON = 0, 1
 MI_REC_MAX_VERTS, MI_REC_MAX_SPLATS = 8, 8
 
 
@@ -78,7 +79,8 @@ class MiSceneDesc(C.Structure):
                 ("num_vtx", C.c_uint64), ("vtx", C.POINTER(MiVtx)),
                 ("num_materials", C.c_uint32), ("materials", C.POINTER(MiMaterial)),
                 ("lights", MiLights), ("cam", MiCamera),
-                ("cie_xyz", C.POINTER(C.c_float)), ("checker", C.POINTER(C.c_float)), ("metal_ior", C.POINTER(C.c_float))]
+                ("cie_xyz", C.POINTER(C.c_float)), ("checker", C.POINTER(C.c_float)), ("metal_ior", C.POINTER(C.c_float)),
+                ("pointsampler", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class MiPathVertex(C.Structure):
@@ -103,7 +105,8 @@ class MiPathRecord(C.Structure):
 class ChOptions(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("max_verts", C.c_uint32), ("sampler", C.c_uint32),
                 ("frame", C.c_uint64), ("cam_file", C.c_char_p), ("rgb2spec_lut", C.c_char_p),
-                ("data_dir", C.c_char_p), ("iso", C.c_float), ("build_threads", C.c_int), ("verbose", C.c_int)]
+                ("data_dir", C.c_char_p), ("iso", C.c_float), ("build_threads", C.c_int), ("verbose", C.c_int),
+                ("pointsampler", C.c_uint32)]
 
 
 def record_dtype():
@@ -165,11 +168,12 @@ class Scene:
     """A scene loaded by the host library (owns the mi_scene_desc)."""
 
     def __init__(self, nra2, width=1024, height=576, max_verts=32, sampler=MI_SAMPLER_PT, frame=1,
-                 rgb2spec_lut=None, verbose=0):
+                 rgb2spec_lut=None, verbose=0, pointsampler=MI_POINTS_RAND):
         h = host_lib()
         opt = ChOptions(width=width, height=height, max_verts=max_verts, sampler=sampler, frame=frame,
                         cam_file=None, rgb2spec_lut=(str(rgb2spec_lut).encode() if rgb2spec_lut else None),
-                        data_dir=str(PKG_DIR / "data").encode(), iso=0.0, build_threads=0, verbose=verbose)
+                        data_dir=str(PKG_DIR / "data").encode(), iso=0.0, build_threads=0, verbose=verbose,
+                        pointsampler=pointsampler)
         self._ptr = C.c_void_p()
         err = h.ch_scene_load(str(nra2).encode(), C.byref(opt), C.byref(self._ptr))
         if err:

@@ -32,6 +32,7 @@ typedef struct ch_options
   float iso;                    /* --iso override, <= 0 = camera file                                  */
   int   build_threads;          /* reserved                                                            */
   int   verbose;
+  uint32_t pointsampler;        /* MI_POINTS_* (MOD_pointsampler: rand or halton)                      */
 } ch_options;
 
 typedef struct ch_scene ch_scene;

@@ -532,6 +532,7 @@ int ch_scene_load(const char *nra2_path, const ch_options *opt_in, ch_scene **ou
   while(d->height & 0x1f) d->height++;
   d->max_verts = s->opt.max_verts ? s->opt.max_verts : 32;
   d->sampler = s->opt.sampler;
+  d->pointsampler = s->opt.pointsampler;
   d->frame = s->opt.frame ? s->opt.frame : 1;
   s->view_gain = 1.0f;
 

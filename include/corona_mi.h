@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 1
+#define MI_ABI_VERSION 2
 
 /* ---- error codes (negative ints, reference style: non-zero == failure) ---------- */
 #define MI_OK              0
@@ -141,6 +141,18 @@ typedef struct mi_lights
   float            p_sky, p_geo, p_vol;
 } mi_lights;
 
+/* ---- point sampler (MOD_pointsampler) ---------------------------------------------
+ * MI_POINTS_RAND   src/pointsampler.d/rand.c:48-55: every dimension is the next number of the per-path generator.
+ * MI_POINTS_HALTON src/pointsampler.d/halton.c:69-84: dimension d of path `index` is the Faure-style permuted radical
+ *                  inverse of the low 32 bits of the index in the d-th prime base (ext/halton/halton.h, 256 dimensions),
+ *                  d = rand_beg of the vertex under construction + the path_sample_dim_t offset (include/pathspace.h:16-53);
+ *                  the permutations are drawn from srand48(frame + (end_index >> 32)) by the backend itself
+ *                  (pointsampler_init / pointsampler_prepare_frame, halton.c:46-52,122-129), where end_index is the end of
+ *                  the mi_render range. The tangent-frame scrambling and ptdl's nee_probability draw stay on the per-path
+ *                  generator as in the reference (src/pathspace.c:213, src/sampler.d/ptdl.c:137). */
+#define MI_POINTS_RAND   0
+#define MI_POINTS_HALTON 1
+
 /* ---- everything the backend needs ------------------------------------------------- */
 typedef struct mi_scene_desc
 {
@@ -176,6 +188,9 @@ typedef struct mi_scene_desc
   const float *cie_xyz;       /* 96 x 3: CIE 1931 2-deg CMF, 360..830 nm step 5 + one zero row (include/spectrum.h:66-170) */
   const float *checker;       /* 140 x 36 colour-checker reflectances, 380 nm step 10 (src/shaders/colorcheckersg.c:51) or NULL */
   const float *metal_ior;     /* 5 x 95 x 2 (n,k) conductor tables, 360 nm step 5 (src/shaders/fresnel.h:21-27) or NULL */
+
+  uint32_t pointsampler;      /* MI_POINTS_*: which MOD_pointsampler maps (path, dimension) to a number in [0,1) */
+  uint32_t reserved;
 } mi_scene_desc;
 
 typedef struct mi_scene mi_scene;   /* opaque, device resident */

@@ -70,6 +70,7 @@ typedef struct o_vertex
   o_volume interior;
   float eta;                     /* diffgeo.eta */
   uint32_t flags, mode, material_modes;
+  int rand_beg, rand_cnt;        /* first random dimension of this vertex and how many it owns (include/pathspace.h:157-158) */
 } o_vertex;
 
 typedef struct o_edge
@@ -105,6 +106,19 @@ typedef struct o_ctx
 /* oracle_rng: src/points.d/xorshift128p.c */
 float o_rand(o_ctx *c);
 void  o_rand_seed(o_ctx *c, uint64_t index, uint64_t frame);
+
+/* pointsampler(path, dim): MOD_pointsampler = rand (src/pointsampler.d/rand.c:48-55, ignores the dimension) or halton
+ * (src/pointsampler.d/halton.c:69-84: dimension = rand_beg of vertex v + dim, index = low 32 bits of the path index).
+ * v = the vertex under construction = path->length at the call (length-1 inside path_russian_roulette, src/pathspace.c:278-281).
+ * rand_beg / rand_cnt are kept as the reference keeps them: thinlens.c:100-103, src/pathspace.c:199,208,298, nee.h:108,225,231. */
+enum { o_dim_image_x = 0, o_dim_image_y = 1, o_dim_lambda = 2, o_dim_time = 3, o_dim_aperture_x = 4, o_dim_aperture_y = 5, o_dim_camid = 6,
+       o_dim_omega_x = 1, o_dim_omega_y = 2, o_dim_scatter_mode = 3, o_dim_russian_r = 4,
+       o_dim_nee_light1 = 0, o_dim_nee_light2 = 1, o_dim_nee_x = 2, o_dim_nee_y = 3 };   /* include/pathspace.h:16-53 */
+float o_point(o_ctx *c, const o_path *p, int v, int dim);
+
+/* oracle_halton.c */
+void  o_halton_prepare(uint64_t seed);
+float o_halton_sample(uint32_t dim, uint32_t index);
 
 /* oracle_geo.c */
 void  o_accel_intersect(o_ctx *c, const o_ray *ray, o_hit *hit);

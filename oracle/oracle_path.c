@@ -31,6 +31,14 @@ void o_rand_seed(o_ctx *c, uint64_t index, uint64_t frame)
   for(int k=0;k<10;k++) (void)o_rand(c);
 }
 
+float o_point(o_ctx *c, const o_path *p, int v, int dim)
+{
+  if(c->s->pointsampler != MI_POINTS_HALTON) return o_rand(c);
+  const int d = p->v[v].rand_beg + dim;
+  if(d >= 256) return o_rand(c);                                      /* "degenerate to pure random", halton.c:78-80 */
+  return o_halton_sample((uint32_t)d, (uint32_t)p->index);            /* "this clips the bits in p->index to 32", halton.c:83 */
+}
+
 float oracle_rand_sequence(uint64_t index, uint64_t frame, int n, float *out)
 {
   o_ctx c; memset(&c, 0, sizeof(c));
@@ -88,14 +96,17 @@ static float o_camera_sample(o_ctx *c, o_path *p)
   const mi_scene_desc *s = c->s;
   const mi_camera *cam = &s->cam;
   const float W = (float)s->width, H = (float)s->height;
-  const float i = o_rand(c)*W;
-  const float j = o_rand(c)*H;
-  const float r1 = o_rand(c);
-  const float r2 = o_rand(c);
+  const float i = o_point(c, p, 0, o_dim_image_x)*W;
+  const float j = o_point(c, p, 0, o_dim_image_y)*H;
+  const float r1 = o_point(c, p, 0, o_dim_aperture_x);
+  const float r2 = o_point(c, p, 0, o_dim_aperture_y);
   const float lens_radius = (.5f/cam->f_stop)*cam->focal_length;
   const float u = cosf(2*M_PI*r1)*sqrtf(r2)*lens_radius;
   const float v = sinf(2*M_PI*r1)*sqrtf(r2)*lens_radius;
 
+  p->v[0].rand_cnt = 7;                                  /* s_dim_num_pt_beg, thinlens.c:100-103 */
+  p->v[1].rand_beg = p->v[0].rand_beg + p->v[0].rand_cnt;
+  p->v[1].rand_cnt = 1;
   o_hit *h = &p->v[0].hit;
   for(int k=0;k<3;k++) { h->a[k] = cam->a[k]; h->b[k] = cam->b[k]; h->n[k] = cam->n[k]; h->gn[k] = cam->n[k]; h->x[k] = cam->pos[k]; }
   const float f = cam->focus/cam->focal_length;
@@ -201,20 +212,22 @@ static int o_path_extend(o_ctx *c, o_path *path)
       path->v[v-1].mode = s_absorb;
       return 1;
     }
+    path->v[v].rand_beg = path->v[v-1].rand_beg + path->v[v-1].rand_cnt;
     path->v[v].pdf = 1.0f;
     path->v[v].throughput = path->v[v-1].throughput;
     path->v[v].throughput = path->v[v].throughput*o_shader_sample(c, path);
+    path->v[v].rand_cnt = 5;                               /* s_dim_num_extend */
   }
   else
   {
     /* draw order: scramble, lambda, time, camid (path_extend), camid again (view_cam_sample,
        src/view.c:846-847), then image x/y, aperture x/y (thinlens.c:117-121) */
     path->scramble = 0.1f + o_rand(c)*(0.9f-0.1f);
-    const float lf = fmodf(o_rand(c) + 0/(float)1, 1.0f);
+    const float lf = fmodf(o_point(c, path, 0, o_dim_lambda) + 0/(float)1, 1.0f);
     path->lambda = 360 + (830 - 360)*lf;                          /* spectrum_sample_lambda, include/spectrum.h:206-210 */
-    path->time = o_rand(c)*s->cam.time_scale;                      /* view_sample_time, src/view.c:881-891 */
-    (void)o_rand(c);                                               /* view_sample_camid: one camera */
-    (void)o_rand(c);
+    path->time = o_point(c, path, 0, o_dim_time)*s->cam.time_scale; /* view_sample_time, src/view.c:881-891 */
+    (void)o_point(c, path, 0, o_dim_camid);                        /* view_sample_camid: one camera */
+    (void)o_point(c, path, 0, o_dim_camid);
     path->v[0].throughput = 1.0f*o_camera_sample(c, path);         /* num_cams * camera_sample */
     path->v[0].throughput = path->v[0].throughput/1.0f;            /* view_pdf_camid */
     path->v[0].interior.ior = 1.0f; path->v[0].interior.shader = -1;   /* shader_exterior_medium: vacuum */
@@ -241,7 +254,7 @@ static int o_path_extend(o_ctx *c, o_path *path)
 static int o_path_russian_roulette(o_ctx *c, o_path *path, float p_survival)
 { /* path_russian_roulette, src/pathspace.c:273-292 */
   const int v = path->length-1;
-  const float rr = o_rand(c);
+  const float rr = o_point(c, path, v, o_dim_russian_r);
   if(rr >= p_survival)
   {
     path->v[v].throughput = path->v[v].throughput*(1.0f/(1.0f-p_survival));
@@ -443,9 +456,9 @@ static float o_lights_sample_next_event(o_ctx *c, o_path *p)
      arguments are drawn right to left by the reference build: nee_y, nee_x, then the light selector */
   const mi_lights *l = &c->s->lights;
   const int v = p->length;
-  const float r3 = o_rand(c);
-  const float r2 = o_rand(c);
-  const float r1 = o_rand(c);
+  const float r3 = o_point(c, p, v, o_dim_nee_y);
+  const float r2 = o_point(c, p, v, o_dim_nee_x);
+  const float r1 = o_point(c, p, v, o_dim_nee_light2);
   const unsigned int t = o_sample_cdf(l->cdf, l->num_prims, r1);
   p->v[v].hit.prim = l->primid[t];
   o_prims_sample(c->s, l->primid[t], r2, r3, &p->v[v].hit);
@@ -479,8 +492,9 @@ static int o_nee_sample(o_ctx *c, o_path *p)
     const float p_sky = s->lights.p_sky, p_geo = s->lights.p_geo;
     memset(p->v + v, 0, sizeof(o_vertex));
     memset(p->e + v, 0, sizeof(o_edge));
+    p->v[v].rand_beg = p->v[v-1].rand_beg + p->v[v-1].rand_cnt;
     p->v[v].tech = s_tech_nee;
-    const float rand = o_rand(c);
+    const float rand = o_point(c, p, v, o_dim_nee_light1);
     if(rand < p_sky) { /* envmap sampling: out of scope (black sky has p_sky == 0) */ }
     else if(rand < p_sky + p_geo)
     {
@@ -511,9 +525,11 @@ static int o_nee_sample(o_ctx *c, o_path *p)
     p->v[v].throughput = 0.0f;
     p->v[v].flags = s_none;
     p->v[v].mode = s_absorb;
+    p->v[v].rand_cnt = 4;                                  /* s_dim_num_nee */
     p->length++;
     return 0;
   }
+  p->v[v].rand_cnt = 4;
   p->length++;
   const float pdf_nee = p->v[v].pdf, pdf_fnee = 0.0f;
   const float weight = pdf_nee/(pdf_nee + pdf_fnee/1.0f);
@@ -527,6 +543,7 @@ static int o_nee_sample(o_ctx *c, o_path *p)
 static void o_path_pop(o_path *path)
 { /* path_pop, src/pathspace.c:294-308 */
   const int v = path->length-1;
+  path->v[v-1].rand_cnt += path->v[v].rand_cnt;
   path->v[v-1].mode &= s_emit;
   path->length--;
   path->throughput = path->v[v-1].total_throughput;
@@ -606,7 +623,20 @@ static void o_trace(o_ctx *c, uint64_t index)
   if(c->rec) o_fill_record(&path, c->rec);
 }
 
+static void o_prepare_points(const mi_scene_desc *s, uint64_t end)
+{ /* pointsampler_init(frame) + pointsampler_prepare_frame, src/pointsampler.d/halton.c:46-52,122-129: the permutations are
+     drawn again with the next seed once the end of the progression passes a multiple of 2^32 path indices */
+  if(s->pointsampler == MI_POINTS_HALTON) o_halton_prepare(s->frame + (end >> 32));
+}
+
+static void o_trace_path(const mi_scene_desc *s, uint64_t index, float *fb, mi_path_record *rec, uint64_t *counters);
 void oracle_trace_path(const mi_scene_desc *s, uint64_t index, float *fb, mi_path_record *rec, uint64_t *counters)
+{
+  o_prepare_points(s, index + 1);
+  o_trace_path(s, index, fb, rec, counters);
+}
+
+static void o_trace_path(const mi_scene_desc *s, uint64_t index, float *fb, mi_path_record *rec, uint64_t *counters)
 {
   o_ctx c;
   memset(&c, 0, sizeof(c));
@@ -618,7 +648,8 @@ void oracle_trace_path(const mi_scene_desc *s, uint64_t index, float *fb, mi_pat
 
 void oracle_trace_records(const mi_scene_desc *s, uint64_t first, uint64_t count, mi_path_record *out)
 {
-  for(uint64_t i=0;i<count;i++) oracle_trace_path(s, first + i, 0, out + i, 0);
+  o_prepare_points(s, first + count);
+  for(uint64_t i=0;i<count;i++) o_trace_path(s, first + i, 0, out + i, 0);
 }
 
 typedef struct o_job
@@ -651,6 +682,7 @@ double oracle_render(const mi_scene_desc *s, uint64_t first, uint64_t count, flo
   if(threads < 1) threads = 1;
   if(threads > 256) threads = 256;
   struct timeval t0, t1;
+  o_prepare_points(s, first + count);
   gettimeofday(&t0, 0);
   uint64_t counter = first;
   o_job job[256];

@@ -175,8 +175,8 @@ float o_shader_prepare(o_ctx *c, o_path *p, int v)
 static float o_sample_diffuse(o_ctx *c, o_path *p)
 { /* sample_d, src/shader.c:165-205 (path tracing direction) */
   const int v = p->length;
-  const float x1 = o_rand(c);
-  const float x2 = o_rand(c);
+  const float x1 = o_point(c, p, v, o_dim_omega_x);
+  const float x2 = o_point(c, p, v, o_dim_omega_y);
   const float sq = sqrtf(x1);
   const float *n = p->v[v-1].hit.n;
   for(int k=0;k<3;k++)
@@ -341,8 +341,8 @@ static float o_sample_dielectric(o_ctx *c, o_path *p)
     const float wit[3] = { -dot3(p->v[v].hit.a, p->e[v].omega), -dot3(p->v[v].hit.b, p->e[v].omega), cos_in };
     /* the reference draws both numbers as call arguments (dielectric.c:266); gcc evaluates them
        right to left: first draw -> U2, second -> U1 */
-    const float U2 = o_rand(c);
-    const float U1 = o_rand(c);
+    const float U2 = o_point(c, p, v+1, o_dim_omega_y);
+    const float U1 = o_point(c, p, v+1, o_dim_omega_x);
     o_ggx_sample_h(wit, r, r, U1, U2, ht);
     for(int k=0;k<3;k++) h[k] = ht[0]*p->v[v].hit.a[k] + ht[1]*p->v[v].hit.b[k] + ht[2]*n[k];
     pdf_h = o_ggx_pdf_h(p->e[v].omega, h, n, r);
@@ -357,7 +357,7 @@ static float o_sample_dielectric(o_ctx *c, o_path *p)
   const float cost = cost2 <= 0.0f ? 0.0f : sqrtf(cost2);
   const float R = o_fresnel(n1, n2, cosr, cost);
 
-  if(o_rand(c) <= R)
+  if(o_point(c, p, v+1, o_dim_scatter_mode) <= R)
   {
     p->v[v].mode = s_reflect;
     for(int k=0;k<3;k++) p->e[v+1].omega[k] = p->e[v].omega[k] + 2.0f*cosr*h[k];
@@ -596,8 +596,8 @@ static float o_sample_metal(o_ctx *c, o_path *p)
   {
     const float wit[3] = { -dot3(p->v[v].hit.a, p->e[v].omega), -dot3(p->v[v].hit.b, p->e[v].omega), -dot3(n, p->e[v].omega) };
     float ht[3];
-    const float U2 = o_rand(c);
-    const float U1 = o_rand(c);
+    const float U2 = o_point(c, p, v+1, o_dim_omega_y);
+    const float U1 = o_point(c, p, v+1, o_dim_omega_x);
     o_ggx_sample_h(wit, r, r, U1, U2, ht);
     for(int k=0;k<3;k++) h[k] = ht[0]*p->v[v].hit.a[k] + ht[1]*p->v[v].hit.b[k] + ht[2]*n[k];
     pdf_h = o_ggx_pdf_h(p->e[v].omega, h, n, r);

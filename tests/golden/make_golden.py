@@ -132,6 +132,10 @@ def main():
         dump_paths("fine_mv8", "dump_pt_xs_mv8", 8, "0054_fine", 1280, 720, 3000)     # needs scenes/geo/plane_fine.geo (tools/make_geo.py)
         dump_paths("metal_mv8", "dump_pt_xs_mv8", 8, "0053_metal", 1280, 720, 3000)
         dump_paths("metal_ptdl_mv8", "dump_ptdl_xs_mv8", 8, "0053_metal", 1280, 720, 3000)
+        # MOD_pointsampler=halton; the mv32 ptdl case reaches dimensions >= 256 (fallback to the per-path generator)
+        dump_paths("halton_pt_mv8", "dump_pt_halton_mv8", 8, "0010_pt", 1280, 720, 3000)
+        dump_paths("halton_ptdl_mv8", "dump_ptdl_halton_mv8", 8, "0010_pt", 1280, 720, 3000)
+        dump_paths("halton_ptdl_rough_mv32", "dump_ptdl_halton_mv32", 32, "0052_rough", 1280, 720, 2000)
         counters()
     if what in ("images", "all"):
         tilemeans("pt_mv8", "corona_pt_sfmt_mv8", 8, "0010_pt", 1280, 720, 2048)

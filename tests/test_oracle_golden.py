@@ -30,6 +30,12 @@ CASES = [
     ("fine_mv8", pkg.MI_SAMPLER_PT, SCENE_FINE, 1.5e-3),         # 16 384-quad backdrop: QBVH of 1711 nodes (host builder vs reference builder)
     ("metal_mv8", pkg.MI_SAMPLER_PT, SCENE_METAL, 1.5e-3),       # row a19: metal.c sample
     ("metal_ptdl_mv8", pkg.MI_SAMPLER_PTDL, SCENE_METAL, 1e-2),  # row a19: metal.c brdf / pdf through next event estimation
+    # SURVEY 8(f) row 2, MOD_pointsampler=halton ("halton_" cases run with MI_POINTS_HALTON): dimension bookkeeping
+    # (rand_beg / rand_cnt incl. the four next-event dimensions path_pop hands to the previous vertex), permutation tables
+    # from srand48(frame), and -- max depth 32 with ptdl -- the fall-back to the per-path generator from dimension 256 on
+    ("halton_pt_mv8", pkg.MI_SAMPLER_PT, SCENE_0010, 1.5e-3),
+    ("halton_ptdl_mv8", pkg.MI_SAMPLER_PTDL, SCENE_0010, 1e-2),
+    ("halton_ptdl_rough_mv32", pkg.MI_SAMPLER_PTDL, SCENE_ROUGH, 1e-2),
 ]
 
 # Fraction of paths that must have the reference's vertex count. The reference's metal Fresnel term (metal.c:79-157)
@@ -51,7 +57,8 @@ def rel(a, b):
 def test_oracle_matches_reference_paths(name, sampler, scene_path, etol):
     g = np.load(GOLDEN / f"paths_{name}.npz")
     ref = g["records"]
-    s = make_scene(scene_path, width=int(g["width"]), height=int(g["height"]), max_verts=int(g["max_verts"]), sampler=sampler)
+    s = make_scene(scene_path, width=int(g["width"]), height=int(g["height"]), max_verts=int(g["max_verts"]), sampler=sampler,
+                   pointsampler=pkg.MI_POINTS_HALTON if name.startswith("halton_") else pkg.MI_POINTS_RAND)
     ora = oracle_records(s, 0, len(ref))
     for f, tol in (("pixel_i", 1e-4), ("pixel_j", 1e-4), ("lambda", 1e-4), ("time", 1e-6), ("scramble", 1e-6)):
         assert np.abs(ref[f] - ora[f]).max() <= tol, f
@@ -148,3 +155,60 @@ def test_oracle_image_statistics_vs_reference_render(name, sampler, scene_path, 
     assert abs(np.median(tiles[..., 1]) - np.median(ref[..., 1])) < 0.1 * np.median(ref[..., 1])
     # and the plain mean within a generous factor given the noise floor at this spp
     assert abs(tiles[..., 1].mean() - ref[..., 1].mean()) < 0.35 * ref[..., 1].mean()
+
+
+def test_halton_falls_back_to_the_generator_from_dimension_256():
+    """ptdl at max depth 32 owns 9 dimensions per vertex (5 extension + 4 next event), so vertex 29 onwards asks for
+    dimensions >= 256 and gets the per-path generator instead (src/pointsampler.d/halton.c:78-80). The fixture holds the
+    198 paths of 29+ vertices among the reference's first 2 000 000 (0052 rough-dielectric scene)."""
+    g = np.load(GOLDEN / "paths_halton_long_mv32.npz")
+    ref = g["records"]
+    assert len(ref) > 100 and ref["length"].min() >= 29
+    s = make_scene(SCENE_ROUGH, width=1280, height=720, max_verts=32, sampler=pkg.MI_SAMPLER_PTDL, pointsampler=pkg.MI_POINTS_HALTON)
+    ora = np.concatenate([oracle_records(s, int(i), 1) for i in ref["index"]])
+    # chains of 29+ rough-dielectric bounces amplify the reference's fast-math noise: most, not all, stay on the same path
+    same = ref["length"] == ora["length"]
+    assert same.mean() >= 0.97, same.mean()
+    assert (ref["num_splats"][same] == ora["num_splats"][same]).mean() >= 0.95
+    m = same & (ref["num_splats"] == ora["num_splats"]) & (ref["num_splats"] > 0)
+    assert m.sum() > 100 and (ref["splat"]["length"][m] == ora["splat"]["length"][m]).all()
+    assert np.median(rel(ref["splat"]["value"][m, 0], ora["splat"]["value"][m, 0])) < 1e-2
+    for k in range(8):
+        assert (ref["v"]["prim"][same, k] == ora["v"]["prim"][same, k]).mean() >= 0.99
+
+
+def test_halton_tables_match_libc_drand48():
+    """the oracle restates srand48/lrand48 (POSIX LCG) to draw the digit permutations (ext/halton/halton.h:3244-3274);
+    rebuild the tables of a few bases with the C library's generator"""
+    import ctypes as C
+    o = oracle_lib()
+    o.oracle_halton_tables.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+    o.oracle_halton_tables.restype = C.c_uint32
+    base, off = np.zeros(256, dtype=np.uint32), np.zeros(256, dtype=np.uint32)
+    n = o.oracle_halton_tables(7, None, base.ctypes.data, off.ctypes.data)
+    table = np.zeros(n, dtype=np.uint16)
+    o.oracle_halton_tables(7, table.ctypes.data, None, None)
+    assert list(base[:6]) == [2, 3, 5, 7, 11, 13] and base[255] == 1619 and n == 193329   # 387 KB of 16-bit entries
+    libc = C.CDLL(None)
+    libc.lrand48.restype = C.c_long
+    libc.srand48(C.c_long(7))
+    perms = {}
+    for b in range(4, 30):                                   # bases are shuffled in order, prime or not
+        perm = list(range(b))
+        for i in range(b - 1):
+            j = i + libc.lrand48() // ((1 << 31) // (b - i) + 1)
+            perm[i], perm[j] = perm[j], perm[i]
+        perms[b] = perm
+    for dim, (b, digits) in {2: (5, 3), 3: (7, 3), 4: (11, 2), 8: (23, 1), 9: (29, 1)}.items():
+        assert base[dim] == b
+        size = b ** digits
+        want = []
+        for i in range(size):
+            r, idx = 0, i
+            for _ in range(digits):
+                r = r * b + perms[b][idx % b]
+                idx //= b
+            want.append(r)
+        assert list(table[off[dim]:off[dim] + size]) == want, b
+    # base 3 keeps the identity permutation: five digits reversed
+    assert table[off[1] + 1] == 81 and table[off[1] + 3] == 27
