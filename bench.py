@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--tree", default="reference", choices=["reference", "device"],
                     help="reference: the QBVH the reference's builder makes, handed over through the ABI (default, the drop-in contract); "
                          "device: no tree handed over, the backend builds its own (csrc/mi_build.h)")
+    ap.add_argument("--points", default="rand", choices=["rand", "halton"],
+                    help="MOD_pointsampler: rand (regression/0010_pt/config.mk, the default) or halton (SURVEY 8(f) row 2)")
     args = ap.parse_args()
 
     import torch
@@ -144,7 +146,8 @@ def main():
     pkg = load_package()
     cfg = CONFIGS[args.config]
     scene = make_scene(REPO / "scenes" / cfg["scene"] / "test.nra2", width=cfg["w"], height=cfg["h"], max_verts=cfg["mv"],
-                       sampler=pkg.MI_SAMPLER_PTDL if cfg["sampler"] == "ptdl" else pkg.MI_SAMPLER_PT)
+                       sampler=pkg.MI_SAMPLER_PTDL if cfg["sampler"] == "ptdl" else pkg.MI_SAMPLER_PT,
+                       pointsampler=pkg.MI_POINTS_HALTON if args.points == "halton" else pkg.MI_POINTS_RAND)
     be = pkg.Backend(scene, device=local_rank, device_build=args.tree == "device")
     per_frame = cfg["spp"] * scene.width * scene.height
     fb = torch.zeros((scene.height, scene.width, 3), dtype=torch.float32, device=f"cuda:{local_rank}")
@@ -213,11 +216,11 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic: regression/0010_pt scene (6 of 7 shapes, scenes/0010_pt), per-path xorshift128+ seeds",
-            "config": {"workload": cfg["name"], "tree": args.tree,
+            "config": {"workload": cfg["name"], "tree": args.tree, "pointsampler": args.points,
                        "paths_per_step_per_gpu": per_frame, "sharding": f"path-index ranges x{world}, framebuffer all-reduce"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic if args.config == "cfg2" else None, "traffic_source": traffic_src if args.config == "cfg2" else None,
-                         "kernel": "mi_path_kernel<false,%s,%s> (RECORD, PTDL, NODES_LDS)" % ("true" if cfg["sampler"] == "ptdl" else "false", "true" if be.nodes_in_lds() else "false"), "kernel_ms": kms,
+                         "kernel": "mi_path_kernel<false,%s,%s,%s> (RECORD, PTDL, NODES_LDS, HALTON)" % ("true" if cfg["sampler"] == "ptdl" else "false", "true" if be.nodes_in_lds() else "false", "true" if args.points == "halton" else "false"), "kernel_ms": kms,
                          "algorithmic_bytes_per_sample": bytes_per_sample,
                          "work_per_sample": {"rays": dc[0] / paths, "node_visits": dc[1] / paths, "prim_tests": dc[3] / paths, "splats": dc[5] / paths}},
         }

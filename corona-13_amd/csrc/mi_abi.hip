@@ -6,6 +6,7 @@
  */
 #include "mi_wavefront.h"
 #include "mi_build.h"
+#include "mi_halton.h"
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -26,7 +27,7 @@
 #endif
 
 /* ======================================================================================= persistent megakernel */
-template<bool RECORD, bool PTDL, bool NODES_LDS>
+template<bool RECORD, bool PTDL, bool NODES_LDS, bool HALTON = false>
 __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned long long first, unsigned long long count,
                                                            const uint32_t *shape_material, const float *shape_L, mi_path_record *records,
                                                            uint2 *stack_overflow)
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
         {
           const unsigned rank = __popcll(m & ((1ull << lane) - 1ull));
           const unsigned long long i = blk_lo + base + rank;
-          if(i < blk_hi) path_generate<RECORD>(sc, ps, first + i, RECORD ? records + i : nullptr, cnt);
+          if(i < blk_hi) path_generate<RECORD, HALTON>(sc, ps, first + i, RECORD ? records + i : nullptr, cnt);
           else exhausted = true;
         }
       }
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
       tracing = false;
       mi_path_record *rec = RECORD ? records + (ps.index - first) : nullptr;
       if(tr_shadow) shadow_resolve<RECORD>(sc, ps, hit, rec, cnt, splat);
-      else path_shade<RECORD, PTDL>(sc, ps, hit, shape_material, shape_L, rec, cnt, splat);
+      else path_shade<RECORD, PTDL, HALTON>(sc, ps, hit, shape_material, shape_L, rec, cnt, splat);
     }
 
     /* ------------------------------------------------------------ splats of this iteration, cooperatively */
@@ -215,6 +216,11 @@ struct mi_scene
   unsigned long long *h_live;       /* pinned ring of `live` read-backs */
   hipEvent_t ev_live[8];
   uint64_t kernel_launches_last;
+  /* Halton point sampler */
+  bool halton;
+  HaltonTables *halton_tables;
+  uint64_t halton_epoch;            /* end index >> 32 the device tables were drawn for */
+  void *d_halton_dim, *d_halton_perm;
 };
 
 extern "C" const char *mi_last_error(void) { return g_err; }
@@ -427,6 +433,7 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   if(!h->width || !h->height || (h->width & 31) || (h->height & 31)) return fail(MI_ERR_ARG, "film size must be a non-zero multiple of 32");
   if(h->max_verts < 2 || h->max_verts > 32) return fail(MI_ERR_ARG, "max_verts must be in [2,32]");
   if(h->sampler != MI_SAMPLER_PT && h->sampler != MI_SAMPLER_PTDL) return fail(MI_ERR_ARG, "unknown sampler");
+  if(h->pointsampler != MI_POINTS_RAND && h->pointsampler != MI_POINTS_HALTON) return fail(MI_ERR_ARG, "unknown point sampler");
   if(!h->cie_xyz) return fail(MI_ERR_ARG, "scene has no tables");
   const bool device_build = !h->nodes;                      /* no tree handed over: build it on the device (mi_build.h) */
   if(!device_build && !h->num_nodes) return fail(MI_ERR_ARG, "scene has no nodes");
@@ -660,10 +667,28 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
       (const void *)mi_path_kernel<false, false, true>, (const void *)mi_path_kernel<true, false, true>,
       (const void *)mi_path_kernel<false, true, true>, (const void *)mi_path_kernel<true, true, true>,
       (const void *)mi_path_kernel<false, false, false>, (const void *)mi_path_kernel<true, false, false>,
-      (const void *)mi_path_kernel<false, true, false>, (const void *)mi_path_kernel<true, true, false> };
+      (const void *)mi_path_kernel<false, true, false>, (const void *)mi_path_kernel<true, true, false>,
+      (const void *)mi_path_kernel<false, false, true, true>, (const void *)mi_path_kernel<true, false, true, true>,
+      (const void *)mi_path_kernel<false, true, true, true>, (const void *)mi_path_kernel<true, true, true, true>,
+      (const void *)mi_path_kernel<false, false, false, true>, (const void *)mi_path_kernel<true, false, false, true>,
+      (const void *)mi_path_kernel<false, true, false, true>, (const void *)mi_path_kernel<true, true, false, true> };
     for(const void *k : kernels)
       if(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess)
       { mi_scene_destroy(s); return fail(MI_ERR_DEVICE, "cannot raise the dynamic LDS limit"); }
+  }
+  if(h->pointsampler == MI_POINTS_HALTON)
+  { /* constants now, permutation tables at the first mi_render / mi_trace_paths (they depend on the end index, ensure_halton) */
+    s->halton = true;
+    s->halton_epoch = ~0ull;
+    s->halton_tables = new HaltonTables;
+    halton_layout(*s->halton_tables);
+    if(!halton_camera_constants_ok(*s->halton_tables)) { mi_scene_destroy(s); return fail(MI_ERR_DEVICE, "internal: Halton camera constants out of date"); }
+    if(hipMalloc(&s->d_halton_dim, sizeof(s->halton_tables->dim)) != hipSuccess ||
+       hipMalloc(&s->d_halton_perm, s->halton_tables->perm.size()*sizeof(uint16_t)) != hipSuccess ||
+       hipMemcpy(s->d_halton_dim, s->halton_tables->dim, sizeof(s->halton_tables->dim), hipMemcpyHostToDevice) != hipSuccess)
+    { mi_scene_destroy(s); return fail(MI_ERR_NOMEM, "cannot allocate the Halton tables"); }
+    d.halton_dim = (const uint4 *)s->d_halton_dim;
+    d.halton_perm = (const unsigned short *)s->d_halton_perm;
   }
   hipDeviceProp_t prop;
   if(hipGetDeviceProperties(&prop, g_device) != hipSuccess) { mi_scene_destroy(s); return fail(MI_ERR_DEVICE, "hipGetDeviceProperties failed"); }
@@ -681,6 +706,8 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
        CORONA_MI_POOL = number of path slots) */
     const char *mode = getenv("CORONA_MI_MODE");
     s->wavefront = (mode && !strcmp(mode, "wave"));
+    if(s->wavefront && h->pointsampler == MI_POINTS_HALTON)
+    { mi_scene_destroy(s); return fail(MI_ERR_UNSUPPORTED, "the Halton point sampler runs in the megakernel only (unset CORONA_MI_MODE)"); }
     const char *pe = getenv("CORONA_MI_POOL");
     uint64_t P = pe ? strtoull(pe, 0, 10) : (1ull << 21);
     if(P < 65536) P = 65536;
@@ -765,20 +792,35 @@ static int render_wavefront(mi_scene *s, uint64_t first_index, uint64_t count)
   return MI_OK;
 }
 
+/* pointsampler_prepare_frame, src/pointsampler.d/halton.c:122-129: the permutations are drawn with seed frame + (end >> 32),
+   i.e. anew whenever the end of the rendered range passes a multiple of 2^32 path indices (the index is cut to 32 bits) */
+static int ensure_halton(mi_scene *s, uint64_t end_index)
+{
+  if(!s->halton) return MI_OK;
+  const uint64_t epoch = end_index >> 32;
+  if(epoch == s->halton_epoch) return MI_OK;
+  halton_fill(*s->halton_tables, s->d.frame + epoch);
+  HIPCHK(hipStreamSynchronize(s->stream));                 /* launches in flight still read the old tables */
+  HIPCHK(hipMemcpy(s->d_halton_perm, s->halton_tables->perm.data(), s->halton_tables->perm.size()*sizeof(uint16_t), hipMemcpyHostToDevice));
+  s->halton_epoch = epoch;
+  return MI_OK;
+}
+
 static void launch_path_kernel(mi_scene *s, bool record, int grid, uint64_t first, uint64_t n, mi_path_record *rec)
-{ /* pick the instantiation: RECORD (test hook) x PTDL (sampler) x NODES_LDS (tree fits LDS) */
-  const bool ptdl = s->d.sampler == MI_SAMPLER_PTDL;
-#define MI_LAUNCH(R, P, L) hipLaunchKernelGGL((mi_path_kernel<R, P, L>), dim3(grid), dim3(MI_BLOCK), s->lds_bytes, s->stream, s->d, \
+{ /* pick the instantiation: RECORD (test hook) x PTDL (sampler) x NODES_LDS (tree fits LDS) x HALTON (point sampler) */
+  const int which = (record ? 1 : 0) | (s->d.sampler == MI_SAMPLER_PTDL ? 2 : 0) | (s->nodes_lds ? 4 : 0) | (s->halton ? 8 : 0);
+#define MI_LAUNCH(R, P, L, H) hipLaunchKernelGGL((mi_path_kernel<R, P, L, H>), dim3(grid), dim3(MI_BLOCK), s->lds_bytes, s->stream, s->d, \
     (unsigned long long)first, (unsigned long long)n, (const uint32_t *)s->d_shape_material, (const float *)s->d_shape_L, rec, (uint2 *)s->d_overflow)
-  if(s->nodes_lds)
+  switch(which)
   {
-    if(record) { if(ptdl) MI_LAUNCH(true, true, true); else MI_LAUNCH(true, false, true); }
-    else       { if(ptdl) MI_LAUNCH(false, true, true); else MI_LAUNCH(false, false, true); }
-  }
-  else
-  {
-    if(record) { if(ptdl) MI_LAUNCH(true, true, false); else MI_LAUNCH(true, false, false); }
-    else       { if(ptdl) MI_LAUNCH(false, true, false); else MI_LAUNCH(false, false, false); }
+    case  0: MI_LAUNCH(false, false, false, false); break;  case  1: MI_LAUNCH(true, false, false, false); break;
+    case  2: MI_LAUNCH(false, true,  false, false); break;  case  3: MI_LAUNCH(true, true,  false, false); break;
+    case  4: MI_LAUNCH(false, false, true,  false); break;  case  5: MI_LAUNCH(true, false, true,  false); break;
+    case  6: MI_LAUNCH(false, true,  true,  false); break;  case  7: MI_LAUNCH(true, true,  true,  false); break;
+    case  8: MI_LAUNCH(false, false, false, true);  break;  case  9: MI_LAUNCH(true, false, false, true);  break;
+    case 10: MI_LAUNCH(false, true,  false, true);  break;  case 11: MI_LAUNCH(true, true,  false, true);  break;
+    case 12: MI_LAUNCH(false, false, true,  true);  break;  case 13: MI_LAUNCH(true, false, true,  true);  break;
+    case 14: MI_LAUNCH(false, true,  true,  true);  break;  default: MI_LAUNCH(true, true,  true,  true);  break;
   }
 #undef MI_LAUNCH
 }
@@ -788,6 +830,7 @@ extern "C" int mi_render(mi_scene *s, uint64_t first_index, uint64_t count)
   if(!s) return fail(MI_ERR_ARG, "null scene");
   if(!count) return MI_OK;
   if(s->wavefront) return render_wavefront(s, first_index, count);
+  { const int e = ensure_halton(s, first_index + count); if(e) return e; }
   HIPCHK(hipEventRecord(s->ev0, s->stream));
   s->kernel_launches_last = 0;
   /* every workgroup hands out its share of the range through a 32-bit LDS counter: keep a share below 2^31 paths */
@@ -859,6 +902,7 @@ extern "C" int mi_trace_paths(mi_scene *s, uint64_t first_index, uint64_t count,
 {
   if(!s || !host_out) return fail(MI_ERR_ARG, "null argument");
   if(!count) return MI_OK;
+  { const int e = ensure_halton(s, first_index + count); if(e) return e; }
   void *d_rec = nullptr;
   HIPCHK(hipMalloc(&d_rec, count*sizeof(mi_path_record)));
   hipError_t e = hipMemsetAsync(d_rec, 0, count*sizeof(mi_path_record), s->stream);
@@ -935,7 +979,9 @@ extern "C" void mi_scene_destroy(mi_scene *s)
   if(s->h_live) (void)hipHostFree(s->h_live);
   for(int k=0;k<8;k++) if(s->ev_live[k]) (void)hipEventDestroy(s->ev_live[k]);
   void *bufs[] = { s->d_nodes, s->d_axes, s->d_prims, s->d_primgeo, s->d_materials, s->d_light_prim, s->d_light_cdf, s->d_light_L,
-                   s->d_cie, s->d_checker, s->d_metal, s->d_counters, s->d_work, s->d_shape_material, s->d_shape_L, s->d_overflow, s->d_fb_own };
+                   s->d_cie, s->d_checker, s->d_metal, s->d_counters, s->d_work, s->d_shape_material, s->d_shape_L, s->d_overflow, s->d_fb_own,
+                   s->d_halton_dim, s->d_halton_perm };
+  delete s->halton_tables;
   for(void *b : bufs) if(b) (void)hipFree(b);
   if(s->stream_own) (void)hipStreamDestroy(s->stream_own);
   if(s->ev0) (void)hipEventDestroy(s->ev0);

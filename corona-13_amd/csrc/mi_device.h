@@ -89,6 +89,10 @@ struct DScene
   unsigned long long *work;        /* wavefront pipeline: [work_shards] consumed-path counters: every workgroup owns a contiguous part of the
                                       index range and its own counter (no same-address atomics between workgroups) */
   uint32_t work_shards;
+  /* Halton point sampler (MI_POINTS_HALTON): per dimension {P = digits looked up at once, floor(2^32/P), table offset | groups << 24,
+     float bits of the scale}; the digit-permutation tables, concatenated (387 KB, L2 resident) */
+  const uint4 *halton_dim;
+  const unsigned short *halton_perm;
 };
 
 #endif

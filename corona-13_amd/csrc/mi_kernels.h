@@ -99,6 +99,93 @@ __device__ __forceinline__ void rng_seed(Rng &r, unsigned long long index, unsig
   for(int k=0;k<10;k++) (void)rng_next(r);
 }
 
+/* ---------------------------------------------------------------------------------- point sampler
+ * pointsampler(path, dim), MOD_pointsampler = rand (src/pointsampler.d/rand.c:48-55: the next number of the per-path
+ * generator whatever the dimension) or halton (src/pointsampler.d/halton.c:69-84 over ext/halton/halton.h: permuted radical
+ * inverse of the low 32 bits of the path index in the (rand_beg + dim)-th prime base; dimensions >= 256 fall back to the
+ * generator). All integer arithmetic is exact, the float conversion and the one multiplication round as on the host. */
+enum { MI_DIM_IMAGE_X = 0, MI_DIM_IMAGE_Y = 1, MI_DIM_LAMBDA = 2, MI_DIM_TIME = 3, MI_DIM_APERTURE_X = 4, MI_DIM_APERTURE_Y = 5, MI_DIM_CAMID = 6,
+       MI_DIM_OMEGA_X = 1, MI_DIM_OMEGA_Y = 2, MI_DIM_SCATTER_MODE = 3, MI_DIM_RUSSIAN_R = 4,
+       MI_DIM_NEE_LIGHT1 = 0, MI_DIM_NEE_LIGHT2 = 1, MI_DIM_NEE_X = 2, MI_DIM_NEE_Y = 3 };      /* include/pathspace.h:16-53 */
+
+__device__ __forceinline__ float halton_sample(const DScene &sc, uint32_t dim, uint32_t index)
+{
+  if(dim == 0) return __uint_as_float(0x3f800000u | (__brev(index) >> 9)) - 1.0f;            /* halton2, ext/halton/halton.h:291-306 */
+  const uint4 d = sc.halton_dim[dim];
+  const uint32_t P = d.x, recip = d.y, groups = d.z >> 24;
+  const unsigned short *perm = sc.halton_perm + (d.z & 0xffffffu);
+  /* at most 7 groups (P = 23: 23^7 < 2^32). First all remainders, then all look-ups (in flight together instead of one
+     load latency per group), then the sum; groups beyond the dimension's own read entry 0 and are left out of the sum */
+  uint32_t rem[7], digit[7];
+#pragma unroll
+  for(int g=0;g<7;g++)
+  { /* index / P and index % P: floor(2^32/P) as reciprocal is at most one too small */
+    uint32_t q = __umulhi(index, recip);
+    uint32_t r = index - q*P;
+    if(r >= P) { q++; r -= P; }
+    rem[g] = (uint32_t)g < groups ? r : 0u;
+    index = q;
+  }
+#pragma unroll
+  for(int g=0;g<7;g++) digit[g] = perm[rem[g]];
+  uint32_t sum = 0;
+#pragma unroll
+  for(int g=0;g<7;g++) if((uint32_t)g < groups) sum = sum*P + digit[g];
+  return (float)sum*__uint_as_float(d.w);
+}
+
+/* the camera's dimensions (1..5: bases 3, 5, 7, 11, 13) are the same for every path: constants instead of the descriptor load,
+ * divisions by constants, all table look-ups in flight together. P, G, OFF as halton_layout (mi_halton.h) computes them. */
+template<uint32_t P, uint32_t G, uint32_t OFF>
+__device__ __forceinline__ float halton_const(const DScene &sc, uint32_t index)
+{
+  const unsigned short *perm = sc.halton_perm + OFF;
+  uint32_t digit[G];
+#pragma unroll
+  for(uint32_t g=0;g<G;g++) { digit[g] = perm[index % P]; index /= P; }
+  uint32_t sum = 0;
+  double M = 1.0;
+#pragma unroll
+  for(uint32_t g=0;g<G;g++) { sum = sum*P + digit[g]; M *= (double)P; }
+  return (float)sum*(float)(0x1.fffffcp-1/M);
+}
+template<int DIM>
+__device__ __forceinline__ float halton_camera(const DScene &sc, uint32_t index)
+{
+  static_assert(DIM >= 0 && DIM <= 5, "camera dimensions");
+  if(DIM == 0) return __uint_as_float(0x3f800000u | (__brev(index) >> 9)) - 1.0f;
+  if(DIM == 1) return halton_const<243, 4, 0>(sc, index);
+  if(DIM == 2) return halton_const<125, 4, 243>(sc, index);
+  if(DIM == 3) return halton_const<343, 3, 368>(sc, index);
+  if(DIM == 4) return halton_const<121, 4, 711>(sc, index);
+  return halton_const<169, 4, 832>(sc, index);
+}
+
+/* vertex v's first dimension: the camera owns 7, v[1] the free-path dimension, every extension 5; ptdl's next-event vertex
+ * owns 4 more, which path_pop hands to the vertex before it (thinlens.c:100-103, src/pathspace.c:199,208,298, nee.h:108,231) */
+template<bool PTDL> __device__ __forceinline__ int rand_beg_extend(int v) { return PTDL ? 12 + 9*(v-2) : 8 + 5*(v-2); }
+__device__ __forceinline__ int rand_beg_nee(int v) { return 8 + 9*(v-2); }
+
+template<bool HALTON>
+struct PointSampler
+{
+  const DScene &sc;
+  Rng &rng;
+  uint32_t index;
+  int beg;                       /* rand_beg of the vertex under construction */
+  __device__ __forceinline__ PointSampler(const DScene &sc_, Rng &rng_, unsigned long long index_, int beg_) : sc(sc_), rng(rng_), index((uint32_t)index_), beg(beg_) {}
+  __device__ __forceinline__ float operator()(int dim)
+  {
+    if(HALTON && beg + dim < 256) return halton_sample(sc, (uint32_t)(beg + dim), index);
+    return rng_next(rng);
+  }
+  template<int DIM> __device__ __forceinline__ float camera()
+  {
+    if(HALTON) return halton_camera<DIM>(sc, index);
+    return rng_next(rng);
+  }
+};
+
 /* ------------------------------------------------------------------------------------------ work counters
  * cnt[0..7]: rays, node visits, box hits, primitive tests, paths, splats, vertices, deepest stack. Development builds
  * append more: -DMI_PROFILE_LOOPS wave-level loop iterations (cnt[8..10]), -DMI_PROFILE_PHASES lane-0 clock ticks per
@@ -958,10 +1045,11 @@ struct BsdfSample
   uint32_t mode;     /* v[v].mode after sampling */
 };
 
-__device__ __forceinline__ void sample_diffuse(Rng &rng, const Surf &sf, const Shading &sh, uint32_t mode_in, BsdfSample &bs)
+template<class PS>
+__device__ __forceinline__ void sample_diffuse(PS &pts, const Surf &sf, const Shading &sh, uint32_t mode_in, BsdfSample &bs)
 { /* sample_d, src/shader.c:165-205 */
-  const float x1 = rng_next(rng);
-  const float x2 = rng_next(rng);
+  const float x1 = pts(MI_DIM_OMEGA_X);
+  const float x2 = pts(MI_DIM_OMEGA_Y);
   const float sq = sqrtf(x1);
   const float c0 = sqrtf((float)(1.0 - (double)x1));
   const float ang = (float)(2*MI_PI_D*(double)x2);
@@ -979,7 +1067,8 @@ __device__ __forceinline__ void sample_diffuse(Rng &rng, const Surf &sf, const S
   if(bs.weight > 0.0f) bs.mode = s_diffuse | s_reflect;
 }
 
-__device__ __forceinline__ void sample_dielectric(Rng &rng, const Surf &sf, const Shading &sh, const V3 wi, float eta_ratio,
+template<class PS>
+__device__ __forceinline__ void sample_dielectric(PS &pts, const Surf &sf, const Shading &sh, const V3 wi, float eta_ratio,
                                                   uint32_t mode_in, BsdfSample &bs)
 { /* sample, dielectric.c:240-415 (MF_COUNT == 1) */
   bs.mode = mode_in; bs.weight = 0.0f; bs.pdf = 1.0f; bs.omega = mk3(0, 0, 0);
@@ -1000,8 +1089,8 @@ __device__ __forceinline__ void sample_dielectric(Rng &rng, const Surf &sf, cons
   if(r > GLOSSY_THR)
   {
     const V3 wit = mk3(-dot3(sf.a, wi), -dot3(sf.b, wi), cos_in);
-    const float U2 = rng_next(rng);          /* argument evaluation order of the reference build, SURVEY app. B */
-    const float U1 = rng_next(rng);
+    const float U2 = pts(MI_DIM_OMEGA_Y);          /* argument evaluation order of the reference build, SURVEY app. B */
+    const float U1 = pts(MI_DIM_OMEGA_X);
     const V3 ht = ggx_sample_h(wit, r, r, U1, U2);
     h = mk3(ht.x*sf.a.x + ht.y*sf.b.x + ht.z*n.x, ht.x*sf.a.y + ht.y*sf.b.y + ht.z*n.y, ht.x*sf.a.z + ht.y*sf.b.z + ht.z*n.z);
     pdf_h = ggx_pdf_h(wi, h, n, r);
@@ -1014,7 +1103,7 @@ __device__ __forceinline__ void sample_dielectric(Rng &rng, const Surf &sf, cons
   const float cost2 = 1.0f - (nr*nr)*(1.0f - cosr*cosr);
   const float cost = cost2 <= 0.0f ? 0.0f : sqrtf(cost2);
   const float R = fresnel_dielectric(n1, n2, cosr, cost);
-  if(rng_next(rng) <= R)
+  if(pts(MI_DIM_SCATTER_MODE) <= R)
   {
     bs.mode = s_reflect;
     bs.omega = mk3(wi.x + 2.0f*cosr*h.x, wi.y + 2.0f*cosr*h.y, wi.z + 2.0f*cosr*h.z);
@@ -1053,7 +1142,8 @@ __device__ __forceinline__ void sample_dielectric(Rng &rng, const Surf &sf, cons
   }
 }
 
-__device__ __forceinline__ void sample_metal(const DScene &sc, Rng &rng, const Surf &sf, const Shading &sh, const V3 wi, float n1,
+template<class PS>
+__device__ __forceinline__ void sample_metal(const DScene &sc, PS &pts, const Surf &sf, const Shading &sh, const V3 wi, float n1,
                                              int mat, float lambda, uint32_t mode_in, BsdfSample &bs)
 { /* sample, metal.c:219-265 */
   bs.mode = mode_in; bs.weight = 0.0f; bs.pdf = 1.0f; bs.omega = mk3(0, 0, 0);
@@ -1064,8 +1154,8 @@ __device__ __forceinline__ void sample_metal(const DScene &sc, Rng &rng, const S
   if(r > 1e-4f)
   {
     const V3 wit = mk3(-dot3(sf.a, wi), -dot3(sf.b, wi), -dot3(n, wi));
-    const float U2 = rng_next(rng);
-    const float U1 = rng_next(rng);
+    const float U2 = pts(MI_DIM_OMEGA_Y);
+    const float U1 = pts(MI_DIM_OMEGA_X);
     const V3 ht = ggx_sample_h(wit, r, r, U1, U2);
     h = mk3(ht.x*sf.a.x + ht.y*sf.b.x + ht.z*n.x, ht.x*sf.a.y + ht.y*sf.b.y + ht.z*n.y, ht.x*sf.a.z + ht.y*sf.b.z + ht.z*n.z);
     pdf_h = ggx_pdf_h(wi, h, n, r);

@@ -64,27 +64,27 @@ __device__ __forceinline__ void rec_vertex(mi_path_record *rec, int v, uint64_t 
 }
 
 /* start path `index`: afterwards ps holds the camera ray as the pending extension ray */
-template<bool RECORD>
+template<bool RECORD, bool HALTON>
 __device__ __forceinline__ void path_generate(const DScene &sc, PathState &ps, unsigned long long index, mi_path_record *rec, uint32_t *cnt)
 {
   /* path_init + first half of path_extend (length == 0), src/pathspace.c:13-28,210-249 */
   ps.index = index;
   rng_seed(ps.rng, ps.index, sc.frame);
-  ps.scramble = 0.1f + rng_next(ps.rng)*(0.9f-0.1f);
-  const float lf0 = rng_next(ps.rng) + 0/(float)1;
+  PointSampler<HALTON> pts(sc, ps.rng, index, 0);
+  ps.scramble = 0.1f + rng_next(ps.rng)*(0.9f-0.1f);          /* points_rand, not the point sampler: src/pathspace.c:213 */
+  const float lf0 = pts.template camera<MI_DIM_LAMBDA>() + 0/(float)1;
   const float lf = lf0 < 1.0f ? lf0 : fmodf(lf0, 1.0f);     /* fmodf(x, 1) == x for 0 <= x < 1; the libm loop only runs otherwise */
   ps.lambda = 360 + (830 - 360)*lf;
-  const float time = rng_next(ps.rng)*sc.cam.time_scale;
-  (void)rng_next(ps.rng);
-  (void)rng_next(ps.rng);
+  const float time = pts.template camera<MI_DIM_TIME>()*sc.cam.time_scale;
+  if(!HALTON) { (void)rng_next(ps.rng); (void)rng_next(ps.rng); }   /* view_sample_camid twice (one camera): src/pathspace.c:226, src/view.c:846-847 */
   /* camera_sample, src/camera.d/thinlens.c:68-128; everything that does not depend on the random numbers is in sc.cc */
   const mi_camera &cam = sc.cam;
   const DCamConst &cc = sc.cc;
   const float W = cc.W, H = cc.H;
-  const float ci = rng_next(ps.rng)*W;
-  const float cj = rng_next(ps.rng)*H;
-  const float r1 = rng_next(ps.rng);
-  const float r2 = rng_next(ps.rng);
+  const float ci = pts.template camera<MI_DIM_IMAGE_X>()*W;
+  const float cj = pts.template camera<MI_DIM_IMAGE_Y>()*H;
+  const float r1 = pts.template camera<MI_DIM_APERTURE_X>();
+  const float r2 = pts.template camera<MI_DIM_APERTURE_Y>();
   const float ang = (float)(2*MI_PI_D*(double)r1);
   float sn, cs;
   sincosf(ang, &sn, &cs);                 /* one range reduction for both (same values as sinf/cosf) */
@@ -161,7 +161,7 @@ __device__ __forceinline__ void shadow_resolve(const DScene &sc, PathState &ps, 
 
 /* the extension ray ps.org/ps.dir has been traced into `hit`: create vertex v = ps.length, then either end the path
  * (ps.active = 0) or leave the next extension ray (and, for ptdl, possibly a shadow ray) in ps */
-template<bool RECORD, bool PTDL>
+template<bool RECORD, bool PTDL, bool HALTON>
 __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, const Hit &hit, const uint32_t *shape_material, const float *shape_L,
                                            mi_path_record *rec, uint32_t *cnt, SplatReq &splat)
 {
@@ -310,7 +310,8 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
         if(!PTDL && ps.length > 3)
         { /* path_russian_roulette, src/pathspace.c:273-292 */
           const float p_survival = DMIN(1.0f, vthr/ps.prev_throughput);
-          const float rr = rng_next(ps.rng);
+          PointSampler<HALTON> pts(sc, ps.rng, ps.index, rand_beg_extend<PTDL>(v));   /* the last vertex's dimensions, src/pathspace.c:278-281 */
+          const float rr = pts(MI_DIM_RUSSIAN_R);
           if(rr >= p_survival) { vthr = vthr*(1.0f/(1.0f-p_survival)); alive = false; }
           else vthr = vthr*(1.0f/p_survival);
           if(RECORD && v < MI_REC_MAX_VERTS)
@@ -326,12 +327,13 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
         (void)rng_next(ps.rng);                                            /* points_rand < nee_probability == 1 */
         if(material_modes & (s_diffuse | s_glossy))
         {
-          const float rnd = rng_next(ps.rng);
+          PointSampler<HALTON> pts(sc, ps.rng, ps.index, rand_beg_nee(v + 1));          /* the next-event vertex is v+1, nee.h:92,108 */
+          const float rnd = pts(MI_DIM_NEE_LIGHT1);
           if(!(rnd < sc.p_sky) && rnd < sc.p_sky + sc.p_geo)
           { /* lights_sample_next_event, src/lights.d/list.c:130-174 (arguments drawn right to left) */
-            const float r3 = rng_next(ps.rng);
-            const float r2 = rng_next(ps.rng);
-            const float r1 = rng_next(ps.rng);
+            const float r3 = pts(MI_DIM_NEE_Y);
+            const float r2 = pts(MI_DIM_NEE_X);
+            const float r1 = pts(MI_DIM_NEE_LIGHT2);
             const uint32_t t = sample_cdf(sc.light_cdf, (int)sc.num_lights, r1);
             const uint32_t lp = sc.light_prim[t];
             Surf ls;
@@ -417,9 +419,10 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
       if(alive)
       {
         BsdfSample bs;
-        if(mat_bsdf == MI_BSDF_DIFFUSE) sample_diffuse(ps.rng, sf, sh, mode, bs);
-        else if(mat_bsdf == MI_BSDF_DIELECTRIC) sample_dielectric(ps.rng, sf, sh, omega, eta_ratio, mode, bs);
-        else sample_metal(sc, ps.rng, sf, sh, omega, ps.cur_ior, (int)mat_p0, ps.lambda, mode, bs);
+        PointSampler<HALTON> pts(sc, ps.rng, ps.index, rand_beg_extend<PTDL>(v + 1));   /* the vertex the sample leads to */
+        if(mat_bsdf == MI_BSDF_DIFFUSE) sample_diffuse(pts, sf, sh, mode, bs);
+        else if(mat_bsdf == MI_BSDF_DIELECTRIC) sample_dielectric(pts, sf, sh, omega, eta_ratio, mode, bs);
+        else sample_metal(sc, pts, sf, sh, omega, ps.cur_ior, (int)mat_p0, ps.lambda, mode, bs);
         MI_PHASE(cnt, 7)
         /* shader_sample tail, src/shader.c:582-589 */
         bs.omega = normalise3(bs.omega);

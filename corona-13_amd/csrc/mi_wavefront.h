@@ -110,7 +110,7 @@ __global__ __launch_bounds__(WF_LOGIC_BLOCK) void wf_logic(DScene sc, WFPool poo
     ps.prev_mode = 0; ps.prev_x = mk3(0, 0, 0);
     Hit hit;
     hit.prim = WF(F_HITPRIM); hit.dist = WFF(F_HITDIST); hit.u = WFF(F_HITU); hit.v = WFF(F_HITV);
-    path_shade<false, PTDL>(sc, ps, hit, shape_material, shape_L, nullptr, cnt, splat);
+    path_shade<false, PTDL, false>(sc, ps, hit, shape_material, shape_L, nullptr, cnt, splat);
   }
   splat_wave(sc, splat.pending, ps.pixel_i, ps.pixel_j, splat.c0, splat.c1, splat.c2);
 
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(WF_LOGIC_BLOCK) void wf_logic(DScene sc, WFPool poo
       const unsigned long long i = blk_base + wave_off + __popcll(m & ((1ull << lane) - 1ull));
       if(i < hi)
       {
-        path_generate<false>(sc, ps, first + i, nullptr, cnt);
+        path_generate<false, false>(sc, ps, first + i, nullptr, cnt);
       }
     }
   }

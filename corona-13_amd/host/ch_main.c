@@ -2,7 +2,7 @@
  * (src/main.c:415-437, usage 420-428; src/view.c:275-292; src/display.d/null.c:50-75):
  *
  *   corona-mi <scene.nra2> [-s spp] [-w width] [-h height] [-x postfix] [--frame n] [--batch n]
- *             [--sampler pt|ptdl] [--max-verts n] [--rgb2spec lut]  [--iso v] [-c cam] [--info] [--device-build]
+ *             [--sampler pt|ptdl] [--pointsampler rand|halton] [--max-verts n] [--rgb2spec lut]  [--iso v] [-c cam] [--info] [--device-build]
  *
  * --info validates the scene files (.nra2, .geo, .cam) on the host and prints what the backend would get, without
  * touching a GPU (validators for the on-disk formats).
@@ -28,7 +28,7 @@ int main(int argc, char *argv[])
   if(argc < 2)
   {
     fprintf(stderr, "usage: %s <scene.nra2> [-s spp] [-w w] [-h h] [-x postfix] [--frame n] [--batch n]\n"
-                    "          [--sampler pt|ptdl] [--max-verts n] [--rgb2spec ergb2spec.coeff] [--iso v] [-c file.cam] [--info]\n", argv[0]);
+                    "          [--sampler pt|ptdl] [--pointsampler rand|halton] [--max-verts n] [--rgb2spec ergb2spec.coeff] [--iso v] [-c file.cam] [--info]\n", argv[0]);
     return 1;
   }
   ch_options opt;
@@ -53,6 +53,7 @@ int main(int argc, char *argv[])
     else if(!strcmp(argv[i], "--info")) info_only = 1;
     else if(!strcmp(argv[i], "--device-build")) device_build = 1;     /* hand the scene over without the host-built tree */
     else if(!strcmp(argv[i], "--sampler") && i+1 < argc) opt.sampler = !strcmp(argv[++i], "ptdl") ? MI_SAMPLER_PTDL : MI_SAMPLER_PT;
+    else if(!strcmp(argv[i], "--pointsampler") && i+1 < argc) opt.pointsampler = !strcmp(argv[++i], "halton") ? MI_POINTS_HALTON : MI_POINTS_RAND;
   }
   if(!batch) batch = 1;
   ch_scene *scene = 0;
@@ -69,8 +70,8 @@ int main(int argc, char *argv[])
       if(cnt) { leaves++; leaf_prims += cnt; if(cnt > leaf_max) leaf_max = cnt; }
     }
     printf("scene    : %s\n", argv[1]);
-    printf("film     : %ux%u (padded to multiples of 32), max path vertices %u, sampler %s, frame %lu\n", d->width, d->height, d->max_verts,
-        d->sampler == MI_SAMPLER_PTDL ? "ptdl" : "pt", (unsigned long)d->frame);
+    printf("film     : %ux%u (padded to multiples of 32), max path vertices %u, sampler %s, points %s, frame %lu\n", d->width, d->height, d->max_verts,
+        d->sampler == MI_SAMPLER_PTDL ? "ptdl" : "pt", d->pointsampler == MI_POINTS_HALTON ? "halton" : "rand", (unsigned long)d->frame);
     printf("shapes   : %u, materials %u\n", d->num_shapes, d->num_materials);
     printf("prims    : %lu (spheres %lu, lines %lu, triangles %lu, quads %lu)\n", (unsigned long)d->num_prims, (unsigned long)kinds[1],
         (unsigned long)kinds[2], (unsigned long)kinds[3], (unsigned long)kinds[4]);
@@ -128,6 +129,7 @@ int main(int argc, char *argv[])
         (unsigned long)overlays, t_prog/overlays, d->max_verts, d->width, d->height, t_prog);
     fprintf(f, "           cam 0 average image intensity (rgb): (%f %f %f)\n", mean[0]*gain/per, mean[1]*gain/per, mean[2]*gain/per);
     fprintf(f, "sampler  : %s\n", d->sampler == MI_SAMPLER_PTDL ? "pathtracer with next event estimation and mis" : "pathtracer");
+    fprintf(f, "mutations: %s\n", d->pointsampler == MI_POINTS_HALTON ? "halton points" : "none");
     fprintf(f, "work     : %.4f rays %.4f node visits %.4f prim tests %.5f splats per sample\n",
         (double)cnt[0]/cnt[4], (double)cnt[1]/cnt[4], (double)cnt[3]/cnt[4], (double)cnt[5]/cnt[4]);
     fclose(f);

@@ -31,12 +31,21 @@ CASES = [
     ("fine backdrop (tree in HBM) ptdl mv8", SCENE_FINE, pkg.MI_SAMPLER_PTDL, 1280, 720, 8, 10000),
     ("metal pt mv8", SCENE_METAL, pkg.MI_SAMPLER_PT, 1280, 720, 8, 8000),
     ("metal ptdl mv8", SCENE_METAL, pkg.MI_SAMPLER_PTDL, 1280, 720, 8, 8000),
+    # MOD_pointsampler = halton; ptdl at depth 32 reaches dimensions >= 256 (generator fall-back)
+    ("halton pt mv8", SCENE_0010, pkg.MI_SAMPLER_PT, 1280, 720, 8, 60000),
+    ("halton ptdl mv8", SCENE_0010, pkg.MI_SAMPLER_PTDL, 1280, 720, 8, 40000),
+    ("halton ptdl rough dielectric mv32", SCENE_ROUGH, pkg.MI_SAMPLER_PTDL, 1280, 720, 32, 30000),
+    ("halton fine backdrop (tree in HBM) pt mv8", SCENE_FINE, pkg.MI_SAMPLER_PT, 1280, 720, 8, 10000),
 ]
+
+
+def points_of(name):
+    return pkg.MI_POINTS_HALTON if name.startswith("halton") else pkg.MI_POINTS_RAND
 
 
 @pytest.mark.parametrize("name,scene_path,sampler,w,h,mv,n", CASES)
 def test_paths_match_oracle(name, scene_path, sampler, w, h, mv, n):
-    scene = make_scene(scene_path, width=w, height=h, max_verts=mv, sampler=sampler)
+    scene = make_scene(scene_path, width=w, height=h, max_verts=mv, sampler=sampler, pointsampler=points_of(name))
     be = pkg.Backend(scene)
     first = 12345
     gpu = be.trace_paths(first, n)
@@ -526,3 +535,67 @@ def test_scene_stats():
     st = be.stats()
     assert st["device_built"] and scene.desc.num_prims // 8 <= st["nodes"] < scene.desc.num_prims
     be.close()
+
+
+def test_halton_long_paths_against_reference_golden():
+    """the reference's own 29..32-vertex ptdl paths (dimension >= 256 falls back to the per-path generator, halton.c:78-80)"""
+    g = np.load(GOLDEN / "paths_halton_long_mv32.npz")
+    ref = g["records"]
+    scene = make_scene(SCENE_ROUGH, width=1280, height=720, max_verts=32, sampler=pkg.MI_SAMPLER_PTDL, pointsampler=pkg.MI_POINTS_HALTON)
+    be = pkg.Backend(scene)
+    gpu = np.concatenate([be.trace_paths(int(i), 1) for i in ref["index"]])
+    ora = np.concatenate([oracle_records(scene, int(i), 1) for i in ref["index"]])
+    assert (gpu["length"] == ora["length"]).mean() >= 0.98 and (gpu["length"] == ref["length"]).mean() >= 0.97
+    same = gpu["length"] == ref["length"]
+    for k in range(8):
+        assert (gpu["v"]["prim"][same, k] == ref["v"]["prim"][same, k]).mean() >= 0.99
+    m = same & (gpu["num_splats"] == ref["num_splats"]) & (ref["num_splats"] > 0)
+    assert m.sum() > 100 and (gpu["splat"]["length"][m] == ref["splat"]["length"][m]).all()
+    be.close()
+
+
+def test_halton_golden_and_reseeding():
+    """the first reference paths directly; and a range whose end passes 2^32 indices is rendered with the permutations of
+    seed frame + 1 (pointsampler_prepare_frame, halton.c:122-129) while the index itself is cut to 32 bits"""
+    g = np.load(GOLDEN / "paths_halton_pt_mv8.npz")
+    ref = g["records"]
+    scene = make_scene(SCENE_0010, width=1280, height=720, max_verts=8, pointsampler=pkg.MI_POINTS_HALTON)
+    be = pkg.Backend(scene)
+    gpu = be.trace_paths(0, len(ref))
+    assert np.abs(gpu["pixel_i"] - ref["pixel_i"]).max() <= 1e-4 and np.abs(gpu["pixel_j"] - ref["pixel_j"]).max() <= 1e-4
+    assert np.abs(gpu["lambda"] - ref["lambda"]).max() <= 1e-4
+    assert (gpu["length"] == ref["length"]).mean() >= 0.998
+    first = (1 << 32) - 700
+    hi = be.trace_paths(first, 1500)                       # end >> 32 == 1
+    ora = oracle_records(scene, first, 1500)
+    assert np.array_equal(hi["pixel_i"], ora["pixel_i"]) and np.array_equal(hi["lambda"], ora["lambda"])
+    assert (hi["length"] == ora["length"]).mean() >= 0.998
+    lo = be.trace_paths(first, 600)                        # end >> 32 == 0: same indices, other permutations
+    assert np.array_equal(lo["pixel_i"], hi["pixel_i"][:600])          # base 2 and 3 are not permuted
+    assert not np.array_equal(lo["lambda"], hi["lambda"][:600])        # base 5 is
+    again = be.trace_paths(0, len(ref))                    # back to the first tables
+    assert np.array_equal(again["lambda"], gpu["lambda"]) and np.array_equal(again["length"], gpu["length"])
+    be.close()
+
+
+def test_halton_image_matches_oracle_and_differs_from_rand(monkeypatch):
+    scene = make_scene(SCENE_0010, width=256, height=256, max_verts=8, pointsampler=pkg.MI_POINTS_HALTON)
+    npx = scene.width * scene.height
+    be = pkg.Backend(scene)
+    be.render(0, 4 * npx)
+    fb = be.fb_read()
+    ofb, ocnt, _ = oracle_render(scene, 0, 4 * npx, threads=8)
+    cnt = be.counters()
+    be.close()
+    rmse = np.sqrt((((fb - ofb) * scene.gain(4)) ** 2).sum() / npx)
+    assert rmse < 0.05, rmse
+    assert cnt[4] == 4 * npx and abs(cnt[0] - ocnt[0]) <= 1e-4 * ocnt[0]
+    rnd = make_scene(SCENE_0010, width=256, height=256, max_verts=8)
+    be = pkg.Backend(rnd)
+    be.render(0, 4 * npx)
+    fr = be.fb_read()
+    be.close()
+    assert abs(fr.sum() - fb.sum()) < 0.25 * fb.sum() and not np.allclose(fr, fb)      # same image in expectation (pt at 4 spp: noisy), other samples
+    monkeypatch.setenv("CORONA_MI_MODE", "wave")
+    with pytest.raises(RuntimeError, match="megakernel"):
+        pkg.Backend(scene)
