@@ -53,7 +53,8 @@ class MiShadeOp(C.Structure):
 
 
 class MiMaterial(C.Structure):
-    _fields_ = [("bsdf", C.c_uint32), ("num_ops", C.c_uint32), ("op", MiShadeOp * 4), ("param", C.c_float * 4)]
+    _fields_ = [("bsdf", C.c_uint32), ("num_ops", C.c_uint32), ("op", MiShadeOp * 4), ("param", C.c_float * 4),
+                ("mean_cos", C.c_float), ("interior", C.c_int32)]
 
 
 class MiCamera(C.Structure):

@@ -19,7 +19,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-enum { SH_DIFFUSE, SH_COLOR, SH_CHECKER, SH_MULT, SH_DIELECTRIC, SH_METAL, SH_OTHER };
+enum { SH_DIFFUSE, SH_COLOR, SH_CHECKER, SH_MULT, SH_DIELECTRIC, SH_METAL, SH_MEDIUM, SH_INTERIOR, SH_OTHER };
 
 typedef struct ch_shader
 {
@@ -30,7 +30,7 @@ typedef struct ch_shader
   float rgb[3], coeff[3], mul, roughness;
   /* mult */
   int num_pre, pre[MI_MAX_OPS], host;
-  /* dielectric: n_d, abbe; metal: table id */
+  /* dielectric: n_d, abbe; metal: table id; medium_rgb: mean cosine (mu_t colour in rgb/coeff/mul); interior: surface, medium in pre[0], host */
   float param[4];
 }
 ch_shader;
@@ -174,6 +174,23 @@ static int parse_shader_line(ch_scene *s, int id, char *line)
     if(m < 0) { fprintf(stderr, "[ch] metal: unknown material `%s', using Ti\n", mat); m = 0; }
     sh->param[0] = (float)m;
   }
+  else if(!strcmp(name, "medium_rgb"))
+  { /* src/shaders/medium_rgb.c:104-129: mean free paths r g b [dm] -> collision coefficients -> spectrum, mean cosine */
+    sh->kind = SH_MEDIUM;
+    float mfp[3];
+    if(sscanf(args, "%f %f %f %f", mfp, mfp+1, mfp+2, sh->param) != 4)
+    { fprintf(stderr, "[ch] medium_rgb: expecting <mean free path r g b> <mean cosine> in shader %d\n", id); return 1; }
+    for(int k=0;k<3;k++) sh->rgb[k] = 1.0f/mfp[k];
+    sh->mul = ch_rgb_to_coeff(sh->rgb, sh->coeff, s->opt.rgb2spec_lut);
+  }
+  else if(!strcmp(name, "interior"))
+  { /* src/shaders/interior.c:52-72: <surface id> <interior id>, negative = relative */
+    sh->kind = SH_INTERIOR;
+    int a = 0, b = 0;
+    if(sscanf(args, "%d %d", &a, &b) != 2) { fprintf(stderr, "[ch] interior: expecting <surface id> <interior id> in shader %d\n", id); return 1; }
+    sh->pre[0] = a < 0 ? id + a : a;
+    sh->host = b < 0 ? id + b : b;
+  }
   else sh->kind = SH_OTHER;                 /* outside the hot-path scope; fine unless a shape uses it */
   return 0;
 }
@@ -183,7 +200,18 @@ static int compile_material(const ch_scene *s, int id, mi_material *m)
 {
   memset(m, 0, sizeof(*m));
   m->bsdf = MI_BSDF_NONE;
+  m->interior = -1;
   const ch_shader *sh = s->shader + id;
+  if(sh->kind == SH_INTERIOR)
+  { /* the surface's material plus a link to the medium that fills the shape (interior.c:101-118) */
+    if(sh->pre[0] < 0 || sh->pre[0] >= s->num_shaders || sh->host < 0 || sh->host >= s->num_shaders) return 1;
+    if(s->shader[sh->pre[0]].kind == SH_INTERIOR) return 1;
+    mi_material medium;
+    if(compile_material(s, sh->host, &medium) || medium.bsdf != MI_BSDF_MEDIUM) return 1;
+    if(compile_material(s, sh->pre[0], m) || m->bsdf == MI_BSDF_MEDIUM) { m->bsdf = MI_BSDF_NONE; return 1; }
+    m->interior = sh->host;
+    return 0;
+  }
   const ch_shader *host = sh;
   if(sh->kind == SH_MULT)
   {
@@ -213,6 +241,7 @@ static int compile_material(const ch_scene *s, int id, mi_material *m)
     case SH_DIFFUSE:    m->bsdf = MI_BSDF_DIFFUSE; break;
     case SH_DIELECTRIC: m->bsdf = MI_BSDF_DIELECTRIC; m->param[0] = host->param[0]; m->param[1] = host->param[1]; break;
     case SH_METAL:      m->bsdf = MI_BSDF_METAL; m->param[0] = host->param[0]; break;
+    case SH_MEDIUM:     m->bsdf = MI_BSDF_MEDIUM; memcpy(m->param, host->coeff, 3*sizeof(float)); m->param[3] = host->mul; m->mean_cos = host->param[0]; break;
     default: return 1;
   }
   return 0;
@@ -467,7 +496,7 @@ static void apply_coeff_cache(ch_scene *s)
   {
     float rgb[3], c[3], mul;
     if(line[0] == '#' || sscanf(line, "%f %f %f %f %f %f %f", rgb, rgb+1, rgb+2, c, c+1, c+2, &mul) != 7) continue;
-    for(int i=0;i<s->num_shaders;i++) if(s->shader[i].kind == SH_COLOR &&
+    for(int i=0;i<s->num_shaders;i++) if((s->shader[i].kind == SH_COLOR || s->shader[i].kind == SH_MEDIUM) &&
         s->shader[i].rgb[0] == rgb[0] && s->shader[i].rgb[1] == rgb[1] && s->shader[i].rgb[2] == rgb[2])
     {
       memcpy(s->shader[i].coeff, c, sizeof(c));
@@ -611,7 +640,7 @@ const char *ch_scene_shader_name(const ch_scene *s, int i) { return (i >= 0 && i
 
 int ch_scene_set_color_coeff(ch_scene *s, int id, const float coeff[3], float mul)
 {
-  if(id < 0 || id >= s->num_shaders || s->shader[id].kind != SH_COLOR) return MI_ERR_ARG;
+  if(id < 0 || id >= s->num_shaders || (s->shader[id].kind != SH_COLOR && s->shader[id].kind != SH_MEDIUM)) return MI_ERR_ARG;
   memcpy(s->shader[id].coeff, coeff, 3*sizeof(float));
   s->shader[id].mul = mul;
   for(int i=0;i<s->num_shaders;i++) compile_material(s, i, s->materials + i);

@@ -85,6 +85,7 @@ typedef struct mi_node
 #define MI_BSDF_DIFFUSE    0   /* builtin diffuse, src/shader.c:157-257          */
 #define MI_BSDF_DIELECTRIC 1   /* src/shaders/dielectric.c                       */
 #define MI_BSDF_METAL      2   /* src/shaders/metal.c                            */
+#define MI_BSDF_MEDIUM     3   /* homogeneous medium, src/shaders/medium_rgb.c: only as the interior of a surface material */
 #define MI_BSDF_NONE       255 /* shader kind outside the scope; error if a shape uses it */
 
 #define MI_OP_COLOR   0        /* src/shaders/color.c:75-82                      */
@@ -94,7 +95,7 @@ typedef struct mi_node
 #define MI_SLOT_SPECULAR 1
 #define MI_SLOT_GLOSSY   2
 #define MI_SLOT_EMISSION 3
-#define MI_SLOT_VOLUME   4
+#define MI_SLOT_VOLUME   4     /* albedo of a medium: mu_s = albedo * mu_t (texture.h:48-53, medium_rgb.c:45-59) */
 #define MI_SLOT_ROUGHNESS 5
 #define MI_SLOT_UNUSED   6
 
@@ -114,7 +115,10 @@ typedef struct mi_material
   uint32_t    bsdf;           /* MI_BSDF_*                                        */
   uint32_t    num_ops;        /* prepare chain, executed in order before the bsdf's own prepare */
   mi_shade_op op[MI_MAX_OPS];
-  float       param[4];       /* dielectric: n_d, abbe ; metal: table id, -, -    */
+  float       param[4];       /* dielectric: n_d, abbe ; metal: table id, -, - ; medium: rgb2spec coefficients of mu_t, scale */
+  float       mean_cos;       /* medium: Henyey-Greenstein mean cosine g                                  */
+  int32_t     interior;       /* `interior <surface> <medium>` (src/shaders/interior.c): shader id of the MI_BSDF_MEDIUM material
+                                 that fills the shape (its colour op in the volume slot = single-scattering albedo), or -1 */
 } mi_material;
 
 /* ---- thin-lens camera, resolved for a static camera (src/camera.d/thinlens.c:68-128,

@@ -59,7 +59,7 @@ typedef struct o_hit
 } o_hit;
 
 typedef struct o_shading { float roughness, rs, rd, rg, em; } o_shading;            /* vertex_shading_t */
-typedef struct o_volume { float ior; int shader; float mu_s, mu_t; } o_volume;     /* vertex_volume_t (vacuum/ior only) */
+typedef struct o_volume { float ior; int shader; float mu_s, mu_t, mean_cos; } o_volume;   /* vertex_volume_t, include/pathspace.h:105-118 (homogeneous, no extra lobes) */
 
 typedef struct o_vertex
 { /* vertex_t */

@@ -146,19 +146,77 @@ static float o_view_cam_pdf(const o_ctx *c, const o_path *p)
   return (1.0f/(cam->film_width*cam->film_height))*(1.0f/A)/G;
 }
 
+/* ---------------------------------------------------------------- homogeneous media on an edge */
+static float o_vol_transmittance(o_path *p, int e)
+{ /* shader_vol_transmittance, src/shader.c:48-74 (homogeneous default case) */
+  p->e[e].contribution = 0.0f;
+  p->e[e].pdf = 1.0f;
+  if(p->e[e].vol.shader >= 0)
+  {
+    if((p->v[e].flags & s_environment) || (p->v[e-1].flags & s_environment)) p->e[e].transmittance = expf(-10000.0f*p->e[e].vol.mu_t);
+    else p->e[e].transmittance = expf(-p->e[e].dist*p->e[e].vol.mu_t);
+    p->e[e].pdf = 1.0f;
+    p->e[e].contribution = 0.0f;
+    return p->e[e].transmittance;
+  }
+  p->e[e].transmittance = 1.0f;
+  return p->e[e].transmittance;
+}
+
+static float o_vol_sample(o_ctx *c, o_path *p, int e)
+{ /* shader_vol_sample, src/shader.c:76-106: free flight distance; pointsampler(p, s_dim_free_path) with p->length == e */
+  float dist = FLT_MAX;
+  p->e[e].contribution = 0.0f;
+  p->e[e].pdf = 1.0f;
+  p->e[e].transmittance = 1.0f;
+  if(p->e[e].vol.shader >= 0)
+  {
+    if(p->e[e].vol.mu_s > 0.0f)
+    {
+      const float rf = o_point(c, p, e, 0);                /* s_dim_free_path */
+      dist = -logf(1.0f - rf)/p->e[e].vol.mu_t;
+      if(!(dist > 0.0)) dist = 1e-15;
+      p->e[e].pdf = p->e[e].transmittance = expf(-dist*p->e[e].vol.mu_t);
+      if(dist < p->e[e].dist) p->e[e].pdf = p->e[e].pdf*p->e[e].vol.mu_t;
+    }
+    else p->e[e].transmittance = expf(-p->e[e].dist*p->e[e].vol.mu_t);
+  }
+  return dist;
+}
+
+static float o_vol_pdf(const o_path *p, int e)
+{ /* shader_vol_pdf, src/shader.c:108-131 */
+  float pdf = 1.0f;
+  if(p->e[e].vol.shader >= 0 && p->e[e].vol.mu_s > 0.0f)
+  {
+    pdf = expf(-p->e[e].dist*p->e[e].vol.mu_t);
+    if(!(p->v[e].flags & s_environment) && p->v[e].hit.prim == MI_PRIMID_INVALID) pdf = pdf*p->e[e].vol.mu_t;
+  }
+  return pdf;
+}
+
 /* ---------------------------------------------------------------- propagate / extend */
 static int o_path_propagate(o_ctx *c, o_path *path, int v)
-{ /* path_propagate(path, v, s_propagate_sample), src/pathspace.c:697-895; vacuum everywhere
-     (shader_vol_sample returns FLT_MAX with transmittance = pdf = 1, src/shader.c:76-106) */
+{ /* path_propagate(path, v, s_propagate_sample), src/pathspace.c:697-895; homogeneous media only */
   const mi_scene_desc *s = c->s;
   if(o_path_edge_init_volume(path, v)) return 1;
   path->v[v].mode = s_absorb;
   path->v[v].flags = s_none;
+  /* homogeneous + scattering: sample the clip distance first, then trace up to it (src/pathspace.c:717-751) */
+  const int sample_vol_first = path->e[v].vol.mu_s > 0.0;
+  int vshader = -1;
+  float clipdist = FLT_MAX;
+  if(sample_vol_first)
+  {
+    path->e[v].dist = FLT_MAX;
+    clipdist = o_vol_sample(c, path, v);
+  }
+  if(clipdist < FLT_MAX) vshader = path->e[v].vol.shader;
   o_hit *hit = &path->v[v].hit;
   o_ray ray;
   hit->prim = MI_PRIMID_INVALID;
-  hit->dist = FLT_MAX;
-  hit->shader = -1;
+  hit->dist = clipdist;
+  hit->shader = vshader;
   for(int k=0;k<3;k++) ray.pos[k] = path->v[v-1].hit.x[k];
   for(int k=0;k<3;k++) ray.dir[k] = path->e[v].omega[k];
   ray.time = path->time;
@@ -176,9 +234,12 @@ static int o_path_propagate(o_ctx *c, o_path *path, int v)
   if((MI_PRIMID_VCNT(hit->prim) > 2 || path->e[v].dist < 1e-4f) &&
       hit->prim != MI_PRIMID_INVALID && hit->prim == path->v[v-1].hit.prim)
     return 5;
-  path->e[v].contribution = 0.0f;
-  path->e[v].pdf = 1.0f;
-  path->e[v].transmittance = 1.0f;
+  if(!sample_vol_first)
+  { /* src/pathspace.c:822-838; a homogeneous medium without scattering only attenuates, the sampled distance is FLT_MAX */
+    (void)o_vol_sample(c, path, v);
+  }
+  else if(path->e[v].vol.shader >= 0 && !(path->v[v].material_modes & s_volume))
+    path->e[v].pdf = path->e[v].transmittance = o_vol_transmittance(path, v);   /* geometry before the sampled distance */
   if(path->e[v].dist >= FLT_MAX)
   { /* environment, src/pathspace.c:856-873 */
     path->v[v].flags |= s_environment;
@@ -402,12 +463,12 @@ static float o_nee_pdf(const o_ctx *c, const o_path *p, int v)
 }
 
 static float o_path_pdf_extend(o_ctx *c, o_path *path, int v)
-{ /* path_pdf_extend, src/pathspace.c:384-400 (vacuum: shader_vol_pdf == 1) */
+{ /* path_pdf_extend, src/pathspace.c:384-400 */
   float pdf;
   if(v == 0) return 1.0f;
   else if(v == 1) pdf = o_view_cam_pdf(c, path);
   else pdf = o_shader_pdf(c, path, v-1);
-  return (1.0f*pdf)*o_path_G(path, v);
+  return (o_vol_pdf(path, v)*pdf)*o_path_G(path, v);
 }
 
 static int o_path_visible(o_ctx *c, o_path *p, int v)
@@ -485,7 +546,7 @@ static int o_nee_sample(o_ctx *c, o_path *p)
   if(p->v[p->length-1].flags & s_environment) return 1;
   if(p->length >= (int)s->max_verts) return 1;
   const int v = p->length;
-  float edf = 0.0f, bsdf = 0.0f;
+  float edf = 0.0f, bsdf = 0.0f, transmittance = 1.0f;
   int failed = 1;
   if(o_nee_possible(p, v-1))
   {
@@ -509,8 +570,7 @@ static int o_nee_sample(o_ctx *c, o_path *p)
       {
         o_shader_prepare(c, p, v);
         const float G = o_path_G(p, v);
-        p->e[v].contribution = 0.0f; p->e[v].pdf = 1.0f; p->e[v].transmittance = 1.0f;   /* shader_vol_transmittance */
-        const float transmittance = 1.0f;
+        transmittance = o_vol_transmittance(p, v);
         p->v[v].throughput = ((p->v[v-1].throughput*bsdf)*(transmittance*edf))*G;
         p->v[v].throughput = p->v[v].throughput + (p->v[v-1].throughput*bsdf)*((p->e[v].contribution*G)/p->v[v].pdf);
         p->throughput = p->v[v].throughput;
@@ -532,7 +592,7 @@ static int o_nee_sample(o_ctx *c, o_path *p)
   p->v[v].rand_cnt = 4;
   p->length++;
   const float pdf_nee = p->v[v].pdf, pdf_fnee = 0.0f;
-  const float weight = pdf_nee/(pdf_nee + pdf_fnee/1.0f);
+  const float weight = pdf_nee/(pdf_nee + pdf_fnee/transmittance);
   p->throughput = p->throughput*weight;
   p->v[v].throughput = p->v[v].throughput*weight;
   p->v[v].total_throughput = p->v[v].throughput;

@@ -89,7 +89,12 @@ static void o_set_slot(o_path *p, int v, uint32_t slot, float val)
     case MI_SLOT_GLOSSY:    p->v[v].shading.rg = val; return;
     case MI_SLOT_ROUGHNESS: p->v[v].shading.roughness = val; return;
     case MI_SLOT_EMISSION:  p->v[v].shading.em = val; return;
-    default: return;   /* volume slot: media are outside the scope */
+    case MI_SLOT_VOLUME:    /* homogeneous interior media get their lobe modes here, texture.h:48-53 */
+      p->v[v].material_modes = s_volume | s_glossy;
+      p->v[v].interior.mu_s = val;
+      p->v[v].interior.mu_t = 1.0f;
+      return;
+    default: return;
   }
 }
 
@@ -131,7 +136,19 @@ float o_shader_prepare(o_ctx *c, o_path *p, int v)
   }
   /* manifold_init, include/pathspace/manifold.h:215-232 (branch compiled without COMPUTE_MANIFOLD_STUFF) */
   o_hit *hit = &p->v[v].hit;
-  if(hit->prim == MI_PRIMID_INVALID) return 1.0f;    /* sensor; media are outside the scope */
+  if(hit->prim == MI_PRIMID_INVALID)
+  {
+    if(p->v[v].mode & s_sensor) return 1.0f;         /* manifold_init leaves the sensor alone, manifold.h:112-114 */
+    /* volume scattering, manifold.h:236-246: the frame looks along the incoming direction */
+    for(int k=0;k<3;k++) hit->n[k] = hit->gn[k] = p->e[v].omega[k];
+    o_get_scrambled_onb(p->scramble, hit->n, hit->a, hit->b);
+    if(p->e[v].vol.shader >= 0 && v > 0)
+    { /* homogeneous medium, src/shader.c:478-501: the vertex takes the edge's volume, assume a glossy lobe */
+      p->v[v].interior = p->e[v].vol;
+      p->v[v].material_modes = s_volume | s_glossy;
+    }
+    return 1.0f;
+  }
   o_prims_get_normal(s, hit->prim, hit);
   if(dot3(p->e[v].omega, hit->gn) > 0.0f)
   {
@@ -144,9 +161,21 @@ float o_shader_prepare(o_ctx *c, o_path *p, int v)
   hit->shader = s->shapes[MI_PRIMID_SHAPE(hit->prim)].material;
   memset(&p->v[v].shading, 0, sizeof(o_shading));
   p->v[v].shading.roughness = 1.0f;
-  p->v[v].interior.ior = 1.0f; p->v[v].interior.shader = -1; p->v[v].interior.mu_s = p->v[v].interior.mu_t = 0.0f;
+  memset(&p->v[v].interior, 0, sizeof(o_volume));    /* path_volume_vacuum */
+  p->v[v].interior.ior = 1.0f; p->v[v].interior.shader = -1;
 
   const mi_material *m = s->materials + hit->shader;
+  if(m->interior >= 0)
+  { /* `interior <surface> <medium>`, src/shaders/interior.c:101-118: the medium's prepare chain first (mult.c:154-167:
+       its colour op in the volume slot, then medium_rgb.c:45-59), then the surface; the volume keeps the medium's shader id */
+    const mi_material *med = s->materials + m->interior;
+    for(uint32_t k=0;k<med->num_ops;k++) o_prepare_op(s, med->op + k, p, v);
+    p->v[v].interior.mean_cos = med->mean_cos;
+    const float old_mu_t = p->v[v].interior.mu_t;
+    p->v[v].interior.mu_t = med->param[3]*o_spectrum_eval(med->param, p->lambda);
+    p->v[v].interior.mu_s = p->v[v].interior.mu_s*(p->v[v].interior.mu_t/old_mu_t);
+    p->v[v].interior.shader = m->interior;
+  }
   for(uint32_t k=0;k<m->num_ops;k++) o_prepare_op(s, m->op + k, p, v);      /* mult.c:154-167 */
   if(m->bsdf == MI_BSDF_DIFFUSE)
   { /* prepare_d, src/shader.c:157-162 */
@@ -676,6 +705,7 @@ static float o_pdf_metal(o_path *p, int v)
 }
 
 /* ---------------------------------------------------------------- dispatch */
+static float o_sample_medium(o_ctx *c, o_path *p);
 float o_shader_sample(o_ctx *c, o_path *p)
 { /* shader_sample, src/shader.c:577-590 */
   const int v = p->length-1;
@@ -684,6 +714,7 @@ float o_shader_sample(o_ctx *c, o_path *p)
   if(m->bsdf == MI_BSDF_DIFFUSE)         throughput = o_sample_diffuse(c, p);
   else if(m->bsdf == MI_BSDF_DIELECTRIC) throughput = o_sample_dielectric(c, p);
   else if(m->bsdf == MI_BSDF_METAL)      throughput = o_sample_metal(c, p);
+  else if(m->bsdf == MI_BSDF_MEDIUM)     throughput = o_sample_medium(c, p);
   o_normalise(p->e[v+1].omega);
   const float dt = ((p->v[v].flags & s_inside) ? -1 : 1)*dot3(p->v[v].hit.gn, p->e[v+1].omega);
   if(((p->v[v].mode & s_reflect) && (dt < 0.f)) || ((p->v[v].mode & s_transmit) && (dt > 0.f)))
@@ -691,9 +722,63 @@ float o_shader_sample(o_ctx *c, o_path *p)
   return throughput;
 }
 
+/* ---------------------------------------------------------------- homogeneous medium: Henyey-Greenstein */
+static float o_eval_hg(float g, const float *wi, const float *wo)
+{ /* sample_eval_hg, include/sampler_common.h:338-355 */
+  if(g == 0.0f) return 1.0f/(4.0f*M_PI);
+  const float cos_theta = dot3(wi, wo);
+  return 1.0f/(4.0f*M_PI)*(1.0f-g*g)/powf(1.0f + g*g - 2.0f*g*cos_theta, 3.0f/2.0f);
+}
+
+static float o_sample_medium(o_ctx *c, o_path *p)
+{ /* medium_rgb.c:61-72 + sample_hg, include/sampler_common.h:286-316. The two numbers are call arguments: drawn right to left
+     (omega_y first) by the reference build, like dielectric.c:266 */
+  const int v = p->length-1;
+  p->v[v].mode |= s_glossy | s_volume;
+  const o_hit *hit = &p->v[v].hit;
+  const float g = p->v[v].interior.mean_cos;
+  const float r2 = o_point(c, p, v+1, o_dim_omega_y);
+  const float r1 = o_point(c, p, v+1, o_dim_omega_x);
+  float out[3], pdf;
+  if(g == 0.0f)
+  { /* sample_sphere, include/sampler_common.h */
+    const float z = 1.0f - 2.0f*r1;
+    const float r = sqrtf(1.0f - z*z);
+    const float phi = 2.0f*M_PI*r2;
+    out[0] = r*cosf(phi); out[1] = r*sinf(phi); out[2] = z;
+    pdf = 1.0f/(4.0f*M_PI);
+  }
+  else
+  {
+    const float sqr = (1.0f-g*g)/(1.0f+g*(2.0f*r1-1.0f));
+    const float cos_theta = 1.0f/(2.0f*g)*(1.0f + g*g - sqr*sqr);
+    const float phi = 2.0f*M_PI*r2;
+    const float l = sqrtf(fmaxf(0.0f, 1.0f-cos_theta*cos_theta));
+    out[0] = cos_theta;
+    out[1] = cosf(phi)*l;
+    out[2] = sinf(phi)*l;
+    pdf = 1.0f/(4.0f*M_PI)*(1.0f-g*g)/powf(1.0f + g*g - 2.0f*g*cos_theta, 3.0f/2.0f);
+  }
+  p->v[v+1].pdf = pdf;
+  for(int k=0;k<3;k++) p->e[v+1].omega[k] = hit->n[k]*out[0] + hit->a[k]*out[1] + hit->b[k]*out[2];
+  return p->v[v].interior.mu_s;
+}
+
+static int o_vertex_shader(const o_path *p, int v)
+{ /* src/shader.c:448-455,568-575: a volume vertex without its own shader falls back on the shader of its volume */
+  int shader = p->v[v].hit.shader;
+  if(shader < 0 && (p->v[v].mode & s_volume)) shader = p->v[v].interior.shader;
+  return shader;
+}
+
 float o_shader_brdf(o_ctx *c, o_path *p, int v)
 { /* shader_brdf, src/shader.c:568-575 */
-  const mi_material *m = c->s->materials + p->v[v].hit.shader;
+  const mi_material *m = c->s->materials + o_vertex_shader(p, v);
+  if(m->bsdf == MI_BSDF_MEDIUM)
+  { /* medium_rgb.c:98-102 */
+    p->v[v].mode |= s_glossy | s_volume;
+    return p->v[v].interior.mu_s*o_eval_hg(p->v[v].interior.mean_cos, p->e[v].omega, p->e[v+1].omega);
+  }
   if(m->bsdf == MI_BSDF_DIFFUSE)    return o_brdf_diffuse(p, v);
   if(m->bsdf == MI_BSDF_DIELECTRIC) return o_brdf_dielectric(p, v);
   if(m->bsdf == MI_BSDF_METAL)      return o_brdf_metal(c, p, v);
@@ -702,7 +787,12 @@ float o_shader_brdf(o_ctx *c, o_path *p, int v)
 
 float o_shader_pdf(o_ctx *c, o_path *p, int v)
 { /* shader_pdf, src/shader.c:448-455 */
-  const mi_material *m = c->s->materials + p->v[v].hit.shader;
+  const mi_material *m = c->s->materials + o_vertex_shader(p, v);
+  if(m->bsdf == MI_BSDF_MEDIUM)
+  { /* medium_rgb.c:92-96 */
+    if(!(p->v[v].mode & s_volume)) return 0.0f;
+    return o_eval_hg(p->v[v].interior.mean_cos, p->e[v].omega, p->e[v+1].omega);
+  }
   if(m->bsdf == MI_BSDF_DIFFUSE)    return 1.0f/M_PI;                  /* pdf_d, src/shader.c:254-257 */
   if(m->bsdf == MI_BSDF_DIELECTRIC) return o_pdf_dielectric(p, v, v, v+1);
   if(m->bsdf == MI_BSDF_METAL)      return o_pdf_metal(p, v);

@@ -121,8 +121,24 @@ def image_pair(name, binary, mv, scene, w, h, spp, threads=8):
           "rmse(a,b)/mean", np.sqrt(((a - b) ** 2).mean()) / a.mean())
 
 
+COLOURS = [(0.3, 0.3, 0.3), (1, 1, 1), (3200, 3200, 3200), (10, 10, 10), (0.99, 0.96, 0.94), (0.5, 0.5, 0.5), (0.8, 0.2, 0.1), (0.1, 0.7, 0.3),
+           (1 / 0.5, 1 / 0.3, 1 / 0.2)]       # the last one: mu_t of `medium_rgb 0.5 0.3 0.2` (scenes/0055_media), medium_rgb.c:113-119
+
+
+def coeffs():
+    """rgb2spec_coeffs.json: the reference LUT's coefficients for every colour the test scenes use (oracle/refharness/unit_harness.c)"""
+    args = [f"{np.float32(c):.9g}" for rgb in COLOURS for c in rgb]
+    out = subprocess.run([str(REF / "unit_harness"), "coeff", "data/ergb2spec.coeff"] + args, cwd=REF, capture_output=True, text=True, check=True)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == len(COLOURS)
+    (GOLD / "rgb2spec_coeffs.json").write_text("\n".join(lines) + "\n")
+    print("wrote", len(lines), "colours")
+
+
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "quick"
+    if what in ("coeffs", "all"):
+        coeffs()
     if what in ("quick", "paths", "all"):
         work = dump_paths("pt_mv8", "dump_pt_xs_mv8", 8, "0010_pt", 1280, 720, 3000)
         dump_tree(work)
@@ -132,6 +148,10 @@ def main():
         dump_paths("fine_mv8", "dump_pt_xs_mv8", 8, "0054_fine", 1280, 720, 3000)     # needs scenes/geo/plane_fine.geo (tools/make_geo.py)
         dump_paths("metal_mv8", "dump_pt_xs_mv8", 8, "0053_metal", 1280, 720, 3000)
         dump_paths("metal_ptdl_mv8", "dump_ptdl_xs_mv8", 8, "0053_metal", 1280, 720, 3000)
+        # homogeneous medium inside the glass sphere (`interior`, `medium_rgb`)
+        dump_paths("media_pt_mv8", "dump_pt_xs_mv8", 8, "0055_media", 1280, 720, 10000)
+        dump_paths("media_ptdl_mv8", "dump_ptdl_xs_mv8", 8, "0055_media", 1280, 720, 10000)
+        dump_paths("media_pt_mv32", "dump_pt_xs_mv32", 32, "0055_media", 1280, 720, 6000)
         # MOD_pointsampler=halton; the mv32 ptdl case reaches dimensions >= 256 (fallback to the per-path generator)
         dump_paths("halton_pt_mv8", "dump_pt_halton_mv8", 8, "0010_pt", 1280, 720, 3000)
         dump_paths("halton_ptdl_mv8", "dump_ptdl_halton_mv8", 8, "0010_pt", 1280, 720, 3000)

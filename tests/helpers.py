@@ -18,6 +18,7 @@ GOLDEN = REPO / "tests" / "golden"
 SCENE_0010 = REPO / "scenes" / "0010_pt" / "test.nra2"
 SCENE_ROUGH = REPO / "scenes" / "0052_rough" / "test.nra2"
 SCENE_FINE = REPO / "scenes" / "0054_fine" / "test.nra2"       # 0010 with every backdrop quad split 2x2 (tools/make_geo.py): 1711 nodes, too big for LDS
+SCENE_MEDIA = REPO / "scenes" / "0055_media" / "test.nra2"     # 0010 with a scattering medium inside the glass sphere (`interior`, `medium_rgb`)
 SCENE_METAL = REPO / "scenes" / "0053_metal" / "test.nra2"     # 0052 with `metal Au`, roughness 0.3 on cone/sphere/cylinder
 
 
@@ -103,8 +104,9 @@ def inject_reference_coeffs(scene):
     nshaders = int(lines[1].split()[0])
     for sid in range(nshaders):
         tok = lines[2 + sid].split('#')[0].split()
-        if tok and tok[0] == "color":
-            rgb = [float(x) for x in tok[2:5]]
+        if tok and tok[0] in ("color", "medium_rgb"):
+            # medium_rgb: the colour is the collision coefficient 1 / mean free path (src/shaders/medium_rgb.c:113-119)
+            rgb = [float(x) for x in tok[2:5]] if tok[0] == "color" else [float(np.float32(1) / np.float32(x)) for x in tok[1:4]]
             if max(rgb) == 0.0:
                 continue
             for e in table:

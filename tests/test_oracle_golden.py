@@ -18,7 +18,7 @@ import json
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, SCENE_0010, SCENE_FINE, SCENE_METAL, SCENE_ROUGH, load_pkg, make_scene, oracle_lib, oracle_records, oracle_render
+from helpers import GOLDEN, SCENE_0010, SCENE_FINE, SCENE_MEDIA, SCENE_METAL, SCENE_ROUGH, load_pkg, make_scene, oracle_lib, oracle_records, oracle_render
 
 pkg = load_pkg()
 
@@ -33,6 +33,13 @@ CASES = [
     # SURVEY 8(f) row 2, MOD_pointsampler=halton ("halton_" cases run with MI_POINTS_HALTON): dimension bookkeeping
     # (rand_beg / rand_cnt incl. the four next-event dimensions path_pop hands to the previous vertex), permutation tables
     # from srand48(frame), and -- max depth 32 with ptdl -- the fall-back to the per-path generator from dimension 256 on
+    # SURVEY 8(f) row 3, homogeneous medium inside the glass sphere (`interior`, `medium_rgb`, `color v`): free-flight sampling,
+    # volume vertices, Henyey-Greenstein, transmittance on next-event connections, volume pdfs in the MIS weights. The energy
+    # tolerance is wider: mu_t(lambda) is a sigmoid evaluated with rsqrtss by the reference (include/rgb2spec.h:145-149) and
+    # above 800 nm, where the sigmoid of this colour is small, that approximation is worth several per cent in exp(-mu_t d)
+    ("media_pt_mv8", pkg.MI_SAMPLER_PT, SCENE_MEDIA, 5e-3),
+    ("media_ptdl_mv8", pkg.MI_SAMPLER_PTDL, SCENE_MEDIA, 1e-2),
+    ("media_pt_mv32", pkg.MI_SAMPLER_PT, SCENE_MEDIA, 5e-3),
     ("halton_pt_mv8", pkg.MI_SAMPLER_PT, SCENE_0010, 1.5e-3),
     ("halton_ptdl_mv8", pkg.MI_SAMPLER_PTDL, SCENE_0010, 1e-2),
     ("halton_ptdl_rough_mv32", pkg.MI_SAMPLER_PTDL, SCENE_ROUGH, 1e-2),
