@@ -8,7 +8,7 @@ import tempfile
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, REPO, SCENE_0010, SCENE_ROUGH, golden_coeffs, load_pkg, make_scene
+from helpers import GOLDEN, REPO, SCENE_0010, SCENE_MEDIA, SCENE_ROUGH, golden_coeffs, load_pkg, make_scene
 
 pkg = load_pkg()
 
@@ -91,14 +91,19 @@ def test_materials_compiled():
     assert abs(m[5].op[1].mul - 3200) < 1e-3
     assert m[10].bsdf == 1 and abs(m[10].param[0] - 1.3) < 1e-6 and m[10].param[1] == 23   # dielectric 1.3 23
     assert abs(m[10].op[0].roughness - 0.04) < 1e-7
-    assert m[8].bsdf == 255                                                         # medium_rgb: out of scope, unused
+    assert m[8].bsdf == 3 and abs(m[8].mean_cos - 0.85) < 1e-7 and m[8].interior == -1   # medium_rgb (unused in 0010): mu_t colour, mean cosine
+    assert m[9].bsdf == 255                                                         # a bare `color` line is no material
+    med = make_scene(SCENE_MEDIA, width=256, height=256, max_verts=4).desc.materials
+    assert med[14].bsdf == 1 and med[14].interior == 13 and med[14].num_ops == 1    # interior 10 13: glass surface + medium link
+    assert med[13].bsdf == 3 and med[13].num_ops == 1 and med[13].op[0].slot == 4 and abs(med[13].mean_cos - 0.6) < 1e-7
+    assert abs(med[13].param[3] - 5.0) < 1e-5                                       # scale of mu_t = 1 / 0.2 dm
     r = make_scene(SCENE_ROUGH, width=256, height=256, max_verts=32)
     assert abs(r.desc.materials[10].param[0] - 1.7) < 1e-6 and abs(r.desc.materials[10].op[0].roughness - 0.4) < 1e-7
 
 
 def test_rgb2spec_direct_fit_close_to_reference_lut():
     """Without the 9.4 MB LUT the host fits coefficients directly; the spectra must agree with the reference
-    LUT's (golden) within 4e-3 absolute reflectance over the wavelengths that carry weight (360..740 nm)."""
+    LUT's (golden) within 4e-3 absolute reflectance (1e-2 for saturated, scaled colours) over the wavelengths that carry weight (360..740 nm)."""
     h = pkg.host_lib()
     # the chromatic fit integrates against the CIE table, which a loaded scene provides
     s = make_scene(SCENE_0010, inject=False, width=256, height=256, max_verts=4)
@@ -110,7 +115,9 @@ def test_rgb2spec_direct_fit_close_to_reference_lut():
         for k, lam in enumerate(range(360, 760, 50)):
             x = (out[0] * lam + out[1]) * lam + out[2]
             val = 0.5 * x / np.sqrt(x * x + 1) + 0.5
-            assert abs(val - e["eval_precise"][k]) < 4e-3, (e["rgb"], lam, val, e["eval_precise"][k])
+            # the two collision-coefficient colours of the media scenes are far more saturated than any reflectance in the tests
+            tol = 4e-3 if e["mul"] <= 1 or min(e["rgb"]) == max(e["rgb"]) else 1e-2
+            assert abs(val - e["eval_precise"][k]) < tol, (e["rgb"], lam, val, e["eval_precise"][k])
     del s
 
 
