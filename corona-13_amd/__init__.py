@@ -81,7 +81,7 @@ class MiSceneDesc(C.Structure):
                 ("num_materials", C.c_uint32), ("materials", C.POINTER(MiMaterial)),
                 ("lights", MiLights), ("cam", MiCamera),
                 ("cie_xyz", C.POINTER(C.c_float)), ("checker", C.POINTER(C.c_float)), ("metal_ior", C.POINTER(C.c_float)),
-                ("pointsampler", C.c_uint32), ("reserved", C.c_uint32)]
+                ("pointsampler", C.c_uint32), ("exterior", C.c_uint32)]
 
 
 class MiPathVertex(C.Structure):

@@ -27,7 +27,7 @@
 #endif
 
 /* ======================================================================================= persistent megakernel */
-template<bool RECORD, bool PTDL, bool NODES_LDS, bool HALTON = false>
+template<bool RECORD, bool PTDL, bool NODES_LDS, bool HALTON = false, bool MEDIA = false>
 __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned long long first, unsigned long long count,
                                                            const uint32_t *shape_material, const float *shape_L, mi_path_record *records,
                                                            uint2 *stack_overflow)
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
         {
           const unsigned rank = __popcll(m & ((1ull << lane) - 1ull));
           const unsigned long long i = blk_lo + base + rank;
-          if(i < blk_hi) path_generate<RECORD, HALTON>(sc, ps, first + i, RECORD ? records + i : nullptr, cnt);
+          if(i < blk_hi) path_generate<RECORD, HALTON, MEDIA>(sc, ps, first + i, RECORD ? records + i : nullptr, cnt);
           else exhausted = true;
         }
       }
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
     if(!tracing && (ps.active || ps.sh_pending))
     {
       tr_shadow = PTDL && ps.sh_pending;
-      hit.prim = MI_NOPRIM; hit.dist = tr_shadow ? ps.sh_dist : FLT_MAX; hit.u = hit.v = 0.0f;
+      hit.prim = MI_NOPRIM; hit.dist = tr_shadow ? ps.sh_dist : (MEDIA ? media_free_flight<PTDL, HALTON>(sc, ps) : FLT_MAX); hit.u = hit.v = 0.0f;
       trace_begin(ts, tr_shadow ? ps.sh_dir : ps.dir, cnt);
       tracing = true;
     }
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
       tracing = false;
       mi_path_record *rec = RECORD ? records + (ps.index - first) : nullptr;
       if(tr_shadow) shadow_resolve<RECORD>(sc, ps, hit, rec, cnt, splat);
-      else path_shade<RECORD, PTDL, HALTON>(sc, ps, hit, shape_material, shape_L, rec, cnt, splat);
+      else path_shade<RECORD, PTDL, HALTON, MEDIA>(sc, ps, hit, shape_material, shape_L, rec, cnt, splat);
     }
 
     /* ------------------------------------------------------------ splats of this iteration, cooperatively */
@@ -216,6 +216,8 @@ struct mi_scene
   unsigned long long *h_live;       /* pinned ring of `live` read-backs */
   hipEvent_t ev_live[8];
   uint64_t kernel_launches_last;
+  bool media;                       /* some shape is filled with a homogeneous medium: MEDIA instantiations */
+  void *d_shape_medium;
   /* Halton point sampler */
   bool halton;
   HaltonTables *halton_tables;
@@ -568,6 +570,45 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
     shape_mat[4*i+0] = m.bsdf; shape_mat[4*i+1] = (uint32_t)h->shapes[i].material;
     memcpy(&shape_mat[4*i+2], &m.param[0], 4); memcpy(&shape_mat[4*i+3], &m.param[1], 4);
   }
+  /* homogeneous media: per shape the interior medium of its material (`interior <surface> <medium>`) */
+  std::vector<DShapeMedium> shape_med((size_t)h->num_shapes + 1);
+  bool any_media = false;
+  auto medium_entry = [&](DShapeMedium &e, uint32_t id) -> const char *
+  { /* the medium's prepare chain: exactly one colour op in the volume slot (the albedo), then medium_rgb */
+    if(id >= h->num_materials || h->materials[id].bsdf != MI_BSDF_MEDIUM) return "not a medium material";
+    const mi_material &med = h->materials[id];
+    if(med.num_ops != 1 || med.op[0].kind != MI_OP_COLOR || med.op[0].slot != MI_SLOT_VOLUME)
+      return "a medium needs exactly one `color v` (albedo) in front of medium_rgb";
+    memcpy(e.albedo, med.op[0].coeff, 12); e.albedo[3] = med.op[0].mul;
+    memcpy(e.mu_t, med.param, 16);
+    e.g = med.mean_cos; e.med = (int32_t)id;
+    return nullptr;
+  };
+  {
+    DShapeMedium &e = shape_med[h->num_shapes];
+    memset(&e, 0, sizeof(e));
+    e.med = -1;
+    if(h->exterior)
+    {
+      const char *why = medium_entry(e, h->exterior - 1);
+      if(why) { free(s); return fail(MI_ERR_ARG, why); }
+      any_media = true;
+    }
+  }
+  for(uint32_t i=0;i<h->num_shapes;i++)
+  {
+    DShapeMedium &e = shape_med[i];
+    memset(&e, 0, sizeof(e));
+    e.med = -1;
+    const mi_material &m = h->materials[h->shapes[i].material];
+    if(m.bsdf == MI_BSDF_MEDIUM) { free(s); return fail(MI_ERR_UNSUPPORTED, "a medium can only be the interior of a surface material"); }
+    if(m.interior < 0) continue;
+    const char *why = medium_entry(e, (uint32_t)m.interior);
+    if(why) { free(s); return fail(MI_ERR_ARG, why); }
+    any_media = true;
+  }
+  if(any_media && h->pointsampler == MI_POINTS_HALTON)
+  { free(s); return fail(MI_ERR_UNSUPPORTED, "participating media with the Halton point sampler are not supported yet"); }
   std::vector<float> shape_L(h->num_shapes ? h->num_shapes : 1, 0.0f);
   for(uint32_t k=0;k<h->lights.num_prims;k++)
   {
@@ -596,6 +637,7 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   UP(d_materials, mats.data(), mats.size());
   UP(d_shape_material, shape_mat.data(), shape_mat.size());
   UP(d_shape_L, shape_L.data(), shape_L.size());
+  if(any_media) { UP(d_shape_medium, shape_med.data(), shape_med.size()); s->media = true; }
   UP(d_light_prim, lprim.data(), lprim.size());
   UP(d_light_cdf, h->lights.cdf, (size_t)h->lights.num_prims);
   UP(d_light_L, h->lights.L, (size_t)h->lights.num_prims);
@@ -627,6 +669,8 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   d.nodes = (const float4 *)s->d_nodes; d.node_axes = (const uint32_t *)s->d_axes;
   d.prims = (const DPrim *)s->d_prims; d.primgeo = (const DPrimGeo *)s->d_primgeo;
   d.materials = (const DMaterial *)s->d_materials;
+  d.shape_medium = (const DShapeMedium *)s->d_shape_medium;
+  d.exterior_index = h->num_shapes;
   d.num_lights = h->lights.num_prims;
   d.light_prim = (const uint32_t *)s->d_light_prim; d.light_cdf = (const float *)s->d_light_cdf; d.light_L = (const float *)s->d_light_L;
   d.p_sky = h->lights.p_sky; d.p_geo = h->lights.p_geo; d.p_vol = h->lights.p_vol;
@@ -671,7 +715,11 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
       (const void *)mi_path_kernel<false, false, true, true>, (const void *)mi_path_kernel<true, false, true, true>,
       (const void *)mi_path_kernel<false, true, true, true>, (const void *)mi_path_kernel<true, true, true, true>,
       (const void *)mi_path_kernel<false, false, false, true>, (const void *)mi_path_kernel<true, false, false, true>,
-      (const void *)mi_path_kernel<false, true, false, true>, (const void *)mi_path_kernel<true, true, false, true> };
+      (const void *)mi_path_kernel<false, true, false, true>, (const void *)mi_path_kernel<true, true, false, true>,
+      (const void *)mi_path_kernel<false, false, true, false, true>, (const void *)mi_path_kernel<true, false, true, false, true>,
+      (const void *)mi_path_kernel<false, true, true, false, true>, (const void *)mi_path_kernel<true, true, true, false, true>,
+      (const void *)mi_path_kernel<false, false, false, false, true>, (const void *)mi_path_kernel<true, false, false, false, true>,
+      (const void *)mi_path_kernel<false, true, false, false, true>, (const void *)mi_path_kernel<true, true, false, false, true> };
     for(const void *k : kernels)
       if(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess)
       { mi_scene_destroy(s); return fail(MI_ERR_DEVICE, "cannot raise the dynamic LDS limit"); }
@@ -706,6 +754,8 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
        CORONA_MI_POOL = number of path slots) */
     const char *mode = getenv("CORONA_MI_MODE");
     s->wavefront = (mode && !strcmp(mode, "wave"));
+    if(s->wavefront && s->media)
+    { mi_scene_destroy(s); return fail(MI_ERR_UNSUPPORTED, "participating media run in the megakernel only (unset CORONA_MI_MODE)"); }
     if(s->wavefront && h->pointsampler == MI_POINTS_HALTON)
     { mi_scene_destroy(s); return fail(MI_ERR_UNSUPPORTED, "the Halton point sampler runs in the megakernel only (unset CORONA_MI_MODE)"); }
     const char *pe = getenv("CORONA_MI_POOL");
@@ -808,11 +858,17 @@ static int ensure_halton(mi_scene *s, uint64_t end_index)
 
 static void launch_path_kernel(mi_scene *s, bool record, int grid, uint64_t first, uint64_t n, mi_path_record *rec)
 { /* pick the instantiation: RECORD (test hook) x PTDL (sampler) x NODES_LDS (tree fits LDS) x HALTON (point sampler) */
-  const int which = (record ? 1 : 0) | (s->d.sampler == MI_SAMPLER_PTDL ? 2 : 0) | (s->nodes_lds ? 4 : 0) | (s->halton ? 8 : 0);
-#define MI_LAUNCH(R, P, L, H) hipLaunchKernelGGL((mi_path_kernel<R, P, L, H>), dim3(grid), dim3(MI_BLOCK), s->lds_bytes, s->stream, s->d, \
+  const int which = (record ? 1 : 0) | (s->d.sampler == MI_SAMPLER_PTDL ? 2 : 0) | (s->nodes_lds ? 4 : 0) | (s->halton ? 8 : 0) | (s->media ? 16 : 0);
+#define MI_LAUNCH(R, P, L, H) MI_LAUNCH5(R, P, L, H, false)
+#define MI_LAUNCH5(R, P, L, H, M) hipLaunchKernelGGL((mi_path_kernel<R, P, L, H, M>), dim3(grid), dim3(MI_BLOCK), s->lds_bytes, s->stream, s->d, \
     (unsigned long long)first, (unsigned long long)n, (const uint32_t *)s->d_shape_material, (const float *)s->d_shape_L, rec, (uint2 *)s->d_overflow)
   switch(which)
   {
+    /* MEDIA (scenes with participating media; rand point sampler only) */
+    case 16: MI_LAUNCH5(false, false, false, false, true); break;  case 17: MI_LAUNCH5(true, false, false, false, true); break;
+    case 18: MI_LAUNCH5(false, true,  false, false, true); break;  case 19: MI_LAUNCH5(true, true,  false, false, true); break;
+    case 20: MI_LAUNCH5(false, false, true,  false, true); break;  case 21: MI_LAUNCH5(true, false, true,  false, true); break;
+    case 22: MI_LAUNCH5(false, true,  true,  false, true); break;  case 23: MI_LAUNCH5(true, true,  true,  false, true); break;
     case  0: MI_LAUNCH(false, false, false, false); break;  case  1: MI_LAUNCH(true, false, false, false); break;
     case  2: MI_LAUNCH(false, true,  false, false); break;  case  3: MI_LAUNCH(true, true,  false, false); break;
     case  4: MI_LAUNCH(false, false, true,  false); break;  case  5: MI_LAUNCH(true, false, true,  false); break;
@@ -823,6 +879,7 @@ static void launch_path_kernel(mi_scene *s, bool record, int grid, uint64_t firs
     case 14: MI_LAUNCH(false, true,  true,  true);  break;  default: MI_LAUNCH(true, true,  true,  true);  break;
   }
 #undef MI_LAUNCH
+#undef MI_LAUNCH5
 }
 
 extern "C" int mi_render(mi_scene *s, uint64_t first_index, uint64_t count)
@@ -980,7 +1037,7 @@ extern "C" void mi_scene_destroy(mi_scene *s)
   for(int k=0;k<8;k++) if(s->ev_live[k]) (void)hipEventDestroy(s->ev_live[k]);
   void *bufs[] = { s->d_nodes, s->d_axes, s->d_prims, s->d_primgeo, s->d_materials, s->d_light_prim, s->d_light_cdf, s->d_light_L,
                    s->d_cie, s->d_checker, s->d_metal, s->d_counters, s->d_work, s->d_shape_material, s->d_shape_L, s->d_overflow, s->d_fb_own,
-                   s->d_halton_dim, s->d_halton_perm };
+                   s->d_halton_dim, s->d_halton_perm, s->d_shape_medium };
   delete s->halton_tables;
   for(void *b : bufs) if(b) (void)hipFree(b);
   if(s->stream_own) (void)hipStreamDestroy(s->stream_own);

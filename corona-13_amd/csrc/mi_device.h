@@ -54,6 +54,15 @@ struct DMaterial                   /* 144 B; the header (one 16-B load) and each
   mi_shade_op op[MI_MAX_OPS];
 };
 
+struct DShapeMedium                /* 48 B per shape: the homogeneous medium filling it (`interior <surface> <medium>`), or med < 0 */
+{
+  float albedo[4];                 /* rgb2spec coefficients + scale of the medium's colour op in the volume slot: single-scattering albedo */
+  float mu_t[4];                   /* coefficients + scale of the extinction coefficient, medium_rgb.c:45-59 */
+  float g;                         /* Henyey-Greenstein mean cosine */
+  int32_t med;                     /* shader id of the medium (vertex records, interior.shader) or -1 */
+  uint32_t pad[2];
+};
+
 struct DCamConst                   /* per-launch camera constants of camera_sample (src/camera.d/thinlens.c:68-128), formed once at
                                       upload with the float / double expressions the kernel would evaluate per path */
 {
@@ -91,6 +100,9 @@ struct DScene
   uint32_t work_shards;
   /* Halton point sampler (MI_POINTS_HALTON): per dimension {P = digits looked up at once, floor(2^32/P), table offset | groups << 24,
      float bits of the scale}; the digit-permutation tables, concatenated (387 KB, L2 resident) */
+  const DShapeMedium *shape_medium; /* [num_shapes + 1] (MEDIA kernels only): the medium filling each shape; the last entry is the global
+                                       exterior medium (`exterior <medium> 0`, src/shader.c:544-565), med < 0 = vacuum */
+  uint32_t exterior_index;          /* = number of shapes */
   const uint4 *halton_dim;
   const unsigned short *halton_perm;
 };

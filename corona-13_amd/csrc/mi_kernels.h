@@ -908,6 +908,31 @@ __device__ __forceinline__ float shape_interior_ior(const DScene &sc, const uint
   return 1.0f;
 }
 
+/* ------------------------------------------------------------------------------------------ homogeneous media
+ * the volume a shape's interior prepare chain leaves on a surface vertex (interior.c:101-118, mult.c:154-167: the colour op in
+ * the volume slot sets mu_s = clamp(albedo), mu_t = 1 (texture.h:48-53), then medium_rgb.c:45-59 scales both by its mu_t) */
+struct Medium { float mu_s, mu_t, g; int med; };
+__device__ __forceinline__ Medium medium_vacuum() { Medium m; m.mu_s = 0.0f; m.mu_t = 0.0f; m.g = 0.0f; m.med = -1; return m; }
+__device__ __forceinline__ Medium shape_interior_medium(const DScene &sc, int shape, float lambda)
+{
+  Medium m = medium_vacuum();
+  const DShapeMedium &e = sc.shape_medium[shape < 0 ? sc.exterior_index : (uint32_t)shape];   /* outside every shape: the exterior medium */
+  if(e.med < 0) return m;
+  const float val = e.albedo[3]*spectrum_eval(e.albedo, lambda);
+  float mu_s = DCLAMP(val, 0.0f, 1.0f);
+  const float old_mu_t = 1.0f;
+  m.mu_t = e.mu_t[3]*spectrum_eval(e.mu_t, lambda);
+  mu_s = mu_s*(m.mu_t/old_mu_t);
+  m.mu_s = mu_s; m.g = e.g; m.med = e.med;
+  return m;
+}
+__device__ __forceinline__ float eval_hg(float g, const V3 wi, const V3 wo)
+{ /* sample_eval_hg, include/sampler_common.h:338-355 */
+  if(g == 0.0f) return (float)(1.0/(4.0*MI_PI_D));
+  const float cos_theta = dot3(wi, wo);
+  return (float)(1.0/(4.0*MI_PI_D)*(double)(1.0f-g*g)/(double)powf(1.0f + g*g - 2.0f*g*cos_theta, 3.0f/2.0f));   /* the reference's double promotion */
+}
+
 /* ------------------------------------------------------------------------------------------ GGX, src/shaders/ggx.h */
 __device__ __forceinline__ float ggx_G1(const V3 w, const V3 n, float roughness)
 { /* ggx.h:29-36 */

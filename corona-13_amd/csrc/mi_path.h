@@ -42,6 +42,10 @@ struct PathState
   float sh_dist, sh_value;
   uint32_t sh_light, sh_ignore;
   int sh_length;
+  /* homogeneous media (MEDIA instantiations only): the volume of the edge under way (e[v].vol) and the free-flight distance
+     sampled for it (FLT_MAX: none) */
+  Medium cur;
+  float clip;
 };
 
 /* a splat to be carried out by the wave (splat_wave) after the divergent part of the iteration */
@@ -64,7 +68,7 @@ __device__ __forceinline__ void rec_vertex(mi_path_record *rec, int v, uint64_t 
 }
 
 /* start path `index`: afterwards ps holds the camera ray as the pending extension ray */
-template<bool RECORD, bool HALTON>
+template<bool RECORD, bool HALTON, bool MEDIA = false>
 __device__ __forceinline__ void path_generate(const DScene &sc, PathState &ps, unsigned long long index, mi_path_record *rec, uint32_t *cnt)
 {
   /* path_init + first half of path_extend (length == 0), src/pathspace.c:13-28,210-249 */
@@ -116,6 +120,8 @@ __device__ __forceinline__ void path_generate(const DScene &sc, PathState &ps, u
   ps.pdfprod = 1.0;
   ps.cur_ior = 1.0f;
   ps.media.ids = 0; ps.media.count = 0; ps.media.broken = 0;
+  ps.cur = medium_vacuum(); ps.clip = FLT_MAX;                /* shader_exterior_medium, src/shader.c:544-565: vacuum or the global medium */
+  if(MEDIA) ps.cur = shape_interior_medium(sc, -1, ps.lambda);
   ps.length = 1;
   ps.active = 1;
   ps.prev_material_modes = s_sensor;
@@ -159,12 +165,201 @@ __device__ __forceinline__ void shadow_resolve(const DScene &sc, PathState &ps, 
   }
 }
 
+/* ------------------------------------------------------------------------------------------ homogeneous media
+ * free-flight distance of the extension ray about to be traced: shader_vol_sample, src/shader.c:76-106, called from
+ * path_propagate before the ray is cast when the edge's medium scatters (src/pathspace.c:717-751). Returns the distance the
+ * traversal is clipped to (FLT_MAX: vacuum or a purely absorbing medium). */
+template<bool PTDL, bool HALTON>
+__device__ __forceinline__ float media_free_flight(const DScene &sc, PathState &ps)
+{
+  ps.clip = FLT_MAX;
+  if(ps.cur.med >= 0 && ps.cur.mu_s > 0.0f)
+  {
+    const int v = ps.length;
+    PointSampler<HALTON> pts(sc, ps.rng, ps.index, v == 1 ? 7 : rand_beg_extend<PTDL>(v));
+    const float rf = pts(0);                                   /* s_dim_free_path */
+    float dist = -logf(1.0f - rf)/ps.cur.mu_t;
+    if(!(dist > 0.0)) dist = 1e-15;
+    ps.clip = dist;
+  }
+  return ps.clip;
+}
+
+/* transmittance of the medium `m` over `dist`, and the pdf factor of the edge when its end point is on geometry
+ * (shader_vol_transmittance src/shader.c:48-74, shader_vol_pdf 108-131) */
+__device__ __forceinline__ float media_transmittance(const Medium &m, float dist) { return m.med >= 0 ? expf(-dist*m.mu_t) : 1.0f; }
+__device__ __forceinline__ float media_pdf_to_surface(const Medium &m, float dist) { return (m.med >= 0 && m.mu_s > 0.0f) ? expf(-dist*m.mu_t) : 1.0f; }
+
+/* the extension ray ended at the sampled free-flight distance ps.clip before any geometry: a volume vertex
+ * (path_propagate src/pathspace.c:745-751,771-776; shader_prepare src/shader.c:476-501; manifold_init manifold.h:236-246;
+ * phase function src/shaders/medium_rgb.c:61-102; next event estimation as for surfaces) */
+template<bool RECORD, bool PTDL, bool HALTON>
+__device__ __forceinline__ void path_shade_volume(const DScene &sc, PathState &ps, mi_path_record *rec, uint32_t *cnt)
+{
+  const int v = ps.length;
+  bool alive = true;
+  const V3 omega = ps.dir;
+  const float dist = ps.clip;
+  const Medium med = ps.cur;
+  Surf sf;
+  sf.x = mk3(ps.org.x + dist*ps.dir.x, ps.org.y + dist*ps.dir.y, ps.org.z + dist*ps.dir.z);
+  sf.n = omega; sf.gn = omega;                               /* the frame looks along the incoming direction */
+  get_scrambled_onb(ps.scramble, sf.n, sf.a, sf.b);
+  sf.u = sf.v = sf.s = sf.t = 0.0f; sf.flags = 0;
+  const uint32_t material_modes = s_volume | s_glossy;
+  /* edge: pdf = transmittance * mu_t at the sampled distance (src/shader.c:95-97), on-"surface" pdf with G = cos / d^2, cos = 1 here */
+  const float eT = expf(-dist*med.mu_t);
+  const float epdf = eT*med.mu_t;
+  const float G = ps.prev_cos*1.0f/(dist*dist);
+  const float vpdf = (ps.pdf*epdf)*G;
+  ps.pdfprod *= (double)vpdf;
+  ps.length++;
+  cnt[6]++;
+  const float vthr = ps.throughput*(eT/epdf);
+  if(RECORD)
+  {
+    Shading z; z.roughness = z.rs = z.rd = z.rg = z.em = 0.0f;
+    rec_vertex<RECORD>(rec, v, MI_PRIMID_INVALID, dist, sf.x, sf.n, sf.gn, omega, s_absorb, 0, vthr, vpdf, 0.0f, 0.0f, z, 0.0f, med.med);
+    rec->length = ps.length; rec->throughput = (ps.throughput*0.0f)/epdf;
+  }
+  if(PTDL && ps.length >= (int)sc.max_verts) alive = false;
+  if(PTDL && alive)
+  { /* next event estimation from the volume vertex, ptdl.c:136-148 */
+    (void)rng_next(ps.rng);
+    PointSampler<HALTON> pts(sc, ps.rng, ps.index, rand_beg_nee(v + 1));
+    const float rnd = pts(MI_DIM_NEE_LIGHT1);
+    if(!(rnd < sc.p_sky) && rnd < sc.p_sky + sc.p_geo)
+    {
+      const float r3 = pts(MI_DIM_NEE_Y);
+      const float r2 = pts(MI_DIM_NEE_X);
+      const float r1 = pts(MI_DIM_NEE_LIGHT2);
+      const uint32_t t = sample_cdf(sc.light_cdf, (int)sc.num_lights, r1);
+      const uint32_t lp = sc.light_prim[t];
+      Surf ls;
+      ls.x = prim_sample(sc.prims[lp], sc.primgeo[lp], r2, r3, ls.u, ls.v);
+      V3 ol = sub3(ls.x, sf.x);
+      const float ldist = sqrtf(dot3(ol, ol));
+      const double il = 1./(double)ldist;
+      ol = mk3((float)((double)ol.x*il), (float)((double)ol.y*il), (float)((double)ol.z*il));
+      const uint4 lhead = *(const uint4 *)&sc.primgeo[lp];
+      surface_setup(sc, lp, lhead, ol, ps.scramble, ls);
+      Shading lsh;
+      run_prepare_ops(sc, sc.materials[lhead.y], sc.materials[lhead.y].num_ops, ls, ps.lambda, lsh);
+      float lpdf = sc.light_L[t];
+      float edf = lsh.em/lpdf;
+      if(lsh.roughness > 1.0f-1e-4f) edf = (float)((double)edf*((double)1.0f/MI_PI_D));
+      else
+      {
+        const float phongexp = 2.0f/(lsh.roughness*lsh.roughness) - 2.0f;
+        edf = (float)((double)edf*((double)(powf(-dot3(ls.gn, ol), phongexp)*(phongexp + 2.0f))/(2.0f*MI_PI_D)));
+      }
+      lpdf = lpdf*sc.p_geo;
+      edf = edf/sc.p_geo;
+      if(edf > 0.0f)
+      {
+        const float hg = eval_hg(med.g, omega, ol);
+        const float bsdf = med.mu_s*hg;                        /* medium_rgb.c:98-102 */
+        if(bsdf > 0.0f)
+        { /* prims_get_ray, src/prims.c:390-492: no offset at a volume vertex, the usual one at the emitter */
+          const float eps = 1e-4f*DMAX(DMAX(.5f, fabsf(sf.x.x)), DMAX(fabsf(sf.x.y), fabsf(sf.x.z)));
+          V3 rd = sub3(ls.x, sf.x);
+          rd = scale3(rd, 1.0f/sqrtf(dot3(rd, rd)));
+          const V3 ro = sf.x;
+          const V3 dv = mk3(ls.x.x - eps*rd.x - ro.x, ls.x.y - eps*rd.y - ro.y, ls.x.z - eps*rd.z - ro.z);
+          const float total_dist = sqrtf(dot3(dv, dv));
+          if(!(dot3(ls.gn, rd) >= 0) && total_dist > 0.0f)
+          {
+            const float Gn = 1.0f*fabsf(dot3(ls.n, ol))/(ldist*ldist);
+            const float T = media_transmittance(med, ldist);
+            float tn = ((vthr*bsdf)*(T*edf))*Gn;
+            tn = tn + (vthr*bsdf)*((0.0f*Gn)/lpdf);
+            const float wn = lpdf/(lpdf + 0.0f/T);
+            tn = tn*wn;
+            const float pe = (media_pdf_to_surface(med, ldist)*hg)*Gn;
+            const double pp = ps.pdfprod;
+            const double our = (double)(1.0f*lpdf)*pp, other = (double)pe*pp;
+            const float wm = (float)our/(float)(other + our);
+            if(tn/1.0f > 0.0f)
+            {
+              ps.sh_pending = 1;
+              ps.sh_org = ro; ps.sh_dir = rd; ps.sh_dist = total_dist;
+              ps.sh_light = lp; ps.sh_ignore = MI_NOPRIM;
+              ps.sh_value = (tn/1.0f)*wm;
+              ps.sh_length = ps.length + 1;
+            }
+          }
+        }
+      }
+    }
+  }
+  if(alive && ps.length >= (int)sc.max_verts) alive = false;
+  if(alive && !(vthr > 0.0f))
+  {
+    alive = false;
+    if(RECORD && v < MI_REC_MAX_VERTS) { rec->v[v].throughput = 0.0f; rec->v[v].mode = s_absorb; }
+  }
+  if(alive)
+  { /* medium_rgb.c:61-72 + sample_hg, include/sampler_common.h:286-316 (the two numbers are call arguments: omega_y is drawn first) */
+    PointSampler<HALTON> pts(sc, ps.rng, ps.index, rand_beg_extend<PTDL>(v + 1));
+    const float r2 = pts(MI_DIM_OMEGA_Y);
+    const float r1 = pts(MI_DIM_OMEGA_X);
+    const float g = med.g;
+    float o0, o1, o2, pdf;
+    if(g == 0.0f)
+    { /* sample_sphere */
+      const float z = 1.f - 2.f*r1;
+      const float r = sqrtf(1.f - z*z);
+      const float phi = (float)(2.f*MI_PI_D*(double)r2);
+      float sn, cs;
+      sincosf(phi, &sn, &cs);
+      o0 = r*cs; o1 = r*sn; o2 = z;
+      pdf = (float)(1.0/(4.0*MI_PI_D));
+    }
+    else
+    {
+      const float sqr = (1.0f-g*g)/(1.0f+g*(2.0f*r1-1.0f));
+      const float cos_theta = 1.0f/(2.0f*g)*(1.0f + g*g - sqr*sqr);
+      const float phi = (float)(2.0f*MI_PI_D*(double)r2);
+      const float l = sqrtf(fmaxf(0.0f, 1.0f-cos_theta*cos_theta));
+      float sn, cs;
+      sincosf(phi, &sn, &cs);
+      o0 = cos_theta; o1 = cs*l; o2 = sn*l;
+      pdf = (float)(1.0/(4.0*MI_PI_D)*(double)(1.0f-g*g)/(double)powf(1.0f + g*g - 2.0f*g*cos_theta, 3.0f/2.0f));
+    }
+    V3 wo = mk3(sf.n.x*o0 + sf.a.x*o1 + sf.b.x*o2, sf.n.y*o0 + sf.a.y*o1 + sf.b.y*o2, sf.n.z*o0 + sf.a.z*o1 + sf.b.z*o2);
+    wo = normalise3(wo);
+    const float nthr = vthr*med.mu_s;
+    const uint32_t vmode = s_glossy | s_volume;
+    if(nthr <= 0.0f) alive = false;
+    if(RECORD && v < MI_REC_MAX_VERTS) rec->v[v].mode = alive ? vmode : (uint32_t)s_absorb;
+    if(alive)
+    { /* the next ray starts at the vertex itself: prims_offset_ray only applies on geometry, src/pathspace.c:759-761 */
+      ps.org = sf.x;
+      ps.dir = wo;
+      ps.ignore = MI_NOPRIM;
+      ps.prev_x = sf.x;
+      ps.prev_cos = 1.0f;                                      /* path_lambert at a volume vertex */
+      ps.prev_throughput = vthr;
+      ps.prev_mode = vmode;
+      ps.prev_material_modes = material_modes;
+      ps.throughput = nthr;
+      ps.pdf = pdf;
+    }
+  }
+  if(!alive) { ps.active = 0; cnt[4]++; }
+}
+
 /* the extension ray ps.org/ps.dir has been traced into `hit`: create vertex v = ps.length, then either end the path
  * (ps.active = 0) or leave the next extension ray (and, for ptdl, possibly a shadow ray) in ps */
-template<bool RECORD, bool PTDL, bool HALTON>
+template<bool RECORD, bool PTDL, bool HALTON, bool MEDIA = false>
 __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, const Hit &hit, const uint32_t *shape_material, const float *shape_L,
                                            mi_path_record *rec, uint32_t *cnt, SplatReq &splat)
 {
+  if(MEDIA && hit.prim == MI_NOPRIM && ps.clip < FLT_MAX)
+  {
+    path_shade_volume<RECORD, PTDL, HALTON>(sc, ps, rec, cnt);
+    return;
+  }
 
   const int v = ps.length;                         /* index of the vertex being created */
   bool alive = true;
@@ -172,7 +367,9 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
   if(hit.prim == MI_NOPRIM)
   { /* left the scene: environment vertex, src/pathspace.c:856-873; black sky => nothing to add, path ends */
     const float G = ps.prev_cos;                   /* path_G with an environment end point */
-    const float vpdf = ps.pdf*G;
+    /* a purely absorbing medium reaches here with clip == FLT_MAX: transmittance exp(-FLT_MAX mu_t), pdf 1 (src/shader.c:99-100) */
+    const float env_T = MEDIA ? media_transmittance(ps.cur, FLT_MAX) : 1.0f;
+    const float vpdf = MEDIA ? (ps.pdf*1.0f)*G : ps.pdf*G;
     ps.pdfprod *= (double)vpdf;
     ps.length++;
     cnt[6]++;
@@ -181,7 +378,7 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
       const V3 x = mk3(ps.prev_x.x + sc.far_dist*omega.x, ps.prev_x.y + sc.far_dist*omega.y, ps.prev_x.z + sc.far_dist*omega.z);
       Shading z; z.roughness = 1.0f; z.rs = z.rd = z.rg = z.em = 0.0f;
       rec_vertex<RECORD>(rec, v, MI_PRIMID_INVALID, FLT_MAX, x, mk3(0, 0, 0), mk3(0, 0, 0), omega, s_absorb, s_environment,
-                         ps.throughput, vpdf, 0.0f, 0.0f, z, 0.0f, -1);
+                         MEDIA ? ps.throughput*(env_T/1.0f) : ps.throughput, vpdf, 0.0f, 0.0f, z, 0.0f, -1);
       rec->length = ps.length; rec->throughput = 0.0f;
     }
     alive = false;
@@ -239,7 +436,12 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
     if((type > 2 || hit.dist < 1e-4f) && hit.prim == ps.ignore)
     {
       alive = false;
-      if(RECORD) { rec->length = ps.length; rec->throughput = 0.0f; }
+      if(RECORD)
+      {
+        rec->length = ps.length; rec->throughput = 0.0f;
+        /* path_extend after a failed propagate, src/pathspace.c:252-257: the vertex the ray left absorbs unless it emits */
+        if(v >= 1 && v-1 < MI_REC_MAX_VERTS && !(ps.prev_mode & s_emit)) rec->v[v-1].mode = s_absorb;
+      }
     }
     else
     {
@@ -247,7 +449,11 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
       if(sh.em > 0.0f && !(sf.flags & s_inside)) { mode = s_emit; material_modes = s_emit; }
       /* path_extend tail, src/pathspace.c:261-270 */
       const float G = ps.prev_cos*fabsf(dot3(sf.n, omega))/(hit.dist*hit.dist);
-      const float vpdf = ps.pdf*G;
+      /* edge in a medium, geometry before the sampled distance: pdf = transmittance (scattering medium, src/pathspace.c:834-838)
+         or transmittance with pdf 1 (absorbing only, src/shader.c:99-100) */
+      const float eT = MEDIA ? media_transmittance(ps.cur, hit.dist) : 1.0f;
+      const float epdf = MEDIA ? media_pdf_to_surface(ps.cur, hit.dist) : 1.0f;
+      const float vpdf = MEDIA ? (ps.pdf*epdf)*G : ps.pdf*G;
       const double pp_before = ps.pdfprod;
       ps.pdfprod *= (double)vpdf;
       ps.length++;
@@ -267,9 +473,9 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
           }
           Le = edf*sh.em;
         }
-        path_throughput = 0.0f + ps.throughput*Le;
+        path_throughput = MEDIA ? (ps.throughput*0.0f)/epdf + (ps.throughput*(eT/epdf))*Le : 0.0f + ps.throughput*Le;
       }
-      float vthr = ps.throughput;
+      float vthr = MEDIA ? ps.throughput*(eT/epdf) : ps.throughput;
       if(RECORD)
       {
         rec_vertex<RECORD>(rec, v, MI_GEO_PRIMID(pshade), hit.dist, sf.x, sf.n, sf.gn, omega, mode, sf.flags, vthr, vpdf, sf.u, sf.v, sh,
@@ -364,11 +570,13 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
               else if(mat_bsdf == MI_BSDF_DIELECTRIC) be = brdf_dielectric(sf, sh, omega, ol, eta_ratio);
               else be = brdf_metal(sc, sf, sh, omega, ol, ps.cur_ior, (int)mat_p0, ps.lambda);
               bool okn = be.value > 0.0f;
+              Medium nmed = ps.cur;                                        /* volume of the connection edge */
               if(okn && (be.mode & s_transmit))
               { /* path_edge_init_volume on the connection edge */
                 Media hyp = ps.media;
                 media_apply(hyp, shape, (sf.flags & s_inside) != 0);
                 if(hyp.broken) okn = false;
+                else if(MEDIA) nmed = shape_interior_medium(sc, media_top_shape(hyp), ps.lambda);
               }
               if(okn)
               { /* prims_get_ray, src/prims.c:390-492 */
@@ -381,16 +589,17 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
                 if(!(dot3(ls.gn, rd) >= 0) && total_dist > 0.0f)
                 {
                   const float Gn = fabsf(dot3(sf.n, ol))*fabsf(dot3(ls.n, ol))/(ldist*ldist);
-                  float tn = ((vthr*be.value)*(1.0f*edf))*Gn;
+                  const float nT = MEDIA ? media_transmittance(nmed, ldist) : 1.0f;
+                  float tn = ((vthr*be.value)*(nT*edf))*Gn;
                   tn = tn + (vthr*be.value)*((0.0f*Gn)/lpdf);
-                  const float wn = lpdf/(lpdf + 0.0f/1.0f);
+                  const float wn = lpdf/(lpdf + 0.0f/nT);
                   tn = tn*wn;
                   /* sampler_mis(path, rr*pdf_nee, path_pdf_extend(path, v+1)), ptdl.c:143-146 */
                   float pb;
                   if(mat_bsdf == MI_BSDF_DIFFUSE) pb = (float)(1.0f/MI_PI_D);
                   else if(mat_bsdf == MI_BSDF_DIELECTRIC) pb = pdf_dielectric(sf, sh, omega, ol, eta_ratio, be.mode);
                   else pb = pdf_metal(sf, sh, omega, ol, be.mode);
-                  const float pe = (1.0f*pb)*Gn;
+                  const float pe = ((MEDIA ? media_pdf_to_surface(nmed, ldist) : 1.0f)*pb)*Gn;
                   const double pp = ps.pdfprod;
                   const double our = (double)(1.0f*lpdf)*pp, other = (double)pe*pp;
                   const float wm = (float)our/(float)(other + our);
@@ -440,6 +649,7 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
           {
             const int top = media_top_shape(ps.media);
             ps.cur_ior = shape_interior_ior(sc, shape_material, top, ps.lambda);
+            if(MEDIA) ps.cur = shape_interior_medium(sc, top, ps.lambda);
           }
         }
         if(!ok)

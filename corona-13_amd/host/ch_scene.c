@@ -19,7 +19,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-enum { SH_DIFFUSE, SH_COLOR, SH_CHECKER, SH_MULT, SH_DIELECTRIC, SH_METAL, SH_MEDIUM, SH_INTERIOR, SH_OTHER };
+enum { SH_DIFFUSE, SH_COLOR, SH_CHECKER, SH_MULT, SH_DIELECTRIC, SH_METAL, SH_MEDIUM, SH_INTERIOR, SH_EXTERIOR, SH_OTHER };
 
 typedef struct ch_shader
 {
@@ -190,6 +190,14 @@ static int parse_shader_line(ch_scene *s, int id, char *line)
     if(sscanf(args, "%d %d", &a, &b) != 2) { fprintf(stderr, "[ch] interior: expecting <surface id> <interior id> in shader %d\n", id); return 1; }
     sh->pre[0] = a < 0 ? id + a : a;
     sh->host = b < 0 ? id + b : b;
+  }
+  else if(!strcmp(name, "exterior"))
+  { /* src/shader.c:699-716: <medium shader id> <light>: the global exterior medium */
+    sh->kind = SH_EXTERIOR;
+    int light = 0;
+    sh->host = -1;
+    sscanf(args, "%d %d", &sh->host, &light);
+    if(light && sh->host >= 0) { fprintf(stderr, "[ch] exterior: volume lights are outside the scope of this backend (shader %d)\n", id); return 2; }
   }
   else sh->kind = SH_OTHER;                 /* outside the hot-path scope; fine unless a shape uses it */
   return 0;
@@ -509,10 +517,20 @@ static void apply_coeff_cache(ch_scene *s)
 static int compile_all_materials(ch_scene *s)
 {
   for(int i=0;i<s->num_shaders;i++) compile_material(s, i, s->materials + i);
+  /* the last `exterior` line wins (src/shader.c:699-716) */
+  s->desc.exterior = 0;
+  for(int i=0;i<s->num_shaders;i++) if(s->shader[i].kind == SH_EXTERIOR)
+  {
+    const int m = s->shader[i].host;
+    if(m < 0) { s->desc.exterior = 0; continue; }
+    if(m >= i || s->materials[m].bsdf != MI_BSDF_MEDIUM)
+    { fprintf(stderr, "[ch] exterior: shader %d is not a medium defined before line %d\n", m, i); return MI_ERR_UNSUPPORTED; }
+    s->desc.exterior = (uint32_t)m + 1;
+  }
   for(uint32_t sid=0;sid<s->geo.num_shapes;sid++)
   {
     const int m = s->geo.shapes[sid].material;
-    if(s->materials[m].bsdf == MI_BSDF_NONE)
+    if(s->materials[m].bsdf == MI_BSDF_NONE || s->materials[m].bsdf == MI_BSDF_MEDIUM)
     {
       fprintf(stderr, "[ch] shape %u uses shader %d (`%s'), which is outside the scope of this backend\n", sid, m, s->shader[m].name);
       return MI_ERR_UNSUPPORTED;

@@ -194,7 +194,8 @@ typedef struct mi_scene_desc
   const float *metal_ior;     /* 5 x 95 x 2 (n,k) conductor tables, 360 nm step 5 (src/shaders/fresnel.h:21-27) or NULL */
 
   uint32_t pointsampler;      /* MI_POINTS_*: which MOD_pointsampler maps (path, dimension) to a number in [0,1) */
-  uint32_t reserved;
+  uint32_t exterior;          /* 0: the scene sits in vacuum; k+1: material k (MI_BSDF_MEDIUM) is the global exterior medium,
+                                 `exterior <k> 0` in the .nra2 (src/shader.c:544-565,699-716; volume lights are out of scope) */
 } mi_scene_desc;
 
 typedef struct mi_scene mi_scene;   /* opaque, device resident */

@@ -129,6 +129,7 @@ float o_prims_get_ray(const o_hit *h1, const o_hit *h2, o_ray *ray);
 
 /* oracle_shade.c */
 float o_shader_prepare(o_ctx *c, o_path *p, int v);
+void  o_prepare_medium(const mi_scene_desc *s, o_path *p, int v, int medium);
 float o_shader_sample(o_ctx *c, o_path *p);
 float o_shader_brdf(o_ctx *c, o_path *p, int v);
 float o_shader_pdf(o_ctx *c, o_path *p, int v);

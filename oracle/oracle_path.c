@@ -291,8 +291,19 @@ static int o_path_extend(o_ctx *c, o_path *path)
     (void)o_point(c, path, 0, o_dim_camid);
     path->v[0].throughput = 1.0f*o_camera_sample(c, path);         /* num_cams * camera_sample */
     path->v[0].throughput = path->v[0].throughput/1.0f;            /* view_pdf_camid */
-    path->v[0].interior.ior = 1.0f; path->v[0].interior.shader = -1;   /* shader_exterior_medium: vacuum */
-    path->e[0].vol = path->v[0].interior;
+    { /* shader_exterior_medium, src/shader.c:544-565: vacuum, or the global medium's prepare chain with mode, material modes
+         and shading of the sensor vertex put back afterwards */
+      memset(&path->v[0].interior, 0, sizeof(o_volume));
+      path->v[0].interior.ior = 1.0f; path->v[0].interior.shader = -1;
+      if(s->exterior)
+      {
+        const uint32_t mode = path->v[0].mode, material_modes = path->v[0].material_modes;
+        const o_shading shading = path->v[0].shading;
+        o_prepare_medium(s, path, 0, (int)s->exterior - 1);
+        path->v[0].mode = mode; path->v[0].material_modes = material_modes; path->v[0].shading = shading;
+      }
+      path->e[0].vol = path->v[0].interior;
+    }
     path->length++;
     path->v[1].throughput = path->v[0].throughput;
     path->v[0].tech = s_tech_extend;

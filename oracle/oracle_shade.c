@@ -5,9 +5,29 @@
 #include "o_core.h"
 
 /* ---------------------------------------------------------------- spectra */
+/* test switch: evaluate the sigmoid the way the reference BUILD does on this host -- fused multiply-adds (its arch flags define
+ * __FMA__) and the hardware's 12-bit rsqrtss (include/rgb2spec.h:130-149). Off by default: the HIP path is compared against the
+ * exact form below. Golden tests turn it on where the approximation would otherwise dominate the comparison with the
+ * reference dumps (thin media: mu_t is a small sigmoid value, the approximation is worth 0.1-0.4 % there). */
+static int o_reference_rsqrt = 0;
+#if defined(__x86_64__)
+#include <xmmintrin.h>
+float oracle_rsqrtss(float x) { return _mm_cvtss_f32(_mm_rsqrt_ss(_mm_set_ss(x))); }
+int oracle_set_reference_rsqrt(int on) { o_reference_rsqrt = on; return 1; }
+#else
+float oracle_rsqrtss(float x) { return 1.0f/sqrtf(x); }
+int oracle_set_reference_rsqrt(int on) { (void)on; return 0; }
+#endif
+
 float o_spectrum_eval(const float coeff[3], float lambda)
 { /* rgb2spec_eval_fast, include/rgb2spec.h:145-149 -- the reference uses the 12-bit rsqrtss
      approximation here; we use the exact reciprocal square root (tolerance stated in the tests) */
+  if(o_reference_rsqrt)
+  {
+    const float xr = fmaf(fmaf(coeff[0], lambda, coeff[1]), lambda, coeff[2]);
+    const float yr = oracle_rsqrtss(fmaf(xr, xr, 1.f));
+    return fmaf(.5f*xr, yr, .5f);
+  }
   const float x = (coeff[0]*lambda + coeff[1])*lambda + coeff[2];
   const float y = 1.0f/sqrtf(x*x + 1.0f);
   return .5f*x*y + .5f;
@@ -124,6 +144,19 @@ static void o_prepare_op(const mi_scene_desc *s, const mi_shade_op *op, o_path *
   }
 }
 
+void o_prepare_medium(const mi_scene_desc *s, o_path *p, int v, int medium)
+{ /* the prepare chain of a medium shader on vertex v: `interior <surface> <medium>` runs it before the surface's
+     (src/shaders/interior.c:101-118), shader_exterior_medium on the sensor (src/shader.c:552-564). mult.c:154-167: its colour
+     op in the volume slot first (texture.h:48-53), then medium_rgb.c:45-59; the volume keeps the medium's shader id */
+  const mi_material *med = s->materials + medium;
+  for(uint32_t k=0;k<med->num_ops;k++) o_prepare_op(s, med->op + k, p, v);
+  p->v[v].interior.mean_cos = med->mean_cos;
+  const float old_mu_t = p->v[v].interior.mu_t;
+  p->v[v].interior.mu_t = med->param[3]*o_spectrum_eval(med->param, p->lambda);
+  p->v[v].interior.mu_s = p->v[v].interior.mu_s*(p->v[v].interior.mu_t/old_mu_t);
+  p->v[v].interior.shader = medium;
+}
+
 float o_shader_prepare(o_ctx *c, o_path *p, int v)
 { /* shader_prepare, src/shader.c:462-542 */
   const mi_scene_desc *s = c->s;
@@ -165,17 +198,7 @@ float o_shader_prepare(o_ctx *c, o_path *p, int v)
   p->v[v].interior.ior = 1.0f; p->v[v].interior.shader = -1;
 
   const mi_material *m = s->materials + hit->shader;
-  if(m->interior >= 0)
-  { /* `interior <surface> <medium>`, src/shaders/interior.c:101-118: the medium's prepare chain first (mult.c:154-167:
-       its colour op in the volume slot, then medium_rgb.c:45-59), then the surface; the volume keeps the medium's shader id */
-    const mi_material *med = s->materials + m->interior;
-    for(uint32_t k=0;k<med->num_ops;k++) o_prepare_op(s, med->op + k, p, v);
-    p->v[v].interior.mean_cos = med->mean_cos;
-    const float old_mu_t = p->v[v].interior.mu_t;
-    p->v[v].interior.mu_t = med->param[3]*o_spectrum_eval(med->param, p->lambda);
-    p->v[v].interior.mu_s = p->v[v].interior.mu_s*(p->v[v].interior.mu_t/old_mu_t);
-    p->v[v].interior.shader = m->interior;
-  }
+  if(m->interior >= 0) o_prepare_medium(s, p, v, m->interior);
   for(uint32_t k=0;k<m->num_ops;k++) o_prepare_op(s, m->op + k, p, v);      /* mult.c:154-167 */
   if(m->bsdf == MI_BSDF_DIFFUSE)
   { /* prepare_d, src/shader.c:157-162 */

@@ -122,8 +122,8 @@ def image_pair(name, binary, mv, scene, w, h, spp, threads=8):
 
 
 COLOURS = [(0.3, 0.3, 0.3), (1, 1, 1), (3200, 3200, 3200), (10, 10, 10), (0.99, 0.96, 0.94), (0.5, 0.5, 0.5), (0.8, 0.2, 0.1), (0.1, 0.7, 0.3),
-           (1 / 0.5, 1 / 0.3, 1 / 0.2), (1 / 0.014, 1 / 0.005, 1 / 0.003)]
-# the last two: mu_t of `medium_rgb 0.5 0.3 0.2` (scenes/0055_media) and of the `medium_rgb 0.014 0.005 0.003` line every 0010-based scene carries
+           (1 / 0.5, 1 / 0.3, 1 / 0.2), (1 / 0.014, 1 / 0.005, 1 / 0.003), (1 / 30, 1 / 40, 1 / 60)]
+# the last three: mu_t of `medium_rgb 0.5 0.3 0.2` (scenes/0055_media), `medium_rgb 30 40 60` (scenes/0056_fog) and of the `medium_rgb 0.014 0.005 0.003` line every 0010-based scene carries
 # unused (regression/0010_pt/test.nra2:10), medium_rgb.c:113-119
 
 

@@ -12,7 +12,7 @@ import json
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, SCENE_0010, SCENE_FINE, SCENE_METAL, SCENE_ROUGH, load_pkg, make_scene, oracle_intersect, oracle_records, oracle_render
+from helpers import GOLDEN, SCENE_0010, SCENE_FINE, SCENE_FOG, SCENE_MEDIA, SCENE_METAL, SCENE_ROUGH, load_pkg, make_scene, oracle_intersect, oracle_records, oracle_render
 
 pkg = load_pkg()
 pytestmark = pytest.mark.gpu
@@ -31,6 +31,16 @@ CASES = [
     ("fine backdrop (tree in HBM) ptdl mv8", SCENE_FINE, pkg.MI_SAMPLER_PTDL, 1280, 720, 8, 10000),
     ("metal pt mv8", SCENE_METAL, pkg.MI_SAMPLER_PT, 1280, 720, 8, 8000),
     ("metal ptdl mv8", SCENE_METAL, pkg.MI_SAMPLER_PTDL, 1280, 720, 8, 8000),
+    # homogeneous medium inside the glass sphere (`interior`, `medium_rgb`): free-flight sampling, volume
+    # vertices, Henyey-Greenstein, transmittance and volume pdfs in next event estimation / MIS; depth 32 = long random walks
+    ("media pt mv8", SCENE_MEDIA, pkg.MI_SAMPLER_PT, 1280, 720, 8, 60000),
+    ("media ptdl mv8", SCENE_MEDIA, pkg.MI_SAMPLER_PTDL, 1280, 720, 8, 40000),
+    ("media pt mv32", SCENE_MEDIA, pkg.MI_SAMPLER_PT, 1280, 720, 32, 20000),
+    ("media ptdl mv32", SCENE_MEDIA, pkg.MI_SAMPLER_PTDL, 1280, 720, 32, 20000),
+    # thin global fog (`exterior <medium> 0`): volume vertices in the open, next event estimation from them reaches the emitters
+    ("fog pt mv8", SCENE_FOG, pkg.MI_SAMPLER_PT, 1280, 720, 8, 40000),
+    ("fog ptdl mv8", SCENE_FOG, pkg.MI_SAMPLER_PTDL, 1280, 720, 8, 40000),
+    ("fog ptdl mv32", SCENE_FOG, pkg.MI_SAMPLER_PTDL, 1280, 720, 32, 10000),
     # MOD_pointsampler = halton; ptdl at depth 32 reaches dimensions >= 256 (generator fall-back)
     ("halton pt mv8", SCENE_0010, pkg.MI_SAMPLER_PT, 1280, 720, 8, 60000),
     ("halton ptdl mv8", SCENE_0010, pkg.MI_SAMPLER_PTDL, 1280, 720, 8, 40000),
@@ -66,9 +76,15 @@ def test_paths_match_oracle(name, scene_path, sampler, w, h, mv, n):
         assert np.quantile(dx, 0.999) < (2e-3 if k <= 2 else 1e-2)
         assert np.quantile(rel(gpu["v"]["throughput"][m, k], ora["v"]["throughput"][m, k]), 0.999) < 1e-3
         assert (gpu["v"]["flags"][m, k] == ora["v"]["flags"][m, k]).mean() >= 0.999
+        assert (gpu["v"]["mode"][m, k] == ora["v"]["mode"][m, k]).mean() >= 0.999
+        assert (gpu["v"]["shader"][m, k] == ora["v"]["shader"][m, k]).mean() >= 0.999
+        assert np.quantile(rel(gpu["v"]["pdf"][m, k], ora["v"]["pdf"][m, k]), 0.999) < 5e-3
     m = same & (gpu["num_splats"] == ora["num_splats"]) & (ora["num_splats"] > 0)
     if m.sum():
-        assert np.quantile(rel(gpu["splat"]["value"][m, 0], ora["splat"]["value"][m, 0]), 0.99) < 1e-3
+        a, b = gpu["splat"]["value"][m, 0], ora["splat"]["value"][m, 0]
+        fin = np.isfinite(a) & np.isfinite(b)     # deep ptdl paths: the reference's own MIS products overflow to NaN, on both sides alike
+        assert np.array_equal(np.isnan(a), np.isnan(b))
+        assert np.quantile(rel(a[fin], b[fin]), 0.99) < 1e-3
     be.close()
 
 

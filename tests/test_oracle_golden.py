@@ -18,7 +18,7 @@ import json
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, SCENE_0010, SCENE_FINE, SCENE_MEDIA, SCENE_METAL, SCENE_ROUGH, load_pkg, make_scene, oracle_lib, oracle_records, oracle_render
+from helpers import GOLDEN, SCENE_0010, SCENE_FINE, SCENE_FOG, SCENE_MEDIA, SCENE_METAL, SCENE_ROUGH, load_pkg, make_scene, oracle_lib, oracle_records, oracle_render
 
 pkg = load_pkg()
 
@@ -40,6 +40,11 @@ CASES = [
     ("media_pt_mv8", pkg.MI_SAMPLER_PT, SCENE_MEDIA, 5e-3),
     ("media_ptdl_mv8", pkg.MI_SAMPLER_PTDL, SCENE_MEDIA, 1e-2),
     ("media_pt_mv32", pkg.MI_SAMPLER_PT, SCENE_MEDIA, 5e-3),
+    # thin global fog (`exterior <medium> 0`, scenes/0056_fog): nearly every path scatters in the open, so next event estimation
+    # from volume vertices reaches the emitters. mu_t is a SMALL sigmoid value here, where the reference's rsqrtss is worth
+    # 0.1-0.4 %: these two cases run the oracle with its reference-build emulation of that instruction (see reference_rsqrt)
+    ("fog_pt_mv8", pkg.MI_SAMPLER_PT, SCENE_FOG, 1.5e-3),
+    ("fog_ptdl_mv8", pkg.MI_SAMPLER_PTDL, SCENE_FOG, 1e-2),
     ("halton_pt_mv8", pkg.MI_SAMPLER_PT, SCENE_0010, 1.5e-3),
     ("halton_ptdl_mv8", pkg.MI_SAMPLER_PTDL, SCENE_0010, 1e-2),
     ("halton_ptdl_rough_mv32", pkg.MI_SAMPLER_PTDL, SCENE_ROUGH, 1e-2),
@@ -56,6 +61,25 @@ _ = [
 ]
 
 
+class reference_rsqrt:
+    """context: the oracle evaluates rgb2spec_eval_fast like the reference build on this host (FMA + hardware rsqrtss,
+    oracle/oracle_shade.c). The fixtures were dumped on an Intel Xeon; rsqrtss tables differ between vendors, so the emulation
+    only counts as exact when the host returns that CPU's values for a few arguments."""
+    KNOWN = {1.5: 1062273024, 2.0: 1060435968, 3.0: 1058260992, 1.0001: 1065349120}
+
+    def __enter__(self):
+        import ctypes as C
+        o = oracle_lib()
+        o.oracle_rsqrtss.restype = C.c_float
+        o.oracle_rsqrtss.argtypes = [C.c_float]
+        self.exact = bool(o.oracle_set_reference_rsqrt(1)) and all(
+            int(np.float32(o.oracle_rsqrtss(x)).view(np.uint32)) == bits for x, bits in self.KNOWN.items())
+        return self
+
+    def __exit__(self, *a):
+        oracle_lib().oracle_set_reference_rsqrt(0)
+
+
 def rel(a, b):
     return np.abs(a - b) / np.maximum(1e-20, np.maximum(np.abs(a), np.abs(b)))
 
@@ -66,7 +90,13 @@ def test_oracle_matches_reference_paths(name, sampler, scene_path, etol):
     ref = g["records"]
     s = make_scene(scene_path, width=int(g["width"]), height=int(g["height"]), max_verts=int(g["max_verts"]), sampler=sampler,
                    pointsampler=pkg.MI_POINTS_HALTON if name.startswith("halton_") else pkg.MI_POINTS_RAND)
-    ora = oracle_records(s, 0, len(ref))
+    if name.startswith("fog_"):
+        with reference_rsqrt() as emu:
+            ora = oracle_records(s, 0, len(ref))
+        if not emu.exact:
+            pytest.skip("rsqrtss of this host differs from the CPU the fixtures were dumped on; thin media need it (see CASES)")
+    else:
+        ora = oracle_records(s, 0, len(ref))
     for f, tol in (("pixel_i", 1e-4), ("pixel_j", 1e-4), ("lambda", 1e-4), ("time", 1e-6), ("scramble", 1e-6)):
         assert np.abs(ref[f] - ora[f]).max() <= tol, f
     same_len = ref["length"] == ora["length"]
@@ -86,15 +116,20 @@ def test_oracle_matches_reference_paths(name, sampler, scene_path, etol):
     same_splats = ref["num_splats"] == ora["num_splats"]
     assert same_splats.mean() >= 0.995
     both = same_len & same_splats
-    devs = []
+    devs, nan_same = [], []
     for k in range(ref["splat"].shape[1]):
         m = both & (ref["num_splats"] > k)
         if m.sum():
             assert (ref["splat"]["length"][m, k] == ora["splat"]["length"][m, k]).all()
-            devs.append(rel(ref["splat"]["value"][m, k], ora["splat"]["value"][m, k]))
+            a, b = ref["splat"]["value"][m, k], ora["splat"]["value"][m, k]
+            # the reference's own weights are NaN for a few connections (inf/inf in its MIS products; view_splat drops them)
+            nan_same.append(np.isnan(a) == np.isnan(b))
+            fin = np.isfinite(a) & np.isfinite(b)
+            devs.append(rel(a[fin], b[fin]))
     devs = np.concatenate(devs)
+    assert np.concatenate(nan_same).mean() >= 0.999
     assert np.median(devs) < 5e-4 and np.quantile(devs, 0.99) < 5e-2
-    e_ref, e_ora = ref["splat"]["col"][both].sum(axis=(0, 1)), ora["splat"]["col"][both].sum(axis=(0, 1))
+    e_ref, e_ora = np.nan_to_num(ref["splat"]["col"][both]).sum(axis=(0, 1)), np.nan_to_num(ora["splat"]["col"][both]).sum(axis=(0, 1))
     assert np.all(np.abs(e_ref - e_ora) <= etol * np.abs(e_ref).max())
 
 
