@@ -40,6 +40,11 @@ CONFIGS = {
     "cfg3": dict(scene="0010_pt", sampler="ptdl", w=1280, h=720, spp=64, mv=8, name="configs[2]: regression/0011_ptdl (0010 scene, ptdl sampler), 1280x720, 64 spp"),
     "cfg4": dict(scene="0052_rough", sampler="pt", w=1280, h=720, spp=256, mv=32, name="configs[3]: regression/0052 parameters (rough dielectric), max depth 32, 1280x720, 256 spp"),
     "cfg5": dict(scene="0010_pt", sampler="pt", w=3840, h=2160, spp=128, mv=8, name="configs[4]: regression/0010_pt at 3840x2160, 1024 spp over 8 GPUs = 128 spp per GPU"),
+    # not BASELINE.json configurations: the SURVEY 8(f) row 3 scenes (participating media), same film and depth as configs[1]
+    "media": dict(scene="0055_media", sampler="pt", w=1280, h=720, spp=64, mv=8, name="0010 scene, scattering medium inside the glass sphere (scenes/0055_media), pt, 1280x720, 64 spp"),
+    "media_ptdl": dict(scene="0055_media", sampler="ptdl", w=1280, h=720, spp=64, mv=8, name="scenes/0055_media, ptdl, 1280x720, 64 spp"),
+    "fog": dict(scene="0056_fog", sampler="pt", w=1280, h=720, spp=64, mv=8, name="0010 scene in a thin global fog (scenes/0056_fog), pt, 1280x720, 64 spp"),
+    "fog_ptdl": dict(scene="0056_fog", sampler="ptdl", w=1280, h=720, spp=64, mv=8, name="scenes/0056_fog, ptdl, 1280x720, 64 spp"),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
@@ -220,7 +225,7 @@ def main():
                        "paths_per_step_per_gpu": per_frame, "sharding": f"path-index ranges x{world}, framebuffer all-reduce"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic if args.config == "cfg2" else None, "traffic_source": traffic_src if args.config == "cfg2" else None,
-                         "kernel": "mi_path_kernel<false,%s,%s,%s> (RECORD, PTDL, NODES_LDS, HALTON)" % ("true" if cfg["sampler"] == "ptdl" else "false", "true" if be.nodes_in_lds() else "false", "true" if args.points == "halton" else "false"), "kernel_ms": kms,
+                         "kernel": "mi_path_kernel<false,%s,%s,%s,%s> (RECORD, PTDL, NODES_LDS, HALTON, MEDIA)" % ("true" if cfg["sampler"] == "ptdl" else "false", "true" if be.nodes_in_lds() else "false", "true" if args.points == "halton" else "false", "true" if cfg["scene"] in ("0055_media", "0056_fog") else "false"), "kernel_ms": kms,
                          "algorithmic_bytes_per_sample": bytes_per_sample,
                          "work_per_sample": {"rays": dc[0] / paths, "node_visits": dc[1] / paths, "prim_tests": dc[3] / paths, "splats": dc[5] / paths}},
         }

@@ -615,3 +615,30 @@ def test_halton_image_matches_oracle_and_differs_from_rand(monkeypatch):
     monkeypatch.setenv("CORONA_MI_MODE", "wave")
     with pytest.raises(RuntimeError, match="megakernel"):
         pkg.Backend(scene)
+
+
+@pytest.mark.parametrize("scene_path,sampler", [(SCENE_MEDIA, pkg.MI_SAMPLER_PT), (SCENE_FOG, pkg.MI_SAMPLER_PTDL)])
+def test_media_image_matches_oracle(scene_path, sampler):
+    """1-spp film through the MEDIA kernels (splats of paths with volume vertices included) against the oracle's"""
+    scene = make_scene(scene_path, width=512, height=288, max_verts=8, sampler=sampler)
+    npx = scene.width * scene.height
+    be = pkg.Backend(scene)
+    be.render(0, npx)
+    fb = be.fb_read()
+    cnt = be.counters()
+    be.close()
+    ofb, ocnt, _ = oracle_render(scene, 0, npx, threads=8)
+    assert np.isfinite(fb).all()
+    rmse = np.sqrt((((fb - ofb) * scene.gain(1)) ** 2).sum() / npx)
+    assert rmse < 0.05, rmse
+    assert cnt[4] == npx and abs(cnt[0] - ocnt[0]) <= 1e-4 * ocnt[0] and abs(cnt[6] - ocnt[6]) <= 1e-4 * ocnt[6]   # paths, rays, vertices
+    assert cnt[5] == ocnt[5] or abs(cnt[5] - ocnt[5]) <= 1e-3 * ocnt[5]                                            # splats
+
+
+def test_media_restrictions_are_reported(monkeypatch):
+    scene = make_scene(SCENE_MEDIA, width=64, height=64, max_verts=4, pointsampler=pkg.MI_POINTS_HALTON)
+    with pytest.raises(RuntimeError, match="Halton"):
+        pkg.Backend(scene)
+    monkeypatch.setenv("CORONA_MI_MODE", "wave")
+    with pytest.raises(RuntimeError, match="megakernel"):
+        pkg.Backend(make_scene(SCENE_FOG, width=64, height=64, max_verts=4))
