@@ -122,8 +122,8 @@ def image_pair(name, binary, mv, scene, w, h, spp, threads=8):
 
 
 COLOURS = [(0.3, 0.3, 0.3), (1, 1, 1), (3200, 3200, 3200), (10, 10, 10), (0.99, 0.96, 0.94), (0.5, 0.5, 0.5), (0.8, 0.2, 0.1), (0.1, 0.7, 0.3),
-           (1 / 0.5, 1 / 0.3, 1 / 0.2), (1 / 0.014, 1 / 0.005, 1 / 0.003), (1 / 30, 1 / 40, 1 / 60)]
-# the last three: mu_t of `medium_rgb 0.5 0.3 0.2` (scenes/0055_media), `medium_rgb 30 40 60` (scenes/0056_fog) and of the `medium_rgb 0.014 0.005 0.003` line every 0010-based scene carries
+           (1 / 0.5, 1 / 0.3, 1 / 0.2), (1 / 0.014, 1 / 0.005, 1 / 0.003), (1 / 30, 1 / 40, 1 / 60), (1 / 1.5, 1 / 0.8, 1 / 0.4)]
+# the last three: mu_t of `medium_rgb 0.5 0.3 0.2` (scenes/0055_media), `medium_rgb 30 40 60` (scenes/0056_fog), `medium_rgb 1.5 0.8 0.4` (scenes/0057_nested) and of the `medium_rgb 0.014 0.005 0.003` line every 0010-based scene carries
 # unused (regression/0010_pt/test.nra2:10), medium_rgb.c:113-119
 
 
@@ -154,6 +154,11 @@ def main():
         dump_paths("media_pt_mv8", "dump_pt_xs_mv8", 8, "0055_media", 1280, 720, 10000)
         dump_paths("media_ptdl_mv8", "dump_ptdl_xs_mv8", 8, "0055_media", 1280, 720, 10000)
         dump_paths("media_pt_mv32", "dump_pt_xs_mv32", 32, "0055_media", 1280, 720, 6000)
+        dump_paths("fog_pt_mv8", "dump_pt_xs_mv8", 8, "0056_fog", 1280, 720, 10000)
+        dump_paths("fog_ptdl_mv8", "dump_ptdl_xs_mv8", 8, "0056_fog", 1280, 720, 10000)
+        dump_paths("media_ptdl_mv32", "dump_ptdl_xs_mv32", 32, "0055_media", 1280, 720, 6000)
+        dump_paths("nested_pt_mv8", "dump_pt_xs_mv8", 8, "0057_nested", 1280, 720, 10000)
+        dump_paths("nested_ptdl_mv8", "dump_ptdl_xs_mv8", 8, "0057_nested", 1280, 720, 10000)
         # MOD_pointsampler=halton; the mv32 ptdl case reaches dimensions >= 256 (fallback to the per-path generator)
         dump_paths("halton_pt_mv8", "dump_pt_halton_mv8", 8, "0010_pt", 1280, 720, 3000)
         dump_paths("halton_ptdl_mv8", "dump_ptdl_halton_mv8", 8, "0010_pt", 1280, 720, 3000)

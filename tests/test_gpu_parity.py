@@ -12,7 +12,7 @@ import json
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, SCENE_0010, SCENE_FINE, SCENE_FOG, SCENE_MEDIA, SCENE_METAL, SCENE_ROUGH, load_pkg, make_scene, oracle_intersect, oracle_records, oracle_render
+from helpers import GOLDEN, SCENE_0010, SCENE_FINE, SCENE_FOG, SCENE_MEDIA, SCENE_NESTED, SCENE_METAL, SCENE_ROUGH, load_pkg, make_scene, oracle_intersect, oracle_records, oracle_render
 
 pkg = load_pkg()
 pytestmark = pytest.mark.gpu
@@ -41,6 +41,9 @@ CASES = [
     ("fog pt mv8", SCENE_FOG, pkg.MI_SAMPLER_PT, 1280, 720, 8, 40000),
     ("fog ptdl mv8", SCENE_FOG, pkg.MI_SAMPLER_PTDL, 1280, 720, 8, 40000),
     ("fog ptdl mv32", SCENE_FOG, pkg.MI_SAMPLER_PTDL, 1280, 720, 32, 10000),
+    # fog outside + scattering medium in the sphere + absorbing medium in the cone
+    ("nested media pt mv8", SCENE_NESTED, pkg.MI_SAMPLER_PT, 1280, 720, 8, 40000),
+    ("nested media ptdl mv32", SCENE_NESTED, pkg.MI_SAMPLER_PTDL, 1280, 720, 32, 10000),
     # MOD_pointsampler = halton; ptdl at depth 32 reaches dimensions >= 256 (generator fall-back)
     ("halton pt mv8", SCENE_0010, pkg.MI_SAMPLER_PT, 1280, 720, 8, 60000),
     ("halton ptdl mv8", SCENE_0010, pkg.MI_SAMPLER_PTDL, 1280, 720, 8, 40000),

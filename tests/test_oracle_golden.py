@@ -18,7 +18,7 @@ import json
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, SCENE_0010, SCENE_FINE, SCENE_FOG, SCENE_MEDIA, SCENE_METAL, SCENE_ROUGH, load_pkg, make_scene, oracle_lib, oracle_records, oracle_render
+from helpers import GOLDEN, SCENE_0010, SCENE_FINE, SCENE_FOG, SCENE_MEDIA, SCENE_NESTED, SCENE_METAL, SCENE_ROUGH, load_pkg, make_scene, oracle_lib, oracle_records, oracle_render
 
 pkg = load_pkg()
 
@@ -45,6 +45,10 @@ CASES = [
     # 0.1-0.4 %: these two cases run the oracle with its reference-build emulation of that instruction (see reference_rsqrt)
     ("fog_pt_mv8", pkg.MI_SAMPLER_PT, SCENE_FOG, 1.5e-3),
     ("fog_ptdl_mv8", pkg.MI_SAMPLER_PTDL, SCENE_FOG, 1e-2),
+    # fog outside, a scattering medium in the sphere, a purely absorbing one (albedo 0: src/shader.c:99-100) in the cone:
+    # every transition of the nested-medium stack between exterior and interior volumes
+    ("nested_pt_mv8", pkg.MI_SAMPLER_PT, SCENE_NESTED, 1.5e-3),
+    ("nested_ptdl_mv8", pkg.MI_SAMPLER_PTDL, SCENE_NESTED, 1e-2),
     ("halton_pt_mv8", pkg.MI_SAMPLER_PT, SCENE_0010, 1.5e-3),
     ("halton_ptdl_mv8", pkg.MI_SAMPLER_PTDL, SCENE_0010, 1e-2),
     ("halton_ptdl_rough_mv32", pkg.MI_SAMPLER_PTDL, SCENE_ROUGH, 1e-2),
@@ -90,7 +94,7 @@ def test_oracle_matches_reference_paths(name, sampler, scene_path, etol):
     ref = g["records"]
     s = make_scene(scene_path, width=int(g["width"]), height=int(g["height"]), max_verts=int(g["max_verts"]), sampler=sampler,
                    pointsampler=pkg.MI_POINTS_HALTON if name.startswith("halton_") else pkg.MI_POINTS_RAND)
-    if name.startswith("fog_"):
+    if name.startswith(("fog_", "nested_")):
         with reference_rsqrt() as emu:
             ora = oracle_records(s, 0, len(ref))
         if not emu.exact:
