@@ -607,8 +607,6 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
     if(why) { free(s); return fail(MI_ERR_ARG, why); }
     any_media = true;
   }
-  if(any_media && h->pointsampler == MI_POINTS_HALTON)
-  { free(s); return fail(MI_ERR_UNSUPPORTED, "participating media with the Halton point sampler are not supported yet"); }
   std::vector<float> shape_L(h->num_shapes ? h->num_shapes : 1, 0.0f);
   for(uint32_t k=0;k<h->lights.num_prims;k++)
   {
@@ -719,7 +717,11 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
       (const void *)mi_path_kernel<false, false, true, false, true>, (const void *)mi_path_kernel<true, false, true, false, true>,
       (const void *)mi_path_kernel<false, true, true, false, true>, (const void *)mi_path_kernel<true, true, true, false, true>,
       (const void *)mi_path_kernel<false, false, false, false, true>, (const void *)mi_path_kernel<true, false, false, false, true>,
-      (const void *)mi_path_kernel<false, true, false, false, true>, (const void *)mi_path_kernel<true, true, false, false, true> };
+      (const void *)mi_path_kernel<false, true, false, false, true>, (const void *)mi_path_kernel<true, true, false, false, true>,
+      (const void *)mi_path_kernel<false, false, true, true, true>, (const void *)mi_path_kernel<true, false, true, true, true>,
+      (const void *)mi_path_kernel<false, true, true, true, true>, (const void *)mi_path_kernel<true, true, true, true, true>,
+      (const void *)mi_path_kernel<false, false, false, true, true>, (const void *)mi_path_kernel<true, false, false, true, true>,
+      (const void *)mi_path_kernel<false, true, false, true, true>, (const void *)mi_path_kernel<true, true, false, true, true> };
     for(const void *k : kernels)
       if(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess)
       { mi_scene_destroy(s); return fail(MI_ERR_DEVICE, "cannot raise the dynamic LDS limit"); }
@@ -864,11 +866,15 @@ static void launch_path_kernel(mi_scene *s, bool record, int grid, uint64_t firs
     (unsigned long long)first, (unsigned long long)n, (const uint32_t *)s->d_shape_material, (const float *)s->d_shape_L, rec, (uint2 *)s->d_overflow)
   switch(which)
   {
-    /* MEDIA (scenes with participating media; rand point sampler only) */
+    /* MEDIA (scenes with participating media) */
     case 16: MI_LAUNCH5(false, false, false, false, true); break;  case 17: MI_LAUNCH5(true, false, false, false, true); break;
     case 18: MI_LAUNCH5(false, true,  false, false, true); break;  case 19: MI_LAUNCH5(true, true,  false, false, true); break;
     case 20: MI_LAUNCH5(false, false, true,  false, true); break;  case 21: MI_LAUNCH5(true, false, true,  false, true); break;
     case 22: MI_LAUNCH5(false, true,  true,  false, true); break;  case 23: MI_LAUNCH5(true, true,  true,  false, true); break;
+    case 24: MI_LAUNCH5(false, false, false, true,  true); break;  case 25: MI_LAUNCH5(true, false, false, true,  true); break;
+    case 26: MI_LAUNCH5(false, true,  false, true,  true); break;  case 27: MI_LAUNCH5(true, true,  false, true,  true); break;
+    case 28: MI_LAUNCH5(false, false, true,  true,  true); break;  case 29: MI_LAUNCH5(true, false, true,  true,  true); break;
+    case 30: MI_LAUNCH5(false, true,  true,  true,  true); break;  case 31: MI_LAUNCH5(true, true,  true,  true,  true); break;
     case  0: MI_LAUNCH(false, false, false, false); break;  case  1: MI_LAUNCH(true, false, false, false); break;
     case  2: MI_LAUNCH(false, true,  false, false); break;  case  3: MI_LAUNCH(true, true,  false, false); break;
     case  4: MI_LAUNCH(false, false, true,  false); break;  case  5: MI_LAUNCH(true, false, true,  false); break;

@@ -162,6 +162,7 @@ def main():
         # MOD_pointsampler=halton; the mv32 ptdl case reaches dimensions >= 256 (fallback to the per-path generator)
         dump_paths("halton_pt_mv8", "dump_pt_halton_mv8", 8, "0010_pt", 1280, 720, 3000)
         dump_paths("halton_ptdl_mv8", "dump_ptdl_halton_mv8", 8, "0010_pt", 1280, 720, 3000)
+        dump_paths("halton_fog_ptdl_mv8", "dump_ptdl_halton_mv8", 8, "0056_fog", 1280, 720, 6000)   # free-flight dimension from the Halton sampler
         dump_paths("halton_ptdl_rough_mv32", "dump_ptdl_halton_mv32", 32, "0052_rough", 1280, 720, 2000)
         counters()
     if what in ("images", "all"):

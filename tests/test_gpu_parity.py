@@ -49,6 +49,8 @@ CASES = [
     ("halton ptdl mv8", SCENE_0010, pkg.MI_SAMPLER_PTDL, 1280, 720, 8, 40000),
     ("halton ptdl rough dielectric mv32", SCENE_ROUGH, pkg.MI_SAMPLER_PTDL, 1280, 720, 32, 30000),
     ("halton fine backdrop (tree in HBM) pt mv8", SCENE_FINE, pkg.MI_SAMPLER_PT, 1280, 720, 8, 10000),
+    ("halton fog ptdl mv8 (free-flight dimension from the sampler)", SCENE_FOG, pkg.MI_SAMPLER_PTDL, 1280, 720, 8, 20000),
+    ("halton nested media pt mv32", SCENE_NESTED, pkg.MI_SAMPLER_PT, 1280, 720, 32, 10000),
 ]
 
 
@@ -639,9 +641,6 @@ def test_media_image_matches_oracle(scene_path, sampler):
 
 
 def test_media_restrictions_are_reported(monkeypatch):
-    scene = make_scene(SCENE_MEDIA, width=64, height=64, max_verts=4, pointsampler=pkg.MI_POINTS_HALTON)
-    with pytest.raises(RuntimeError, match="Halton"):
-        pkg.Backend(scene)
     monkeypatch.setenv("CORONA_MI_MODE", "wave")
     with pytest.raises(RuntimeError, match="megakernel"):
         pkg.Backend(make_scene(SCENE_FOG, width=64, height=64, max_verts=4))

@@ -52,6 +52,7 @@ CASES = [
     ("halton_pt_mv8", pkg.MI_SAMPLER_PT, SCENE_0010, 1.5e-3),
     ("halton_ptdl_mv8", pkg.MI_SAMPLER_PTDL, SCENE_0010, 1e-2),
     ("halton_ptdl_rough_mv32", pkg.MI_SAMPLER_PTDL, SCENE_ROUGH, 1e-2),
+    ("halton_fog_ptdl_mv8", pkg.MI_SAMPLER_PTDL, SCENE_FOG, 1e-2),          # the free-flight dimension (rand_beg + 0) from the Halton sampler
 ]
 
 # Fraction of paths that must have the reference's vertex count. The reference's metal Fresnel term (metal.c:79-157)
@@ -94,7 +95,7 @@ def test_oracle_matches_reference_paths(name, sampler, scene_path, etol):
     ref = g["records"]
     s = make_scene(scene_path, width=int(g["width"]), height=int(g["height"]), max_verts=int(g["max_verts"]), sampler=sampler,
                    pointsampler=pkg.MI_POINTS_HALTON if name.startswith("halton_") else pkg.MI_POINTS_RAND)
-    if name.startswith(("fog_", "nested_")):
+    if name.startswith(("fog_", "nested_", "halton_fog_")):
         with reference_rsqrt() as emu:
             ora = oracle_records(s, 0, len(ref))
         if not emu.exact:
