@@ -61,7 +61,8 @@ class MiCamera(C.Structure):
     _fields_ = [("pos", C.c_float * 3), ("a", C.c_float * 3), ("b", C.c_float * 3), ("n", C.c_float * 3),
                 ("focus", C.c_float), ("focal_length", C.c_float), ("film_width", C.c_float),
                 ("film_height", C.c_float), ("f_stop", C.c_float), ("exposure_time", C.c_float),
-                ("iso", C.c_float), ("time_scale", C.c_float)]
+                ("iso", C.c_float), ("time_scale", C.c_float),
+                ("moving", C.c_uint32), ("pos_t1", C.c_float * 3), ("orient", C.c_float * 4), ("orient_t1", C.c_float * 4)]
 
 
 class MiLights(C.Structure):

@@ -67,6 +67,49 @@ __device__ __forceinline__ void rec_vertex(mi_path_record *rec, int v, uint64_t 
   d.rd = sh.rd; d.rg = sh.rg; d.em = sh.em; d.roughness = sh.roughness; d.eta = eta; d.shader = shader;
 }
 
+/* view_cam_init_frame, src/view.c:903-919: the camera frame at `time` in the shutter interval -- quaternion_slerp of the
+ * shutter-open and shutter-close orientations (include/quaternion.h:86-110), the three axes through quaternion_transform
+ * (60-75), normalised; position interpolated linearly. Quaternions are w, x, y, z. */
+__device__ __forceinline__ void quat_mult(float *in, const float *p)
+{ /* quaternion_mult, include/quaternion.h:41-48 */
+  const float r0 = in[0], r1 = in[1], r2 = in[2], r3 = in[3];
+  in[1] = r0*p[1] + r1*p[0] + r2*p[3] - r3*p[2];
+  in[2] = r0*p[2] - r1*p[3] + r2*p[0] + r3*p[1];
+  in[3] = r0*p[3] + r1*p[2] - r2*p[1] + r3*p[0];
+  in[0] = r0*p[0] - r1*p[1] - r2*p[2] - r3*p[3];
+}
+__device__ __forceinline__ V3 quat_transform(const float *q, const V3 v)
+{
+  const float vq[4] = { 0.0f, v.x, v.y, v.z }, inv[4] = { q[0], -q[1], -q[2], -q[3] };
+  float res[4] = { q[0], q[1], q[2], q[3] };
+  quat_mult(res, vq);
+  quat_mult(res, inv);
+  return mk3(res[1], res[2], res[3]);
+}
+__device__ __forceinline__ void camera_frame_at(const mi_camera &cam, float time, V3 &a, V3 &b, V3 &n, V3 &pos)
+{
+  const float *q = cam.orient, *p = cam.orient_t1;
+  float r[4];
+  const float cos_theta_2 = q[0]*p[0] + (q[1]*p[1] + q[2]*p[2] + q[3]*p[3]);
+  if(fabsf(cos_theta_2) >= 1.0f) { r[0] = q[0]; r[1] = q[1]; r[2] = q[2]; r[3] = q[3]; }
+  else
+  {
+    const float theta_2 = acosf(cos_theta_2);
+    const float sin_theta_2 = sqrtf(1.0f - cos_theta_2*cos_theta_2);
+    if(fabsf(sin_theta_2) < 1e-10f) for(int k=0;k<4;k++) r[k] = (q[k] + p[k])*.5f;
+    else
+    {
+      const float wa = sinf((1.0f - time)*theta_2)/sin_theta_2;
+      const float wb = sinf(time*theta_2)/sin_theta_2;
+      for(int k=0;k<4;k++) r[k] = q[k]*wa + p[k]*wb;
+    }
+  }
+  a = normalise3(quat_transform(r, mk3(1.0f, 0.0f, 0.0f)));
+  b = normalise3(quat_transform(r, mk3(0.0f, 1.0f, 0.0f)));
+  n = normalise3(quat_transform(r, mk3(0.0f, 0.0f, 1.0f)));
+  pos = mk3(cam.pos[0]*(1.0f-time) + cam.pos_t1[0]*time, cam.pos[1]*(1.0f-time) + cam.pos_t1[1]*time, cam.pos[2]*(1.0f-time) + cam.pos_t1[2]*time);
+}
+
 /* start path `index`: afterwards ps holds the camera ray as the pending extension ray */
 template<bool RECORD, bool HALTON, bool MEDIA = false>
 __device__ __forceinline__ void path_generate(const DScene &sc, PathState &ps, unsigned long long index, mi_path_record *rec, uint32_t *cnt)
@@ -94,7 +137,8 @@ __device__ __forceinline__ void path_generate(const DScene &sc, PathState &ps, u
   sincosf(ang, &sn, &cs);                 /* one range reduction for both (same values as sinf/cosf) */
   const float lu = cs*sqrtf(r2)*cc.lens_radius;
   const float lv = sn*sqrtf(r2)*cc.lens_radius;
-  const V3 ca = ld3(cam.a), cb = ld3(cam.b), cn = ld3(cam.n);
+  V3 ca = ld3(cam.a), cb = ld3(cam.b), cn = ld3(cam.n), cpos = ld3(cam.pos);
+  if(cam.moving) camera_frame_at(cam, time, ca, cb, cn, cpos);        /* camera motion blur, src/view.c:903-919 */
   const V3 aoff = mk3(lu*ca.x + lv*cb.x, lu*ca.y + lv*cb.y, lu*ca.z + lv*cb.z);
   const float ki = (ci-.5f*W)*cc.f_rg, kj = (cj-.5f*H)*cc.f_up;
   V3 om = mk3(cc.f_dir*cn.x + (ki*ca.x + kj*cb.x) - aoff.x,
@@ -109,7 +153,7 @@ __device__ __forceinline__ void path_generate(const DScene &sc, PathState &ps, u
   const float G = dot4/cc.fl2;
   const float pdf_v = cc.pdf_v;
   ps.pdf = pdf_v*pdf_a/G;
-  const V3 x0 = mk3(cam.pos[0] + aoff.x, cam.pos[1] + aoff.y, cam.pos[2] + aoff.z);
+  const V3 x0 = mk3(cpos.x + aoff.x, cpos.y + aoff.y, cpos.z + aoff.z);
   const float thr0 = sensor*G/cc.pdf_av;
   ps.org = x0; ps.dir = om; ps.ignore = MI_NOPRIM;
   ps.prev_x = x0;

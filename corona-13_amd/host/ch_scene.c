@@ -416,12 +416,12 @@ static int load_camera(ch_scene *s)
   if(av < 0 || av >= 17) av = 9;
   if(iso < 1 || iso > 409600) iso = 100;
   if(s->opt.iso > 0) iso = s->opt.iso;
-  if(memcmp(pos, pos1, 12) || memcmp(&q, &q1, 16))
-  {
-    fprintf(stderr, "[ch] camera motion blur is outside the scope of this backend\n");
-    return MI_ERR_UNSUPPORTED;
-  }
   mi_camera *c = &s->desc.cam;
+  /* shutter-open and shutter-close state differ: camera motion blur, the frame is interpolated per path (src/view.c:903-919) */
+  c->moving = (memcmp(pos, pos1, 12) || memcmp(&q, &q1, 16)) ? 1 : 0;
+  memcpy(c->pos_t1, pos1, 12);
+  c->orient[0] = q.w; memcpy(c->orient + 1, q.x, 12);
+  c->orient_t1[0] = q1.w; memcpy(c->orient_t1 + 1, q1.x, 12);
   const float w = (float)s->desc.width, h = (float)s->desc.height;
   if(s->desc.width > s->desc.height) { c->film_width = 0.35f/crop; c->film_height = h/w*c->film_width; }
   else                               { c->film_height = 0.35f/crop; c->film_width = w/h*c->film_height; }

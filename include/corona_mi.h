@@ -133,6 +133,11 @@ typedef struct mi_camera
   float exposure_time;        /* view_tv2time(exposure_value)                     */
   float iso;
   float time_scale;           /* view_sample_time: min(1, exposure/ (1/30))       */
+  /* camera motion blur (src/view.c:903-919): the frame of a path is the slerp of the two orientations at the path's time in
+     [0, time_scale], the position the lerp of pos and pos_t1. moving == 0: pos/a/b/n above are the (static) frame. */
+  uint32_t moving;
+  float pos_t1[3];
+  float orient[4], orient_t1[4];   /* quaternions w, x, y, z (include/quaternion.h:23-27) */
 } mi_camera;
 
 /* ---- emitter list (src/lights.d/list.c:56-104) ---------------------------------- */

@@ -90,6 +90,54 @@ static void o_path_update_throughput(o_path *path, int v)
 }
 
 /* ---------------------------------------------------------------- camera */
+static void o_quaternion_mult(float *in, const float *p)
+{ /* quaternion_mult, include/quaternion.h:41-48; quaternions as w, x, y, z */
+  const float r[4] = { in[0], in[1], in[2], in[3] };
+  in[1] = r[0]*p[1] + r[1]*p[0] + r[2]*p[3] - r[3]*p[2];
+  in[2] = r[0]*p[2] - r[1]*p[3] + r[2]*p[0] + r[3]*p[1];
+  in[3] = r[0]*p[3] + r[1]*p[2] - r[2]*p[1] + r[3]*p[0];
+  in[0] = r[0]*p[0] - r[1]*p[1] - r[2]*p[2] - r[3]*p[3];
+}
+
+static void o_quaternion_transform(const float *q, float *v)
+{ /* quaternion_transform, include/quaternion.h:60-75: q v q' */
+  const float vq[4] = { 0.0f, v[0], v[1], v[2] }, inv[4] = { q[0], -q[1], -q[2], -q[3] };
+  float res[4] = { q[0], q[1], q[2], q[3] };
+  o_quaternion_mult(res, vq);
+  o_quaternion_mult(res, inv);
+  for(int k=0;k<3;k++) v[k] = res[k+1];
+}
+
+static void o_view_cam_init_frame(const mi_camera *cam, float time, o_hit *hit)
+{ /* view_cam_init_frame, src/view.c:903-919 + quaternion_slerp, include/quaternion.h:86-110 */
+  const float *q = cam->orient, *p = cam->orient_t1;
+  float r[4];
+  const float cos_theta_2 = q[0]*p[0] + (q[1]*p[1] + q[2]*p[2] + q[3]*p[3]);
+  if(fabsf(cos_theta_2) >= 1.0f) memcpy(r, q, sizeof(r));
+  else
+  {
+    const float theta_2 = acosf(cos_theta_2);
+    const float sin_theta_2 = sqrtf(1.0f - cos_theta_2*cos_theta_2);
+    if(fabsf(sin_theta_2) < 1e-10f) for(int k=0;k<4;k++) r[k] = (q[k] + p[k])*.5f;
+    else
+    {
+      const float a = sinf((1.0f - time)*theta_2)/sin_theta_2;
+      const float b = sinf(time*theta_2)/sin_theta_2;
+      for(int k=0;k<4;k++) r[k] = q[k]*a + p[k]*b;
+    }
+  }
+  hit->a[0] = hit->b[1] = hit->n[2] = 1.0f;
+  hit->a[1] = hit->a[2] = hit->b[0] = hit->b[2] = hit->n[0] = hit->n[1] = 0.0f;
+  o_quaternion_transform(r, hit->a);
+  o_quaternion_transform(r, hit->b);
+  o_quaternion_transform(r, hit->n);
+  for(int k=0;k<3;k++) hit->gn[k] = hit->n[k];
+  for(int k=0;k<3;k++) hit->x[k] = cam->pos[k]*(1.0f-time) + cam->pos_t1[k]*time;
+  o_normalise(hit->a);
+  o_normalise(hit->b);
+  o_normalise(hit->n);
+}
+
 static float o_camera_sample(o_ctx *c, o_path *p)
 { /* camera_sample + _camera_sample_internal, src/camera.d/thinlens.c:68-128; view_cam_init_frame,
      src/view.c:903-919 (static camera: frame precomputed by the host) */
@@ -109,6 +157,7 @@ static float o_camera_sample(o_ctx *c, o_path *p)
   p->v[1].rand_cnt = 1;
   o_hit *h = &p->v[0].hit;
   for(int k=0;k<3;k++) { h->a[k] = cam->a[k]; h->b[k] = cam->b[k]; h->n[k] = cam->n[k]; h->gn[k] = cam->n[k]; h->x[k] = cam->pos[k]; }
+  if(cam->moving) o_view_cam_init_frame(cam, p->time, h);
   const float f = cam->focus/cam->focal_length;
   const float f_dir = cam->focus;
   const float f_rg = -cam->film_width*f/W;

@@ -26,7 +26,7 @@ def test_struct_sizes_match_header():
     # sizes as laid out by the C compiler for include/corona_mi.h (x86-64)
     assert C.sizeof(pkg.MiNode) == 144
     assert C.sizeof(pkg.MiShadeOp) == 32 and C.sizeof(pkg.MiMaterial) == 160
-    assert C.sizeof(pkg.MiCamera) == 80
+    assert C.sizeof(pkg.MiCamera) == 128
     assert C.sizeof(pkg.MiPathVertex) == 112 and C.sizeof(pkg.MiPathSplat) == 24
     assert C.sizeof(pkg.MiPathRecord) == 40 + 8 * 24 + 8 * 112
     ray, hit = pkg.ray_dtypes()

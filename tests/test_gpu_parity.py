@@ -12,7 +12,7 @@ import json
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, SCENE_0010, SCENE_FINE, SCENE_FOG, SCENE_MEDIA, SCENE_NESTED, SCENE_METAL, SCENE_ROUGH, load_pkg, make_scene, oracle_intersect, oracle_records, oracle_render
+from helpers import GOLDEN, SCENE_0010, SCENE_CAM_MB, SCENE_FINE, SCENE_FOG, SCENE_MEDIA, SCENE_NESTED, SCENE_METAL, SCENE_ROUGH, load_pkg, make_scene, oracle_intersect, oracle_records, oracle_render
 
 pkg = load_pkg()
 pytestmark = pytest.mark.gpu
@@ -44,6 +44,9 @@ CASES = [
     # fog outside + scattering medium in the sphere + absorbing medium in the cone
     ("nested media pt mv8", SCENE_NESTED, pkg.MI_SAMPLER_PT, 1280, 720, 8, 40000),
     ("nested media ptdl mv32", SCENE_NESTED, pkg.MI_SAMPLER_PTDL, 1280, 720, 32, 10000),
+    # camera motion blur: the camera frame is interpolated per path (acosf / sinf differ in the last ulp between host and device)
+    ("camera motion blur pt mv8", SCENE_CAM_MB, pkg.MI_SAMPLER_PT, 1280, 720, 8, 40000),
+    ("camera motion blur ptdl mv8", SCENE_CAM_MB, pkg.MI_SAMPLER_PTDL, 1280, 720, 8, 20000),
     # MOD_pointsampler = halton; ptdl at depth 32 reaches dimensions >= 256 (generator fall-back)
     ("halton pt mv8", SCENE_0010, pkg.MI_SAMPLER_PT, 1280, 720, 8, 60000),
     ("halton ptdl mv8", SCENE_0010, pkg.MI_SAMPLER_PTDL, 1280, 720, 8, 40000),
@@ -79,11 +82,12 @@ def test_paths_match_oracle(name, scene_path, sampler, w, h, mv, n):
         dx = np.abs(gpu["v"]["x"][m, k] - ora["v"]["x"][m, k]).max(axis=1)
         # positions drift with every glossy bounce (libm sin/cos/atan2 differ in the last ulp between host and device)
         assert np.quantile(dx, 0.999) < (2e-3 if k <= 2 else 1e-2)
-        assert np.quantile(rel(gpu["v"]["throughput"][m, k], ora["v"]["throughput"][m, k]), 0.999) < 1e-3
+        # a moving camera's frame comes out of acosf / sinf per path: the last-ulp libm difference sits on every vertex from the start
+        assert np.quantile(rel(gpu["v"]["throughput"][m, k], ora["v"]["throughput"][m, k]), 0.999) < (2e-2 if name.startswith("camera motion blur") else 1e-3)
         assert (gpu["v"]["flags"][m, k] == ora["v"]["flags"][m, k]).mean() >= 0.999
         assert (gpu["v"]["mode"][m, k] == ora["v"]["mode"][m, k]).mean() >= 0.999
         assert (gpu["v"]["shader"][m, k] == ora["v"]["shader"][m, k]).mean() >= 0.999
-        assert np.quantile(rel(gpu["v"]["pdf"][m, k], ora["v"]["pdf"][m, k]), 0.999) < 5e-3
+        assert np.quantile(rel(gpu["v"]["pdf"][m, k], ora["v"]["pdf"][m, k]), 0.999) < (2e-2 if name.startswith("camera motion blur") else 5e-3)
     m = same & (gpu["num_splats"] == ora["num_splats"]) & (ora["num_splats"] > 0)
     if m.sum():
         a, b = gpu["splat"]["value"][m, 0], ora["splat"]["value"][m, 0]

@@ -200,3 +200,19 @@ def test_cli_info_validates_scene_files(tmp_path):
     assert "sphere" in bad.stderr and ("spheres 0" in bad.stdout or bad.returncode != 0)
     # a missing scene file is an error
     assert subprocess.run([str(cli), str(tmp_path / "nothing.nra2"), "--info"], capture_output=True, text=True).returncode != 0
+
+
+def test_camera_files_static_and_moving():
+    """legacy 152-byte camera (0010) resolves to a static frame; the CCAM v1 file of scenes/0058_cam_mb carries distinct shutter-open
+    and shutter-close states: both quaternions and positions are handed over, the kernel interpolates per path"""
+    from helpers import SCENE_CAM_MB
+    st = make_scene(SCENE_0010, width=256, height=256, max_verts=4).desc.cam
+    assert st.moving == 0 and list(st.pos) == list(st.pos_t1) and list(st.orient) == list(st.orient_t1)
+    n = np.array(st.n)
+    assert abs(np.linalg.norm(n) - 1) < 1e-6 and abs(st.time_scale - (1 / 125) / (1 / 30)) < 1e-6
+    mv = make_scene(SCENE_CAM_MB, width=256, height=256, max_verts=4).desc.cam
+    assert mv.moving == 1 and abs(mv.time_scale - 1.0) < 1e-7
+    assert np.allclose(np.array(mv.pos_t1) - np.array(mv.pos), [0.6, 0.3, 0.15], atol=1e-5)
+    q0, q1 = np.array(mv.orient), np.array(mv.orient_t1)
+    assert abs(np.linalg.norm(q0) - 1) < 1e-5 and abs(np.linalg.norm(q1) - 1) < 1e-5
+    assert abs(2 * np.degrees(np.arccos(min(1.0, abs(float(q0 @ q1))))) - 4.0) < 1e-2      # turned by 4 degrees
