@@ -214,5 +214,5 @@ def test_camera_files_static_and_moving():
     assert mv.moving == 1 and abs(mv.time_scale - 1.0) < 1e-7
     assert np.allclose(np.array(mv.pos_t1) - np.array(mv.pos), [0.6, 0.3, 0.15], atol=1e-5)
     q0, q1 = np.array(mv.orient), np.array(mv.orient_t1)
-    assert abs(np.linalg.norm(q0) - 1) < 1e-5 and abs(np.linalg.norm(q1) - 1) < 1e-5
-    assert abs(2 * np.degrees(np.arccos(min(1.0, abs(float(q0 @ q1))))) - 4.0) < 1e-2      # turned by 4 degrees
+    assert abs(np.linalg.norm(q0) - 1) < 1e-4 and abs(np.linalg.norm(q1) - 1) < 1e-4      # the 0010 camera file itself is normalised to 3e-5
+    assert abs(2 * np.degrees(np.arccos(min(1.0, abs(float(q0 @ q1) / float(np.linalg.norm(q0) * np.linalg.norm(q1)))))) - 4.0) < 5e-2   # turned by 4 degrees
