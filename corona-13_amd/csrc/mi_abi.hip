@@ -635,7 +635,8 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   UP(d_materials, mats.data(), mats.size());
   UP(d_shape_material, shape_mat.data(), shape_mat.size());
   UP(d_shape_L, shape_L.data(), shape_L.size());
-  if(any_media) { UP(d_shape_medium, shape_med.data(), shape_med.size()); s->media = true; }
+  /* the MEDIA instantiations are the "extended" kernels: participating media and/or a moving camera (mi_path.h, path_generate) */
+  if(any_media || h->cam.moving) { UP(d_shape_medium, shape_med.data(), shape_med.size()); s->media = true; }
   UP(d_light_prim, lprim.data(), lprim.size());
   UP(d_light_cdf, h->lights.cdf, (size_t)h->lights.num_prims);
   UP(d_light_L, h->lights.L, (size_t)h->lights.num_prims);
@@ -757,7 +758,7 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
     const char *mode = getenv("CORONA_MI_MODE");
     s->wavefront = (mode && !strcmp(mode, "wave"));
     if(s->wavefront && s->media)
-    { mi_scene_destroy(s); return fail(MI_ERR_UNSUPPORTED, "participating media run in the megakernel only (unset CORONA_MI_MODE)"); }
+    { mi_scene_destroy(s); return fail(MI_ERR_UNSUPPORTED, "participating media and moving cameras run in the megakernel only (unset CORONA_MI_MODE)"); }
     if(s->wavefront && h->pointsampler == MI_POINTS_HALTON)
     { mi_scene_destroy(s); return fail(MI_ERR_UNSUPPORTED, "the Halton point sampler runs in the megakernel only (unset CORONA_MI_MODE)"); }
     const char *pe = getenv("CORONA_MI_POOL");
