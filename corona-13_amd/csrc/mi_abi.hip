@@ -21,6 +21,9 @@
 #ifndef MI_TAIL_LANES
 #define MI_TAIL_LANES 16       /* a traversal slice ends when fewer rays than this are still under way */
 #endif
+#ifndef MI_TAIL_LANES_PTDL
+#define MI_TAIL_LANES_PTDL 8   /* ptdl shades more per vertex (next event estimation): shorter tails pay, A/B 4/8/12/16/24/32 */
+#endif
 #define MI_WORK_SHARDS 262144   /* upper bound on workgroups of one launch (path pool / 256) */
 #ifndef MI_STACK
 #define MI_STACK 12      /* LDS traversal stack entries per lane; deeper entries overflow to HBM (mi_device.h) */
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
     {
       const V3 o = tr_shadow ? ps.sh_org : ps.org, d = tr_shadow ? ps.sh_dir : ps.dir;
       const uint32_t ignore = tr_shadow ? ps.sh_ignore : ps.ignore;
-      const unsigned tail = exhausted_wave ? 1u : (unsigned)MI_TAIL_LANES;
+      const unsigned tail = exhausted_wave ? 1u : (unsigned)(PTDL ? MI_TAIL_LANES_PTDL : MI_TAIL_LANES);
       while(true)
       {
         const bool busy = tracing && !ts.done;
