@@ -43,6 +43,8 @@ CONFIGS = {
     # not BASELINE.json configurations: the SURVEY 8(f) row 3 scenes (participating media), same film and depth as configs[1]
     "media": dict(scene="0055_media", sampler="pt", w=1280, h=720, spp=64, mv=8, name="0010 scene, scattering medium inside the glass sphere (scenes/0055_media), pt, 1280x720, 64 spp"),
     "media_ptdl": dict(scene="0055_media", sampler="ptdl", w=1280, h=720, spp=64, mv=8, name="scenes/0055_media, ptdl, 1280x720, 64 spp"),
+    "mb": dict(scene="0059_mb", sampler="pt", w=1280, h=720, spp=64, mv=8, name="0010 scene with a moving backdrop and cylinder cap (scenes/0059_mb, motion blur), pt, 1280x720, 64 spp"),
+    "cam_mb": dict(scene="0058_cam_mb", sampler="pt", w=1280, h=720, spp=64, mv=8, name="0010 scene seen by a moving camera (scenes/0058_cam_mb), pt, 1280x720, 64 spp"),
     "fog": dict(scene="0056_fog", sampler="pt", w=1280, h=720, spp=64, mv=8, name="0010 scene in a thin global fog (scenes/0056_fog), pt, 1280x720, 64 spp"),
     "fog_ptdl": dict(scene="0056_fog", sampler="ptdl", w=1280, h=720, spp=64, mv=8, name="scenes/0056_fog, ptdl, 1280x720, 64 spp"),
 }
@@ -225,7 +227,7 @@ def main():
                        "paths_per_step_per_gpu": per_frame, "sharding": f"path-index ranges x{world}, framebuffer all-reduce"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic if args.config == "cfg2" else None, "traffic_source": traffic_src if args.config == "cfg2" else None,
-                         "kernel": "mi_path_kernel<false,%s,%s,%s,%s> (RECORD, PTDL, NODES_LDS, HALTON, MEDIA)" % ("true" if cfg["sampler"] == "ptdl" else "false", "true" if be.nodes_in_lds() else "false", "true" if args.points == "halton" else "false", "true" if cfg["scene"] in ("0055_media", "0056_fog") else "false"), "kernel_ms": kms,
+                         "kernel": "mi_path_kernel<false,%s,%s,%s,%s> (RECORD, PTDL, NODES_LDS, HALTON, MEDIA)" % ("true" if cfg["sampler"] == "ptdl" else "false", "true" if be.nodes_in_lds() else "false", "true" if args.points == "halton" else "false", "true" if cfg["scene"] in ("0055_media", "0056_fog", "0058_cam_mb", "0059_mb") else "false"), "kernel_ms": kms,
                          "algorithmic_bytes_per_sample": bytes_per_sample,
                          "work_per_sample": {"rays": dc[0] / paths, "node_visits": dc[1] / paths, "prim_tests": dc[3] / paths, "splats": dc[5] / paths}},
         }

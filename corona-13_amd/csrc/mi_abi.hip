@@ -92,6 +92,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
       tr_shadow = PTDL && ps.sh_pending;
       hit.prim = MI_NOPRIM; hit.dist = tr_shadow ? ps.sh_dist : (MEDIA ? media_free_flight<PTDL, HALTON>(sc, ps) : FLT_MAX); hit.u = hit.v = 0.0f;
       trace_begin(ts, tr_shadow ? ps.sh_dir : ps.dir, cnt);
+      if(MEDIA) { ts.time = ps.time; ts.prims_t1 = sc.prims_t1; }   /* motion-blurred primitives are tested at the path's time */
       tracing = true;
     }
     /* ------------------------------------------------------------ a slice of traversal: while-while rounds until only a tail of
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
         const unsigned nbusy = __popcll(__ballot(busy));
         if(!nbusy) break;
         if(nbusy < tail && __any(tracing && ts.done)) break;
-        if(busy) trace_round<MI_BLOCK, MI_STACK>(lds, sc.prims, o, d, ignore, hit, ts, cnt);
+        if(busy) trace_round<MI_BLOCK, MI_STACK, MEDIA>(lds, sc.prims, o, d, ignore, hit, ts, cnt);
       }
     }
     MI_PHASE(cnt, 1)
@@ -220,7 +221,7 @@ struct mi_scene
   hipEvent_t ev_live[8];
   uint64_t kernel_launches_last;
   bool media;                       /* some shape is filled with a homogeneous medium: MEDIA instantiations */
-  void *d_shape_medium;
+  void *d_shape_medium, *d_prims_t1;
   /* Halton point sampler */
   bool halton;
   HaltonTables *halton_tables;
@@ -495,13 +496,16 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   /* primitives: resolve primid -> vtxidx -> vtx once */
   std::vector<DPrim> prims(h->num_prims ? h->num_prims : 1);
   std::vector<DPrimGeo> pgeo(h->num_prims ? h->num_prims : 1);
+  std::vector<DPrimT1> prims_t1;                            /* allocated when the first motion-blurred primitive shows up */
   memset(pgeo.data(), 0, pgeo.size()*sizeof(DPrimGeo));
   memset(prims.data(), 0, prims.size()*sizeof(DPrim));
   for(uint64_t i=0;i<h->num_prims;i++)
   {
     const mi_primid pi = h->primid[i];
     const uint32_t shape = MI_PRIMID_SHAPE(pi), vc = MI_PRIMID_VCNT(pi);
-    if(shape >= h->num_shapes || vc < 1 || vc > 4 || MI_PRIMID_MB(pi)) { free(s); return fail(MI_ERR_UNSUPPORTED, "primitive kind outside the scope"); }
+    const uint32_t mb = MI_PRIMID_MB(pi);
+    if(shape >= h->num_shapes || vc < 1 || vc > 4 || (mb && vc < 3)) { free(s); return fail(MI_ERR_UNSUPPORTED, "primitive kind outside the scope"); }
+    if(mb && device_build) { free(s); return fail(MI_ERR_UNSUPPORTED, "motion-blurred primitives need the caller's tree (device build: static primitives only)"); }
     const mi_shape &sh = h->shapes[shape];
     const mi_vtxidx *vi = h->vtxidx + sh.vtxidx_base + MI_PRIMID_VI(pi);
     const mi_vtx *vtx = h->vtx + sh.vtx_base;
@@ -536,6 +540,25 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
       g[10] = ac.x; g[11] = ac.y; g[12] = ac.z; g[13] = bc.x; g[14] = bc.y; g[15] = bc.z;
       g[26] = v1.x; g[27] = v1.y; g[28] = v1.z; g[29] = v0.x; g[30] = v0.y; g[31] = v0.z;
       g[32] = p.v[1][0]; g[33] = p.v[1][1];           /* r0, r1 (dwords 3, 4 of the line record) */
+    }
+    else if(mb)
+    { /* motion-blurred triangle / quad (vertices interleaved: 2 v = shutter open, 2 v + 1 = shutter close, include/geo.h:108-138):
+         DPrim type 0 holds the shutter-open vertices, DPrimT1 the shutter-close vertices and normals; everything else is
+         formed per ray / per hit at the path's time (analytic_intersect<true>, surface_setup<true>) */
+      float *g = pgeo[i].f;
+      if(prims_t1.empty()) { prims_t1.resize(h->num_prims); memset(prims_t1.data(), 0, prims_t1.size()*sizeof(DPrimT1)); }
+      DPrimT1 &t1 = prims_t1[i];
+      p.type = 0; p.pad[0] = vc;
+      q.type = vc | MI_GEO_MB;
+      for(uint32_t k=0;k<vc;k++)
+      {
+        const mi_vtx &a = vtx[2*vi[k].v], &b = vtx[2*vi[k].v + 1];
+        memcpy(p.v[k], a.v, 12);
+        memcpy(t1.v[k], b.v, 12);
+        const V3 n0 = decode_normal(a.n), n1 = decode_normal(b.n);
+        g[3*k] = n0.x; g[3*k+1] = n0.y; g[3*k+2] = n0.z;
+        t1.n[k][0] = n1.x; t1.n[k][1] = n1.y; t1.n[k][2] = n1.z;
+      }
     }
     else
     {
@@ -639,7 +662,11 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   UP(d_shape_material, shape_mat.data(), shape_mat.size());
   UP(d_shape_L, shape_L.data(), shape_L.size());
   /* the MEDIA instantiations are the "extended" kernels: participating media and/or a moving camera (mi_path.h, path_generate) */
-  if(any_media || h->cam.moving) { UP(d_shape_medium, shape_med.data(), shape_med.size()); s->media = true; }
+  if(!prims_t1.empty())
+  {
+    UP(d_prims_t1, prims_t1.data(), prims_t1.size());
+  }
+  if(any_media || h->cam.moving || !prims_t1.empty()) { UP(d_shape_medium, shape_med.data(), shape_med.size()); s->media = true; }
   UP(d_light_prim, lprim.data(), lprim.size());
   UP(d_light_cdf, h->lights.cdf, (size_t)h->lights.num_prims);
   UP(d_light_L, h->lights.L, (size_t)h->lights.num_prims);
@@ -672,6 +699,7 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   d.prims = (const DPrim *)s->d_prims; d.primgeo = (const DPrimGeo *)s->d_primgeo;
   d.materials = (const DMaterial *)s->d_materials;
   d.shape_medium = (const DShapeMedium *)s->d_shape_medium;
+  d.prims_t1 = (const DPrimT1 *)s->d_prims_t1;
   d.exterior_index = h->num_shapes;
   d.num_lights = h->lights.num_prims;
   d.light_prim = (const uint32_t *)s->d_light_prim; d.light_cdf = (const float *)s->d_light_cdf; d.light_L = (const float *)s->d_light_L;
@@ -991,6 +1019,7 @@ extern "C" int mi_trace_paths(mi_scene *s, uint64_t first_index, uint64_t count,
 extern "C" int mi_intersect(mi_scene *s, const mi_ray *rays, uint64_t n, mi_hit *host_out)
 {
   if(!s || !rays || !host_out) return fail(MI_ERR_ARG, "null argument");
+  if(s->d_prims_t1) return fail(MI_ERR_UNSUPPORTED, "mi_intersect: rays carry no time, the scene has motion-blurred primitives");
   if(!n) return MI_OK;
   void *d_rays = nullptr, *d_hits = nullptr;
   hipError_t e = hipMalloc(&d_rays, n*sizeof(mi_ray));
@@ -1047,7 +1076,7 @@ extern "C" void mi_scene_destroy(mi_scene *s)
   for(int k=0;k<8;k++) if(s->ev_live[k]) (void)hipEventDestroy(s->ev_live[k]);
   void *bufs[] = { s->d_nodes, s->d_axes, s->d_prims, s->d_primgeo, s->d_materials, s->d_light_prim, s->d_light_cdf, s->d_light_L,
                    s->d_cie, s->d_checker, s->d_metal, s->d_counters, s->d_work, s->d_shape_material, s->d_shape_L, s->d_overflow, s->d_fb_own,
-                   s->d_halton_dim, s->d_halton_perm, s->d_shape_medium };
+                   s->d_halton_dim, s->d_halton_perm, s->d_shape_medium, s->d_prims_t1 };
   delete s->halton_tables;
   for(void *b : bufs) if(b) (void)hipFree(b);
   if(s->stream_own) (void)hipStreamDestroy(s->stream_own);

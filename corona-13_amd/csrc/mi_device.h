@@ -28,6 +28,15 @@ struct DPrim                       /* 64 B */
   uint32_t pad[3];
 };
 
+struct DPrimT1                     /* 96 B, motion-blurred triangles / quads only: the shutter-close state of a primitive whose DPrim (type 0,
+                                      pad[0] = vertex count) holds the four shutter-open VERTICES instead of v0 + edges. Vertices and normals
+                                      are interpolated per ray / hit at the path's time (include/geo.h:120-162) */
+{
+  float v[4][3];
+  float n[4][3];                   /* decoded vertex normals at shutter close (those at shutter open are in DPrimGeo) */
+};
+#define MI_GEO_MB 8u               /* DPrimGeo.type bit: motion blurred (type & 7 = vertex count) */
+
 struct DPrimGeo                    /* 176 B: everything the shading side needs about one primitive, in one record; the float
                                       constants are precomputed at upload with the kernel's own (host+device) functions */
 {
@@ -100,6 +109,7 @@ struct DScene
   uint32_t work_shards;
   /* Halton point sampler (MI_POINTS_HALTON): per dimension {P = digits looked up at once, floor(2^32/P), table offset | groups << 24,
      float bits of the scale}; the digit-permutation tables, concatenated (387 KB, L2 resident) */
+  const DPrimT1 *prims_t1;          /* [num_prims] or NULL: shutter-close state of motion-blurred primitives (extended kernels only) */
   const DShapeMedium *shape_medium; /* [num_shapes + 1] (MEDIA kernels only): the medium filling each shape; the last entry is the global
                                        exterior medium (`exterior <medium> 0`, src/shader.c:544-565), med < 0 = vacuum */
   uint32_t exterior_index;          /* = number of shapes */

@@ -381,7 +381,10 @@ __device__ __forceinline__ void triquad_intersect(const PrimRegs &r, uint32_t ty
   }
 }
 
-__device__ __forceinline__ void analytic_intersect(const DPrim *prims, uint32_t prim, const V3 o, const V3 d, uint32_t ignore, Hit &hit)
+struct TraceState;
+template<bool MB>
+__device__ __forceinline__ void analytic_intersect(const DPrim *prims, uint32_t prim, const V3 o, const V3 d, uint32_t ignore, Hit &hit,
+                                                   float time, const DPrimT1 *prims_t1)
 { /* prims_intersect for spheres and lines, src/prims.c:665-668 */
   /* the whole 64-B record in four 16-B loads up front (one memory round trip), then registers only */
   const float4 *q = (const float4 *)(prims + prim);
@@ -391,6 +394,24 @@ __device__ __forceinline__ void analytic_intersect(const DPrim *prims, uint32_t 
   p.v[1][1] = q1.x; p.v[1][2] = q1.y; p.v[2][0] = q1.z; p.v[2][1] = q1.w;
   p.v[2][2] = q2.x; p.v[3][0] = q2.y; p.v[3][1] = q2.z; p.v[3][2] = q2.w;
   p.type = __float_as_uint(q3.x); p.pad[0] = __float_as_uint(q3.y); p.pad[1] = __float_as_uint(q3.z); p.pad[2] = __float_as_uint(q3.w);
+  if(MB && p.type == 0)
+  { /* motion-blurred triangle / quad: the record holds the shutter-open vertices, prims_t1 the shutter-close ones.
+       geo_get_vertex_time (include/geo.h:120-138): (1-t) v(open) + t v(close) per component, then the usual test on the
+       edges of the interpolated vertices (prims_intersect, src/prims.c:645-663) */
+    if(prim == ignore) return;
+    const float4 *q1p = (const float4 *)(prims_t1 + prim);
+    const float4 c0 = q1p[0], c1 = q1p[1], c2 = q1p[2];
+    const float w0 = 1.0f - time, w1 = time;
+    const V3 v0 = mk3(w0*q0.x + w1*c0.x, w0*q0.y + w1*c0.y, w0*q0.z + w1*c0.z);
+    const V3 v1 = mk3(w0*q0.w + w1*c0.w, w0*q1.x + w1*c1.x, w0*q1.y + w1*c1.y);
+    const V3 v2 = mk3(w0*q1.z + w1*c1.z, w0*q1.w + w1*c1.w, w0*q2.x + w1*c2.x);
+    const V3 v3 = mk3(w0*q2.y + w1*c2.y, w0*q2.z + w1*c2.z, w0*q2.w + w1*c2.w);
+    const V3 e1 = sub3(v1, v0), e2 = sub3(v2, v0), e3 = sub3(v3, v0);
+    PrimRegs r;
+    r.q0 = make_float4(v0.x, v0.y, v0.z, e1.x); r.q1 = make_float4(e1.y, e1.z, e2.x, e2.y); r.q2 = make_float4(e2.z, e3.x, e3.y, e3.z); r.q3 = q3;
+    triquad_intersect(r, p.pad[0], o, d, hit, prim);
+    return;
+  }
   if(p.type == MI_PRIM_SPHERE)
   { /* geo_sphere_intersect, include/geo/sphere.h:146-166; u,v are recomputed at shading time */
     const float t = sphere_t(ld3(p.v[0]), p.v[1][0], o, d);
@@ -465,6 +486,9 @@ struct TraceState
   uint32_t current;
   bool done;
   float idx, idy, idz;   /* 1/dir, computed once per ray (qbvhmp.c:1291-1295) */
+  /* motion blur (MB instantiations only): the ray's time and the shutter-close records */
+  float time;
+  const DPrimT1 *prims_t1;
 };
 
 __device__ __forceinline__ void trace_begin(TraceState &ts, const V3 d, uint32_t *cnt)
@@ -478,7 +502,7 @@ __device__ __forceinline__ void trace_begin(TraceState &ts, const V3 d, uint32_t
 
 /* one "while-while" round of accel_intersect (src/accel.d/qbvhmp.c:1262-1390, static boxes): descend inner nodes until this
  * lane holds a leaf (or runs out of work), then intersect that leaf and pop the next subtree */
-template<int BLOCK, int STACK>
+template<int BLOCK, int STACK, bool MB = false>
 __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, const V3 o, const V3 d, uint32_t ignore,
                                             Hit &hit, TraceState &ts, uint32_t *cnt)
 {
@@ -638,7 +662,7 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
 #endif
         const uint32_t i = __ffs(analytic) - 1;
         analytic &= analytic - 1;
-        analytic_intersect(prims, idxp + i, o, d, ignore, hit);
+        analytic_intersect<MB>(prims, idxp + i, o, d, ignore, hit, MB ? ts.time : 0.0f, MB ? ts.prims_t1 : nullptr);
       }
       current = MI_LEAF32;
       done = true;
@@ -709,11 +733,12 @@ MI_HD V3 tri_geo_normal(const V3 v0, const V3 v1, const V3 v2)
                         (v1.x-v0.x)*(v2.y-v0.y) - (v1.y-v0.y)*(v2.x-v0.x)));
 }
 
-__device__ __forceinline__ void surface_setup(const DScene &sc, uint32_t prim, const uint4 head, const V3 omega, float scramble, Surf &sf)
+template<bool MB = false>
+__device__ __forceinline__ void surface_setup(const DScene &sc, uint32_t prim, const uint4 head, const V3 omega, float scramble, Surf &sf, float time = 0.0f)
 { /* prims_get_normal_time (src/prims.c:254-366) + manifold_init (include/pathspace/manifold.h:215-232) */
   const DPrimGeo &geo = sc.primgeo[prim];
   const float *g = geo.f;                   /* per-primitive constants, see DPrimGeo */
-  const uint32_t type = head.x;             /* head = the record's first 16 bytes: type, material, uv0, primid_lo */
+  const uint32_t type = MB ? head.x & 7u : head.x;   /* head = the record's first 16 bytes: type (| MI_GEO_MB), material, uv0, primid_lo */
   if(type < MI_PRIM_TRI)
   { /* sphere (sphere.h:51-62,160-161) and line (line.h:123-161). The two share one atan2f site: a wave that holds hits
        of both kinds runs the long libm sequence once. */
@@ -753,6 +778,26 @@ __device__ __forceinline__ void surface_setup(const DScene &sc, uint32_t prim, c
         sf.gn = sf.n;
       }
     }
+  }
+  else if(MB && (head.x & MI_GEO_MB))
+  { /* motion blurred: vertices and decoded normals of the hit half at the path's time (geo_get_vertex_time / geo_get_normal_time,
+       include/geo.h:120-162), then geo_tri_get_normal (include/geo/triangle.h:63-82) on them */
+    const bool second = type == MI_PRIM_QUAD && !(sf.v >= sf.u);
+    const float u = second ? sf.u - sf.v : sf.u;
+    const float v = type == MI_PRIM_TRI ? sf.v : second ? sf.v : sf.v - sf.u;
+    const int i1 = second ? 2 : 1, i2 = second ? 3 : 2;
+    const DPrim &p0 = sc.prims[prim];
+    const DPrimT1 &p1 = sc.prims_t1[prim];
+    const float w0 = 1.0f - time, w1 = time;
+    const V3 v0 = mk3(w0*p0.v[0][0] + w1*p1.v[0][0], w0*p0.v[0][1] + w1*p1.v[0][1], w0*p0.v[0][2] + w1*p1.v[0][2]);
+    const V3 va = mk3(w0*p0.v[i1][0] + w1*p1.v[i1][0], w0*p0.v[i1][1] + w1*p1.v[i1][1], w0*p0.v[i1][2] + w1*p1.v[i1][2]);
+    const V3 vb = mk3(w0*p0.v[i2][0] + w1*p1.v[i2][0], w0*p0.v[i2][1] + w1*p1.v[i2][1], w0*p0.v[i2][2] + w1*p1.v[i2][2]);
+    const V3 n0 = mk3(w0*g[0] + w1*p1.n[0][0], w0*g[1] + w1*p1.n[0][1], w0*g[2] + w1*p1.n[0][2]);
+    const V3 na = mk3(w0*g[3*i1] + w1*p1.n[i1][0], w0*g[3*i1+1] + w1*p1.n[i1][1], w0*g[3*i1+2] + w1*p1.n[i1][2]);
+    const V3 nb = mk3(w0*g[3*i2] + w1*p1.n[i2][0], w0*g[3*i2+1] + w1*p1.n[i2][1], w0*g[3*i2+2] + w1*p1.n[i2][2]);
+    sf.gn = tri_geo_normal(v0, va, vb);
+    const float w = 1.0f - u - v;
+    sf.n = normalise3(mk3(u*nb.x + v*na.x + w*n0.x, u*nb.y + v*na.y + w*n0.y, u*nb.z + v*na.z + w*n0.z));
   }
   else
   { /* triangle / quad halves (v0 v1 v2) and (v0 v2 v3): decoded vertex normals and both geometric normals come from DPrimGeo */

@@ -46,6 +46,7 @@ struct PathState
      sampled for it (FLT_MAX: none) */
   Medium cur;
   float clip;
+  float time;               /* the path's time in the shutter interval (motion-blurred primitives) */
 };
 
 /* a splat to be carried out by the wave (splat_wave) after the divergent part of the iteration */
@@ -141,6 +142,7 @@ __device__ __forceinline__ void path_generate(const DScene &sc, PathState &ps, u
   /* camera motion blur, src/view.c:903-919. Only in the MEDIA ("extended") instantiations: even as a never-taken uniform branch
      it cost the plain kernels 0.9 % (A/B on one box: 2722 vs 2746 Msamples/s), so scenes with a moving camera run those */
   if(MEDIA && cam.moving) camera_frame_at(cam, time, ca, cb, cn, cpos);
+  ps.time = time;
   const V3 aoff = mk3(lu*ca.x + lv*cb.x, lu*ca.y + lv*cb.y, lu*ca.z + lv*cb.z);
   const float ki = (ci-.5f*W)*cc.f_rg, kj = (cj-.5f*H)*cc.f_up;
   V3 om = mk3(cc.f_dir*cn.x + (ki*ca.x + kj*cb.x) - aoff.x,
@@ -443,7 +445,7 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
     const uint4 mhead = *(const uint4 *)&mat;                       /* bsdf, num_ops, param[0..1] */
     const uint32_t mat_bsdf = mhead.x;
     const float mat_p0 = __uint_as_float(mhead.z), mat_p1 = __uint_as_float(mhead.w);
-    surface_setup(sc, hit.prim, head, omega, ps.scramble, sf);
+    surface_setup<MEDIA>(sc, hit.prim, head, omega, ps.scramble, sf, ps.time);
     MI_PHASE(cnt, 2)
     const uint32_t shape = (head.w >> 3) & 0x1fffffffu;             /* MI_PRIMID_SHAPE */
     Shading sh;
@@ -478,7 +480,7 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
 
     MI_PHASE(cnt, 3)
     /* self-intersection, src/pathspace.c:807-820 */
-    const uint32_t type = head.x;
+    const uint32_t type = MEDIA ? head.x & 7u : head.x;             /* the extended kernels flag motion blur in bit 3 (MI_GEO_MB) */
     if((type > 2 || hit.dist < 1e-4f) && hit.prim == ps.ignore)
     {
       alive = false;

@@ -81,12 +81,16 @@ void ch_prim_bounds(const ch_geo *g, mi_primid pi, float *box)
   }
   else
   { /* include/geo/triangle.h:7-19 */
+    /* motion-blurred triangles / quads (vertices interleaved shutter open / close, include/geo.h:108-138): the box encloses both
+       states, i.e. the whole linear motion. The reference keeps one box per state and interpolates them per ray
+       (src/accel.d/qbvhmp.c:1208-1224); a static enclosing box gives the same closest hits with more node visits */
+    const uint32_t mb = MI_PRIMID_MB(pi);
     for(int d=0;d<3;d++)
     {
-      float m = vtx[vi[0].v].v[d], M = m;
-      for(uint32_t k=1;k<vcnt;k++)
+      float m = vtx[(mb+1)*vi[0].v].v[d], M = m;
+      for(uint32_t k=0;k<vcnt;k++) for(uint32_t t=0;t<=mb;t++)
       {
-        const float x = vtx[vi[k].v].v[d];
+        const float x = vtx[(mb+1)*vi[k].v + t].v[d];
         m = fminf(x, m); M = fmaxf(x, M);
       }
       box[d] = m; box[3+d] = M;

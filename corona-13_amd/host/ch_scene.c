@@ -297,11 +297,12 @@ static int load_geo(ch_scene *s, uint32_t shapeid, const char *name)
   {
     mi_primid p; memcpy(&p, d + sizeof(h) + 8*k, 8);
     p = (p & ~(0x1fffffffull << 3)) | ((uint64_t)shapeid << 3);
-    if(MI_PRIMID_MB(p)) { fprintf(stderr, "[ch] geo `%s': motion-blurred primitives are outside the scope of this backend\n", name); free(d); return 1; }
-    const uint32_t vc = MI_PRIMID_VCNT(p);
+    const uint32_t vc = MI_PRIMID_VCNT(p), mb = MI_PRIMID_MB(p);
     if(vc < 1 || vc > 4) { fprintf(stderr, "[ch] geo `%s': primitive kind %u unsupported\n", name, vc); free(d); return 1; }
+    if(mb && vc < 3) { fprintf(stderr, "[ch] geo `%s': motion-blurred spheres and lines are outside the scope of this backend\n", name); free(d); return 1; }
     if(MI_PRIMID_VI(p) + vc > nvi) { fprintf(stderr, "[ch] geo `%s': vertex index out of range\n", name); free(d); return 1; }
-    for(uint32_t j=0;j<vc;j++) if(g->vtxidx[sh->vtxidx_base + MI_PRIMID_VI(p) + j].v >= nv)
+    /* a motion-blurred primitive addresses vertex pairs: 2 v = shutter open, 2 v + 1 = shutter close (include/geo.h:108-138) */
+    for(uint32_t j=0;j<vc;j++) if((uint64_t)(mb+1)*g->vtxidx[sh->vtxidx_base + MI_PRIMID_VI(p) + j].v + mb >= nv)
     { fprintf(stderr, "[ch] geo `%s': vertex out of range\n", name); free(d); return 1; }
     s->primid[old + k] = p;
   }
@@ -466,6 +467,8 @@ static int init_lights(ch_scene *s)
       const float L = m->op[k].mul*(ch_coeff_eval(c, 400.0f) + ch_coeff_eval(c, 480.0f) + ch_coeff_eval(c, 560.0f) + ch_coeff_eval(c, 660.0f))/4.0f;
       for(uint32_t i=0;i<sh->num_prims;i++)
       { /* list.c:56-74 */
+        if(MI_PRIMID_MB(s->primid[prim_base + i]))
+        { fprintf(stderr, "[ch] shape %u: motion-blurred emitters are outside the scope of this backend\n", sid); return MI_ERR_UNSUPPORTED; }
         s->light_primid[off+i] = s->primid[prim_base + i];
         s->light_cdf[off+i] = ch_prim_area(&s->geo, s->primid[prim_base + i])*L;
         s->light_L[off+i] = L;

@@ -5,10 +5,31 @@
 #include "o_core.h"
 
 /* ---------------------------------------------------------------- geometry fetch */
+static void o_decode_normal(uint32_t enc, float *vec);
 static inline const mi_vtx *o_vtx(const mi_scene_desc *s, mi_primid pi, int k)
-{ /* geo_get_vertex, include/geo.h:108-112 (no motion blur in scope) */
+{ /* geo_get_vertex, include/geo.h:108-112: shutter-open vertex; a motion-blurred primitive keeps its two states interleaved */
   const mi_shape *sh = s->shapes + MI_PRIMID_SHAPE(pi);
-  return s->vtx + sh->vtx_base + s->vtxidx[sh->vtxidx_base + MI_PRIMID_VI(pi) + k].v;
+  return s->vtx + sh->vtx_base + (MI_PRIMID_MB(pi)+1)*s->vtxidx[sh->vtxidx_base + MI_PRIMID_VI(pi) + k].v;
+}
+
+static inline void o_vertex_time(const mi_scene_desc *s, mi_primid pi, int k, float time, float *out)
+{ /* geo_get_vertex_time, include/geo.h:120-138 (mul, mul, add per component as the SSE code does) */
+  const mi_vtx *v0 = o_vtx(s, pi, k);
+  if(MI_PRIMID_MB(pi)) for(int i=0;i<3;i++) out[i] = (1.0f-time)*v0->v[i] + time*v0[1].v[i];
+  else for(int i=0;i<3;i++) out[i] = v0->v[i];
+}
+
+static inline void o_normal_time(const mi_scene_desc *s, mi_primid pi, int k, float time, float *n)
+{ /* geo_get_normal_time, include/geo.h:152-162 */
+  const mi_vtx *v0 = o_vtx(s, pi, k);
+  if(MI_PRIMID_MB(pi))
+  {
+    float n0[3], n1[3];
+    o_decode_normal(v0->n, n0);
+    o_decode_normal(v0[1].n, n1);
+    for(int i=0;i<3;i++) n[i] = (1.0f-time)*n0[i] + time*n1[i];
+  }
+  else o_decode_normal(v0->n, n);
 }
 
 static inline uint32_t o_uvbits(const mi_scene_desc *s, mi_primid pi, int k)
@@ -242,12 +263,13 @@ static void o_prims_intersect(const mi_scene_desc *s, mi_primid pi, const o_ray 
   const uint32_t vcnt = MI_PRIMID_VCNT(pi);
   if(vcnt == MI_PRIM_TRI || vcnt == MI_PRIM_QUAD)
   {
-    const float *v0 = o_vtx(s, pi, 0)->v, *v1 = o_vtx(s, pi, 1)->v, *v2 = o_vtx(s, pi, 2)->v;
+    float v0[3], v1[3], v2[3], v3[3];
+    o_vertex_time(s, pi, 0, ray->time, v0); o_vertex_time(s, pi, 1, ray->time, v1); o_vertex_time(s, pi, 2, ray->time, v2);
     if(vcnt == 3) o_tri_intersect(v0, v1, v2, pi, ray, hit);
     else
     {
       if(o_tri_intersect(v0, v1, v2, pi, ray, hit)) { hit->v += hit->u; return; }
-      const float *v3 = o_vtx(s, pi, 3)->v;
+      o_vertex_time(s, pi, 3, ray->time, v3);
       if(o_tri_intersect(v0, v2, v3, pi, ray, hit)) hit->u += hit->v;
     }
   }
@@ -381,7 +403,7 @@ static void o_decode_uv(uint32_t enc, float *uv)
   uv[1] = o_half2float(enc >> 16);
 }
 
-void o_prims_get_normal(const mi_scene_desc *s, mi_primid pi, o_hit *hit)
+void o_prims_get_normal(const mi_scene_desc *s, mi_primid pi, o_hit *hit, float time)
 { /* prims_get_normal_time, src/prims.c:254-366 */
   const uint32_t vcnt = MI_PRIMID_VCNT(pi);
   if(vcnt == MI_PRIM_SPHERE)
@@ -423,29 +445,25 @@ void o_prims_get_normal(const mi_scene_desc *s, mi_primid pi, o_hit *hit)
   }
   else
   {
-    float n0[3], n1[3], n2[3], n3[3];
-    const mi_vtx *v0 = o_vtx(s, pi, 0), *v2 = o_vtx(s, pi, 2);
-    o_decode_normal(v0->n, n0);
-    o_decode_normal(v2->n, n2);
+    float n0[3], n1[3], n2[3], n3[3], v0[3], v1[3], v2[3], v3[3];
+    o_vertex_time(s, pi, 0, time, v0); o_normal_time(s, pi, 0, time, n0);
+    o_vertex_time(s, pi, 2, time, v2); o_normal_time(s, pi, 2, time, n2);
     if(vcnt == 3)
     {
-      const mi_vtx *v1 = o_vtx(s, pi, 1);
-      o_decode_normal(v1->n, n1);
-      o_tri_normal(v0->v, v1->v, v2->v, n0, n1, n2, hit->u, hit->v, hit);
+      o_vertex_time(s, pi, 1, time, v1); o_normal_time(s, pi, 1, time, n1);
+      o_tri_normal(v0, v1, v2, n0, n1, n2, hit->u, hit->v, hit);
     }
     else if(vcnt == 4)
     {
       if(hit->v >= hit->u)
       {
-        const mi_vtx *v1 = o_vtx(s, pi, 1);
-        o_decode_normal(v1->n, n1);
-        o_tri_normal(v0->v, v1->v, v2->v, n0, n1, n2, hit->u, hit->v - hit->u, hit);
+        o_vertex_time(s, pi, 1, time, v1); o_normal_time(s, pi, 1, time, n1);
+        o_tri_normal(v0, v1, v2, n0, n1, n2, hit->u, hit->v - hit->u, hit);
       }
       else
       {
-        const mi_vtx *v3 = o_vtx(s, pi, 3);
-        o_decode_normal(v3->n, n3);
-        o_tri_normal(v0->v, v2->v, v3->v, n0, n2, n3, hit->u - hit->v, hit->v, hit);
+        o_vertex_time(s, pi, 3, time, v3); o_normal_time(s, pi, 3, time, n3);
+        o_tri_normal(v0, v2, v3, n0, n2, n3, hit->u - hit->v, hit->v, hit);
       }
     }
   }

@@ -182,7 +182,7 @@ float o_shader_prepare(o_ctx *c, o_path *p, int v)
     }
     return 1.0f;
   }
-  o_prims_get_normal(s, hit->prim, hit);
+  o_prims_get_normal(s, hit->prim, hit, p->time);
   if(dot3(p->e[v].omega, hit->gn) > 0.0f)
   {
     for(int i=0;i<3;i++) hit->n[i] = -hit->n[i];

@@ -12,7 +12,7 @@ import json
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, SCENE_0010, SCENE_CAM_MB, SCENE_FINE, SCENE_FOG, SCENE_MEDIA, SCENE_NESTED, SCENE_METAL, SCENE_ROUGH, load_pkg, make_scene, oracle_intersect, oracle_records, oracle_render
+from helpers import GOLDEN, SCENE_0010, SCENE_CAM_MB, SCENE_FINE, SCENE_FOG, SCENE_MB, SCENE_MEDIA, SCENE_NESTED, SCENE_METAL, SCENE_ROUGH, load_pkg, make_scene, oracle_intersect, oracle_records, oracle_render
 
 pkg = load_pkg()
 pytestmark = pytest.mark.gpu
@@ -47,6 +47,9 @@ CASES = [
     # camera motion blur: the camera frame is interpolated per path (acosf / sinf differ in the last ulp between host and device)
     ("camera motion blur pt mv8", SCENE_CAM_MB, pkg.MI_SAMPLER_PT, 1280, 720, 8, 40000),
     ("camera motion blur ptdl mv8", SCENE_CAM_MB, pkg.MI_SAMPLER_PTDL, 1280, 720, 8, 20000),
+    # motion-blurred geometry: 4096 backdrop quads and the cylinder cap move during the exposure
+    ("moving geometry pt mv8", SCENE_MB, pkg.MI_SAMPLER_PT, 1280, 720, 8, 40000),
+    ("moving geometry ptdl mv8", SCENE_MB, pkg.MI_SAMPLER_PTDL, 1280, 720, 8, 20000),
     # MOD_pointsampler = halton; ptdl at depth 32 reaches dimensions >= 256 (generator fall-back)
     ("halton pt mv8", SCENE_0010, pkg.MI_SAMPLER_PT, 1280, 720, 8, 60000),
     ("halton ptdl mv8", SCENE_0010, pkg.MI_SAMPLER_PTDL, 1280, 720, 8, 40000),
@@ -83,11 +86,11 @@ def test_paths_match_oracle(name, scene_path, sampler, w, h, mv, n):
         # positions drift with every glossy bounce (libm sin/cos/atan2 differ in the last ulp between host and device)
         assert np.quantile(dx, 0.999) < (2e-3 if k <= 2 else 1e-2)
         # a moving camera's frame comes out of acosf / sinf per path: the last-ulp libm difference sits on every vertex from the start
-        assert np.quantile(rel(gpu["v"]["throughput"][m, k], ora["v"]["throughput"][m, k]), 0.999) < (2e-2 if name.startswith("camera motion blur") else 1e-3)
+        assert np.quantile(rel(gpu["v"]["throughput"][m, k], ora["v"]["throughput"][m, k]), 0.999) < (2e-2 if name.startswith(("camera motion blur", "moving geometry")) else 1e-3)
         assert (gpu["v"]["flags"][m, k] == ora["v"]["flags"][m, k]).mean() >= 0.999
         assert (gpu["v"]["mode"][m, k] == ora["v"]["mode"][m, k]).mean() >= 0.999
         assert (gpu["v"]["shader"][m, k] == ora["v"]["shader"][m, k]).mean() >= 0.999
-        assert np.quantile(rel(gpu["v"]["pdf"][m, k], ora["v"]["pdf"][m, k]), 0.999) < (2e-2 if name.startswith("camera motion blur") else 5e-3)
+        assert np.quantile(rel(gpu["v"]["pdf"][m, k], ora["v"]["pdf"][m, k]), 0.999) < (2e-2 if name.startswith(("camera motion blur", "moving geometry")) else 5e-3)
     m = same & (gpu["num_splats"] == ora["num_splats"]) & (ora["num_splats"] > 0)
     if m.sum():
         a, b = gpu["splat"]["value"][m, 0], ora["splat"]["value"][m, 0]
@@ -648,3 +651,28 @@ def test_media_restrictions_are_reported(monkeypatch):
     monkeypatch.setenv("CORONA_MI_MODE", "wave")
     with pytest.raises(RuntimeError, match="megakernel"):
         pkg.Backend(make_scene(SCENE_FOG, width=64, height=64, max_verts=4))
+
+
+def test_motion_blur_image_and_restrictions():
+    """1-spp film of the moving-geometry scene against the oracle; what the backend cannot do with moving primitives is reported"""
+    scene = make_scene(SCENE_MB, width=512, height=288, max_verts=8)
+    npx = scene.width * scene.height
+    be = pkg.Backend(scene)
+    be.render(0, npx)
+    fb = be.fb_read()
+    cnt = be.counters()
+    ofb, ocnt, _ = oracle_render(scene, 0, npx, threads=8)
+    rmse = np.sqrt((((fb - ofb) * scene.gain(1)) ** 2).sum() / npx)
+    assert rmse < 0.05, rmse
+    assert cnt[4] == npx and abs(cnt[0] - ocnt[0]) <= 1e-4 * ocnt[0] and abs(cnt[6] - ocnt[6]) <= 1e-4 * ocnt[6]
+    with pytest.raises(RuntimeError, match="no time"):
+        be.intersect(np.zeros((4, 3), np.float32), np.tile(np.float32([0, 0, 1]), (4, 1)))
+    be.close()
+    with pytest.raises(RuntimeError, match="caller's tree"):
+        pkg.Backend(scene, device_build=True)
+    # the same geometry frozen at shutter open gives another image: the interpolation is really applied
+    still = make_scene(SCENE_0010, width=512, height=288, max_verts=8)
+    bs = pkg.Backend(still)
+    bs.render(0, npx)
+    assert not np.allclose(bs.fb_read(), fb)
+    bs.close()

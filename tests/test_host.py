@@ -216,3 +216,18 @@ def test_camera_files_static_and_moving():
     q0, q1 = np.array(mv.orient), np.array(mv.orient_t1)
     assert abs(np.linalg.norm(q0) - 1) < 1e-4 and abs(np.linalg.norm(q1) - 1) < 1e-4      # the 0010 camera file itself is normalised to 3e-5
     assert abs(2 * np.degrees(np.arccos(min(1.0, abs(float(q0 @ q1) / float(np.linalg.norm(q0) * np.linalg.norm(q1)))))) - 4.0) < 5e-2   # turned by 4 degrees
+
+
+def test_motion_blurred_geo_is_loaded_with_enclosing_boxes():
+    """tools/make_geo.py mb: primid bit 60 set, vertices interleaved shutter open / close; the host tree's leaf boxes enclose both states"""
+    from helpers import SCENE_MB
+    s = make_scene(SCENE_MB, width=256, height=256, max_verts=4)
+    d = s.desc
+    prim = np.ctypeslib.as_array(d.primid, shape=(d.num_prims,))
+    mb = (prim >> np.uint64(60)) & np.uint64(1)
+    assert mb.sum() == 4096 + 6 and d.num_prims == 4108            # backdrop + cylinder cap move, emitter / sphere / lines do not
+    assert d.num_vtx > 2 * 4096                                     # two states per vertex of the moving shapes
+    # scene box: the backdrop rises by 0.15 dm, the box must contain the shutter-close state
+    st = make_scene(SCENE_0010, width=256, height=256, max_verts=4).desc
+    assert d.aabb[5] >= st.aabb[5] - 1e-6 and d.aabb[2] <= st.aabb[2] + 1e-6
+    assert max(d.aabb[3] - st.aabb[3], d.aabb[5] - st.aabb[5]) > 0.1

@@ -39,6 +39,23 @@ def write_geo(fn, primid, vtxidx, vtx):
         f.write(np.ascontiguousarray(vtx, dtype=VTX).tobytes())
 
 
+def motion_blur(primid, vtxidx, vtx, delta, turn_deg=0.0):
+    """every primitive gets the motion-blur bit; vertices are stored interleaved: 2i = shutter open, 2i+1 = shutter close
+    (include/geo.h:108-138). Shutter close = shutter open turned by turn_deg about the z axis through the centroid, then moved by delta."""
+    f32 = np.float32
+    P0 = vtx["p"].astype(np.float32)
+    c = P0.mean(axis=0, dtype=np.float64).astype(np.float32)
+    a = np.radians(turn_deg)
+    R = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], dtype=np.float32)
+    P1 = ((P0 - c) @ R.T + c + np.asarray(delta, dtype=np.float32)).astype(np.float32)
+    out = np.zeros(2 * len(vtx), dtype=VTX)
+    out["p"][0::2] = P0
+    out["p"][1::2] = P1
+    out["n"][0::2] = vtx["n"]
+    out["n"][1::2] = vtx["n"]          # the encoded normals are kept (exact for a pure translation)
+    return primid | (np.uint64(1) << np.uint64(60)), vtxidx, out
+
+
 def subdivide_quads(primid, vtxidx, vtx, k):
     vcnt = (primid >> np.uint64(61)) & np.uint64(7)
     if not (vcnt == 4).all():
@@ -76,6 +93,9 @@ def subdivide_quads(primid, vtxidx, vtx, k):
 if __name__ == "__main__":
     if len(sys.argv) == 5 and sys.argv[1] == "subdivide":
         write_geo(sys.argv[3], *subdivide_quads(*read_geo(sys.argv[2]), int(sys.argv[4])))
+    elif len(sys.argv) in (7, 8) and sys.argv[1] == "mb":
+        # python3 tools/make_geo.py mb in.geo out.geo dx dy dz [turn degrees about z]
+        write_geo(sys.argv[3], *motion_blur(*read_geo(sys.argv[2]), [float(x) for x in sys.argv[4:7]], float(sys.argv[7]) if len(sys.argv) == 8 else 0.0))
     elif len(sys.argv) == 3 and sys.argv[1] == "info":
         p, vi, v = read_geo(sys.argv[2])
         print(len(p), "prims", len(vi), "vtxidx", len(v), "vertices; kinds", sorted(set(int(x) for x in (p >> np.uint64(61)) & np.uint64(7))))
