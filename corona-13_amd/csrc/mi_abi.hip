@@ -338,7 +338,7 @@ static int build_on_device(mi_scene *s, const mi_scene_desc *h, uint32_t *num_no
   const float3 sinv = make_float3(ext[0] > 0 ? 1.0f/ext[0] : 0.0f, ext[1] > 0 ? 1.0f/ext[1] : 0.0f, ext[2] > 0 ? 1.0f/ext[2] : 0.0f);
   if(e == hipSuccess)
   {
-    hipLaunchKernelGGL(bl_boxes, dim3(grid), dim3(BL_BLOCK), 0, 0, b, (const DPrim *)s->d_prims, (const DPrimGeo *)s->d_primgeo, slo, sinv);
+    hipLaunchKernelGGL(bl_boxes, dim3(grid), dim3(BL_BLOCK), 0, 0, b, (const DPrim *)s->d_prims, (const DPrimGeo *)s->d_primgeo, (const DPrimT1 *)s->d_prims_t1, slo, sinv);
     e = hipGetLastError();
   }
   if(e == hipSuccess)
@@ -396,11 +396,13 @@ static int build_on_device(mi_scene *s, const mi_scene_desc *h, uint32_t *num_no
   }
   if(e == hipSuccess)
   { /* primitive records into sorted order; emitter indices follow */
-    void *np = nullptr, *ng = nullptr;
+    void *np = nullptr, *ng = nullptr, *nt = nullptr;
     uint32_t *inv = (uint32_t *)dev(sizeof(uint32_t)*(size_t)n);
     if(!inv || hipMalloc(&np, sizeof(DPrim)*(size_t)n) != hipSuccess || hipMalloc(&ng, sizeof(DPrimGeo)*(size_t)n) != hipSuccess) e = hipErrorOutOfMemory;
+    if(e == hipSuccess && s->d_prims_t1 && hipMalloc(&nt, sizeof(DPrimT1)*(size_t)n) != hipSuccess) e = hipErrorOutOfMemory;
     if(e == hipSuccess)
     {
+      if(nt) hipLaunchKernelGGL(bl_gather<DPrimT1>, dim3(grid), dim3(BL_BLOCK), 0, 0, (DPrimT1 *)nt, (const DPrimT1 *)s->d_prims_t1, (const uint32_t *)b.perm, n);
       hipLaunchKernelGGL(bl_gather<DPrim>, dim3(grid), dim3(BL_BLOCK), 0, 0, (DPrim *)np, (const DPrim *)s->d_prims, (const uint32_t *)b.perm, n);
       hipLaunchKernelGGL(bl_gather<DPrimGeo>, dim3(grid), dim3(BL_BLOCK), 0, 0, (DPrimGeo *)ng, (const DPrimGeo *)s->d_primgeo, (const uint32_t *)b.perm, n);
       hipLaunchKernelGGL(bl_invert, dim3(grid), dim3(BL_BLOCK), 0, 0, inv, (const uint32_t *)b.perm, n);
@@ -409,10 +411,15 @@ static int build_on_device(mi_scene *s, const mi_scene_desc *h, uint32_t *num_no
                            h->lights.num_prims);
       e = hipGetLastError();
       if(e == hipSuccess) e = hipDeviceSynchronize();
-      if(e == hipSuccess) { (void)hipFree(s->d_prims); (void)hipFree(s->d_primgeo); s->d_prims = np; s->d_primgeo = ng; np = ng = nullptr; }
+      if(e == hipSuccess)
+      {
+        (void)hipFree(s->d_prims); (void)hipFree(s->d_primgeo); s->d_prims = np; s->d_primgeo = ng; np = ng = nullptr;
+        if(nt) { (void)hipFree(s->d_prims_t1); s->d_prims_t1 = nt; nt = nullptr; }
+      }
     }
     if(np) (void)hipFree(np);
     if(ng) (void)hipFree(ng);
+    if(nt) (void)hipFree(nt);
   }
   if(verbose) (void)hipEventRecord(t1, 0);
   if(e == hipSuccess) e = hipDeviceSynchronize();
@@ -505,7 +512,6 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
     const uint32_t shape = MI_PRIMID_SHAPE(pi), vc = MI_PRIMID_VCNT(pi);
     const uint32_t mb = MI_PRIMID_MB(pi);
     if(shape >= h->num_shapes || vc < 1 || vc > 4 || (mb && vc < 3)) { free(s); return fail(MI_ERR_UNSUPPORTED, "primitive kind outside the scope"); }
-    if(mb && device_build) { free(s); return fail(MI_ERR_UNSUPPORTED, "motion-blurred primitives need the caller's tree (device build: static primitives only)"); }
     const mi_shape &sh = h->shapes[shape];
     const mi_vtxidx *vi = h->vtxidx + sh.vtxidx_base + MI_PRIMID_VI(pi);
     const mi_vtx *vtx = h->vtx + sh.vtx_base;

@@ -44,14 +44,24 @@ __device__ __forceinline__ uint32_t bl_expand(uint32_t v)
   return v;
 }
 
-__global__ __launch_bounds__(BL_BLOCK) void bl_boxes(BuildBufs b, const DPrim *prims, const DPrimGeo *geo, float3 slo, float3 sinv)
+__global__ __launch_bounds__(BL_BLOCK) void bl_boxes(BuildBufs b, const DPrim *prims, const DPrimGeo *geo, const DPrimT1 *t1, float3 slo, float3 sinv)
 {
   const uint32_t i = blockIdx.x*BL_BLOCK + threadIdx.x;
   if(i >= b.n) return;
   const DPrim &p = prims[i];
   const float *g = geo[i].f;
   float lo[3], hi[3];
-  if(p.type >= MI_PRIM_TRI)
+  if(p.type == 0)
+  { /* motion-blurred triangle / quad: the record holds the shutter-open vertices, t1 the shutter-close ones; the box encloses
+       both states, i.e. the whole linear motion */
+    for(int k=0;k<3;k++) lo[k] = hi[k] = p.v[0][k];
+    for(uint32_t v=0;v<p.pad[0];v++) for(int k=0;k<3;k++)
+    {
+      const float x0 = p.v[v][k], x1 = t1[i].v[v][k];
+      lo[k] = fminf(lo[k], fminf(x0, x1)); hi[k] = fmaxf(hi[k], fmaxf(x0, x1));
+    }
+  }
+  else if(p.type >= MI_PRIM_TRI)
   {
     for(int k=0;k<3;k++) lo[k] = hi[k] = p.v[0][k];
     for(uint32_t v=1;v<p.type;v++) for(int k=0;k<3;k++)

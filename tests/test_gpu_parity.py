@@ -667,9 +667,14 @@ def test_motion_blur_image_and_restrictions():
     assert cnt[4] == npx and abs(cnt[0] - ocnt[0]) <= 1e-4 * ocnt[0] and abs(cnt[6] - ocnt[6]) <= 1e-4 * ocnt[6]
     with pytest.raises(RuntimeError, match="no time"):
         be.intersect(np.zeros((4, 3), np.float32), np.tile(np.float32([0, 0, 1]), (4, 1)))
+    host_paths = be.trace_paths(777, 8000)
     be.close()
-    with pytest.raises(RuntimeError, match="caller's tree"):
-        pkg.Backend(scene, device_build=True)
+    # the device-built tree (boxes enclosing both states of a moving primitive) finds the same paths
+    bd = pkg.Backend(scene, device_build=True)
+    dev_paths = bd.trace_paths(777, 8000)
+    bd.close()
+    assert np.array_equal(host_paths["length"], dev_paths["length"]) and np.array_equal(host_paths["v"]["prim"], dev_paths["v"]["prim"])
+    assert np.array_equal(host_paths["v"]["dist"].view(np.uint32), dev_paths["v"]["dist"].view(np.uint32))
     # the same geometry frozen at shutter open gives another image: the interpolation is really applied
     still = make_scene(SCENE_0010, width=512, height=288, max_verts=8)
     bs = pkg.Backend(still)
