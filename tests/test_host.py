@@ -231,3 +231,27 @@ def test_motion_blurred_geo_is_loaded_with_enclosing_boxes():
     st = make_scene(SCENE_0010, width=256, height=256, max_verts=4).desc
     assert d.aabb[5] >= st.aabb[5] - 1e-6 and d.aabb[2] <= st.aabb[2] + 1e-6
     assert max(d.aabb[3] - st.aabb[3], d.aabb[5] - st.aabb[5]) > 0.1
+
+
+def test_regression_report_pieces(tmp_path):
+    """tests/regression_report.py (the reference's regression/createres.sh flow): per-test files exist for every scene, the PNG
+    writer produces a decodable image and the report lists every test with its verdict"""
+    import importlib.util, zlib, struct
+    spec = importlib.util.spec_from_file_location("regression_report", REPO / "tests" / "regression_report.py")
+    rr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rr)
+    for d in sorted((REPO / "scenes").iterdir()):
+        if d.is_dir() and d.name[:4].isdigit():
+            assert (d / "args").exists() and (d / "maxerror").exists() and (d / "title").exists() and (d / "config.mk").read_text().startswith("MOD_sampler=")
+    img = np.random.default_rng(0).uniform(0, 1, size=(8, 16, 3)).astype(np.float32)
+    rr.write_png(tmp_path / "a.png", img)
+    raw = (tmp_path / "a.png").read_bytes()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n" and struct.unpack(">II", raw[16:24]) == (16, 8)
+    idat = raw[raw.index(b"IDAT") + 4:raw.index(b"IEND") - 8]
+    assert len(zlib.decompress(idat)) == 8 * (1 + 16 * 3)
+    (tmp_path / "0010_pt").mkdir()
+    rr.write_png(tmp_path / "0010_pt" / "testrender.png", img)
+    rr.write_report(tmp_path, [dict(name="0010_pt", title="simplemost path tracing", maxerror=4.0, rmse=1.25, status="pass_1", log="ok", ref_seconds=7.5, seconds=0.1),
+                               dict(name="0059_mb", title="motion-blurred geometry", maxerror=4.0, rmse=None, status="pass_crash", log="boom", ref_seconds=None)])
+    page = (tmp_path / "report.html").read_text()
+    assert "0010_pt" in page and "rmse=1.25" in page and 'class="pass_crash"' in page and "testrender.png" in page
