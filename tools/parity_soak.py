@@ -7,9 +7,15 @@ from helpers import *
 pkg = load_pkg()
 total = int(sys.argv[1]) if len(sys.argv) > 1 else 2000000
 chunk = 250000
-for name, path, sampler, mv in (("cfg2 pt mv8", SCENE_0010, pkg.MI_SAMPLER_PT, 8), ("cfg3 ptdl mv8", SCENE_0010, pkg.MI_SAMPLER_PTDL, 8),
-                                ("cfg4 rough mv32", SCENE_ROUGH, pkg.MI_SAMPLER_PT, 32), ("metal ptdl mv8", SCENE_METAL, pkg.MI_SAMPLER_PTDL, 8)):
-    scene = make_scene(path, width=1280, height=720, max_verts=mv, sampler=sampler)
+CASES = {"base": (("cfg2 pt mv8", SCENE_0010, pkg.MI_SAMPLER_PT, 8), ("cfg3 ptdl mv8", SCENE_0010, pkg.MI_SAMPLER_PTDL, 8),
+                  ("cfg4 rough mv32", SCENE_ROUGH, pkg.MI_SAMPLER_PT, 32), ("metal ptdl mv8", SCENE_METAL, pkg.MI_SAMPLER_PTDL, 8)),
+         # the extended kernels (python3 tools/parity_soak.py N ext): media, fog, nested media, moving camera, moving geometry, Halton
+         "ext": (("media ptdl mv32", SCENE_MEDIA, pkg.MI_SAMPLER_PTDL, 32), ("fog ptdl mv8", SCENE_FOG, pkg.MI_SAMPLER_PTDL, 8),
+                 ("nested pt mv32", SCENE_NESTED, pkg.MI_SAMPLER_PT, 32), ("cam mb ptdl mv8", SCENE_CAM_MB, pkg.MI_SAMPLER_PTDL, 8),
+                 ("mb ptdl mv8", SCENE_MB, pkg.MI_SAMPLER_PTDL, 8), ("halton ptdl mv8", SCENE_0010, pkg.MI_SAMPLER_PTDL, 8))}
+for name, path, sampler, mv in CASES[sys.argv[2] if len(sys.argv) > 2 else "base"]:
+    scene = make_scene(path, width=1280, height=720, max_verts=mv, sampler=sampler,
+                       pointsampler=pkg.MI_POINTS_HALTON if name.startswith("halton") else pkg.MI_POINTS_RAND)
     be = pkg.Backend(scene)
     n = same_len = same_prims = same_splats = 0
     worst_thr = 0.0
