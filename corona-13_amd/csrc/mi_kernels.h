@@ -1478,8 +1478,26 @@ __device__ __forceinline__ V3 tri_retime(const V3 v0, const V3 v1, const V3 v2, 
   return mk3(w*v0.x + v*v1.x + u*v2.x, w*v0.y + v*v1.y + u*v2.y, w*v0.z + v*v1.z + u*v2.z);
 }
 
-__device__ __forceinline__ V3 prim_sample(const DPrim &p, const DPrimGeo &geo, float r0, float r1, float &hu, float &hv)
+template<bool MB = false>
+__device__ __forceinline__ V3 prim_sample(const DPrim &p, const DPrimGeo &geo, float r0, float r1, float &hu, float &hv,
+                                          const DPrimT1 *t1 = nullptr, float time = 0.0f)
 { /* prims_sample + prims_retime, src/prims.c:178-252 */
+  if(MB && p.type == 0)
+  { /* moving emitter (triangle / quad): the record holds the shutter-open vertices, *t1 the shutter-close ones; sample the
+       primitive as it is at the path's time */
+    const float w0 = 1.0f - time, w1 = time;
+    V3 vt[4];
+    for(int k=0;k<4;k++) vt[k] = mk3(w0*p.v[k][0] + w1*t1->v[k][0], w0*p.v[k][1] + w1*t1->v[k][1], w0*p.v[k][2] + w1*t1->v[k][2]);
+    if(p.pad[0] == MI_PRIM_QUAD)
+    {
+      hu = r0; hv = r1;
+      if(hv >= hu) return tri_retime(vt[0], vt[1], vt[2], hu, hv - hu);
+      return tri_retime(vt[0], vt[2], vt[3], hu - hv, hv);
+    }
+    const float a = sqrtf(r0);
+    hu = r1*a; hv = (1.0f-r1)*a;
+    return tri_retime(vt[0], vt[1], vt[2], hu, hv);
+  }
   const uint32_t type = p.type;
   const float *gv = geo.f + 26;             /* v1, v2, v3 of a triangle / quad (DPrim keeps v0 and the edges) */
   if(type == MI_PRIM_QUAD)

@@ -284,13 +284,13 @@ __device__ __forceinline__ void path_shade_volume(const DScene &sc, PathState &p
       const uint32_t t = sample_cdf(sc.light_cdf, (int)sc.num_lights, r1);
       const uint32_t lp = sc.light_prim[t];
       Surf ls;
-      ls.x = prim_sample(sc.prims[lp], sc.primgeo[lp], r2, r3, ls.u, ls.v);
+      ls.x = prim_sample<true>(sc.prims[lp], sc.primgeo[lp], r2, r3, ls.u, ls.v, sc.prims_t1 ? sc.prims_t1 + lp : nullptr, ps.time);
       V3 ol = sub3(ls.x, sf.x);
       const float ldist = sqrtf(dot3(ol, ol));
       const double il = 1./(double)ldist;
       ol = mk3((float)((double)ol.x*il), (float)((double)ol.y*il), (float)((double)ol.z*il));
       const uint4 lhead = *(const uint4 *)&sc.primgeo[lp];
-      surface_setup(sc, lp, lhead, ol, ps.scramble, ls);
+      surface_setup<true>(sc, lp, lhead, ol, ps.scramble, ls, ps.time);
       Shading lsh;
       run_prepare_ops(sc, sc.materials[lhead.y], sc.materials[lhead.y].num_ops, ls, ps.lambda, lsh);
       float lpdf = sc.light_L[t];
@@ -591,13 +591,13 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
             const uint32_t t = sample_cdf(sc.light_cdf, (int)sc.num_lights, r1);
             const uint32_t lp = sc.light_prim[t];
             Surf ls;
-            ls.x = prim_sample(sc.prims[lp], sc.primgeo[lp], r2, r3, ls.u, ls.v);
+            ls.x = prim_sample<MEDIA>(sc.prims[lp], sc.primgeo[lp], r2, r3, ls.u, ls.v, MEDIA && sc.prims_t1 ? sc.prims_t1 + lp : nullptr, ps.time);
             V3 ol = sub3(ls.x, sf.x);
             const float ldist = sqrtf(dot3(ol, ol));
             const double il = 1./(double)ldist;
             ol = mk3((float)((double)ol.x*il), (float)((double)ol.y*il), (float)((double)ol.z*il));
             const uint4 lhead = *(const uint4 *)&sc.primgeo[lp];
-            surface_setup(sc, lp, lhead, ol, ps.scramble, ls);
+            surface_setup<MEDIA>(sc, lp, lhead, ol, ps.scramble, ls, ps.time);
             Shading lsh;
             run_prepare_ops(sc, sc.materials[lhead.y], sc.materials[lhead.y].num_ops, ls, ps.lambda, lsh);
             float lpdf = sc.light_L[t];

@@ -332,10 +332,11 @@ float ch_prim_area(const ch_geo *g, mi_primid pi)
     return (float)M_PI*r1*l - (float)M_PI*r0*l;
   }
   float area = 0.0f;
-  const float *v0 = vtx[vi[0].v].v;
+  const uint32_t st = MI_PRIMID_MB(pi) + 1;           /* shutter-open area of a moving primitive, src/prims.c:140-152 */
+  const float *v0 = vtx[st*vi[0].v].v;
   for(uint32_t t=0;t+2<vcnt;t++)
   {
-    const float *v1 = vtx[vi[t+1].v].v, *v2 = vtx[vi[t+2].v].v;
+    const float *v1 = vtx[st*vi[t+1].v].v, *v2 = vtx[st*vi[t+2].v].v;
     float e1[3], e2[3], n[3];
     for(int k=0;k<3;k++) { e1[k] = v1[k]-v0[k]; e2[k] = v2[k]-v0[k]; }
     n[0] = e1[1]*e2[2] - e2[1]*e1[2];
@@ -467,8 +468,6 @@ static int init_lights(ch_scene *s)
       const float L = m->op[k].mul*(ch_coeff_eval(c, 400.0f) + ch_coeff_eval(c, 480.0f) + ch_coeff_eval(c, 560.0f) + ch_coeff_eval(c, 660.0f))/4.0f;
       for(uint32_t i=0;i<sh->num_prims;i++)
       { /* list.c:56-74 */
-        if(MI_PRIMID_MB(s->primid[prim_base + i]))
-        { fprintf(stderr, "[ch] shape %u: motion-blurred emitters are outside the scope of this backend\n", sid); return MI_ERR_UNSUPPORTED; }
         s->light_primid[off+i] = s->primid[prim_base + i];
         s->light_cdf[off+i] = ch_prim_area(&s->geo, s->primid[prim_base + i])*L;
         s->light_L[off+i] = L;

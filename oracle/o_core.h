@@ -123,7 +123,7 @@ float o_halton_sample(uint32_t dim, uint32_t index);
 /* oracle_geo.c */
 void  o_accel_intersect(o_ctx *c, const o_ray *ray, o_hit *hit);
 void  o_prims_get_normal(const mi_scene_desc *s, mi_primid pi, o_hit *hit, float time);   /* prims_get_normal_time, src/prims.c:254-366 */
-void  o_prims_sample(const mi_scene_desc *s, mi_primid pi, float r0, float r1, o_hit *hit);
+void  o_prims_sample(const mi_scene_desc *s, mi_primid pi, float r0, float r1, o_hit *hit, float time);
 void  o_prims_offset_ray(const o_hit *hit, o_ray *ray);
 float o_prims_get_ray(const o_hit *h1, const o_hit *h2, o_ray *ray);
 

@@ -530,8 +530,8 @@ static void o_tri_retime(const float *v0, const float *v1, const float *v2, floa
   for(int k=0;k<3;k++) hit->x[k] = w*v0[k] + v*v1[k] + u*v2[k];
 }
 
-static void o_prims_retime(const mi_scene_desc *s, mi_primid pi, o_hit *hit)
-{ /* prims_retime, src/prims.c:178-214 (time has no effect without motion blur) */
+static void o_prims_retime(const mi_scene_desc *s, mi_primid pi, o_hit *hit, float time)
+{ /* prims_retime, src/prims.c:178-214 */
   hit->prim = pi;
   const uint32_t vcnt = MI_PRIMID_VCNT(pi);
   if(vcnt == MI_PRIM_SPHERE)
@@ -562,15 +562,20 @@ static void o_prims_retime(const mi_scene_desc *s, mi_primid pi, o_hit *hit)
   }
   else if(vcnt == MI_PRIM_QUAD)
   {
-    const float *v0 = o_vtx(s, pi, 0)->v, *v2 = o_vtx(s, pi, 2)->v;
-    if(hit->v >= hit->u) o_tri_retime(v0, o_vtx(s, pi, 1)->v, v2, hit->u, hit->v - hit->u, hit);
-    else                 o_tri_retime(v0, v2, o_vtx(s, pi, 3)->v, hit->u - hit->v, hit->v, hit);
+    float v0[3], v1[3], v2[3];
+    o_vertex_time(s, pi, 0, time, v0); o_vertex_time(s, pi, 2, time, v2);
+    if(hit->v >= hit->u) { o_vertex_time(s, pi, 1, time, v1); o_tri_retime(v0, v1, v2, hit->u, hit->v - hit->u, hit); }
+    else                 { o_vertex_time(s, pi, 3, time, v1); o_tri_retime(v0, v2, v1, hit->u - hit->v, hit->v, hit); }
   }
   else if(vcnt == MI_PRIM_TRI)
-    o_tri_retime(o_vtx(s, pi, 0)->v, o_vtx(s, pi, 1)->v, o_vtx(s, pi, 2)->v, hit->u, hit->v, hit);
+  {
+    float v0[3], v1[3], v2[3];
+    o_vertex_time(s, pi, 0, time, v0); o_vertex_time(s, pi, 1, time, v1); o_vertex_time(s, pi, 2, time, v2);
+    o_tri_retime(v0, v1, v2, hit->u, hit->v, hit);
+  }
 }
 
-void o_prims_sample(const mi_scene_desc *s, mi_primid pi, float r0, float r1, o_hit *hit)
+void o_prims_sample(const mi_scene_desc *s, mi_primid pi, float r0, float r1, o_hit *hit, float time)
 { /* prims_sample, src/prims.c:216-252 */
   const uint32_t vcnt = MI_PRIMID_VCNT(pi);
   if(vcnt == MI_PRIM_SPHERE) { hit->u = r0; hit->v = acosf(r1)/M_PI; }
@@ -581,7 +586,7 @@ void o_prims_sample(const mi_scene_desc *s, mi_primid pi, float r0, float r1, o_
     hit->u = r1*a;
     hit->v = (1.0f-r1)*a;
   }
-  o_prims_retime(s, pi, hit);
+  o_prims_retime(s, pi, hit, time);
 }
 
 /* ---------------------------------------------------------------- ray bias */

@@ -582,7 +582,7 @@ static float o_lights_sample_next_event(o_ctx *c, o_path *p)
   const float r1 = o_point(c, p, v, o_dim_nee_light2);
   const unsigned int t = o_sample_cdf(l->cdf, l->num_prims, r1);
   p->v[v].hit.prim = l->primid[t];
-  o_prims_sample(c->s, l->primid[t], r2, r3, &p->v[v].hit);
+  o_prims_sample(c->s, l->primid[t], r2, r3, &p->v[v].hit, p->time);
   for(int k=0;k<3;k++) p->e[v].omega[k] = p->v[v].hit.x[k] - p->v[v-1].hit.x[k];
   p->e[v].dist = sqrtf(dot3(p->e[v].omega, p->e[v].omega));
   for(int k=0;k<3;k++) p->e[v].omega[k] *= 1./p->e[v].dist;
