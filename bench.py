@@ -227,7 +227,7 @@ def main():
                        "paths_per_step_per_gpu": per_frame, "sharding": f"path-index ranges x{world}, framebuffer all-reduce"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic if args.config == "cfg2" else None, "traffic_source": traffic_src if args.config == "cfg2" else None,
-                         "kernel": "mi_path_kernel<false,%s,%s,%s,%s> (RECORD, PTDL, NODES_LDS, HALTON, MEDIA)" % ("true" if cfg["sampler"] == "ptdl" else "false", "true" if be.nodes_in_lds() else "false", "true" if args.points == "halton" else "false", "true" if cfg["scene"] in ("0055_media", "0056_fog", "0058_cam_mb", "0059_mb") else "false"), "kernel_ms": kms,
+                         "kernel": "mi_path_kernel<false,%s,%s,%s,%s,%s> (RECORD, PTDL, NODES_LDS, HALTON, MEDIA, MB)" % ("true" if cfg["sampler"] == "ptdl" else "false", "true" if be.nodes_in_lds() else "false", "true" if args.points == "halton" else "false", "true" if cfg["scene"] in ("0055_media", "0056_fog", "0058_cam_mb", "0059_mb") else "false", "true" if cfg["scene"] == "0059_mb" else "false"), "kernel_ms": kms,
                          "algorithmic_bytes_per_sample": bytes_per_sample,
                          "work_per_sample": {"rays": dc[0] / paths, "node_visits": dc[1] / paths, "prim_tests": dc[3] / paths, "splats": dc[5] / paths}},
         }

@@ -30,7 +30,7 @@
 #endif
 
 /* ======================================================================================= persistent megakernel */
-template<bool RECORD, bool PTDL, bool NODES_LDS, bool HALTON = false, bool MEDIA = false>
+template<bool RECORD, bool PTDL, bool NODES_LDS, bool HALTON = false, bool MEDIA = false, bool MB = false>
 __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned long long first, unsigned long long count,
                                                            const uint32_t *shape_material, const float *shape_L, mi_path_record *records,
                                                            uint2 *stack_overflow)
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
       tr_shadow = PTDL && ps.sh_pending;
       hit.prim = MI_NOPRIM; hit.dist = tr_shadow ? ps.sh_dist : (MEDIA ? media_free_flight<PTDL, HALTON>(sc, ps) : FLT_MAX); hit.u = hit.v = 0.0f;
       trace_begin(ts, tr_shadow ? ps.sh_dir : ps.dir, cnt);
-      if(MEDIA) { ts.time = ps.time; ts.prims_t1 = sc.prims_t1; }   /* motion-blurred primitives are tested at the path's time */
+      if(MB) { ts.time = ps.time; ts.prims_t1 = sc.prims_t1; }      /* motion-blurred primitives are tested at the path's time */
       tracing = true;
     }
     /* ------------------------------------------------------------ a slice of traversal: while-while rounds until only a tail of
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
         const unsigned nbusy = __popcll(__ballot(busy));
         if(!nbusy) break;
         if(nbusy < tail && __any(tracing && ts.done)) break;
-        if(busy) trace_round<MI_BLOCK, MI_STACK, MEDIA>(lds, sc.prims, o, d, ignore, hit, ts, cnt);
+        if(busy) trace_round<MI_BLOCK, MI_STACK, MB>(lds, sc.prims, o, d, ignore, hit, ts, cnt);
       }
     }
     MI_PHASE(cnt, 1)
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
       tracing = false;
       mi_path_record *rec = RECORD ? records + (ps.index - first) : nullptr;
       if(tr_shadow) shadow_resolve<RECORD>(sc, ps, hit, rec, cnt, splat);
-      else path_shade<RECORD, PTDL, HALTON, MEDIA>(sc, ps, hit, shape_material, shape_L, rec, cnt, splat);
+      else path_shade<RECORD, PTDL, HALTON, MEDIA, MB>(sc, ps, hit, shape_material, shape_L, rec, cnt, splat);
     }
 
     /* ------------------------------------------------------------ splats of this iteration, cooperatively */
@@ -759,7 +759,15 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
       (const void *)mi_path_kernel<false, false, true, true, true>, (const void *)mi_path_kernel<true, false, true, true, true>,
       (const void *)mi_path_kernel<false, true, true, true, true>, (const void *)mi_path_kernel<true, true, true, true, true>,
       (const void *)mi_path_kernel<false, false, false, true, true>, (const void *)mi_path_kernel<true, false, false, true, true>,
-      (const void *)mi_path_kernel<false, true, false, true, true>, (const void *)mi_path_kernel<true, true, false, true, true> };
+      (const void *)mi_path_kernel<false, true, false, true, true>, (const void *)mi_path_kernel<true, true, false, true, true>,
+      (const void *)mi_path_kernel<false, false, true, false, true, true>, (const void *)mi_path_kernel<true, false, true, false, true, true>,
+      (const void *)mi_path_kernel<false, true, true, false, true, true>, (const void *)mi_path_kernel<true, true, true, false, true, true>,
+      (const void *)mi_path_kernel<false, false, false, false, true, true>, (const void *)mi_path_kernel<true, false, false, false, true, true>,
+      (const void *)mi_path_kernel<false, true, false, false, true, true>, (const void *)mi_path_kernel<true, true, false, false, true, true>,
+      (const void *)mi_path_kernel<false, false, true, true, true, true>, (const void *)mi_path_kernel<true, false, true, true, true, true>,
+      (const void *)mi_path_kernel<false, true, true, true, true, true>, (const void *)mi_path_kernel<true, true, true, true, true, true>,
+      (const void *)mi_path_kernel<false, false, false, true, true, true>, (const void *)mi_path_kernel<true, false, false, true, true, true>,
+      (const void *)mi_path_kernel<false, true, false, true, true, true>, (const void *)mi_path_kernel<true, true, false, true, true, true> };
     for(const void *k : kernels)
       if(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess)
       { mi_scene_destroy(s); return fail(MI_ERR_DEVICE, "cannot raise the dynamic LDS limit"); }
@@ -898,12 +906,23 @@ static int ensure_halton(mi_scene *s, uint64_t end_index)
 
 static void launch_path_kernel(mi_scene *s, bool record, int grid, uint64_t first, uint64_t n, mi_path_record *rec)
 { /* pick the instantiation: RECORD (test hook) x PTDL (sampler) x NODES_LDS (tree fits LDS) x HALTON (point sampler) */
-  const int which = (record ? 1 : 0) | (s->d.sampler == MI_SAMPLER_PTDL ? 2 : 0) | (s->nodes_lds ? 4 : 0) | (s->halton ? 8 : 0) | (s->media ? 16 : 0);
+  const int which = (record ? 1 : 0) | (s->d.sampler == MI_SAMPLER_PTDL ? 2 : 0) | (s->nodes_lds ? 4 : 0) | (s->halton ? 8 : 0) | (s->media ? 16 : 0) |
+                    (s->d_prims_t1 ? 32 : 0);            /* moving primitives: the MEDIA + MB instantiations */
 #define MI_LAUNCH(R, P, L, H) MI_LAUNCH5(R, P, L, H, false)
-#define MI_LAUNCH5(R, P, L, H, M) hipLaunchKernelGGL((mi_path_kernel<R, P, L, H, M>), dim3(grid), dim3(MI_BLOCK), s->lds_bytes, s->stream, s->d, \
+#define MI_LAUNCH5(R, P, L, H, M) MI_LAUNCH6(R, P, L, H, M, false)
+#define MI_LAUNCH6(R, P, L, H, M, B) hipLaunchKernelGGL((mi_path_kernel<R, P, L, H, M, B>), dim3(grid), dim3(MI_BLOCK), s->lds_bytes, s->stream, s->d, \
     (unsigned long long)first, (unsigned long long)n, (const uint32_t *)s->d_shape_material, (const float *)s->d_shape_L, rec, (uint2 *)s->d_overflow)
   switch(which)
   {
+    /* MEDIA + MB (scenes with motion-blurred primitives) */
+    case 48: MI_LAUNCH6(false, false, false, false, true, true); break;  case 49: MI_LAUNCH6(true, false, false, false, true, true); break;
+    case 50: MI_LAUNCH6(false, true,  false, false, true, true); break;  case 51: MI_LAUNCH6(true, true,  false, false, true, true); break;
+    case 52: MI_LAUNCH6(false, false, true,  false, true, true); break;  case 53: MI_LAUNCH6(true, false, true,  false, true, true); break;
+    case 54: MI_LAUNCH6(false, true,  true,  false, true, true); break;  case 55: MI_LAUNCH6(true, true,  true,  false, true, true); break;
+    case 56: MI_LAUNCH6(false, false, false, true,  true, true); break;  case 57: MI_LAUNCH6(true, false, false, true,  true, true); break;
+    case 58: MI_LAUNCH6(false, true,  false, true,  true, true); break;  case 59: MI_LAUNCH6(true, true,  false, true,  true, true); break;
+    case 60: MI_LAUNCH6(false, false, true,  true,  true, true); break;  case 61: MI_LAUNCH6(true, false, true,  true,  true, true); break;
+    case 62: MI_LAUNCH6(false, true,  true,  true,  true, true); break;  case 63: MI_LAUNCH6(true, true,  true,  true,  true, true); break;
     /* MEDIA (scenes with participating media) */
     case 16: MI_LAUNCH5(false, false, false, false, true); break;  case 17: MI_LAUNCH5(true, false, false, false, true); break;
     case 18: MI_LAUNCH5(false, true,  false, false, true); break;  case 19: MI_LAUNCH5(true, true,  false, false, true); break;
@@ -924,6 +943,7 @@ static void launch_path_kernel(mi_scene *s, bool record, int grid, uint64_t firs
   }
 #undef MI_LAUNCH
 #undef MI_LAUNCH5
+#undef MI_LAUNCH6
 }
 
 extern "C" int mi_render(mi_scene *s, uint64_t first_index, uint64_t count)

@@ -241,7 +241,7 @@ __device__ __forceinline__ float media_pdf_to_surface(const Medium &m, float dis
 /* the extension ray ended at the sampled free-flight distance ps.clip before any geometry: a volume vertex
  * (path_propagate src/pathspace.c:745-751,771-776; shader_prepare src/shader.c:476-501; manifold_init manifold.h:236-246;
  * phase function src/shaders/medium_rgb.c:61-102; next event estimation as for surfaces) */
-template<bool RECORD, bool PTDL, bool HALTON>
+template<bool RECORD, bool PTDL, bool HALTON, bool MB>
 __device__ __forceinline__ void path_shade_volume(const DScene &sc, PathState &ps, mi_path_record *rec, uint32_t *cnt)
 {
   const int v = ps.length;
@@ -284,13 +284,13 @@ __device__ __forceinline__ void path_shade_volume(const DScene &sc, PathState &p
       const uint32_t t = sample_cdf(sc.light_cdf, (int)sc.num_lights, r1);
       const uint32_t lp = sc.light_prim[t];
       Surf ls;
-      ls.x = prim_sample<true>(sc.prims[lp], sc.primgeo[lp], r2, r3, ls.u, ls.v, sc.prims_t1 ? sc.prims_t1 + lp : nullptr, ps.time);
+      ls.x = prim_sample<MB>(sc.prims[lp], sc.primgeo[lp], r2, r3, ls.u, ls.v, MB ? sc.prims_t1 + lp : nullptr, ps.time);
       V3 ol = sub3(ls.x, sf.x);
       const float ldist = sqrtf(dot3(ol, ol));
       const double il = 1./(double)ldist;
       ol = mk3((float)((double)ol.x*il), (float)((double)ol.y*il), (float)((double)ol.z*il));
       const uint4 lhead = *(const uint4 *)&sc.primgeo[lp];
-      surface_setup<true>(sc, lp, lhead, ol, ps.scramble, ls, ps.time);
+      surface_setup<MB>(sc, lp, lhead, ol, ps.scramble, ls, ps.time);
       Shading lsh;
       run_prepare_ops(sc, sc.materials[lhead.y], sc.materials[lhead.y].num_ops, ls, ps.lambda, lsh);
       float lpdf = sc.light_L[t];
@@ -399,13 +399,13 @@ __device__ __forceinline__ void path_shade_volume(const DScene &sc, PathState &p
 
 /* the extension ray ps.org/ps.dir has been traced into `hit`: create vertex v = ps.length, then either end the path
  * (ps.active = 0) or leave the next extension ray (and, for ptdl, possibly a shadow ray) in ps */
-template<bool RECORD, bool PTDL, bool HALTON, bool MEDIA = false>
+template<bool RECORD, bool PTDL, bool HALTON, bool MEDIA = false, bool MB = false>
 __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, const Hit &hit, const uint32_t *shape_material, const float *shape_L,
                                            mi_path_record *rec, uint32_t *cnt, SplatReq &splat)
 {
   if(MEDIA && hit.prim == MI_NOPRIM && ps.clip < FLT_MAX)
   {
-    path_shade_volume<RECORD, PTDL, HALTON>(sc, ps, rec, cnt);
+    path_shade_volume<RECORD, PTDL, HALTON, MB>(sc, ps, rec, cnt);
     return;
   }
 
@@ -445,7 +445,7 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
     const uint4 mhead = *(const uint4 *)&mat;                       /* bsdf, num_ops, param[0..1] */
     const uint32_t mat_bsdf = mhead.x;
     const float mat_p0 = __uint_as_float(mhead.z), mat_p1 = __uint_as_float(mhead.w);
-    surface_setup<MEDIA>(sc, hit.prim, head, omega, ps.scramble, sf, ps.time);
+    surface_setup<MB>(sc, hit.prim, head, omega, ps.scramble, sf, ps.time);
     MI_PHASE(cnt, 2)
     const uint32_t shape = (head.w >> 3) & 0x1fffffffu;             /* MI_PRIMID_SHAPE */
     Shading sh;
@@ -480,7 +480,7 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
 
     MI_PHASE(cnt, 3)
     /* self-intersection, src/pathspace.c:807-820 */
-    const uint32_t type = MEDIA ? head.x & 7u : head.x;             /* the extended kernels flag motion blur in bit 3 (MI_GEO_MB) */
+    const uint32_t type = MB ? head.x & 7u : head.x;                /* the motion-blur kernels flag moving primitives in bit 3 (MI_GEO_MB) */
     if((type > 2 || hit.dist < 1e-4f) && hit.prim == ps.ignore)
     {
       alive = false;
@@ -591,13 +591,13 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
             const uint32_t t = sample_cdf(sc.light_cdf, (int)sc.num_lights, r1);
             const uint32_t lp = sc.light_prim[t];
             Surf ls;
-            ls.x = prim_sample<MEDIA>(sc.prims[lp], sc.primgeo[lp], r2, r3, ls.u, ls.v, MEDIA && sc.prims_t1 ? sc.prims_t1 + lp : nullptr, ps.time);
+            ls.x = prim_sample<MB>(sc.prims[lp], sc.primgeo[lp], r2, r3, ls.u, ls.v, MB ? sc.prims_t1 + lp : nullptr, ps.time);
             V3 ol = sub3(ls.x, sf.x);
             const float ldist = sqrtf(dot3(ol, ol));
             const double il = 1./(double)ldist;
             ol = mk3((float)((double)ol.x*il), (float)((double)ol.y*il), (float)((double)ol.z*il));
             const uint4 lhead = *(const uint4 *)&sc.primgeo[lp];
-            surface_setup<MEDIA>(sc, lp, lhead, ol, ps.scramble, ls, ps.time);
+            surface_setup<MB>(sc, lp, lhead, ol, ps.scramble, ls, ps.time);
             Shading lsh;
             run_prepare_ops(sc, sc.materials[lhead.y], sc.materials[lhead.y].num_ops, ls, ps.lambda, lsh);
             float lpdf = sc.light_L[t];

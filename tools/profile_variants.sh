@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: rocprofv3 kernel-trace summaries of the non-headline kernels (ptdl, device-built tree, Halton, media), one bench run each.
+# GPU box: rocprofv3 kernel-trace summaries of the non-headline kernels (ptdl, device-built tree, Halton, media, motion blur), one bench run each.
 #   tools/profile_variants.sh <tag>  -> gpurun_out/<tag>/variants_kernel_stats.csv (+ variants_bench.jsonl)
 TAG=${1:-prof}
 R=${GRAFT_REPO_ROOT:-$PWD}
@@ -30,4 +30,6 @@ run media_pt --config media
 run media_ptdl --config media_ptdl
 run fog_pt --config fog
 run fog_ptdl --config fog_ptdl
+run cam_mb --config cam_mb
+run mb --config mb
 cat $OUT/variants_kernel_stats.csv
