@@ -161,9 +161,12 @@ def main():
     stream = torch.cuda.current_stream()
     be.set_framebuffer(fb.data_ptr())
     be.set_stream(stream.cuda_stream)
+    # N > 1: two framebuffers, the all-reduce of step k (RCCL over xGMI) overlaps the render of step k+1
+    reducer = pkg.FrameReducer([fb, torch.zeros_like(fb)], dist) if use_dist else None
 
     def barrier():
         if use_dist:
+            reducer.drain()                                # every step's reduce is part of the timed region
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -171,10 +174,10 @@ def main():
         # rank r renders its own contiguous block of path indices of "frame" k: no data-path collective
         first, count = pkg.shard_range(k * world * per_frame, world * per_frame, rank, world)
         if use_dist:
-            fb.zero_()                                     # the reduce works on this step's partial sums only
+            be.set_framebuffer(reducer.begin(k).data_ptr())    # cleared: the reduce works on this step's partial sums only
         be.render(first, count)
         if use_dist:
-            dist.all_reduce(fb, op=dist.ReduceOp.SUM)      # framebuffer reduce over xGMI (RCCL)
+            reducer.end(k)                                 # framebuffer reduce over xGMI (RCCL), asynchronous
 
     for k in range(args.warmup):
         step(k)

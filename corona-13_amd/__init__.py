@@ -135,6 +135,45 @@ def shard_range(first, count, rank, world):
     return start, my
 
 
+class FrameReducer:
+    """Double-buffered framebuffer all-reduce for the multi-GPU path (one process per GPU, paths sharded by index range,
+    SURVEY 8(e)): the reduce of frame k runs while frame k+1 is rendered into the other buffer, so the exchange
+    (11.3 MB at 1280x736, one ring all-reduce over xGMI) is off the critical path except for the last frame.
+    `dist` is torch.distributed (nccl = RCCL on the GPU box, gloo in the CPU tests); buffers are torch tensors."""
+
+    def __init__(self, buffers, dist):
+        assert len(buffers) == 2
+        self.buffers, self.dist, self.pending = list(buffers), dist, [None, None]
+
+    def begin(self, k):
+        """the buffer frame k renders into: its previous reduce (frame k-2) has completed, it is cleared"""
+        b = k & 1
+        if self.pending[b] is not None:
+            self.pending[b].wait()
+            self.pending[b] = None
+        self.buffers[b].zero_()
+        return self.buffers[b]
+
+    def end(self, k):
+        """frame k has been enqueued: start its all-reduce (asynchronous; ordered after the render on the device)"""
+        b = k & 1
+        self.pending[b] = self.dist.all_reduce(self.buffers[b], op=self.dist.ReduceOp.SUM, async_op=True)
+
+    def finished(self, k):
+        """wait for frame k's reduce and return its buffer (the sum over all ranks)"""
+        b = k & 1
+        if self.pending[b] is not None:
+            self.pending[b].wait()
+            self.pending[b] = None
+        return self.buffers[b]
+
+    def drain(self):
+        for b in (0, 1):
+            if self.pending[b] is not None:
+                self.pending[b].wait()
+                self.pending[b] = None
+
+
 # ---------------------------------------------------------------- host library
 _host = None
 

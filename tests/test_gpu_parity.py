@@ -682,3 +682,42 @@ def test_motion_blur_image_and_restrictions():
     bs.render(0, npx)
     assert not np.allclose(bs.fb_read(), fb)
     bs.close()
+
+
+def test_frame_reducer_on_device_matches_plain_render():
+    """bench.py's multi-GPU step on one GPU: RCCL process group of one rank, renders into the two buffers of FrameReducer with the
+    asynchronous all-reduce in flight; every reduced frame equals a plain render of the same path indices"""
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        scene = make_scene(SCENE_0010, width=256, height=256, max_verts=8)
+        per = 4 * scene.width * scene.height
+        be = pkg.Backend(scene, device=0)
+        be.set_stream(torch.cuda.current_stream().cuda_stream)
+        shape = (scene.height, scene.width, 3)
+        red = pkg.FrameReducer([torch.zeros(shape, device="cuda:0"), torch.zeros(shape, device="cuda:0")], dist)
+        got = []
+        for k in range(4):
+            be.set_framebuffer(red.begin(k).data_ptr())
+            be.render(k * per, per)
+            red.end(k)
+            if k:
+                got.append(red.finished(k - 1).clone())
+        got.append(red.finished(3).clone())
+        red.drain()
+        torch.cuda.synchronize()
+        plain = torch.zeros(shape, device="cuda:0")
+        be.set_framebuffer(plain.data_ptr())
+        for k in range(4):
+            plain.zero_()
+            be.render(k * per, per)
+            be.sync()
+            err = float((got[k] - plain).abs().max())
+            assert err <= 1e-4 * float(plain.abs().max()) and float(plain.sum()) > 0, (k, err, float(plain.abs().max()), float(got[k].sum()), float(plain.sum()))
+        be.close()
+    finally:
+        dist.destroy_process_group()

@@ -22,12 +22,20 @@ def _worker(rank, world, port, outdir):
     scene = make_scene(SCENE_0010, width=64, height=64, max_verts=4)
     per_frame = 2 * scene.width * scene.height
     total = np.zeros((scene.height, scene.width, 3), dtype=np.float32)
-    for k in range(2):                                              # two "frames", as bench.py's step(k)
+    shape = (scene.height, scene.width, 3)
+    reducer = pkg.FrameReducer([torch.zeros(shape), torch.zeros(shape)], dist)     # bench.py's double-buffered reduce
+    frames = 3
+    for k in range(frames):                                         # as bench.py's step(k)
         first, count = pkg.shard_range(k * world * per_frame, world * per_frame, rank, world)
+        buf = reducer.begin(k)
+        assert float(buf.abs().sum()) == 0.0                        # cleared, its previous reduce (frame k-2) is complete
         fb, _, _ = oracle_render(scene, first, count, threads=1)
-        t = torch.from_numpy(fb)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)                    # the framebuffer reduce (RCCL on the GPU box)
-        total += t.numpy()
+        buf += torch.from_numpy(fb)
+        reducer.end(k)                                              # the framebuffer reduce (RCCL on the GPU box), asynchronous
+        if k >= 1:
+            total += reducer.finished(k - 1).numpy()                # frame k-1 is complete while frame k's reduce is in flight
+    total += reducer.finished(frames - 1).numpy()
+    reducer.drain()
     if rank == 0:
         np.save(os.path.join(outdir, "reduced.npy"), total)
     dist.barrier()
@@ -52,6 +60,6 @@ def test_two_ranks_equal_single_process():
         reduced = np.load(os.path.join(d, "reduced.npy"))
     scene = make_scene(SCENE_0010, width=64, height=64, max_verts=4)
     per_frame = 2 * scene.width * scene.height
-    single, _, _ = oracle_render(scene, 0, 2 * world * per_frame, threads=1)
+    single, _, _ = oracle_render(scene, 0, 3 * world * per_frame, threads=1)
     assert np.allclose(reduced, single, rtol=1e-5, atol=1e-4)
     assert reduced.sum() > 0
