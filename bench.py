@@ -160,7 +160,7 @@ def main():
     fb = torch.zeros((scene.height, scene.width, 3), dtype=torch.float32, device=f"cuda:{local_rank}")
     stream = torch.cuda.current_stream()
     be.set_framebuffer(fb.data_ptr())
-    be.set_stream(stream.cuda_stream)
+    be.set_stream(stream.cuda_stream)      # torch's current stream (the default stream, passed as MI_STREAM_DEFAULT): clears and RCCL are ordered with the renders
     # N > 1: two framebuffers, the all-reduce of step k (RCCL over xGMI) overlaps the render of step k+1
     reducer = pkg.FrameReducer([fb, torch.zeros_like(fb)], dist) if use_dist else None
 

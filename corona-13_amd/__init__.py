@@ -336,7 +336,11 @@ class Backend:
         self._check(self.m.mi_scene_set_framebuffer(self._ptr, C.c_void_p(device_ptr)), "mi_scene_set_framebuffer")
 
     def set_stream(self, stream_handle):
-        self._check(self.m.mi_scene_set_stream(self._ptr, C.c_void_p(stream_handle)), "mi_scene_set_stream")
+        """launch on this HIP stream (torch: torch.cuda.current_stream().cuda_stream). Handle 0 is the device's default
+        stream -- torch's current stream unless told otherwise -- and is passed as MI_STREAM_DEFAULT: a NULL pointer would
+        select the backend's own stream, which is not ordered with torch's clears and collectives."""
+        ptr = C.c_void_p(stream_handle) if stream_handle else C.c_void_p(-1)
+        self._check(self.m.mi_scene_set_stream(self._ptr, ptr), "mi_scene_set_stream")
 
     def render(self, first, count):
         self._check(self.m.mi_render(self._ptr, first, count), "mi_render")

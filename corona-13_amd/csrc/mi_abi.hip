@@ -845,7 +845,7 @@ extern "C" int mi_scene_set_framebuffer(mi_scene *s, float *device_fb)
 extern "C" int mi_scene_set_stream(mi_scene *s, void *hip_stream)
 {
   if(!s) return fail(MI_ERR_ARG, "null scene");
-  s->stream = hip_stream ? (hipStream_t)hip_stream : s->stream_own;
+  s->stream = hip_stream == MI_STREAM_DEFAULT ? (hipStream_t)0 : hip_stream ? (hipStream_t)hip_stream : s->stream_own;
   return MI_OK;
 }
 

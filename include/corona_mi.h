@@ -217,7 +217,10 @@ int  mi_scene_create(const mi_scene_desc *host, mi_scene **out);
  * torch tensor, so that torch.distributed (RCCL) can reduce it in place. NULL = internal. */
 int  mi_scene_set_framebuffer(mi_scene *s, float *device_fb);
 
-/* Launch on this HIP stream (a hipStream_t passed as void*); NULL = the backend's own stream. */
+/* Launch on this HIP stream (a hipStream_t passed as void*); NULL = the backend's own (non-blocking) stream, which is NOT ordered
+ * with the device's default stream; MI_STREAM_DEFAULT = the device's default (null) stream itself -- what a caller whose other
+ * work (clears, RCCL collectives of a framework running on the null stream) must be ordered with the renders has to pass. */
+#define MI_STREAM_DEFAULT ((void *)(intptr_t)-1)
 int  mi_scene_set_stream(mi_scene *s, void *hip_stream);
 
 /* Trace path indices [first, first+count) and splat them into the device framebuffer.
