@@ -1,5 +1,5 @@
 import sys
-sys.path.insert(0,'/root/repo/tests')
+sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parent.parent))
 from helpers import *
 import numpy as np
 pkg = load_pkg()

@@ -2,7 +2,7 @@
 """Quick on-GPU check used during development: HIP path vs oracle records + image + timing."""
 import sys, time, json
 import numpy as np
-sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parent.parent / "tests"))
+sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parent.parent))
 from helpers import *
 
 pkg = load_pkg()

@@ -1,7 +1,7 @@
 """development helper (GPU box): GPU path records against the oracle on millions of paths, in chunks
-(python3 tools/parity_soak.py [paths per configuration])"""
+(python3 tests/dev/parity_soak.py [paths per configuration])"""
 import sys, time
-sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parent.parent / "tests"))
+sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parent.parent))
 import numpy as np
 from helpers import *
 pkg = load_pkg()
@@ -9,7 +9,7 @@ total = int(sys.argv[1]) if len(sys.argv) > 1 else 2000000
 chunk = 250000
 CASES = {"base": (("cfg2 pt mv8", SCENE_0010, pkg.MI_SAMPLER_PT, 8), ("cfg3 ptdl mv8", SCENE_0010, pkg.MI_SAMPLER_PTDL, 8),
                   ("cfg4 rough mv32", SCENE_ROUGH, pkg.MI_SAMPLER_PT, 32), ("metal ptdl mv8", SCENE_METAL, pkg.MI_SAMPLER_PTDL, 8)),
-         # the extended kernels (python3 tools/parity_soak.py N ext): media, fog, nested media, moving camera, moving geometry, Halton
+         # the extended kernels (python3 tests/dev/parity_soak.py N ext): media, fog, nested media, moving camera, moving geometry, Halton
          "ext": (("media ptdl mv32", SCENE_MEDIA, pkg.MI_SAMPLER_PTDL, 32), ("fog ptdl mv8", SCENE_FOG, pkg.MI_SAMPLER_PTDL, 8),
                  ("nested pt mv32", SCENE_NESTED, pkg.MI_SAMPLER_PT, 32), ("cam mb ptdl mv8", SCENE_CAM_MB, pkg.MI_SAMPLER_PTDL, 8),
                  ("mb ptdl mv8", SCENE_MB, pkg.MI_SAMPLER_PTDL, 8), ("halton ptdl mv8", SCENE_0010, pkg.MI_SAMPLER_PTDL, 8))}
