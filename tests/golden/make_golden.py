@@ -165,6 +165,8 @@ def main():
         dump_paths("mb_ptdl_mv8", "dump_ptdl_xs_mv8", 8, "0059_mb", 1280, 720, 6000)
         dump_paths("mb_light_pt_mv8", "dump_pt_xs_mv8", 8, "0060_mb_light", 1280, 720, 6000)        # moving emitter
         dump_paths("mb_light_ptdl_mv8", "dump_ptdl_xs_mv8", 8, "0060_mb_light", 1280, 720, 6000)
+        dump_paths("halton_all_ptdl_mv8", "dump_ptdl_halton_mv8", 8, "0061_all", 1280, 720, 6000)    # every feature in one scene
+        dump_paths("all_pt_mv32", "dump_pt_xs_mv32", 32, "0061_all", 1280, 720, 4000)
         # MOD_pointsampler=halton; the mv32 ptdl case reaches dimensions >= 256 (fallback to the per-path generator)
         dump_paths("halton_pt_mv8", "dump_pt_halton_mv8", 8, "0010_pt", 1280, 720, 3000)
         dump_paths("halton_ptdl_mv8", "dump_ptdl_halton_mv8", 8, "0010_pt", 1280, 720, 3000)

@@ -12,7 +12,7 @@ import json
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, SCENE_0010, SCENE_CAM_MB, SCENE_FINE, SCENE_FOG, SCENE_MB, SCENE_MB_LIGHT, SCENE_MEDIA, SCENE_NESTED, SCENE_METAL, SCENE_ROUGH, load_pkg, make_scene, oracle_intersect, oracle_records, oracle_render
+from helpers import GOLDEN, SCENE_0010, SCENE_ALL, SCENE_CAM_MB, SCENE_FINE, SCENE_FOG, SCENE_MB, SCENE_MB_LIGHT, SCENE_MEDIA, SCENE_NESTED, SCENE_METAL, SCENE_ROUGH, load_pkg, make_scene, oracle_intersect, oracle_records, oracle_render
 
 pkg = load_pkg()
 pytestmark = pytest.mark.gpu
@@ -58,6 +58,9 @@ CASES = [
     ("halton fine backdrop (tree in HBM) pt mv8", SCENE_FINE, pkg.MI_SAMPLER_PT, 1280, 720, 8, 10000),
     ("halton fog ptdl mv8 (free-flight dimension from the sampler)", SCENE_FOG, pkg.MI_SAMPLER_PTDL, 1280, 720, 8, 20000),
     ("halton nested media pt mv32", SCENE_NESTED, pkg.MI_SAMPLER_PT, 1280, 720, 32, 10000),
+    # every feature in one scene: the RECORD x PTDL x HALTON x MEDIA x MB instantiations
+    ("halton everything at once ptdl mv8", SCENE_ALL, pkg.MI_SAMPLER_PTDL, 1280, 720, 8, 30000),
+    ("moving geometry: everything at once pt mv32", SCENE_ALL, pkg.MI_SAMPLER_PT, 1280, 720, 32, 10000),
 ]
 
 

@@ -18,7 +18,7 @@ import json
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, SCENE_0010, SCENE_CAM_MB, SCENE_FINE, SCENE_FOG, SCENE_MB, SCENE_MB_LIGHT, SCENE_MEDIA, SCENE_NESTED, SCENE_METAL, SCENE_ROUGH, load_pkg, make_scene, oracle_lib, oracle_records, oracle_render
+from helpers import GOLDEN, SCENE_0010, SCENE_ALL, SCENE_CAM_MB, SCENE_FINE, SCENE_FOG, SCENE_MB, SCENE_MB_LIGHT, SCENE_MEDIA, SCENE_NESTED, SCENE_METAL, SCENE_ROUGH, load_pkg, make_scene, oracle_lib, oracle_records, oracle_render
 
 pkg = load_pkg()
 
@@ -60,6 +60,9 @@ CASES = [
     ("halton_pt_mv8", pkg.MI_SAMPLER_PT, SCENE_0010, 1.5e-3),
     ("halton_ptdl_mv8", pkg.MI_SAMPLER_PTDL, SCENE_0010, 1e-2),
     ("halton_ptdl_rough_mv32", pkg.MI_SAMPLER_PTDL, SCENE_ROUGH, 1e-2),
+    # everything at once (scenes/0061_all): fog + interior media, moving camera, moving geometry and emitter -- with Halton ptdl, and pt at depth 32
+    ("halton_all_ptdl_mv8", pkg.MI_SAMPLER_PTDL, SCENE_ALL, 1e-2),
+    ("all_pt_mv32", pkg.MI_SAMPLER_PT, SCENE_ALL, 5e-3),
     ("halton_fog_ptdl_mv8", pkg.MI_SAMPLER_PTDL, SCENE_FOG, 1e-2),          # the free-flight dimension (rand_beg + 0) from the Halton sampler
 ]
 
@@ -103,7 +106,7 @@ def test_oracle_matches_reference_paths(name, sampler, scene_path, etol):
     ref = g["records"]
     s = make_scene(scene_path, width=int(g["width"]), height=int(g["height"]), max_verts=int(g["max_verts"]), sampler=sampler,
                    pointsampler=pkg.MI_POINTS_HALTON if name.startswith("halton_") else pkg.MI_POINTS_RAND)
-    if name.startswith(("fog_", "nested_", "halton_fog_")):
+    if name.startswith(("fog_", "nested_", "halton_fog_", "halton_all_", "all_")):
         with reference_rsqrt() as emu:
             ora = oracle_records(s, 0, len(ref))
         if not emu.exact:
