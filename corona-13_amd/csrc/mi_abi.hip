@@ -259,43 +259,6 @@ template<typename T> static int upload(void **dst, const T *src, size_t count)
 /* per-primitive constants of a line (truncated cone) primitive, computed once with the same float operations the
  * reference performs inside every intersection test (include/geo/line.h:313-335,401-416, include/corona_common.h:178-198);
  * layout documented at line_intersect (mi_kernels.h) */
-static void pack_line(DPrim &p, const mi_vtx &a0, const mi_vtx &a1)
-{
-  float *f = &p.v[0][0];
-  uint32_t *fu = (uint32_t *)f;
-  const uint32_t type = p.type;
-  float r0, r1;
-  memcpy(&r0, &a0.n, 4); memcpy(&r1, &a1.n, 4);
-  const float v0[3] = {a0.v[0], a0.v[1], a0.v[2]}, v1[3] = {a1.v[0], a1.v[1], a1.v[2]};
-  float d[3] = {v1[0]-v0[0], v1[1]-v0[1], v1[2]-v0[2]};
-  const float dlen = sqrtf(d[0]*d[0] + d[1]*d[1] + d[2]*d[2]);
-  memset(f, 0, 64);
-  f[0] = v0[0]; f[1] = v0[1]; f[2] = v0[2]; f[3] = r0; f[4] = r1; f[5] = dlen;
-  if(fabsf(r1-r0) < 1e-3)
-  { /* cylinder: d *= 1.0f/dlen; get_onb(d, a, b) */
-    const float inv = 1.0f/dlen;
-    for(int k=0;k<3;k++) d[k] *= inv;
-    float a[3], b[3];
-    if(fabsf(d[1]) < 0.5) { a[0] = d[1]*0.0f - 1.0f*d[2]; a[1] = d[2]*0.0f - 0.0f*d[0]; a[2] = d[0]*1.0f - 0.0f*d[1]; }   /* d x (0,1,0) */
-    else                  { a[0] = d[1]*0.0f - 0.0f*d[2]; a[1] = d[2]*1.0f - 0.0f*d[0]; a[2] = d[0]*0.0f - 1.0f*d[1]; }   /* d x (1,0,0) */
-    const float il = 1.0f/sqrtf(a[0]*a[0] + a[1]*a[1] + a[2]*a[2]);
-    for(int k=0;k<3;k++) a[k] *= il;
-    b[0] = d[1]*a[2] - a[1]*d[2]; b[1] = d[2]*a[0] - a[2]*d[0]; b[2] = d[0]*a[1] - a[0]*d[1];
-    f[6] = d[0]; f[7] = d[1]; f[8] = d[2];
-    f[9] = a[0]; f[10] = a[1]; f[11] = a[2];
-    f[13] = b[0]; f[14] = b[1]; f[15] = b[2];
-  }
-  else
-  { /* cone: d *= 1.0/d_len (double), cos_a2 */
-    for(int k=0;k<3;k++) d[k] = (float)(d[k]*(1.0/dlen));
-    f[6] = d[0]; f[7] = d[1]; f[8] = d[2];
-    const float tt = -r0*dlen/(r1-r0);            /* apex of the cone, line.h:395-397 */
-    f[9] = v0[0] + tt*d[0]; f[10] = v0[1] + tt*d[1]; f[11] = v0[2] + tt*d[2];
-    f[13] = dlen*dlen/((r1-r0)*(r1-r0) + dlen*dlen);
-  }
-  fu[12] = type;
-}
-
 static int tree_depth(const mi_scene_desc *h, uint32_t node, int depth)
 {
   int best = depth;
@@ -511,7 +474,7 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
     const mi_primid pi = h->primid[i];
     const uint32_t shape = MI_PRIMID_SHAPE(pi), vc = MI_PRIMID_VCNT(pi);
     const uint32_t mb = MI_PRIMID_MB(pi);
-    if(shape >= h->num_shapes || vc < 1 || vc > 4 || (mb && vc < 3)) { free(s); return fail(MI_ERR_UNSUPPORTED, "primitive kind outside the scope"); }
+    if(shape >= h->num_shapes || vc < 1 || vc > 4) { free(s); return fail(MI_ERR_UNSUPPORTED, "primitive kind outside the scope"); }
     const mi_shape &sh = h->shapes[shape];
     const mi_vtxidx *vi = h->vtxidx + sh.vtxidx_base + MI_PRIMID_VI(pi);
     const mi_vtx *vtx = h->vtx + sh.vtx_base;
@@ -523,7 +486,21 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
     { free(s); return fail(MI_ERR_UNSUPPORTED, "shape uses a material outside the scope"); }
     if(vc == MI_PRIM_LINE) { pgeo[i].f[18] = (vi[0].uv >> 21)/2048.0f; pgeo[i].f[19] = ((vi[0].uv & 0x1ffc00u) >> 10)/2048.0f; }
     else for(uint32_t k=0;k<vc;k++) { pgeo[i].f[18+2*k] = half2float(vi[k].uv & 0xffffu); pgeo[i].f[19+2*k] = half2float(vi[k].uv >> 16); }
-    if(vc == MI_PRIM_SPHERE)
+    if(mb && vc < MI_PRIM_TRI)
+    { /* moving sphere / line: DPrim type 0 keeps the shutter-open positions and radii, DPrimT1 the shutter-close positions; the
+         packed record and the shading constants are formed per ray / per hit at the path's time (moving_analytic_at) */
+      if(prims_t1.empty()) { prims_t1.resize(h->num_prims); memset(prims_t1.data(), 0, prims_t1.size()*sizeof(DPrimT1)); }
+      DPrimT1 &t1 = prims_t1[i];
+      p.type = 0; p.pad[0] = vc;
+      q.type = vc | MI_GEO_MB;
+      for(uint32_t k=0;k<vc;k++)
+      {
+        memcpy(p.v[k], vtx[2*vi[k].v].v, 12);
+        memcpy(t1.v[k], vtx[2*vi[k].v + 1].v, 12);
+        memcpy(&p.v[2][k], &vtx[2*vi[k].v].n, 4);              /* radii: those of the shutter-open vertices */
+      }
+    }
+    else if(vc == MI_PRIM_SPHERE)
     {
       memcpy(p.v[0], vtx[vi[0].v].v, 12);
       memcpy(&p.v[1][0], &vtx[vi[0].v].n, 4);
@@ -532,20 +509,12 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
     }
     else if(vc == MI_PRIM_LINE)
     {
-      pack_line(p, vtx[vi[0].v], vtx[vi[1].v]);
-      /* shading-side frame of the line (line.h:123-161), with the functions the kernel would run per vertex */
-      float *g = pgeo[i].f;
       const V3 v0 = ld3(vtx[vi[0].v].v), v1 = ld3(vtx[vi[1].v].v);
-      V3 d = sub3(v1, v0);
-      const float ilen_d = 1.0f/sqrtf(dot3(d, d));
-      d = scale3(d, ilen_d);
-      V3 a, b; get_onb(d, a, b);
-      V3 ac, bc; get_onb(mk3(p.v[2][0], p.v[2][1], p.v[2][2]), ac, bc);    /* dwords 6..8: the intersection's unit axis */
-      g[0] = d.x; g[1] = d.y; g[2] = d.z; g[3] = ilen_d;
-      g[4] = a.x; g[5] = a.y; g[6] = a.z; g[7] = b.x; g[8] = b.y; g[9] = b.z;
-      g[10] = ac.x; g[11] = ac.y; g[12] = ac.z; g[13] = bc.x; g[14] = bc.y; g[15] = bc.z;
-      g[26] = v1.x; g[27] = v1.y; g[28] = v1.z; g[29] = v0.x; g[30] = v0.y; g[31] = v0.z;
-      g[32] = p.v[1][0]; g[33] = p.v[1][1];           /* r0, r1 (dwords 3, 4 of the line record) */
+      float r0, r1;
+      memcpy(&r0, &vtx[vi[0].v].n, 4); memcpy(&r1, &vtx[vi[1].v].n, 4);
+      pack_line(p, v0, v1, r0, r1);
+      /* shading-side frame of the line (line.h:123-161), with the functions the kernel would run per vertex */
+      line_shading_consts(pgeo[i].f, p, v0, v1);
     }
     else if(mb)
     { /* motion-blurred triangle / quad (vertices interleaved: 2 v = shutter open, 2 v + 1 = shutter close, include/geo.h:108-138):

@@ -60,6 +60,11 @@ __global__ __launch_bounds__(BL_BLOCK) void bl_boxes(BuildBufs b, const DPrim *p
       const float x0 = p.v[v][k], x1 = t1[i].v[v][k];
       lo[k] = fminf(lo[k], fminf(x0, x1)); hi[k] = fmaxf(hi[k], fmaxf(x0, x1));
     }
+    if(p.pad[0] < MI_PRIM_TRI)
+    { /* moving sphere / line: pad by the (larger) radius */
+      const float r = fmaxf(p.v[2][0], p.v[2][1])*1.0001f + 1e-6f;
+      for(int k=0;k<3;k++) { lo[k] -= r; hi[k] += r; }
+    }
   }
   else if(p.type >= MI_PRIM_TRI)
   {

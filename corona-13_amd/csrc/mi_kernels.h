@@ -381,6 +381,74 @@ __device__ __forceinline__ void triquad_intersect(const PrimRegs &r, uint32_t ty
   }
 }
 
+/* the 64-byte record of a line segment (truncated cone / cylinder) as line_intersect reads it, from its two end points and
+ * radii: formed once at upload for a static line, per ray for a moving one (include/geo/line.h:313-462) */
+MI_HD void pack_line(DPrim &p, const V3 v0, const V3 v1, float r0, float r1)
+{
+  float *f = &p.v[0][0];
+  float d[3] = {v1.x-v0.x, v1.y-v0.y, v1.z-v0.z};
+  const float dlen = sqrtf(d[0]*d[0] + d[1]*d[1] + d[2]*d[2]);
+  for(int k=0;k<16;k++) f[k] = 0.0f;
+  f[0] = v0.x; f[1] = v0.y; f[2] = v0.z; f[3] = r0; f[4] = r1; f[5] = dlen;
+  if(fabsf(r1-r0) < 1e-3)
+  { /* cylinder: d *= 1.0f/dlen; get_onb(d, a, b) */
+    const float inv = 1.0f/dlen;
+    for(int k=0;k<3;k++) d[k] *= inv;
+    float a[3], b[3];
+    if(fabsf(d[1]) < 0.5) { a[0] = d[1]*0.0f - 1.0f*d[2]; a[1] = d[2]*0.0f - 0.0f*d[0]; a[2] = d[0]*1.0f - 0.0f*d[1]; }   /* d x (0,1,0) */
+    else                  { a[0] = d[1]*0.0f - 0.0f*d[2]; a[1] = d[2]*1.0f - 0.0f*d[0]; a[2] = d[0]*0.0f - 1.0f*d[1]; }   /* d x (1,0,0) */
+    const float il = 1.0f/sqrtf(a[0]*a[0] + a[1]*a[1] + a[2]*a[2]);
+    for(int k=0;k<3;k++) a[k] *= il;
+    b[0] = d[1]*a[2] - a[1]*d[2]; b[1] = d[2]*a[0] - a[2]*d[0]; b[2] = d[0]*a[1] - a[0]*d[1];
+    f[6] = d[0]; f[7] = d[1]; f[8] = d[2];
+    f[9] = a[0]; f[10] = a[1]; f[11] = a[2];
+    f[13] = b[0]; f[14] = b[1]; f[15] = b[2];
+  }
+  else
+  { /* cone: d *= 1.0/d_len (double), cos_a2 */
+    for(int k=0;k<3;k++) d[k] = (float)(d[k]*(1.0/dlen));
+    f[6] = d[0]; f[7] = d[1]; f[8] = d[2];
+    const float tt = -r0*dlen/(r1-r0);            /* apex of the cone, line.h:395-397 */
+    f[9] = v0.x + tt*d[0]; f[10] = v0.y + tt*d[1]; f[11] = v0.z + tt*d[2];
+    f[13] = dlen*dlen/((r1-r0)*(r1-r0) + dlen*dlen);
+  }
+  p.type = MI_PRIM_LINE;
+}
+
+/* shading-side constants of a line (DPrimGeo.f[0..15], [26..33]; line.h:123-161) from its end points and the packed record */
+MI_HD void line_shading_consts(float *g, const DPrim &p, const V3 v0, const V3 v1)
+{
+  V3 d = sub3(v1, v0);
+  const float ilen_d = 1.0f/sqrtf(dot3(d, d));
+  d = scale3(d, ilen_d);
+  V3 a, b; get_onb(d, a, b);
+  V3 ac, bc; get_onb(mk3(p.v[2][0], p.v[2][1], p.v[2][2]), ac, bc);    /* dwords 6..8: the intersection's unit axis */
+  g[0] = d.x; g[1] = d.y; g[2] = d.z; g[3] = ilen_d;
+  g[4] = a.x; g[5] = a.y; g[6] = a.z; g[7] = b.x; g[8] = b.y; g[9] = b.z;
+  g[10] = ac.x; g[11] = ac.y; g[12] = ac.z; g[13] = bc.x; g[14] = bc.y; g[15] = bc.z;
+  g[26] = v1.x; g[27] = v1.y; g[28] = v1.z; g[29] = v0.x; g[30] = v0.y; g[31] = v0.z;
+  g[32] = p.v[1][0]; g[33] = p.v[1][1];           /* r0, r1 (dwords 3, 4 of the line record) */
+}
+
+/* a moving sphere / line (DPrim type 0, pad[0] = 1 / 2: shutter-open centre / end points in v[0], v[1], radii in v[2][0..1];
+ * shutter-close positions in t1.v[0], v[1]) as the static record it is at `time` (geo_get_vertex_time; radii stay those of
+ * the shutter-open vertices, sphere.h:7-11, line.h:10-16) */
+__device__ __forceinline__ DPrim moving_analytic_at(const DPrim &p, const DPrimT1 &t1, float time, V3 &v0, V3 &v1)
+{
+  const float w0 = 1.0f - time, w1 = time;
+  v0 = mk3(w0*p.v[0][0] + w1*t1.v[0][0], w0*p.v[0][1] + w1*t1.v[0][1], w0*p.v[0][2] + w1*t1.v[0][2]);
+  v1 = mk3(w0*p.v[1][0] + w1*t1.v[1][0], w0*p.v[1][1] + w1*t1.v[1][1], w0*p.v[1][2] + w1*t1.v[1][2]);
+  DPrim r;
+  if(p.pad[0] == MI_PRIM_SPHERE)
+  {
+    for(int k=0;k<16;k++) (&r.v[0][0])[k] = 0.0f;
+    r.v[0][0] = v0.x; r.v[0][1] = v0.y; r.v[0][2] = v0.z; r.v[1][0] = p.v[2][0];
+    r.type = MI_PRIM_SPHERE;
+  }
+  else pack_line(r, v0, v1, p.v[2][0], p.v[2][1]);
+  return r;
+}
+
 struct TraceState;
 template<bool MB>
 __device__ __forceinline__ void analytic_intersect(const DPrim *prims, uint32_t prim, const V3 o, const V3 d, uint32_t ignore, Hit &hit,
@@ -394,6 +462,11 @@ __device__ __forceinline__ void analytic_intersect(const DPrim *prims, uint32_t 
   p.v[1][1] = q1.x; p.v[1][2] = q1.y; p.v[2][0] = q1.z; p.v[2][1] = q1.w;
   p.v[2][2] = q2.x; p.v[3][0] = q2.y; p.v[3][1] = q2.z; p.v[3][2] = q2.w;
   p.type = __float_as_uint(q3.x); p.pad[0] = __float_as_uint(q3.y); p.pad[1] = __float_as_uint(q3.z); p.pad[2] = __float_as_uint(q3.w);
+  if(MB && p.type == 0 && p.pad[0] < MI_PRIM_TRI)
+  { /* moving sphere / cone / cylinder: the static record at the ray's time, then the usual tests below */
+    V3 a0, a1;
+    p = moving_analytic_at(p, prims_t1[prim], time, a0, a1);
+  }
   if(MB && p.type == 0)
   { /* motion-blurred triangle / quad: the record holds the shutter-open vertices, prims_t1 the shutter-close ones.
        geo_get_vertex_time (include/geo.h:120-138): (1-t) v(open) + t v(close) per component, then the usual test on the
@@ -739,6 +812,16 @@ __device__ __forceinline__ void surface_setup(const DScene &sc, uint32_t prim, c
   const DPrimGeo &geo = sc.primgeo[prim];
   const float *g = geo.f;                   /* per-primitive constants, see DPrimGeo */
   const uint32_t type = MB ? head.x & 7u : head.x;   /* head = the record's first 16 bytes: type (| MI_GEO_MB), material, uv0, primid_lo */
+  float gm[35];
+  if(MB && type < MI_PRIM_TRI && (head.x & MI_GEO_MB))
+  { /* moving sphere / line: its constants at the path's time (those of a static one are precomputed in DPrimGeo) */
+    V3 a0, a1;
+    const DPrim at = moving_analytic_at(sc.prims[prim], sc.prims_t1[prim], time, a0, a1);
+    for(int k=0;k<35;k++) gm[k] = geo.f[k];                 /* texture coordinates stay (f[18..25]) */
+    if(type == MI_PRIM_SPHERE) { gm[29] = a0.x; gm[30] = a0.y; gm[31] = a0.z; gm[32] = at.v[1][0]; }
+    else line_shading_consts(gm, at, a0, a1);
+    g = gm;
+  }
   if(type < MI_PRIM_TRI)
   { /* sphere (sphere.h:51-62,160-161) and line (line.h:123-161). The two share one atan2f site: a wave that holds hits
        of both kinds runs the long libm sequence once. */

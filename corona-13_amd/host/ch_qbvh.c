@@ -56,6 +56,37 @@ void ch_prim_bounds(const ch_geo *g, mi_primid pi, float *box)
   const mi_vtxidx *vi = g->vtxidx + sh->vtxidx_base + MI_PRIMID_VI(pi);
   const mi_vtx *vtx = g->vtx + sh->vtx_base;
   const uint32_t vcnt = MI_PRIMID_VCNT(pi);
+  if(vcnt < MI_PRIM_TRI && MI_PRIMID_MB(pi))
+  { /* moving sphere / line: the box of each state (radii are those of the shutter-open vertices, sphere.h:7-11, line.h:10-16),
+       then the box enclosing both */
+    ch_geo one = *g;
+    mi_vtxidx idx[2];
+    mi_vtx v[2];
+    mi_shape sh1 = *sh;
+    sh1.vtxidx_base = 0; sh1.vtx_base = 0;
+    mi_shape shapes[256];                                   /* the loader admits at most 255 shapes */
+    if(MI_PRIMID_SHAPE(pi) > 255) { for(int d=0;d<6;d++) box[d] = 0.0f; return; }
+    shapes[MI_PRIMID_SHAPE(pi)] = sh1;
+    one.shapes = shapes; one.vtxidx = idx; one.vtx = v;
+    const mi_primid still = (pi & ~(1ull << 60)) & ~(0x0fffffffull << 32);     /* same primitive, not moving, vertex index 0 */
+    for(uint32_t t=0;t<2;t++)
+    {
+      for(uint32_t k=0;k<vcnt;k++)
+      {
+        idx[k].v = k; idx[k].uv = vi[k].uv;
+        v[k] = vtx[2*vi[k].v + t];
+        v[k].n = vtx[2*vi[k].v].n;
+      }
+      float b[6];
+      ch_prim_bounds(&one, still, b);
+      for(int d=0;d<3;d++)
+      {
+        box[d] = t ? fminf(box[d], b[d]) : b[d];
+        box[3+d] = t ? fmaxf(box[3+d], b[3+d]) : b[3+d];
+      }
+    }
+    return;
+  }
   if(vcnt == MI_PRIM_SPHERE)
   { /* include/geo/sphere.h:16-22 */
     const mi_vtx *c = vtx + vi[0].v;

@@ -299,7 +299,6 @@ static int load_geo(ch_scene *s, uint32_t shapeid, const char *name)
     p = (p & ~(0x1fffffffull << 3)) | ((uint64_t)shapeid << 3);
     const uint32_t vc = MI_PRIMID_VCNT(p), mb = MI_PRIMID_MB(p);
     if(vc < 1 || vc > 4) { fprintf(stderr, "[ch] geo `%s': primitive kind %u unsupported\n", name, vc); free(d); return 1; }
-    if(mb && vc < 3) { fprintf(stderr, "[ch] geo `%s': motion-blurred spheres and lines are outside the scope of this backend\n", name); free(d); return 1; }
     if(MI_PRIMID_VI(p) + vc > nvi) { fprintf(stderr, "[ch] geo `%s': vertex index out of range\n", name); free(d); return 1; }
     /* a motion-blurred primitive addresses vertex pairs: 2 v = shutter open, 2 v + 1 = shutter close (include/geo.h:108-138) */
     for(uint32_t j=0;j<vc;j++) if((uint64_t)(mb+1)*g->vtxidx[sh->vtxidx_base + MI_PRIMID_VI(p) + j].v + mb >= nv)
@@ -317,15 +316,16 @@ float ch_prim_area(const ch_geo *g, mi_primid pi)
   const mi_vtxidx *vi = g->vtxidx + sh->vtxidx_base + MI_PRIMID_VI(pi);
   const mi_vtx *vtx = g->vtx + sh->vtx_base;
   const uint32_t vcnt = MI_PRIMID_VCNT(pi);
+  const uint32_t so = MI_PRIMID_MB(pi) + 1;           /* shutter-open state of a moving primitive */
   if(vcnt == MI_PRIM_SPHERE)
   {
-    float r; memcpy(&r, &vtx[vi[0].v].n, 4);
+    float r; memcpy(&r, &vtx[so*vi[0].v].n, 4);
     return 4.0f*(float)M_PI*r*r;
   }
   if(vcnt == MI_PRIM_LINE)
   {
-    const float *v0 = vtx[vi[0].v].v, *v1 = vtx[vi[1].v].v;
-    float r0, r1; memcpy(&r0, &vtx[vi[0].v].n, 4); memcpy(&r1, &vtx[vi[1].v].n, 4);
+    const float *v0 = vtx[so*vi[0].v].v, *v1 = vtx[so*vi[1].v].v;
+    float r0, r1; memcpy(&r0, &vtx[so*vi[0].v].n, 4); memcpy(&r1, &vtx[so*vi[1].v].n, 4);
     const float d[3] = {v1[0]-v0[0], v1[1]-v0[1], v1[2]-v0[2]};
     const float h = sqrtf(d[0]*d[0]+d[1]*d[1]+d[2]*d[2]);
     const float l = sqrtf(r0*r0 + h*h);
@@ -468,6 +468,8 @@ static int init_lights(ch_scene *s)
       const float L = m->op[k].mul*(ch_coeff_eval(c, 400.0f) + ch_coeff_eval(c, 480.0f) + ch_coeff_eval(c, 560.0f) + ch_coeff_eval(c, 660.0f))/4.0f;
       for(uint32_t i=0;i<sh->num_prims;i++)
       { /* list.c:56-74 */
+        if(MI_PRIMID_MB(s->primid[prim_base + i]) && MI_PRIMID_VCNT(s->primid[prim_base + i]) < 3)
+        { fprintf(stderr, "[ch] shape %u: moving spheres / lines as emitters are outside the scope of this backend\n", sid); return MI_ERR_UNSUPPORTED; }
         s->light_primid[off+i] = s->primid[prim_base + i];
         s->light_cdf[off+i] = ch_prim_area(&s->geo, s->primid[prim_base + i])*L;
         s->light_L[off+i] = L;

@@ -19,6 +19,13 @@ static inline void o_vertex_time(const mi_scene_desc *s, mi_primid pi, int k, fl
   else for(int i=0;i<3;i++) out[i] = v0->v[i];
 }
 
+static inline mi_vtx o_vtx_at(const mi_scene_desc *s, mi_primid pi, int k, float time)
+{ /* position at `time` (geo_get_vertex_time), radius / normal word of the shutter-open vertex (sphere.h:7-11, line.h:10-16) */
+  mi_vtx r = *o_vtx(s, pi, k);
+  o_vertex_time(s, pi, k, time, r.v);
+  return r;
+}
+
 static inline void o_normal_time(const mi_scene_desc *s, mi_primid pi, int k, float time, float *n)
 { /* geo_get_normal_time, include/geo.h:152-162 */
   const mi_vtx *v0 = o_vtx(s, pi, k);
@@ -121,7 +128,7 @@ static float o_sphere_t(const float *center, float radius, const o_ray *ray)
 
 static int o_sphere_intersect(const mi_scene_desc *s, mi_primid pi, const o_ray *ray, o_hit *hit)
 { /* geo_sphere_intersect, include/geo/sphere.h:146-166 (no `ignore` test: relies on the ray offset) */
-  const mi_vtx *c = o_vtx(s, pi, 0);
+  const mi_vtx c_ = o_vtx_at(s, pi, 0, ray->time), *c = &c_;
   const float radius = o_bits2float(c->n);
   const float t = o_sphere_t(c->v, radius, ray);
   if(t > ray->min_dist && t < hit->dist)
@@ -230,7 +237,7 @@ static float o_cone_t(const float *v0, const float *v1, float r0, float r1, cons
 
 static int o_line_intersect(const mi_scene_desc *s, mi_primid pi, const o_ray *ray, o_hit *hit)
 { /* geo_line_intersect, include/geo/line.h:464-505 */
-  const mi_vtx *v0 = o_vtx(s, pi, 0), *v1 = o_vtx(s, pi, 1);
+  const mi_vtx v0_ = o_vtx_at(s, pi, 0, ray->time), v1_ = o_vtx_at(s, pi, 1, ray->time), *v0 = &v0_, *v1 = &v1_;
   const float r0 = o_bits2float(v0->n), r1 = o_bits2float(v1->n);
   const int linestrip = OMAX(r0, r1) <= 1e-2f;
   if(linestrip && ray->ignore == pi) return 0;
@@ -408,14 +415,14 @@ void o_prims_get_normal(const mi_scene_desc *s, mi_primid pi, o_hit *hit, float 
   const uint32_t vcnt = MI_PRIMID_VCNT(pi);
   if(vcnt == MI_PRIM_SPHERE)
   { /* geo_sphere_get_normal_time, include/geo/sphere.h:51-62 */
-    const mi_vtx *c = o_vtx(s, pi, 0);
+    const mi_vtx c_ = o_vtx_at(s, pi, 0, time), *c = &c_;
     for(int k=0;k<3;k++) hit->gn[k] = hit->x[k] - c->v[k];
     o_normalise(hit->gn);
     memcpy(hit->n, hit->gn, sizeof(float)*3);
   }
   else if(vcnt == MI_PRIM_LINE)
   { /* geo_line_get_normal_time, include/geo/line.h:123-161 */
-    const mi_vtx *v0 = o_vtx(s, pi, 0), *v1 = o_vtx(s, pi, 1);
+    const mi_vtx v0_ = o_vtx_at(s, pi, 0, time), v1_ = o_vtx_at(s, pi, 1, time), *v0 = &v0_, *v1 = &v1_;
     const float r0 = o_bits2float(v0->n), r1 = o_bits2float(v1->n);
     if(fabsf(r0-r1) < 1e-3f && r0 < 0.01f)
     {
@@ -536,7 +543,7 @@ static void o_prims_retime(const mi_scene_desc *s, mi_primid pi, o_hit *hit, flo
   const uint32_t vcnt = MI_PRIMID_VCNT(pi);
   if(vcnt == MI_PRIM_SPHERE)
   { /* geo_sphere_retime, include/geo/sphere.h:38-49 + sample_sphere (include/sampler_common.h) */
-    const mi_vtx *c = o_vtx(s, pi, 0);
+    const mi_vtx c_ = o_vtx_at(s, pi, 0, time), *c = &c_;
     const float r = o_bits2float(c->n);
     const float x1 = -(cosf(hit->v*M_PI)-1.f)/2.f, x2 = hit->u;
     const float z = 1.f - 2.f*x1, rr = sqrtf(1.f - z*z);
@@ -546,7 +553,7 @@ static void o_prims_retime(const mi_scene_desc *s, mi_primid pi, o_hit *hit, flo
   }
   else if(vcnt == MI_PRIM_LINE)
   { /* geo_line_retime, include/geo/line.h:88-121 */
-    const mi_vtx *v0 = o_vtx(s, pi, 0), *v1 = o_vtx(s, pi, 1);
+    const mi_vtx v0_ = o_vtx_at(s, pi, 0, time), v1_ = o_vtx_at(s, pi, 1, time), *v0 = &v0_, *v1 = &v1_;
     const float r0 = o_bits2float(v0->n), r1 = o_bits2float(v1->n);
     float y;
     if(fabsf(r1-r0) < 1e-3f) y = hit->u;

@@ -163,6 +163,8 @@ def main():
         dump_paths("cam_mb_ptdl_mv8", "dump_ptdl_xs_mv8", 8, "0058_cam_mb", 1280, 720, 4000)
         dump_paths("mb_pt_mv8", "dump_pt_xs_mv8", 8, "0059_mb", 1280, 720, 6000)                # motion-blurred backdrop and cylinder cap (tools/make_geo.py mb)
         dump_paths("mb_ptdl_mv8", "dump_ptdl_xs_mv8", 8, "0059_mb", 1280, 720, 6000)
+        dump_paths("mb_round_pt_mv8", "dump_pt_xs_mv8", 8, "0062_mb_round", 1280, 720, 6000)        # moving sphere / cone / cylinder
+        dump_paths("mb_round_ptdl_mv8", "dump_ptdl_xs_mv8", 8, "0062_mb_round", 1280, 720, 6000)
         dump_paths("mb_light_pt_mv8", "dump_pt_xs_mv8", 8, "0060_mb_light", 1280, 720, 6000)        # moving emitter
         dump_paths("mb_light_ptdl_mv8", "dump_ptdl_xs_mv8", 8, "0060_mb_light", 1280, 720, 6000)
         dump_paths("halton_all_ptdl_mv8", "dump_ptdl_halton_mv8", 8, "0061_all", 1280, 720, 6000)    # every feature in one scene

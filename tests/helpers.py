@@ -25,6 +25,7 @@ SCENE_CAM_MB = REPO / "scenes" / "0058_cam_mb" / "test.nra2"   # 0010 seen by a 
 SCENE_MB = REPO / "scenes" / "0059_mb" / "test.nra2"           # 0010 with the backdrop rising 0.15 dm and the cylinder cap sliding 0.8 dm during a 1/30 s exposure
 SCENE_MB_LIGHT = REPO / "scenes" / "0060_mb_light" / "test.nra2"   # 0059 with the emitter moving and turning as well
 SCENE_ALL = REPO / "scenes" / "0061_all" / "test.nra2"         # fog, media in sphere and cone, moving camera, moving backdrop / cap / emitter
+SCENE_MB_ROUND = REPO / "scenes" / "0062_mb_round" / "test.nra2"   # 0059 with sphere, cone and cylinder moving as well
 SCENE_METAL = REPO / "scenes" / "0053_metal" / "test.nra2"     # 0052 with `metal Au`, roughness 0.3 on cone/sphere/cylinder
 
 
