@@ -478,6 +478,10 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
     const mi_shape &sh = h->shapes[shape];
     const mi_vtxidx *vi = h->vtxidx + sh.vtxidx_base + MI_PRIMID_VI(pi);
     const mi_vtx *vtx = h->vtx + sh.vtx_base;
+    /* the descriptor is the caller's: every index this primitive uses must lie inside the arrays handed over */
+    bool in_range = (uint64_t)sh.vtxidx_base + MI_PRIMID_VI(pi) + vc <= h->num_vtxidx;
+    for(uint32_t k=0;in_range && k<vc;k++) in_range = (uint64_t)sh.vtx_base + (uint64_t)(mb + 1)*vi[k].v + mb < h->num_vtx;
+    if(!in_range) { free(s); return fail(MI_ERR_ARG, "primitive refers to vertices outside the arrays of the descriptor"); }
     DPrim &p = prims[i]; DPrimGeo &q = pgeo[i];
     p.type = vc;
     q.type = vc; q.material = (uint32_t)sh.material; q.uv0 = vi[0].uv;

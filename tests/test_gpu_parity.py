@@ -263,6 +263,13 @@ def test_errors_are_reported():
     d.contents.struct_size = 3
     assert m.mi_scene_create(d, C.byref(out)) < 0
     d.contents.struct_size = C.sizeof(pkg.MiSceneDesc)
+    nv = d.contents.num_vtx
+    d.contents.num_vtx = 10                                  # a descriptor whose primitives point past its vertex array
+    assert m.mi_scene_create(d, C.byref(out)) < 0 and b"outside the arrays" in m.mi_last_error()
+    d.contents.num_vtx = nv
+    d.contents.pointsampler = 7
+    assert m.mi_scene_create(d, C.byref(out)) < 0
+    d.contents.pointsampler = 0
     assert m.mi_render(None, 0, 1) < 0
 
 
