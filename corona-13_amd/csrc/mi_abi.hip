@@ -456,6 +456,7 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
       if(nd.child[c] & MI_NODE_LEAF)
       {
         const uint64_t first = (nd.child[c] ^ MI_NODE_LEAF) >> 5, cntp = nd.child[c] & 31;
+        if(first + cntp > h->num_prims) { free(s); return fail(MI_ERR_ARG, "a leaf of the tree points outside the primitive list"); }
         link = MI_LEAF32 | (uint32_t)(first << 5) | (uint32_t)cntp;
       }
       else link = (uint32_t)nd.child[c];
