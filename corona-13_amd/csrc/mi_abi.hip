@@ -186,6 +186,9 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_intersect_kernel(DScene sc, const
 static thread_local char g_err[512] = "";
 static int g_device = -1;
 
+/* first line of every entry point that takes a scene: the device is a property of the scene, not of the calling thread */
+#define MI_ENTER(s, what) do { if(!(s)) return fail(MI_ERR_ARG, what); \
+  if(hipSetDevice((s)->device) != hipSuccess) return fail(MI_ERR_DEVICE, "cannot select the scene's device"); } while(0)
 #define HIPCHK(x) do { hipError_t e_ = (x); if(e_ != hipSuccess) { \
   snprintf(g_err, sizeof(g_err), "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
   fprintf(stderr, "[mi] %s\n", g_err); return MI_ERR_DEVICE; } } while(0)
@@ -201,6 +204,7 @@ struct mi_scene
 {
   DScene d;
   uint32_t width, height;
+  int device;                       /* the GPU this scene lives on: every entry point selects it (hipSetDevice is per host thread) */
   void *d_nodes, *d_axes, *d_prims, *d_primgeo, *d_materials, *d_light_prim, *d_light_cdf, *d_light_L;
   void *d_cie, *d_checker, *d_metal, *d_counters, *d_work, *d_shape_material, *d_shape_L, *d_overflow;
   float *d_fb_own, *d_fb;
@@ -240,7 +244,7 @@ extern "C" int mi_init(int device)
     const char *lr = getenv("LOCAL_RANK");
     device = lr ? atoi(lr) : 0;
   }
-  if(device >= n) device = device % n;
+  if(device >= n) return fail(MI_ERR_ARG, "mi_init: no such device (one process per GPU: pass LOCAL_RANK, not a global rank)");
   HIPCHK(hipSetDevice(device));
   g_device = device;
   return MI_OK;
@@ -259,17 +263,28 @@ template<typename T> static int upload(void **dst, const T *src, size_t count)
 /* per-primitive constants of a line (truncated cone) primitive, computed once with the same float operations the
  * reference performs inside every intersection test (include/geo/line.h:313-335,401-416, include/corona_common.h:178-198);
  * layout documented at line_intersect (mi_kernels.h) */
-static int tree_depth(const mi_scene_desc *h, uint32_t node, int depth)
-{
-  int best = depth;
-  for(int c=0;c<4;c++)
+static int tree_depth(const mi_scene_desc *h)
+{ /* depth of the handed-over tree, or -1 if it is not one: a child link out of range, a node reached twice (cycle or shared
+     subtree) or deeper than 200 levels. Every node is visited at most once, so this is O(num_nodes) whatever the links say. */
+  std::vector<bool> seen(h->num_nodes, false);
+  std::vector<std::pair<uint32_t, int>> todo;
+  todo.push_back({0u, 0});
+  seen[0] = true;
+  int best = 0;
+  while(!todo.empty())
   {
-    const uint64_t ch = h->nodes[node].child[c];
-    if(!(ch & MI_NODE_LEAF))
+    const uint32_t node = todo.back().first;
+    const int depth = todo.back().second;
+    todo.pop_back();
+    if(depth > best) best = depth;
+    if(depth > 200) return -1;
+    for(int c=0;c<4;c++)
     {
-      if(ch >= h->num_nodes || depth > 200) return 1000;
-      const int d = tree_depth(h, (uint32_t)ch, depth+1);
-      if(d > best) best = d;
+      const uint64_t ch = h->nodes[node].child[c];
+      if(ch & MI_NODE_LEAF) continue;
+      if(ch >= h->num_nodes || seen[ch]) return -1;
+      seen[ch] = true;
+      todo.push_back({(uint32_t)ch, depth + 1});
     }
   }
   return best;
@@ -417,13 +432,19 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   if(h->num_shapes > 255) return fail(MI_ERR_UNSUPPORTED, "more than 255 shapes");
   if(h->num_prims >= (1u << 26)) return fail(MI_ERR_UNSUPPORTED, "more than 2^26 primitives");
 
-  const int depth = device_build ? 0 : tree_depth(h, 0, 0);
-  if(depth > 200) return fail(MI_ERR_ARG, "BVH deeper than 200 levels or cyclic");
+  const int depth = device_build ? 0 : tree_depth(h);
+  if(depth < 0) return fail(MI_ERR_ARG, "the BVH is not a tree of at most 200 levels (child link out of range, node reached twice, or too deep)");
+  /* every shape's material is used below (per-primitive records, per-shape tables), also for shapes without primitives */
+  for(uint32_t i=0;i<h->num_shapes;i++)
+    if(h->shapes[i].material < 0 || (uint32_t)h->shapes[i].material >= h->num_materials)
+      return fail(MI_ERR_ARG, "a shape refers to a material outside the descriptor's material list");
   int stack_need = 3*(depth+1);                             /* at most 3 pushes per inner node on the way down */
 
   mi_scene *s = (mi_scene *)calloc(1, sizeof(mi_scene));
   if(!s) return fail(MI_ERR_NOMEM, "out of host memory");
   s->width = h->width; s->height = h->height;
+  s->device = g_device;
+  if(hipSetDevice(s->device) != hipSuccess) { free(s); return fail(MI_ERR_DEVICE, "cannot select the device"); }   /* mi_init may have run on another thread */
   DScene &d = s->d;
   d.width = h->width; d.height = h->height; d.max_verts = h->max_verts; d.sampler = h->sampler; d.frame = h->frame;
   d.num_nodes = h->num_nodes; d.num_prims = (uint32_t)h->num_prims;
@@ -716,6 +737,11 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   s->lds_bytes = (s->nodes_lds ? node_bytes : 0) + stack_bytes;
   s->device_built = device_build; s->stack_need = stack_need;
   {
+#ifdef MI_DEV_FAST   /* development builds (tools/variants.sh): only the plain tree-in-LDS kernels, 20 s instead of 2 min to compile */
+    const void *kernels[] = { (const void *)mi_intersect_kernel<true>, (const void *)mi_intersect_kernel<false>,
+      (const void *)mi_path_kernel<false, false, true>, (const void *)mi_path_kernel<true, false, true>,
+      (const void *)mi_path_kernel<false, true, true>, (const void *)mi_path_kernel<true, true, true> };
+#else
     const void *kernels[] = {
       (const void *)mi_intersect_kernel<true>, (const void *)mi_intersect_kernel<false>,
       (const void *)mi_path_kernel<false, false, true>, (const void *)mi_path_kernel<true, false, true>,
@@ -742,6 +768,7 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
       (const void *)mi_path_kernel<false, true, true, true, true, true>, (const void *)mi_path_kernel<true, true, true, true, true, true>,
       (const void *)mi_path_kernel<false, false, false, true, true, true>, (const void *)mi_path_kernel<true, false, false, true, true, true>,
       (const void *)mi_path_kernel<false, true, false, true, true, true>, (const void *)mi_path_kernel<true, true, false, true, true, true> };
+#endif
     for(const void *k : kernels)
       if(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess)
       { mi_scene_destroy(s); return fail(MI_ERR_DEVICE, "cannot raise the dynamic LDS limit"); }
@@ -761,7 +788,7 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
     d.halton_perm = (const unsigned short *)s->d_halton_perm;
   }
   hipDeviceProp_t prop;
-  if(hipGetDeviceProperties(&prop, g_device) != hipSuccess) { mi_scene_destroy(s); return fail(MI_ERR_DEVICE, "hipGetDeviceProperties failed"); }
+  if(hipGetDeviceProperties(&prop, s->device) != hipSuccess) { mi_scene_destroy(s); return fail(MI_ERR_DEVICE, "hipGetDeviceProperties failed"); }
   int per_cu = (int)((160*1024)/s->lds_bytes);
   if(per_cu < 1) per_cu = 1;
   if(per_cu*MI_BLOCK > 2048) per_cu = 2048/MI_BLOCK;
@@ -804,13 +831,15 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
       { mi_scene_destroy(s); return fail(MI_ERR_DEVICE, "cannot raise the dynamic LDS limit"); }
     }
   }
+  /* uploads and clears above ran on the null stream, rendering runs on a non-blocking one: everything is in place before the first launch */
+  if(hipDeviceSynchronize() != hipSuccess) { mi_scene_destroy(s); return fail(MI_ERR_DEVICE, "device synchronisation failed after the scene upload"); }
   *out = s;
   return MI_OK;
 }
 
 extern "C" int mi_scene_set_framebuffer(mi_scene *s, float *device_fb)
 {
-  if(!s) return fail(MI_ERR_ARG, "null scene");
+  MI_ENTER(s, "null scene");
   s->d_fb = device_fb ? device_fb : s->d_fb_own;
   s->d.fb = s->d_fb;
   return MI_OK;
@@ -818,7 +847,7 @@ extern "C" int mi_scene_set_framebuffer(mi_scene *s, float *device_fb)
 
 extern "C" int mi_scene_set_stream(mi_scene *s, void *hip_stream)
 {
-  if(!s) return fail(MI_ERR_ARG, "null scene");
+  MI_ENTER(s, "null scene");
   s->stream = hip_stream == MI_STREAM_DEFAULT ? (hipStream_t)0 : hip_stream ? (hipStream_t)hip_stream : s->stream_own;
   return MI_OK;
 }
@@ -886,6 +915,14 @@ static void launch_path_kernel(mi_scene *s, bool record, int grid, uint64_t firs
 #define MI_LAUNCH5(R, P, L, H, M) MI_LAUNCH6(R, P, L, H, M, false)
 #define MI_LAUNCH6(R, P, L, H, M, B) hipLaunchKernelGGL((mi_path_kernel<R, P, L, H, M, B>), dim3(grid), dim3(MI_BLOCK), s->lds_bytes, s->stream, s->d, \
     (unsigned long long)first, (unsigned long long)n, (const uint32_t *)s->d_shape_material, (const float *)s->d_shape_L, rec, (uint2 *)s->d_overflow)
+#ifdef MI_DEV_FAST
+  switch(which)
+  {
+    case  4: MI_LAUNCH(false, false, true,  false); break;  case  5: MI_LAUNCH(true, false, true,  false); break;
+    case  6: MI_LAUNCH(false, true,  true,  false); break;  case  7: MI_LAUNCH(true, true,  true,  false); break;
+    default: fprintf(stderr, "[mi] MI_DEV_FAST build: only the plain tree-in-LDS kernels exist\n"); abort();
+  }
+#else
   switch(which)
   {
     /* MEDIA + MB (scenes with motion-blurred primitives) */
@@ -915,6 +952,7 @@ static void launch_path_kernel(mi_scene *s, bool record, int grid, uint64_t firs
     case 12: MI_LAUNCH(false, false, true,  true);  break;  case 13: MI_LAUNCH(true, false, true,  true);  break;
     case 14: MI_LAUNCH(false, true,  true,  true);  break;  default: MI_LAUNCH(true, true,  true,  true);  break;
   }
+#endif
 #undef MI_LAUNCH
 #undef MI_LAUNCH5
 #undef MI_LAUNCH6
@@ -922,7 +960,7 @@ static void launch_path_kernel(mi_scene *s, bool record, int grid, uint64_t firs
 
 extern "C" int mi_render(mi_scene *s, uint64_t first_index, uint64_t count)
 {
-  if(!s) return fail(MI_ERR_ARG, "null scene");
+  MI_ENTER(s, "null scene");
   if(!count) return MI_OK;
   if(s->wavefront) return render_wavefront(s, first_index, count);
   { const int e = ensure_halton(s, first_index + count); if(e) return e; }
@@ -948,7 +986,7 @@ extern "C" int mi_render(mi_scene *s, uint64_t first_index, uint64_t count)
 
 extern "C" int mi_sync(mi_scene *s)
 {
-  if(!s) return fail(MI_ERR_ARG, "null scene");
+  MI_ENTER(s, "null scene");
   HIPCHK(hipStreamSynchronize(s->stream));
   return MI_OK;
 }
@@ -956,6 +994,7 @@ extern "C" int mi_sync(mi_scene *s)
 extern "C" int mi_fb_read(mi_scene *s, float *host_fb, int accumulate)
 {
   if(!s || !host_fb) return fail(MI_ERR_ARG, "null argument");
+  MI_ENTER(s, "null scene");
   const size_t n = 3*(size_t)s->width*s->height;
   HIPCHK(hipStreamSynchronize(s->stream));
   if(!accumulate) { HIPCHK(hipMemcpy(host_fb, s->d_fb, n*sizeof(float), hipMemcpyDeviceToHost)); return MI_OK; }
@@ -967,7 +1006,7 @@ extern "C" int mi_fb_read(mi_scene *s, float *host_fb, int accumulate)
 
 extern "C" int mi_fb_clear(mi_scene *s)
 {
-  if(!s) return fail(MI_ERR_ARG, "null scene");
+  MI_ENTER(s, "null scene");
   HIPCHK(hipMemsetAsync(s->d_fb, 0, sizeof(float)*3*(size_t)s->width*s->height, s->stream));
   return MI_OK;
 }
@@ -977,6 +1016,7 @@ extern "C" float *mi_fb_device_ptr(mi_scene *s) { return s ? s->d_fb : nullptr; 
 extern "C" int mi_counters(mi_scene *s, uint64_t out[8])
 {
   if(!s || !out) return fail(MI_ERR_ARG, "null argument");
+  MI_ENTER(s, "null scene");
   HIPCHK(hipStreamSynchronize(s->stream));
   std::vector<unsigned long long> tmp((size_t)8*MI_COUNTER_SHARDS);
   HIPCHK(hipMemcpy(tmp.data(), s->d_counters, tmp.size()*sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -996,6 +1036,7 @@ extern "C" int mi_counters(mi_scene *s, uint64_t out[8])
 extern "C" int mi_trace_paths(mi_scene *s, uint64_t first_index, uint64_t count, mi_path_record *host_out)
 {
   if(!s || !host_out) return fail(MI_ERR_ARG, "null argument");
+  MI_ENTER(s, "null scene");
   if(!count) return MI_OK;
   { const int e = ensure_halton(s, first_index + count); if(e) return e; }
   void *d_rec = nullptr;
@@ -1019,6 +1060,7 @@ extern "C" int mi_trace_paths(mi_scene *s, uint64_t first_index, uint64_t count,
 extern "C" int mi_intersect(mi_scene *s, const mi_ray *rays, uint64_t n, mi_hit *host_out)
 {
   if(!s || !rays || !host_out) return fail(MI_ERR_ARG, "null argument");
+  MI_ENTER(s, "null scene");
   if(s->d_prims_t1) return fail(MI_ERR_UNSUPPORTED, "mi_intersect: rays carry no time, the scene has motion-blurred primitives");
   if(!n) return MI_OK;
   void *d_rays = nullptr, *d_hits = nullptr;
@@ -1047,6 +1089,7 @@ extern "C" int mi_intersect(mi_scene *s, const mi_ray *rays, uint64_t n, mi_hit 
 extern "C" int mi_last_kernel_ms(mi_scene *s, float *ms)
 {
   if(!s || !ms) return fail(MI_ERR_ARG, "null argument");
+  MI_ENTER(s, "null scene");
   if(!s->have_timing) { *ms = 0.0f; return MI_OK; }
   HIPCHK(hipEventSynchronize(s->ev1));
   HIPCHK(hipEventElapsedTime(ms, s->ev0, s->ev1));
@@ -1070,6 +1113,7 @@ extern "C" int mi_scene_stats(mi_scene *s, uint32_t out[4])
 extern "C" void mi_scene_destroy(mi_scene *s)
 {
   if(!s) return;
+  (void)hipSetDevice(s->device);
   if(s->d_pool) (void)hipFree(s->d_pool);
   if(s->d_wfcnt) (void)hipFree(s->d_wfcnt);
   if(s->h_live) (void)hipHostFree(s->h_live);

@@ -22,5 +22,7 @@ float ch_prim_area(const ch_geo *g, mi_primid pi);
 
 /* sigmoid-polynomial spectrum at wavelength lambda [nm] (include/rgb2spec.h:139-149, exact rsqrt) */
 float ch_coeff_eval(const float coeff[3], float lambda);
+/* spectrum_rgb_to_coeff through a reference-format table (ch_rgb2spec_lut.c): coefficients and scale of a non-black rgb; 0 = ok */
+int ch_lut_rgb_to_coeff(const char *lut_path, const float rgb[3], float coeff[3], float *mul_out);
 
 #endif

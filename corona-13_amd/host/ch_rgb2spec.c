@@ -25,52 +25,6 @@ float ch_coeff_eval(const float coeff[3], float lambda)
   return .5f*x*y + .5f;
 }
 
-typedef struct lut_t { uint32_t res; float *scale; float *data; } lut_t;
-
-static int lut_load(const char *fn, lut_t *l)
-{
-  FILE *f = fopen(fn, "rb");
-  if(!f) return 1;
-  char magic[4];
-  if(fread(magic, 4, 1, f) != 1 || memcmp(magic, "SPEC", 4) || fread(&l->res, 4, 1, f) != 1 || l->res < 2 || l->res > 1024)
-  { fclose(f); return 1; }
-  const size_t ns = l->res, nd = (size_t)l->res*l->res*l->res*9;
-  l->scale = (float *)malloc(ns*sizeof(float));
-  l->data  = (float *)malloc(nd*sizeof(float));
-  if(!l->scale || !l->data || fread(l->scale, sizeof(float), ns, f) != ns || fread(l->data, sizeof(float), nd, f) != nd)
-  { fclose(f); free(l->scale); free(l->data); return 1; }
-  fclose(f);
-  return 0;
-}
-
-static void lut_fetch(const lut_t *l, const float rgb[3], float out[3])
-{
-  const int res = (int)l->res;
-  int i = 0;
-  for(int j=1;j<3;j++) if(rgb[j] >= rgb[i]) i = j;          /* largest component, ties to the last */
-  const float z = rgb[i], sc = (res-1)/z;
-  const float x = rgb[(i+1)%3]*sc, y = rgb[(i+2)%3]*sc;
-  uint32_t xi = (uint32_t)x, yi = (uint32_t)y;
-  if(xi > (uint32_t)res-2) xi = res-2;
-  if(yi > (uint32_t)res-2) yi = res-2;
-  /* largest zi with scale[zi] < z (binary search over res-1 intervals) */
-  int left = 0, last = res-2, size = last;
-  while(size > 0)
-  {
-    const int half = size >> 1, mid = left + half + 1;
-    if(l->scale[mid] < z) { left = mid; size -= half+1; } else size = half;
-  }
-  const uint32_t zi = left < last ? left : last;
-  size_t off = ((((size_t)i*res + zi)*res + yi)*res + xi)*3;
-  const size_t dx = 3, dy = 3*(size_t)res, dz = 3*(size_t)res*res;
-  const float x1 = x - xi, x0 = 1.f - x1, y1 = y - yi, y0 = 1.f - y1;
-  const float z1 = (z - l->scale[zi])/(l->scale[zi+1] - l->scale[zi]), z0 = 1.f - z1;
-  const float *d = l->data;
-  for(int j=0;j<3;j++, off++)
-    out[j] = ((d[off]*x0 + d[off+dx]*x1)*y0 + (d[off+dy]*x0 + d[off+dy+dx]*x1)*y1)*z0
-           + ((d[off+dz]*x0 + d[off+dz+dx]*x1)*y0 + (d[off+dz+dy]*x0 + d[off+dz+dy+dx]*x1)*y1)*z1;
-}
-
 /* --- direct fit ----------------------------------------------------------------------- */
 /* eRGB ("linear rec709 adapted to illuminant E") -> XYZ, rows sum to the E white point (1,1,1). */
 static const double ergb_to_xyz[3][3] = {
@@ -179,21 +133,15 @@ float ch_rgb_to_coeff(const float rgb[3], float coeff[3], const char *lut_path)
     coeff[0] = coeff[1] = coeff[2] = 0.0f;
     return 0.0f;
   }
+  if(lut_path)
+  {
+    float lmul;
+    if(!ch_lut_rgb_to_coeff(lut_path, rgb, coeff, &lmul)) return lmul;
+    fprintf(stderr, "[ch] could not load rgb2spec lut `%s', fitting coefficients directly\n", lut_path);
+  }
   if(mul < 1.0f) mul = 1.0f;
   float col[3];
   for(int k=0;k<3;k++) col[k] = rgb[k]/mul;
-
-  if(lut_path)
-  {
-    lut_t l;
-    if(!lut_load(lut_path, &l))
-    {
-      lut_fetch(&l, col, coeff);
-      free(l.scale); free(l.data);
-      return mul;
-    }
-    fprintf(stderr, "[ch] could not load rgb2spec lut `%s', fitting coefficients directly\n", lut_path);
-  }
   if(col[0] == col[1] && col[1] == col[2])
   { /* constant spectrum s: invert the sigmoid. s = 1 saturates; cap like the published optimiser (|c| <= 200) */
     const float s = col[0];

@@ -272,7 +272,8 @@ static int load_geo(ch_scene *s, uint32_t shapeid, const char *name)
   struct { int32_t magic, version; uint64_t num_prims, vtxidx_offset, vertex_offset; } h;
   if(size < (long)sizeof(h)) { free(d); return 1; }
   memcpy(&h, d, sizeof(h));
-  if(h.magic != 0xc01337 || h.version != 2 ||
+  /* the header is untrusted: bound num_prims by the file size (and the backend's 2^26 limit) before any arithmetic on it */
+  if(h.magic != 0xc01337 || h.version != 2 || h.num_prims > ((uint64_t)size - sizeof(h))/8 || h.num_prims >= (1ull << 26) ||
      h.vtxidx_offset < sizeof(h) + 8*h.num_prims || h.vertex_offset < h.vtxidx_offset || h.vertex_offset > (uint64_t)size)
   {
     fprintf(stderr, "[ch] geo `%s': bad magic/version/offsets\n", name);
@@ -282,17 +283,22 @@ static int load_geo(ch_scene *s, uint32_t shapeid, const char *name)
   const uint64_t nv  = ((uint64_t)size - h.vertex_offset)/sizeof(mi_vtx);
   ch_geo *g = &s->geo;
   mi_shape *sh = g->shapes + shapeid;
+  const uint64_t old = s->desc.num_prims;
+  if(g->num_vtxidx + nvi >= (1ull << 32) || g->num_vtx + nv >= (1ull << 32) || old + h.num_prims >= (1ull << 26))
+  { fprintf(stderr, "[ch] geo `%s': scene too large for this backend\n", name); free(d); return 1; }
+  mi_vtxidx *nvidx = (mi_vtxidx *)realloc(g->vtxidx, (g->num_vtxidx + nvi + 1)*sizeof(mi_vtxidx));
+  if(nvidx) g->vtxidx = nvidx;
+  mi_vtx *nvtx = (mi_vtx *)realloc(g->vtx, (g->num_vtx + nv + 1)*sizeof(mi_vtx));
+  if(nvtx) g->vtx = nvtx;
+  /* append primids, stamping the shape id (src/prims.c:751-752) */
+  mi_primid *nprim = (mi_primid *)realloc(s->primid, (old + h.num_prims + 1)*sizeof(mi_primid));
+  if(nprim) s->primid = nprim;
+  if(!nvidx || !nvtx || !nprim) { fprintf(stderr, "[ch] geo `%s': out of memory\n", name); free(d); return 1; }
   sh->num_prims = (uint32_t)h.num_prims;
   sh->vtxidx_base = (uint32_t)g->num_vtxidx;
   sh->vtx_base = (uint32_t)g->num_vtx;
-  g->vtxidx = (mi_vtxidx *)realloc(g->vtxidx, (g->num_vtxidx + nvi + 1)*sizeof(mi_vtxidx));
-  g->vtx    = (mi_vtx *)realloc(g->vtx, (g->num_vtx + nv + 1)*sizeof(mi_vtx));
   memcpy(g->vtxidx + g->num_vtxidx, d + h.vtxidx_offset, nvi*sizeof(mi_vtxidx));
   memcpy(g->vtx + g->num_vtx, d + h.vertex_offset, nv*sizeof(mi_vtx));
-  g->num_vtxidx += nvi; g->num_vtx += nv;
-  /* append primids, stamping the shape id (src/prims.c:751-752) */
-  const uint64_t old = s->desc.num_prims;
-  s->primid = (mi_primid *)realloc(s->primid, (old + h.num_prims + 1)*sizeof(mi_primid));
   for(uint64_t k=0;k<h.num_prims;k++)
   {
     mi_primid p; memcpy(&p, d + sizeof(h) + 8*k, 8);
@@ -305,6 +311,7 @@ static int load_geo(ch_scene *s, uint32_t shapeid, const char *name)
     { fprintf(stderr, "[ch] geo `%s': vertex out of range\n", name); free(d); return 1; }
     s->primid[old + k] = p;
   }
+  g->num_vtxidx += nvi; g->num_vtx += nv;
   s->desc.num_prims = old + h.num_prims;
   free(d);
   return 0;
@@ -499,6 +506,8 @@ static int init_lights(ch_scene *s)
  * numbers of a particular LUT without shipping the 9.4 MB table). */
 static void apply_coeff_cache(ch_scene *s)
 {
+  const char *mode = getenv("CORONA_MI_RGB2SPEC");      /* "fit": ignore the file, use the host's own fit (tests of that path) */
+  if(mode && !strcmp(mode, "fit")) return;
   char fn[2048];
   snprintf(fn, sizeof(fn), "%s.rgb2spec", s->basename);
   FILE *f = fopen(fn, "rb");

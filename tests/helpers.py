@@ -1,4 +1,4 @@
-"""Test helpers: package loader, oracle (ctypes) binding, golden-coefficient injection.
+"""Test helpers: package loader, oracle (ctypes) binding, golden coefficients.
 
 The oracle (oracle/liboracle.so) is the CPU restatement of the reference used as the CHECKER.
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch it.
@@ -100,41 +100,17 @@ def golden_coeffs():
         return [json.loads(l) for l in f if l.strip()]
 
 
-def inject_reference_coeffs(scene):
-    """Replace the coefficients of the scene's `color` shaders by the reference LUT's values so that
-    hot-path comparisons are not polluted by init-time LUT differences."""
-    pkg = load_pkg()
-    names = scene.shader_names()
-    table = golden_coeffs()
-    with open(scene_path_of(scene)) as f:
-        lines = f.read().splitlines()
-    nshaders = int(lines[1].split()[0])
-    for sid in range(nshaders):
-        tok = lines[2 + sid].split('#')[0].split()
-        if tok and tok[0] in ("color", "medium_rgb"):
-            # medium_rgb: the colour is the collision coefficient 1 / mean free path (src/shaders/medium_rgb.c:113-119)
-            rgb = [float(x) for x in tok[2:5]] if tok[0] == "color" else [float(np.float32(1) / np.float32(x)) for x in tok[1:4]]
-            if max(rgb) == 0.0:
-                continue
-            for e in table:
-                if np.allclose(e["rgb"], rgb, rtol=1e-6):
-                    scene.set_color_coeff(sid, e["coeff"], e["mul"])
-                    break
-            else:
-                raise KeyError(f"no golden coefficients for {rgb}")
-    return scene
-
-
-_scene_paths = {}
-
-
-def make_scene(path=SCENE_0010, inject=True, **kw):
+def make_scene(path=SCENE_0010, inject=None, **kw):
+    """pkg.Scene(path): the scenes under scenes/ carry the reference table's RGB -> spectrum coefficients for their colours
+    (test.rgb2spec, written by tests/golden/make_rgb2spec_cache.py, applied by the host loader), so the shipped default IS
+    the reference's init-time constants -- nothing is injected by the tests any more (`inject` is accepted and ignored)."""
     pkg = load_pkg()
     s = pkg.Scene(path, **kw)
     _scene_paths[id(s)] = path
-    if inject:
-        inject_reference_coeffs(s)
     return s
+
+
+_scene_paths = {}
 
 
 def scene_path_of(scene):

@@ -1,0 +1,62 @@
+"""bench.py's multi-GPU entry point without a GPU: `python bench.py --gpus 2 --stub` must start TWO ranks on its own (children
+of a process that never touches the GPU), shard the path indices, all-reduce the frame (gloo here, RCCL on the GPU box) and
+report n_gpus == 2. The stub backend renders nothing -- it adds the number of indices it was handed to one framebuffer
+element -- so the reduced last frame must sum to the size of the job."""
+import json
+import os
+import subprocess
+import sys
+
+from helpers import REPO
+
+
+def run_bench(*argv, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, str(REPO / "bench.py"), *argv], capture_output=True, text=True, env=env, timeout=600)
+
+
+def json_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+def test_gpus_2_starts_two_ranks_weak():
+    r = run_bench("--gpus", "2", "--stub", "--steps", "2", "--warmup", "1", "--config", "cfg1")
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json_line(r.stdout)
+    per_frame = 4 * 256 * 256
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["scaling"] == "weak"
+    assert out["config"]["paths_per_step"] == 2 * per_frame and out["config"]["paths_per_step_per_gpu"] == per_frame
+    assert out["stub"]["reduced_sum_last_frame"] == out["stub"]["expected"] == 2 * per_frame     # both ranks' shares arrived in the reduced frame
+    assert out["metric"].startswith("STUB")                                                     # never mistaken for a measurement
+
+
+def test_gpus_2_strong_scaling_keeps_the_job_fixed():
+    r = run_bench("--gpus", "2", "--stub", "--steps", "2", "--warmup", "0", "--config", "cfg1", "--scaling", "strong")
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json_line(r.stdout)
+    per_frame = 4 * 256 * 256
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong"
+    assert out["config"]["paths_per_step"] == per_frame and out["config"]["paths_per_step_per_gpu"] == per_frame // 2
+    assert out["stub"]["reduced_sum_last_frame"] == per_frame
+
+
+def test_single_rank_and_launcher_mismatch():
+    r = run_bench("--gpus", "1", "--stub", "--steps", "1", "--warmup", "0", "--config", "cfg1")
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json_line(r.stdout)
+    assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1 and out["stub"]["reduced_sum_last_frame"] == 4 * 256 * 256
+    # a launcher that started a different number of ranks than --gpus says: refuse instead of reporting a wrong n_gpus
+    r = run_bench("--gpus", "4", "--stub", "--steps", "1", "--config", "cfg1", env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "--gpus 4" in (r.stdout + r.stderr)
+
+
+def test_cfg5_defaults_to_strong_scaling():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", REPO / "bench.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.CONFIGS["cfg5"]["scaling"] == "strong" and mod.CONFIGS["cfg5"]["spp"] == 1024
+    assert abs(128 * mod.REFERENCE_WORK["cfg2"]["node_visits"] + 104 * mod.REFERENCE_WORK["cfg2"]["prim_tests"] + 384 * mod.REFERENCE_WORK["cfg2"]["splats"] - 2822) < 2

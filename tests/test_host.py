@@ -1,6 +1,7 @@
 """Host side (plain C): scene files, QBVH builder, emitters, camera, rgb2spec, PFM. CPU only."""
 import ctypes as C
 import json
+import sys
 import os
 import struct
 import tempfile
@@ -93,7 +94,8 @@ def test_materials_compiled():
     assert abs(m[10].op[0].roughness - 0.04) < 1e-7
     assert m[8].bsdf == 3 and abs(m[8].mean_cos - 0.85) < 1e-7 and m[8].interior == -1   # medium_rgb (unused in 0010): mu_t colour, mean cosine
     assert m[9].bsdf == 255                                                         # a bare `color` line is no material
-    med = make_scene(SCENE_MEDIA, width=256, height=256, max_verts=4).desc.materials
+    med_scene = make_scene(SCENE_MEDIA, width=256, height=256, max_verts=4)      # keep the owner of the descriptor alive
+    med = med_scene.desc.materials
     assert med[14].bsdf == 1 and med[14].interior == 13 and med[14].num_ops == 1    # interior 10 13: glass surface + medium link
     assert med[13].bsdf == 3 and med[13].num_ops == 1 and med[13].op[0].slot == 4 and abs(med[13].mean_cos - 0.6) < 1e-7
     assert abs(med[13].param[3] - 5.0) < 1e-5                                       # scale of mu_t = 1 / 0.2 dm
@@ -119,6 +121,62 @@ def test_rgb2spec_direct_fit_close_to_reference_lut():
             tol = 4e-3 if e["mul"] <= 1 or min(e["rgb"]) == max(e["rgb"]) else 1e-2
             assert abs(val - e["eval_precise"][k]) < tol, (e["rgb"], lam, val, e["eval_precise"][k])
     del s
+
+
+REF_LUT = REPO / "oracle" / "_ref" / "data" / "ergb2spec.coeff"
+
+
+@pytest.mark.skipif(not REF_LUT.exists(), reason="the reference's coefficient table is only there where oracle/_ref was built")
+def test_lut_reader_equals_reference_fetch_bit_for_bit():
+    """ch_rgb_to_coeff(rgb, out, lut) -- the host's reader of the reference-format table -- against coefficients dumped from
+    the reference's own rgb2spec_fetch (include/rgb2spec.h:87-128 via oracle/refharness/unit_harness.c): every colour, every bit."""
+    h = pkg.host_lib()
+    for e in golden_coeffs():
+        out = (C.c_float * 3)()
+        mul = h.ch_rgb_to_coeff((C.c_float * 3)(*e["rgb"]), out, str(REF_LUT).encode())
+        assert np.float32(mul) == np.float32(e["mul"])
+        assert [np.float32(x) for x in out] == [np.float32(x) for x in e["coeff"]], (e["rgb"], list(out), e["coeff"])
+
+
+def test_shipped_scenes_carry_the_reference_coefficients(monkeypatch):
+    """scenes/*/test.rgb2spec pin the colour shaders to the reference table's coefficients: a plainly loaded scene (no test-side
+    injection) has bit-for-bit the golden coefficients on every colour the reference dump knows; CORONA_MI_RGB2SPEC=fit
+    switches back to the host's own fit."""
+    table = {tuple(np.float32(e["rgb"])): e for e in golden_coeffs()}
+    seen = 0
+    for path in (SCENE_0010, SCENE_ROUGH, SCENE_MEDIA):
+        s = make_scene(path, width=64, height=64, max_verts=4)
+        mats = s.desc.materials
+        lines = path.read_text().splitlines()
+        for sid in range(int(lines[1].split()[0])):
+            tok = lines[2 + sid].split("#")[0].split()
+            if not tok or tok[0] != "color":
+                continue
+            rgb = tuple(np.float32(x) for x in tok[2:5])
+            if max(rgb) == 0 or rgb not in table:
+                continue
+            # a bare colour line is compiled into the materials that use it: look for its op
+            ops = [m.op[k] for m in (mats[i] for i in range(s.desc.num_materials)) for k in range(m.num_ops) if m.op[k].kind == 0]
+            want = [np.float32(x) for x in table[rgb]["coeff"]]
+            used = any(str(sid) in l.split("#")[0].split()[1:] for l in lines[2:2 + int(lines[1].split()[0])] if l.split()[0] in ("mult", "interior"))
+            if not used:
+                continue                                      # e.g. the medium lines of 0010, which no material refers to
+            assert any([np.float32(c) for c in op.coeff] == want and np.float32(op.mul) == np.float32(table[rgb]["mul"]) for op in ops), (path, rgb)
+            seen += 1
+    assert seen >= 9
+    monkeypatch.setenv("CORONA_MI_RGB2SPEC", "fit")
+    s = make_scene(SCENE_0010, width=64, height=64, max_verts=4)
+    white = [np.float32(x) for x in table[(np.float32(1), np.float32(1), np.float32(1))]["coeff"]]
+    ops = [m.op[k] for m in (s.desc.materials[i] for i in range(s.desc.num_materials)) for k in range(m.num_ops) if m.op[k].kind == 0]
+    assert ops and not any([np.float32(c) for c in op.coeff] == white for op in ops)       # the closed form for greys, not the table
+
+
+@pytest.mark.skipif(not REF_LUT.exists(), reason="needs the reference's coefficient table (oracle/_ref)")
+def test_scene_caches_are_up_to_date():
+    sys.path.insert(0, str(GOLDEN))
+    import make_rgb2spec_cache as mk
+    for nra2 in sorted((REPO / "scenes").glob("*/test.nra2")):
+        assert (nra2.parent / "test.rgb2spec").read_text().splitlines() == mk.cache_lines(nra2), nra2
 
 
 def test_black_is_special_cased():
@@ -206,11 +264,13 @@ def test_camera_files_static_and_moving():
     """legacy 152-byte camera (0010) resolves to a static frame; the CCAM v1 file of scenes/0058_cam_mb carries distinct shutter-open
     and shutter-close states: both quaternions and positions are handed over, the kernel interpolates per path"""
     from helpers import SCENE_CAM_MB
-    st = make_scene(SCENE_0010, width=256, height=256, max_verts=4).desc.cam
+    st_scene = make_scene(SCENE_0010, width=256, height=256, max_verts=4)        # keep the owners of the descriptors alive
+    st = st_scene.desc.cam
     assert st.moving == 0 and list(st.pos) == list(st.pos_t1) and list(st.orient) == list(st.orient_t1)
     n = np.array(st.n)
     assert abs(np.linalg.norm(n) - 1) < 1e-6 and abs(st.time_scale - (1 / 125) / (1 / 30)) < 1e-6
-    mv = make_scene(SCENE_CAM_MB, width=256, height=256, max_verts=4).desc.cam
+    mv_scene = make_scene(SCENE_CAM_MB, width=256, height=256, max_verts=4)
+    mv = mv_scene.desc.cam
     assert mv.moving == 1 and abs(mv.time_scale - 1.0) < 1e-7
     assert np.allclose(np.array(mv.pos_t1) - np.array(mv.pos), [0.6, 0.3, 0.15], atol=1e-5)
     q0, q1 = np.array(mv.orient), np.array(mv.orient_t1)
@@ -228,7 +288,8 @@ def test_motion_blurred_geo_is_loaded_with_enclosing_boxes():
     assert mb.sum() == 4096 + 6 and d.num_prims == 4108            # backdrop + cylinder cap move, emitter / sphere / lines do not
     assert d.num_vtx > 2 * 4096                                     # two states per vertex of the moving shapes
     # scene box: the backdrop rises by 0.15 dm, the box must contain the shutter-close state
-    st = make_scene(SCENE_0010, width=256, height=256, max_verts=4).desc
+    st_scene = make_scene(SCENE_0010, width=256, height=256, max_verts=4)
+    st = st_scene.desc
     assert d.aabb[5] >= st.aabb[5] - 1e-6 and d.aabb[2] <= st.aabb[2] + 1e-6
     assert max(d.aabb[3] - st.aabb[3], d.aabb[5] - st.aabb[5]) > 0.1
 
