@@ -283,6 +283,7 @@ def mi_lib():
         m.mi_fb_device_ptr.argtypes = [C.c_void_p]
         m.mi_fb_device_ptr.restype = C.c_void_p
         m.mi_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        m.mi_scene_set_counters.argtypes = [C.c_void_p, C.c_int]
         m.mi_trace_paths.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
         m.mi_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         m.mi_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
@@ -297,7 +298,7 @@ def mi_lib():
 
 
 MI_SYMBOLS = ["mi_init", "mi_scene_create", "mi_scene_set_framebuffer", "mi_scene_set_stream", "mi_render",
-              "mi_sync", "mi_fb_read", "mi_fb_clear", "mi_fb_device_ptr", "mi_counters", "mi_trace_paths", "mi_intersect",
+              "mi_sync", "mi_fb_read", "mi_fb_clear", "mi_fb_device_ptr", "mi_counters", "mi_scene_set_counters", "mi_trace_paths", "mi_intersect",
               "mi_last_kernel_ms", "mi_last_kernel_launches", "mi_scene_stats", "mi_scene_destroy", "mi_shutdown", "mi_last_error"]
 
 
@@ -312,9 +313,11 @@ def ray_dtypes():
 class Backend:
     """Device-resident scene on one MI355X, driven through the C ABI."""
 
-    def __init__(self, scene: Scene, device: int = -1, device_build: bool = False):
+    def __init__(self, scene: Scene, device: int = -1, device_build: bool = False, counters: bool = True):
         """device_build: hand the scene over WITHOUT the host-built tree (mi_scene_desc.nodes = NULL); the backend then
-        builds its own 4-wide BVH on the GPU (csrc/mi_build.h)"""
+        builds its own 4-wide BVH on the GPU (csrc/mi_build.h).
+        counters: render with the counting kernels (mi_scene_set_counters) so that counters() reports the traversal work --
+        this Python view is the test / measurement harness, so they are on unless asked otherwise; the C ABI's default is off."""
         self.m = mi_lib()
         self._check(self.m.mi_init(device), "mi_init")
         self._ptr = C.c_void_p()
@@ -327,6 +330,10 @@ class Backend:
             desc_ptr = C.pointer(self._desc)
         self._check(self.m.mi_scene_create(desc_ptr, C.byref(self._ptr)), "mi_scene_create")
         self.scene = scene
+        self.set_counters(counters)
+
+    def set_counters(self, enable):
+        self._check(self.m.mi_scene_set_counters(self._ptr, 1 if enable else 0), "mi_scene_set_counters")
 
     def _check(self, err, what):
         if err:

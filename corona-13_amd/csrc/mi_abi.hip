@@ -4,7 +4,7 @@
  * Replaces everything the reference reaches from work_sample() (src/view.c:618-628): one launch
  * traces path indices [first, first+count) and splats them into the device framebuffer.
  */
-#include "mi_wavefront.h"
+#include "mi_path.h"
 #include "mi_build.h"
 #include "mi_halton.h"
 #include <cstring>
@@ -24,13 +24,15 @@
 #ifndef MI_TAIL_LANES_PTDL
 #define MI_TAIL_LANES_PTDL 8   /* ptdl shades more per vertex (next event estimation): shorter tails pay, A/B 4/8/12/16/24/32 */
 #endif
-#define MI_WORK_SHARDS 262144   /* upper bound on workgroups of one launch (path pool / 256) */
+#ifndef MI_ANYHIT
+#define MI_ANYHIT 1      /* shadow rays towards flagged emitters stop at the first occluder (MI_LIGHT_ANYHIT, mi_device.h) */
+#endif
 #ifndef MI_STACK
 #define MI_STACK 12      /* LDS traversal stack entries per lane; deeper entries overflow to HBM (mi_device.h) */
 #endif
 
 /* ======================================================================================= persistent megakernel */
-template<bool RECORD, bool PTDL, bool NODES_LDS, bool HALTON = false, bool MEDIA = false, bool MB = false>
+template<bool RECORD, bool PTDL, bool NODES_LDS, bool HALTON = false, bool MEDIA = false, bool MB = false, bool COUNT = true>
 __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned long long first, unsigned long long count,
                                                            const uint32_t *shape_material, const float *shape_L, mi_path_record *records,
                                                            uint2 *stack_overflow)
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
   const unsigned long long blk_lo = count/nb*blockIdx.x + (blockIdx.x < count%nb ? blockIdx.x : count%nb);
   const unsigned long long blk_hi = blk_lo + count/nb + (blockIdx.x < count%nb ? 1 : 0);
 
-  uint32_t cnt[MI_CNT] = {0};
+  Counters<COUNT || RECORD> cnt;        /* COUNT = false: only the path count (see Counters, mi_kernels.h) */
   PathState ps;
   ps.active = 0;
   ps.sh_pending = 0;
@@ -92,6 +94,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
       tr_shadow = PTDL && ps.sh_pending;
       hit.prim = MI_NOPRIM; hit.dist = tr_shadow ? ps.sh_dist : (MEDIA ? media_free_flight<PTDL, HALTON>(sc, ps) : FLT_MAX); hit.u = hit.v = 0.0f;
       trace_begin(ts, tr_shadow ? ps.sh_dir : ps.dir, cnt);
+      if(PTDL && MI_ANYHIT) ts.anyhit = tr_shadow && (ps.sh_light & MI_LIGHT_ANYHIT);
       if(MB) { ts.time = ps.time; ts.prims_t1 = sc.prims_t1; }      /* motion-blurred primitives are tested at the path's time */
       tracing = true;
     }
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
         const unsigned nbusy = __popcll(__ballot(busy));
         if(!nbusy) break;
         if(nbusy < tail && __any(tracing && ts.done)) break;
-        if(busy) trace_round<MI_BLOCK, MI_STACK, MB>(lds, sc.prims, o, d, ignore, hit, ts, cnt);
+        if(busy) trace_round<MI_BLOCK, MI_STACK, MB, PTDL && MI_ANYHIT>(lds, sc.prims, o, d, ignore, hit, ts, cnt);
       }
     }
     MI_PHASE(cnt, 1)
@@ -129,21 +132,22 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
   }
 
 #ifdef MI_PROFILE_LOOPS    /* development build: box hits / splats / vertices become wave-level inner iterations / leaf slots / analytic passes */
-  cnt[2] = cnt[8]; cnt[5] = cnt[9]; cnt[6] = cnt[10];
+  cnt.c[2] = cnt.c[8]; cnt.c[5] = cnt.c[9]; cnt.c[6] = cnt.c[10];
 #endif
 #ifdef MI_PROFILE_PHASES   /* development build: the 8 counters become lane 0's phase ticks | occurrences << 36 (tools/phase_probe.py) */
   unsigned long long phase_out[8];
-  for(int k=0;k<8;k++) phase_out[k] = lane ? 0ull : ((unsigned long long)cnt[8 + k] | ((unsigned long long)cnt[16 + k] << 36));
+  for(int k=0;k<8;k++) phase_out[k] = lane ? 0ull : ((unsigned long long)cnt.c[8 + k] | ((unsigned long long)cnt.c[16 + k] << 36));
 #endif
   unsigned long long *shard = sc.counters + (size_t)(blockIdx.x % MI_COUNTER_SHARDS)*8;
 #ifndef MI_PROFILE_PHASES
-  atomicMax(shard + 7, (unsigned long long)cnt[7]);     /* deepest traversal stack use */
+  if(cnt.on) atomicMax(shard + 7, (unsigned long long)cnt.c[7]);     /* deepest traversal stack use */
 #endif
   /* ------------------------------------------------------------ flush work counters: wave reduction, one atomic per wave */
 #pragma unroll
   for(int k=0;k<8;k++)
   {
-    unsigned long long c = cnt[k];
+    if(!cnt.on && k != 4) continue;         /* the plain kernels only count paths */
+    unsigned long long c = cnt.c[k];
 #ifdef MI_PROFILE_PHASES
     c = phase_out[k];
     if(k == 7) { if(lane == 0 && c) atomicAdd(shard + 7, c); continue; }
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_intersect_kernel(DScene sc, const
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const Lds lds = lds_setup<MI_BLOCK, NODES_LDS>(sc, smem, stack_overflow);
-  uint32_t cnt[MI_CNT] = {0};
+  Counters<true> cnt;
   for(unsigned long long base=(unsigned long long)blockIdx.x*MI_BLOCK; base<n; base+=(unsigned long long)gridDim.x*MI_BLOCK)
   {
     const unsigned long long i = base + threadIdx.x;
@@ -178,8 +182,8 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_intersect_kernel(DScene sc, const
     }
   }
   unsigned long long *shard = sc.counters + (size_t)(blockIdx.x % MI_COUNTER_SHARDS)*8;
-  atomicMax(shard + 7, (unsigned long long)cnt[7]);
-  for(int k=0;k<4;k++) if(cnt[k]) atomicAdd(shard + k, (unsigned long long)cnt[k]);
+  atomicMax(shard + 7, (unsigned long long)cnt.c[7]);
+  for(int k=0;k<4;k++) if(cnt.c[k]) atomicAdd(shard + k, (unsigned long long)cnt.c[k]);
 }
 
 /* ======================================================================================= host side */
@@ -206,7 +210,7 @@ struct mi_scene
   uint32_t width, height;
   int device;                       /* the GPU this scene lives on: every entry point selects it (hipSetDevice is per host thread) */
   void *d_nodes, *d_axes, *d_prims, *d_primgeo, *d_materials, *d_light_prim, *d_light_cdf, *d_light_L;
-  void *d_cie, *d_checker, *d_metal, *d_counters, *d_work, *d_shape_material, *d_shape_L, *d_overflow;
+  void *d_cie, *d_checker, *d_metal, *d_counters, *d_shape_material, *d_shape_L, *d_overflow;
   float *d_fb_own, *d_fb;
   hipStream_t stream_own, stream;
   hipEvent_t ev0, ev1;
@@ -217,21 +221,51 @@ struct mi_scene
   int stack_need;                   /* stack entries a ray may need */
   int grid;
   uint64_t launches;
-  /* wavefront pipeline (mi_wavefront.h) */
-  int wavefront;                    /* 1: wf_logic/wf_trace, 0: persistent megakernel */
-  WFPool pool;
-  void *d_pool, *d_wfcnt;           /* d_wfcnt: [0] trace_head, [1] live */
-  unsigned long long *h_live;       /* pinned ring of `live` read-backs */
-  hipEvent_t ev_live[8];
   uint64_t kernel_launches_last;
+  int counting;                     /* launch the COUNT instantiations (mi_scene_set_counters / CORONA_MI_COUNTERS) */
   bool media;                       /* some shape is filled with a homogeneous medium: MEDIA instantiations */
-  void *d_shape_medium, *d_prims_t1;
+  void *d_shape_medium, *d_prims_t1, *d_lights;
   /* Halton point sampler */
   bool halton;
   HaltonTables *halton_tables;
   uint64_t halton_epoch;            /* end index >> 32 the device tables were drawn for */
   void *d_halton_dim, *d_halton_perm;
 };
+
+/* ---------------------------------------------------------------------------------------- kernel table
+ * bit 0 RECORD, 1 PTDL, 2 NODES_LDS, 3 HALTON, 4 MEDIA, 5 MB, 6 COUNT. MB implies MEDIA; the RECORD kernels always count.
+ * MI_DEV_FAST (development builds, tools/variants.sh): only the plain tree-in-LDS kernels, 20 s instead of minutes to compile. */
+struct PathLaunch { mi_scene *s; int grid; uint64_t first, n; mi_path_record *rec; };
+static bool path_kernel_valid(unsigned which)
+{
+  if((which & 32u) && !(which & 16u)) return false;
+  if((which & 1u) && !(which & 64u)) return false;
+#ifdef MI_DEV_FAST
+  if((which & (8u | 16u | 32u)) || !(which & 4u)) return false;
+#endif
+  return true;
+}
+template<bool... B> static const void *path_kernel_go(PathLaunch *L)
+{
+  if(L) hipLaunchKernelGGL((mi_path_kernel<B...>), dim3(L->grid), dim3(MI_BLOCK), L->s->lds_bytes, L->s->stream, L->s->d, (unsigned long long)L->first,
+                           (unsigned long long)L->n, (const uint32_t *)L->s->d_shape_material, (const float *)L->s->d_shape_L, L->rec, (uint2 *)L->s->d_overflow);
+  return (const void *)mi_path_kernel<B...>;
+}
+template<bool R, bool P, bool N, bool H, bool M, bool MBk, bool C> static const void *path_kernel_leaf(PathLaunch *L)
+{
+  constexpr bool valid = !(MBk && !M) && !(R && !C)
+#ifdef MI_DEV_FAST
+                         && !H && !M && !MBk && N
+#endif
+                         ;
+  if constexpr(valid) return path_kernel_go<R, P, N, H, M, MBk, C>(L);
+  else { fprintf(stderr, "[mi] internal: kernel variant not built\n"); abort(); }
+}
+template<int LEFT, bool... B> static const void *path_kernel_dispatch(unsigned which, PathLaunch *L)
+{
+  if constexpr(LEFT == 0) return path_kernel_leaf<B...>(L);
+  else return (which & 1u) ? path_kernel_dispatch<LEFT - 1, B..., true>(which >> 1, L) : path_kernel_dispatch<LEFT - 1, B..., false>(which >> 1, L);
+}
 
 extern "C" const char *mi_last_error(void) { return g_err; }
 
@@ -650,6 +684,24 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
     lprim[k] = found;
   }
 
+  /* any-hit shadow rays (MI_LIGHT_ANYHIT, mi_device.h): emitter primitives a connection ray cannot cross inside the connection */
+  std::vector<uint32_t> lflag(lprim.size(), 0u);
+  {
+    const char *sm = getenv("CORONA_MI_SHADOW");          /* "closest": the reference's traversal for every shadow ray (counter parity) */
+    const bool closest = sm && !strcmp(sm, "closest");
+    for(uint32_t k=0;k<h->lights.num_prims && !closest;k++)
+    {
+      const DPrim &p = prims[lprim[k]];
+      if(p.type == MI_PRIM_TRI) lflag[k] = MI_LIGHT_ANYHIT;
+      else if(p.type == MI_PRIM_QUAD)
+      { /* planar: v3 - v0 has no component along the normal of (v0 v1 v2), to float accuracy */
+        const V3 e1 = ld3(p.v[1]), e2 = ld3(p.v[2]), e3 = ld3(p.v[3]);
+        const V3 n = cross3(e1, e2);
+        const float off = fabsf(dot3(n, e3)), scale = sqrtf(dot3(n, n))*sqrtf(dot3(e3, e3));
+        if(off <= 1e-5f*scale) lflag[k] = MI_LIGHT_ANYHIT;
+      }
+    }
+  }
   int e = MI_OK;
 #define UP(dst, src, cnt) if(!e) e = upload(&s->dst, src, cnt)
   if(!device_build)
@@ -667,7 +719,8 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   {
     UP(d_prims_t1, prims_t1.data(), prims_t1.size());
   }
-  if(any_media || h->cam.moving || !prims_t1.empty()) { UP(d_shape_medium, shape_med.data(), shape_med.size()); s->media = true; }
+  if(any_media || h->cam.moving || !prims_t1.empty()) s->media = true;
+  UP(d_shape_medium, shape_med.data(), shape_med.size());        /* small; the extended kernels read it (all-vacuum entries for scenes without media) */
   UP(d_light_prim, lprim.data(), lprim.size());
   UP(d_light_cdf, h->lights.cdf, (size_t)h->lights.num_prims);
   UP(d_light_L, h->lights.L, (size_t)h->lights.num_prims);
@@ -675,12 +728,48 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   UP(d_checker, h->checker, h->checker ? (size_t)140*36 : 0);
   UP(d_metal, h->metal_ior, h->metal_ior ? (size_t)5*95*2 : 0);
   UP(d_counters, (const unsigned long long *)nullptr, (size_t)8*MI_COUNTER_SHARDS);
-  UP(d_work, (const unsigned long long *)nullptr, (size_t)MI_WORK_SHARDS);
 #undef UP
   if(!e && device_build)
   {
     e = build_on_device(s, h, &N, &stack_need);
     d.num_nodes = N;
+  }
+  if(!e && h->lights.num_prims)
+  { /* the list is in its final (builder or device-sorted) order now: set the any-hit flags */
+    std::vector<uint32_t> cur(h->lights.num_prims);
+    if(hipMemcpy(cur.data(), s->d_light_prim, cur.size()*4, hipMemcpyDeviceToHost) != hipSuccess) e = fail(MI_ERR_DEVICE, "cannot read back the emitter list");
+    for(size_t k=0;k<cur.size();k++) cur[k] |= lflag[k];
+    if(!e && hipMemcpy(s->d_light_prim, cur.data(), cur.size()*4, hipMemcpyHostToDevice) != hipSuccess) e = fail(MI_ERR_DEVICE, "cannot update the emitter list");
+    /* one-burst emitter records for next event estimation (DLight, mi_device.h): possible when every emitter primitive is a static
+       triangle / quad and its material's prepare chain consists of plain colours; any other scene runs the generic branch, which
+       only the extended kernels carry */
+    std::vector<DLight> lights(h->lights.num_prims);
+    bool fast = true;
+    for(uint32_t k=0;k<h->lights.num_prims && fast;k++)
+    {
+      const DPrim &p = prims[lprim[k]];
+      const DPrimGeo &g = pgeo[lprim[k]];
+      const mi_material &m = h->materials[g.material];
+      if(p.type != MI_PRIM_TRI && p.type != MI_PRIM_QUAD) { fast = false; break; }
+      DLight &L = lights[k];
+      memset(&L, 0, sizeof(L));
+      memcpy(L.v[0], p.v[0], 12);
+      memcpy(L.v[1], &g.f[26], 36);                    /* v1, v2, v3 */
+      memcpy(L.n[0], &g.f[0], 48);
+      memcpy(L.gn[0], &g.f[12], 24);
+      L.roughness = 1.0f;                               /* run_prepare_ops' initial state */
+      for(uint32_t o=0;o<m.num_ops;o++)
+      {
+        if(m.op[o].kind != MI_OP_COLOR) { fast = false; break; }
+        L.roughness = m.op[o].roughness;
+        if(m.op[o].slot == MI_SLOT_EMISSION) { memcpy(L.em_coeff, m.op[o].coeff, 12); L.em_mul = m.op[o].mul; }
+      }
+      L.L = h->lights.L[k];
+      L.prim = cur[k];
+      L.type = p.type;
+    }
+    if(fast) { if(!e) e = upload(&s->d_lights, lights.data(), lights.size()); }
+    else s->media = true;                               /* the extended kernels keep the generic emitter code */
   }
   if(!e)
   {
@@ -704,6 +793,8 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   d.exterior_index = h->num_shapes;
   d.num_lights = h->lights.num_prims;
   d.light_prim = (const uint32_t *)s->d_light_prim; d.light_cdf = (const float *)s->d_light_cdf; d.light_L = (const float *)s->d_light_L;
+  d.lights = (const DLight *)s->d_lights;
+  for(uint32_t k=0;k<4;k++) d.light_cdf4[k] = k < h->lights.num_prims ? h->lights.cdf[k] : 1.0f;
   d.p_sky = h->lights.p_sky; d.p_geo = h->lights.p_geo; d.p_vol = h->lights.p_vol;
   d.cam = h->cam;
   { /* same expressions, same order as path_generate evaluated them per path before (thinlens.c:68-128) */
@@ -726,7 +817,6 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   d.cie_xyz = (const float *)s->d_cie; d.checker = (const float *)s->d_checker; d.metal_ior = (const float *)s->d_metal;
   d.fb = s->d_fb;
   d.counters = (unsigned long long *)s->d_counters;
-  d.work = (unsigned long long *)s->d_work;
 
   const size_t node_bytes = (((size_t)MI_NODE_FIELDS*N*16 + (size_t)N*4) + 15) & ~(size_t)15;
   const size_t stack_bytes = (size_t)MI_STACK*MI_BLOCK*sizeof(uint2);
@@ -736,39 +826,10 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   s->nodes_lds = node_bytes + stack_bytes <= 160*1024 && !(nodes_env && !strcmp(nodes_env, "global"));
   s->lds_bytes = (s->nodes_lds ? node_bytes : 0) + stack_bytes;
   s->device_built = device_build; s->stack_need = stack_need;
+  { const char *ce = getenv("CORONA_MI_COUNTERS"); s->counting = ce && atoi(ce) ? 1 : 0; }
   {
-#ifdef MI_DEV_FAST   /* development builds (tools/variants.sh): only the plain tree-in-LDS kernels, 20 s instead of 2 min to compile */
-    const void *kernels[] = { (const void *)mi_intersect_kernel<true>, (const void *)mi_intersect_kernel<false>,
-      (const void *)mi_path_kernel<false, false, true>, (const void *)mi_path_kernel<true, false, true>,
-      (const void *)mi_path_kernel<false, true, true>, (const void *)mi_path_kernel<true, true, true> };
-#else
-    const void *kernels[] = {
-      (const void *)mi_intersect_kernel<true>, (const void *)mi_intersect_kernel<false>,
-      (const void *)mi_path_kernel<false, false, true>, (const void *)mi_path_kernel<true, false, true>,
-      (const void *)mi_path_kernel<false, true, true>, (const void *)mi_path_kernel<true, true, true>,
-      (const void *)mi_path_kernel<false, false, false>, (const void *)mi_path_kernel<true, false, false>,
-      (const void *)mi_path_kernel<false, true, false>, (const void *)mi_path_kernel<true, true, false>,
-      (const void *)mi_path_kernel<false, false, true, true>, (const void *)mi_path_kernel<true, false, true, true>,
-      (const void *)mi_path_kernel<false, true, true, true>, (const void *)mi_path_kernel<true, true, true, true>,
-      (const void *)mi_path_kernel<false, false, false, true>, (const void *)mi_path_kernel<true, false, false, true>,
-      (const void *)mi_path_kernel<false, true, false, true>, (const void *)mi_path_kernel<true, true, false, true>,
-      (const void *)mi_path_kernel<false, false, true, false, true>, (const void *)mi_path_kernel<true, false, true, false, true>,
-      (const void *)mi_path_kernel<false, true, true, false, true>, (const void *)mi_path_kernel<true, true, true, false, true>,
-      (const void *)mi_path_kernel<false, false, false, false, true>, (const void *)mi_path_kernel<true, false, false, false, true>,
-      (const void *)mi_path_kernel<false, true, false, false, true>, (const void *)mi_path_kernel<true, true, false, false, true>,
-      (const void *)mi_path_kernel<false, false, true, true, true>, (const void *)mi_path_kernel<true, false, true, true, true>,
-      (const void *)mi_path_kernel<false, true, true, true, true>, (const void *)mi_path_kernel<true, true, true, true, true>,
-      (const void *)mi_path_kernel<false, false, false, true, true>, (const void *)mi_path_kernel<true, false, false, true, true>,
-      (const void *)mi_path_kernel<false, true, false, true, true>, (const void *)mi_path_kernel<true, true, false, true, true>,
-      (const void *)mi_path_kernel<false, false, true, false, true, true>, (const void *)mi_path_kernel<true, false, true, false, true, true>,
-      (const void *)mi_path_kernel<false, true, true, false, true, true>, (const void *)mi_path_kernel<true, true, true, false, true, true>,
-      (const void *)mi_path_kernel<false, false, false, false, true, true>, (const void *)mi_path_kernel<true, false, false, false, true, true>,
-      (const void *)mi_path_kernel<false, true, false, false, true, true>, (const void *)mi_path_kernel<true, true, false, false, true, true>,
-      (const void *)mi_path_kernel<false, false, true, true, true, true>, (const void *)mi_path_kernel<true, false, true, true, true, true>,
-      (const void *)mi_path_kernel<false, true, true, true, true, true>, (const void *)mi_path_kernel<true, true, true, true, true, true>,
-      (const void *)mi_path_kernel<false, false, false, true, true, true>, (const void *)mi_path_kernel<true, false, false, true, true, true>,
-      (const void *)mi_path_kernel<false, true, false, true, true, true>, (const void *)mi_path_kernel<true, true, false, true, true, true> };
-#endif
+    std::vector<const void *> kernels = { (const void *)mi_intersect_kernel<true>, (const void *)mi_intersect_kernel<false> };
+    for(unsigned which=0;which<128;which++) if(path_kernel_valid(which)) kernels.push_back(path_kernel_dispatch<7>(which, nullptr));
     for(const void *k : kernels)
       if(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess)
       { mi_scene_destroy(s); return fail(MI_ERR_DEVICE, "cannot raise the dynamic LDS limit"); }
@@ -798,39 +859,6 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
     if(hipMalloc(&s->d_overflow, extra*(size_t)s->grid*MI_BLOCK*sizeof(uint2)) != hipSuccess)
     { mi_scene_destroy(s); return fail(MI_ERR_NOMEM, "cannot allocate the traversal stack overflow area"); }
   }
-  {
-    /* kernel organisation: the persistent megakernel (default, faster) or the wavefront pipeline (CORONA_MI_MODE=wave,
-       CORONA_MI_POOL = number of path slots) */
-    const char *mode = getenv("CORONA_MI_MODE");
-    s->wavefront = (mode && !strcmp(mode, "wave"));
-    if(s->wavefront && s->media)
-    { mi_scene_destroy(s); return fail(MI_ERR_UNSUPPORTED, "participating media and moving cameras run in the megakernel only (unset CORONA_MI_MODE)"); }
-    if(s->wavefront && h->pointsampler == MI_POINTS_HALTON)
-    { mi_scene_destroy(s); return fail(MI_ERR_UNSUPPORTED, "the Halton point sampler runs in the megakernel only (unset CORONA_MI_MODE)"); }
-    const char *pe = getenv("CORONA_MI_POOL");
-    uint64_t P = pe ? strtoull(pe, 0, 10) : (1ull << 21);
-    if(P < 65536) P = 65536;
-    if(P > (size_t)MI_WORK_SHARDS*256) P = (size_t)MI_WORK_SHARDS*256;
-    P = (P + 4095) & ~4095ull;
-    s->pool.P = (uint32_t)P;
-    if(s->wavefront)
-    {
-      if(hipMalloc(&s->d_pool, (size_t)F_COUNT*P*sizeof(uint32_t)) != hipSuccess ||
-         hipMalloc(&s->d_wfcnt, (1 + WF_LIVE_SHARDS)*sizeof(unsigned long long)) != hipSuccess ||
-         hipHostMalloc((void **)&s->h_live, 8*WF_LIVE_SHARDS*sizeof(unsigned long long)) != hipSuccess)
-      { mi_scene_destroy(s); return fail(MI_ERR_NOMEM, "cannot allocate the path pool"); }
-      s->pool.s = (uint32_t *)s->d_pool;
-      s->pool.trace_head = (unsigned long long *)s->d_wfcnt;
-      s->pool.live = (unsigned long long *)s->d_wfcnt + 1;
-      for(int k=0;k<8;k++) if(hipEventCreateWithFlags(&s->ev_live[k], hipEventDisableTiming) != hipSuccess)
-      { mi_scene_destroy(s); return fail(MI_ERR_DEVICE, "cannot create events"); }
-      if(hipFuncSetAttribute((const void *)wf_trace<MI_BLOCK, MI_STACK, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess ||
-         hipFuncSetAttribute((const void *)wf_trace<MI_BLOCK, MI_STACK, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess ||
-         hipFuncSetAttribute((const void *)wf_trace<MI_BLOCK, MI_STACK, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess ||
-         hipFuncSetAttribute((const void *)wf_trace<MI_BLOCK, MI_STACK, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess)
-      { mi_scene_destroy(s); return fail(MI_ERR_DEVICE, "cannot raise the dynamic LDS limit"); }
-    }
-  }
   /* uploads and clears above ran on the null stream, rendering runs on a non-blocking one: everything is in place before the first launch */
   if(hipDeviceSynchronize() != hipSuccess) { mi_scene_destroy(s); return fail(MI_ERR_DEVICE, "device synchronisation failed after the scene upload"); }
   *out = s;
@@ -845,51 +873,17 @@ extern "C" int mi_scene_set_framebuffer(mi_scene *s, float *device_fb)
   return MI_OK;
 }
 
+extern "C" int mi_scene_set_counters(mi_scene *s, int enable)
+{
+  MI_ENTER(s, "null scene");
+  s->counting = enable ? 1 : 0;
+  return MI_OK;
+}
+
 extern "C" int mi_scene_set_stream(mi_scene *s, void *hip_stream)
 {
   MI_ENTER(s, "null scene");
   s->stream = hip_stream == MI_STREAM_DEFAULT ? (hipStream_t)0 : hip_stream ? (hipStream_t)hip_stream : s->stream_own;
-  return MI_OK;
-}
-
-static int render_wavefront(mi_scene *s, uint64_t first_index, uint64_t count)
-{ /* host loop of the wavefront pipeline: [wf_logic, wf_trace]* until a logic pass leaves no ray pending.
-     The `live` counter is read back asynchronously, two iterations behind, so the queue never drains. */
-  const uint32_t P = s->pool.P;
-  const bool ptdl = s->d.sampler == MI_SAMPLER_PTDL;
-  HIPCHK(hipMemsetAsync(s->d_work, 0, (size_t)MI_WORK_SHARDS*sizeof(unsigned long long), s->stream));
-  HIPCHK(hipMemsetAsync(s->d_pool, 0, (size_t)F_COUNT*P*sizeof(uint32_t), s->stream));   /* all slots idle */
-  const int lgrid = (int)(P/WF_LOGIC_BLOCK);
-  s->kernel_launches_last = 0;
-  HIPCHK(hipEventRecord(s->ev0, s->stream));
-  for(int it=0;;it++)
-  {
-    HIPCHK(hipMemsetAsync(s->d_wfcnt, 0, (1 + WF_LIVE_SHARDS)*sizeof(unsigned long long), s->stream));
-    if(ptdl) hipLaunchKernelGGL((wf_logic<true>), dim3(lgrid), dim3(WF_LOGIC_BLOCK), 0, s->stream, s->d, s->pool, (unsigned long long)first_index,
-                                (unsigned long long)count, (const uint32_t *)s->d_shape_material, (const float *)s->d_shape_L);
-    else     hipLaunchKernelGGL((wf_logic<false>), dim3(lgrid), dim3(WF_LOGIC_BLOCK), 0, s->stream, s->d, s->pool, (unsigned long long)first_index,
-                                (unsigned long long)count, (const uint32_t *)s->d_shape_material, (const float *)s->d_shape_L);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(s->h_live + (size_t)(it & 7)*WF_LIVE_SHARDS, s->pool.live, WF_LIVE_SHARDS*sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
-    HIPCHK(hipEventRecord(s->ev_live[it & 7], s->stream));
-#define MI_WF_TRACE(P, L) hipLaunchKernelGGL((wf_trace<MI_BLOCK, MI_STACK, P, L>), dim3(s->grid), dim3(MI_BLOCK), s->lds_bytes, s->stream, s->d, s->pool, (uint2 *)s->d_overflow)
-    if(s->nodes_lds) { if(ptdl) MI_WF_TRACE(true, true); else MI_WF_TRACE(false, true); }
-    else             { if(ptdl) MI_WF_TRACE(true, false); else MI_WF_TRACE(false, false); }
-#undef MI_WF_TRACE
-    HIPCHK(hipGetLastError());
-    s->kernel_launches_last++;
-    if(it >= 2)
-    { /* look at the pass two iterations back (it has certainly been submitted; wait for it to bound the queue depth) */
-      HIPCHK(hipEventSynchronize(s->ev_live[(it - 2) & 7]));
-      unsigned long long any = 0;
-      for(int k=0;k<WF_LIVE_SHARDS;k++) any |= s->h_live[(size_t)((it - 2) & 7)*WF_LIVE_SHARDS + k];
-      if(!any) break;
-    }
-    if(it > (1 << 24)) return fail(MI_ERR_DEVICE, "wavefront pipeline did not terminate");
-  }
-  HIPCHK(hipEventRecord(s->ev1, s->stream));
-  s->have_timing = 1;
-  s->launches += s->kernel_launches_last;
   return MI_OK;
 }
 
@@ -908,61 +902,18 @@ static int ensure_halton(mi_scene *s, uint64_t end_index)
 }
 
 static void launch_path_kernel(mi_scene *s, bool record, int grid, uint64_t first, uint64_t n, mi_path_record *rec)
-{ /* pick the instantiation: RECORD (test hook) x PTDL (sampler) x NODES_LDS (tree fits LDS) x HALTON (point sampler) */
-  const int which = (record ? 1 : 0) | (s->d.sampler == MI_SAMPLER_PTDL ? 2 : 0) | (s->nodes_lds ? 4 : 0) | (s->halton ? 8 : 0) | (s->media ? 16 : 0) |
-                    (s->d_prims_t1 ? 32 : 0);            /* moving primitives: the MEDIA + MB instantiations */
-#define MI_LAUNCH(R, P, L, H) MI_LAUNCH5(R, P, L, H, false)
-#define MI_LAUNCH5(R, P, L, H, M) MI_LAUNCH6(R, P, L, H, M, false)
-#define MI_LAUNCH6(R, P, L, H, M, B) hipLaunchKernelGGL((mi_path_kernel<R, P, L, H, M, B>), dim3(grid), dim3(MI_BLOCK), s->lds_bytes, s->stream, s->d, \
-    (unsigned long long)first, (unsigned long long)n, (const uint32_t *)s->d_shape_material, (const float *)s->d_shape_L, rec, (uint2 *)s->d_overflow)
-#ifdef MI_DEV_FAST
-  switch(which)
-  {
-    case  4: MI_LAUNCH(false, false, true,  false); break;  case  5: MI_LAUNCH(true, false, true,  false); break;
-    case  6: MI_LAUNCH(false, true,  true,  false); break;  case  7: MI_LAUNCH(true, true,  true,  false); break;
-    default: fprintf(stderr, "[mi] MI_DEV_FAST build: only the plain tree-in-LDS kernels exist\n"); abort();
-  }
-#else
-  switch(which)
-  {
-    /* MEDIA + MB (scenes with motion-blurred primitives) */
-    case 48: MI_LAUNCH6(false, false, false, false, true, true); break;  case 49: MI_LAUNCH6(true, false, false, false, true, true); break;
-    case 50: MI_LAUNCH6(false, true,  false, false, true, true); break;  case 51: MI_LAUNCH6(true, true,  false, false, true, true); break;
-    case 52: MI_LAUNCH6(false, false, true,  false, true, true); break;  case 53: MI_LAUNCH6(true, false, true,  false, true, true); break;
-    case 54: MI_LAUNCH6(false, true,  true,  false, true, true); break;  case 55: MI_LAUNCH6(true, true,  true,  false, true, true); break;
-    case 56: MI_LAUNCH6(false, false, false, true,  true, true); break;  case 57: MI_LAUNCH6(true, false, false, true,  true, true); break;
-    case 58: MI_LAUNCH6(false, true,  false, true,  true, true); break;  case 59: MI_LAUNCH6(true, true,  false, true,  true, true); break;
-    case 60: MI_LAUNCH6(false, false, true,  true,  true, true); break;  case 61: MI_LAUNCH6(true, false, true,  true,  true, true); break;
-    case 62: MI_LAUNCH6(false, true,  true,  true,  true, true); break;  case 63: MI_LAUNCH6(true, true,  true,  true,  true, true); break;
-    /* MEDIA (scenes with participating media) */
-    case 16: MI_LAUNCH5(false, false, false, false, true); break;  case 17: MI_LAUNCH5(true, false, false, false, true); break;
-    case 18: MI_LAUNCH5(false, true,  false, false, true); break;  case 19: MI_LAUNCH5(true, true,  false, false, true); break;
-    case 20: MI_LAUNCH5(false, false, true,  false, true); break;  case 21: MI_LAUNCH5(true, false, true,  false, true); break;
-    case 22: MI_LAUNCH5(false, true,  true,  false, true); break;  case 23: MI_LAUNCH5(true, true,  true,  false, true); break;
-    case 24: MI_LAUNCH5(false, false, false, true,  true); break;  case 25: MI_LAUNCH5(true, false, false, true,  true); break;
-    case 26: MI_LAUNCH5(false, true,  false, true,  true); break;  case 27: MI_LAUNCH5(true, true,  false, true,  true); break;
-    case 28: MI_LAUNCH5(false, false, true,  true,  true); break;  case 29: MI_LAUNCH5(true, false, true,  true,  true); break;
-    case 30: MI_LAUNCH5(false, true,  true,  true,  true); break;  case 31: MI_LAUNCH5(true, true,  true,  true,  true); break;
-    case  0: MI_LAUNCH(false, false, false, false); break;  case  1: MI_LAUNCH(true, false, false, false); break;
-    case  2: MI_LAUNCH(false, true,  false, false); break;  case  3: MI_LAUNCH(true, true,  false, false); break;
-    case  4: MI_LAUNCH(false, false, true,  false); break;  case  5: MI_LAUNCH(true, false, true,  false); break;
-    case  6: MI_LAUNCH(false, true,  true,  false); break;  case  7: MI_LAUNCH(true, true,  true,  false); break;
-    case  8: MI_LAUNCH(false, false, false, true);  break;  case  9: MI_LAUNCH(true, false, false, true);  break;
-    case 10: MI_LAUNCH(false, true,  false, true);  break;  case 11: MI_LAUNCH(true, true,  false, true);  break;
-    case 12: MI_LAUNCH(false, false, true,  true);  break;  case 13: MI_LAUNCH(true, false, true,  true);  break;
-    case 14: MI_LAUNCH(false, true,  true,  true);  break;  default: MI_LAUNCH(true, true,  true,  true);  break;
-  }
-#endif
-#undef MI_LAUNCH
-#undef MI_LAUNCH5
-#undef MI_LAUNCH6
+{ /* pick the instantiation: RECORD (test hook) x PTDL (sampler) x NODES_LDS (tree fits LDS) x HALTON (point sampler) x MEDIA
+     ("extended": media, moving camera, emitters without a one-burst record) x MB (moving primitives) x COUNT (debug counters) */
+  const unsigned which = (record ? 1u : 0u) | (s->d.sampler == MI_SAMPLER_PTDL ? 2u : 0u) | (s->nodes_lds ? 4u : 0u) | (s->halton ? 8u : 0u) |
+                         (s->media ? 16u : 0u) | (s->d_prims_t1 ? 48u : 0u) | ((s->counting || record) ? 64u : 0u);
+  PathLaunch L = { s, grid, first, n, rec };
+  (void)path_kernel_dispatch<7>(which, &L);
 }
 
 extern "C" int mi_render(mi_scene *s, uint64_t first_index, uint64_t count)
 {
   MI_ENTER(s, "null scene");
   if(!count) return MI_OK;
-  if(s->wavefront) return render_wavefront(s, first_index, count);
   { const int e = ensure_halton(s, first_index + count); if(e) return e; }
   HIPCHK(hipEventRecord(s->ev0, s->stream));
   s->kernel_launches_last = 0;
@@ -1114,13 +1065,9 @@ extern "C" void mi_scene_destroy(mi_scene *s)
 {
   if(!s) return;
   (void)hipSetDevice(s->device);
-  if(s->d_pool) (void)hipFree(s->d_pool);
-  if(s->d_wfcnt) (void)hipFree(s->d_wfcnt);
-  if(s->h_live) (void)hipHostFree(s->h_live);
-  for(int k=0;k<8;k++) if(s->ev_live[k]) (void)hipEventDestroy(s->ev_live[k]);
   void *bufs[] = { s->d_nodes, s->d_axes, s->d_prims, s->d_primgeo, s->d_materials, s->d_light_prim, s->d_light_cdf, s->d_light_L,
-                   s->d_cie, s->d_checker, s->d_metal, s->d_counters, s->d_work, s->d_shape_material, s->d_shape_L, s->d_overflow, s->d_fb_own,
-                   s->d_halton_dim, s->d_halton_perm, s->d_shape_medium, s->d_prims_t1 };
+                   s->d_cie, s->d_checker, s->d_metal, s->d_counters, s->d_shape_material, s->d_shape_L, s->d_overflow, s->d_fb_own,
+                   s->d_halton_dim, s->d_halton_perm, s->d_shape_medium, s->d_prims_t1, s->d_lights };
   delete s->halton_tables;
   for(void *b : bufs) if(b) (void)hipFree(b);
   if(s->stream_own) (void)hipStreamDestroy(s->stream_own);

@@ -19,6 +19,14 @@
 #define MI_LEAF32 0x80000000u
 #define MI_NODE_FIELDS 7
 #define MI_COUNTER_SHARDS 256
+/* light_prim[] bit 31: a shadow ray towards this emitter primitive may stop at the FIRST occluder it finds (any-hit) instead of
+ * running the closest-hit traversal to its end like the reference's live path_visible (src/pathspace.c:311-344 -> accel_intersect;
+ * its accel_visible, src/accel.d/qbvhmp.c:1392-1490, is the any-hit the reference keeps for this). The verdict
+ *   visible = closest hit beyond the connection || no hit || closest hit IS the emitter primitive
+ * is the same boolean as "some other primitive is hit inside the connection" exactly when the emitter primitive itself cannot be
+ * hit inside the (shortened) connection: a triangle or a planar quad is crossed once, at the sampled point, which lies eps
+ * beyond the ray's end. Spheres, cones, cylinders, non-planar or moving quads keep the closest-hit traversal (flag clear). */
+#define MI_LIGHT_ANYHIT 0x80000000u
 
 struct DPrim                       /* 64 B */
 {
@@ -72,6 +80,22 @@ struct DShapeMedium                /* 48 B per shape: the homogeneous medium fil
   uint32_t pad[2];
 };
 
+struct DLight                      /* 160 B: everything next event estimation needs about ONE emitter primitive, when that is a static triangle / quad whose
+                                      material is a chain of plain `color` lines (no texture): fetched whole in one burst instead of the chain
+                                      emitter list -> primitive record -> shading record -> material -> ops (five dependent round trips).
+                                      Scenes with any other emitter run the generic path of the extended kernels. */
+{
+  float v[4][3];                   /* vertices (prims_sample / prims_retime, src/prims.c:178-252) */
+  float n[4][3];                   /* decoded vertex normals (prims_get_normal_time, src/prims.c:254-366) */
+  float gn[2][3];                  /* geometric normals of (v0 v1 v2) and (v0 v2 v3) */
+  float em_coeff[3], em_mul;       /* the emission the material's prepare chain leaves: em_mul * S(em_coeff, lambda) (color.c:75-82) */
+  float roughness;                 /* ... and the roughness its last colour line leaves */
+  float L;                         /* light_L[] of this entry (lights_pdf_next_event, src/lights.d/list.c:106-128) */
+  uint32_t prim;                   /* builder-order primitive index | MI_LIGHT_ANYHIT (= light_prim[]) */
+  uint32_t type;                   /* MI_PRIM_TRI / MI_PRIM_QUAD */
+  uint32_t pad[2];
+};
+
 struct DCamConst                   /* per-launch camera constants of camera_sample (src/camera.d/thinlens.c:68-128), formed once at
                                       upload with the float / double expressions the kernel would evaluate per path */
 {
@@ -94,8 +118,10 @@ struct DScene
   /* materials / lights / camera / tables */
   const DMaterial *materials;
   uint32_t num_lights;
-  const uint32_t *light_prim;      /* builder-order primitive index of each emitter prim */
+  const uint32_t *light_prim;      /* builder-order primitive index of each emitter prim | MI_LIGHT_ANYHIT */
   const float *light_cdf, *light_L;
+  const DLight *lights;            /* [num_lights] or NULL: the one-burst records of next event estimation (plain kernels) */
+  float light_cdf4[4];             /* light_cdf[0..3] by value (kernel argument = scalar registers) when there are at most four emitter primitives */
   float p_sky, p_geo, p_vol;
   mi_camera cam;
   DCamConst cc;
@@ -104,9 +130,6 @@ struct DScene
   float *fb;
   unsigned long long *counters;    /* [MI_COUNTER_SHARDS][8]: same-address atomics serialise at ~11 ns each, so every
                                       workgroup adds into its own shard; mi_counters() sums them */
-  unsigned long long *work;        /* wavefront pipeline: [work_shards] consumed-path counters: every workgroup owns a contiguous part of the
-                                      index range and its own counter (no same-address atomics between workgroups) */
-  uint32_t work_shards;
   /* Halton point sampler (MI_POINTS_HALTON): per dimension {P = digits looked up at once, floor(2^32/P), table offset | groups << 24,
      float bits of the scale}; the digit-permutation tables, concatenated (387 KB, L2 resident) */
   const DPrimT1 *prims_t1;          /* [num_prims] or NULL: shutter-close state of motion-blurred primitives (extended kernels only) */

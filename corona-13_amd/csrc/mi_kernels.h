@@ -1,7 +1,6 @@
 /* mi_kernels.h -- HIP device code of the pt/ptdl path tracing hot path for gfx950 (MI355X).
  *
- * This header holds the device functions shared by the kernel organisations (persistent megakernel in mi_abi.hip,
- * wavefront pipeline in mi_wavefront.h): random numbers, primitive tests, resumable QBVH traversal (trace_round),
+ * This header holds the device functions of the persistent megakernel (mi_abi.hip): random numbers, primitive tests, resumable QBVH traversal (trace_round),
  * surface set-up, materials and BSDFs, emitter sampling, splat. Every lane owns one path at a time,
  *      NEW -> [ EXTEND-ray -> traverse -> shade ( -> SHADOW-ray -> traverse -> connect ) ]* -> NEW
  * and a lane whose path ends re-fills itself in place (wave64 ballot + prefix rank on a workgroup-local counter).
@@ -187,21 +186,32 @@ struct PointSampler
 };
 
 /* ------------------------------------------------------------------------------------------ work counters
- * cnt[0..7]: rays, node visits, box hits, primitive tests, paths, splats, vertices, deepest stack. Development builds
- * append more: -DMI_PROFILE_LOOPS wave-level loop iterations (cnt[8..10]), -DMI_PROFILE_PHASES lane-0 clock ticks per
- * phase (cnt[8+k]), their occurrences (cnt[16+k]), the last marker (cnt[30]) and time stamp (cnt[31]). */
+ * c[0..7]: rays, node visits, box hits, primitive tests, paths, splats, vertices, deepest stack -- the reference's -DACCEL_DEBUG
+ * counters (src/accel.d/qbvhmp.c:83-90,1168-1173) and a few more. Like there they are a debug facility: the COUNT = false
+ * instantiations of the kernels keep only the path count c[4] (the seven others are live in every loop and cost the ptdl kernel
+ * 10 % through register pressure, the pt kernel 1 %); mi_scene_set_counters() selects the counting kernels.
+ * Development builds append more: -DMI_PROFILE_LOOPS wave-level loop iterations (c[8..10]), -DMI_PROFILE_PHASES lane-0 clock
+ * ticks per phase (c[8+k]), their occurrences (c[16+k]), the last marker (c[30]) and time stamp (c[31]). */
 #if defined(MI_PROFILE_PHASES) || defined(MI_PROFILE_LOOPS)
 #define MI_CNT 32
 #else
 #define MI_CNT 8
 #endif
+template<bool ON> struct Counters
+{
+  static constexpr bool on = ON;
+  uint32_t c[MI_CNT];
+  __device__ __forceinline__ Counters() { for(int k=0;k<MI_CNT;k++) c[k] = 0; }
+};
+#define MI_COUNT(cnt, k, v) do { if((cnt).on) (cnt).c[k] += (v); } while(0)
+#define MI_COUNT_MAX(cnt, k, v) do { if((cnt).on) (cnt).c[k] = (cnt).c[k] > (v) ? (cnt).c[k] : (v); } while(0)
 #ifdef MI_PROFILE_PHASES
-#define MI_PHASE_INIT(cnt) { (cnt)[31] = (uint32_t)clock64(); (cnt)[30] = 6; }
+#define MI_PHASE_INIT(cnt) { (cnt).c[31] = (uint32_t)clock64(); (cnt).c[30] = 6; }
 /* markers run 0 1 [2 3 4 7] 5 6 per iteration; an interval counts only if this lane also passed the marker before it */
 #define MI_PHASE(cnt, k) { const uint32_t t_ = (uint32_t)clock64(); \
   const uint32_t pred_ = (k) == 0 ? 6 : (k) == 5 ? 7 : (k) == 7 ? 4 : (k) - 1; \
-  if((cnt)[30] == pred_) { (cnt)[8 + (k)] += t_ - (cnt)[31]; (cnt)[16 + (k)]++; } \
-  (cnt)[31] = t_; (cnt)[30] = (k); }
+  if((cnt).c[30] == pred_) { (cnt).c[8 + (k)] += t_ - (cnt).c[31]; (cnt).c[16 + (k)]++; } \
+  (cnt).c[31] = t_; (cnt).c[30] = (k); }
 #else
 #define MI_PHASE_INIT(cnt)
 #define MI_PHASE(cnt, k)
@@ -553,31 +563,35 @@ __device__ __forceinline__ Lds lds_setup(const DScene &sc, unsigned char *smem, 
 #ifndef MI_TAIL_INNER
 #define MI_TAIL_INNER 4
 #endif
+
 struct TraceState
 { /* resumable traversal of one ray: survives between rounds so that a wave can re-fill idle lanes in between */
   int sp;
   uint32_t current;
   bool done;
+  bool anyhit;           /* shadow ray that may end at the first occluder (MI_LIGHT_ANYHIT); only read by the ANYHIT instantiations */
   float idx, idy, idz;   /* 1/dir, computed once per ray (qbvhmp.c:1291-1295) */
   /* motion blur (MB instantiations only): the ray's time and the shutter-close records */
   float time;
   const DPrimT1 *prims_t1;
 };
 
-__device__ __forceinline__ void trace_begin(TraceState &ts, const V3 d, uint32_t *cnt)
+template<class CNT>
+__device__ __forceinline__ void trace_begin(TraceState &ts, const V3 d, CNT &cnt)
 {
-  cnt[0]++;
+  MI_COUNT(cnt, 0, 1);
   ts.idx = 1.0f/d.x; ts.idy = 1.0f/d.y; ts.idz = 1.0f/d.z;
   ts.sp = 0;
   ts.current = 0;      /* node 0 = root */
   ts.done = false;
+  ts.anyhit = false;
 }
 
 /* one "while-while" round of accel_intersect (src/accel.d/qbvhmp.c:1262-1390, static boxes): descend inner nodes until this
  * lane holds a leaf (or runs out of work), then intersect that leaf and pop the next subtree */
-template<int BLOCK, int STACK, bool MB = false>
+template<int BLOCK, int STACK, bool MB = false, bool ANYHIT = false, class CNT>
 __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, const V3 o, const V3 d, uint32_t ignore,
-                                            Hit &hit, TraceState &ts, uint32_t *cnt)
+                                            Hit &hit, TraceState &ts, CNT &cnt)
 {
   const uint32_t near_x = __float_as_uint(d.x) >> 31, near_y = __float_as_uint(d.y) >> 31, near_z = __float_as_uint(d.z) >> 31;
   const uint32_t nearbits = near_x | (near_y << 1) | (near_z << 2);
@@ -598,9 +612,12 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
       const unsigned ninner = __popcll(__ballot(inner));
       if(!ninner) break;
       if(ninner < MI_TAIL_INNER && __any((current & MI_LEAF32) && !done)) break;
+#ifdef MI_PROFILE_LOOPS
+      const unsigned nround = __popcll(__ballot(!done));    /* lanes of this round whose ray is still under way */
+#endif
       if(!inner) continue;
 #ifdef MI_PROFILE_LOOPS
-      if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) cnt[8]++;   /* wave-level inner iterations */
+      if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) cnt.c[8] += MI_PROFILE_LOOPS == 2 ? nround : 1;   /* wave-level inner iterations (2: lanes still under way) */
 #endif
       const uint32_t node = current;
       const uint4 child = *(const uint4 *)&lds.nodes[6*N + node];
@@ -647,8 +664,8 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
       }
       if(mask)
       {
-        cnt[1]++;
-        cnt[2] += __popc(mask);
+        MI_COUNT(cnt, 1, 1);
+        MI_COUNT(cnt, 2, __popc(mask));
         /* front-to-back order from split axes and ray signs, qbvhmp.c:1313-1320: the near half is children
            {2*near0, 2*near0+1}, ordered by the sign along its own split axis; likewise the far half */
         const uint32_t axis0 = ax & 3u;
@@ -684,7 +701,7 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
           if(p01) { stack_push<BLOCK, STACK>(lds, sp, make_uint2(c01, __float_as_uint(t01))); sp++; }
         }
         current = h00 ? c00 : h01 ? c01 : h10 ? c10 : c11;
-        cnt[7] = cnt[7] > (uint32_t)sp ? cnt[7] : (uint32_t)sp;
+        MI_COUNT_MAX(cnt, 7, (uint32_t)sp);
       }
       else
       { /* pop, skipping entries that start behind the current hit (qbvhmp.c:1357-1364) */
@@ -709,7 +726,7 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
       uint32_t analytic = 0;
       /* two record buffers in ping-pong: the load of primitive i+1 is in flight while i is intersected, and no
          16-register copy is needed per iteration */
-#define MI_LEAF_STEP(R, I) { cnt[3]++; \
+#define MI_LEAF_STEP(R, I) { MI_COUNT(cnt, 3, 1); \
         const uint32_t type = __float_as_uint((R).q3.x); \
         if(type >= MI_PRIM_TRI) { if(idxp + (I) != ignore) triquad_intersect((R), type, o, d, hit, idxp + (I)); }   /* triangle.h:271 */ \
         else analytic |= 1u << (I); }
@@ -717,7 +734,7 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
       for(uint32_t i=0;i<num;i+=2)
       {
 #ifdef MI_PROFILE_LOOPS
-        if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) cnt[9] += 2;   /* wave-level leaf slots */
+        if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) cnt.c[9] += MI_PROFILE_LOOPS == 2 ? 2*__popcll(__ballot(1)) : 2;   /* wave-level leaf slots (2: lane slots of lanes with a leaf) */
 #endif
         if(i + 1 < num) rb = prim_load(prims, idxp + i + 1);
         MI_LEAF_STEP(ra, i)
@@ -731,7 +748,7 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
       while(analytic)
       {
 #ifdef MI_PROFILE_LOOPS
-        if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) cnt[10]++;   /* wave-level analytic passes */
+        if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) cnt.c[10]++;   /* wave-level analytic passes */
 #endif
         const uint32_t i = __ffs(analytic) - 1;
         analytic &= analytic - 1;
@@ -739,6 +756,7 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
       }
       current = MI_LEAF32;
       done = true;
+      if(ANYHIT && ts.anyhit && hit.prim != MI_NOPRIM) sp = 0;   /* an occluder is all a shadow ray needs to know (MI_LIGHT_ANYHIT) */
       while(sp > 0)
       {
         sp--;
@@ -750,9 +768,9 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
   ts.sp = sp; ts.current = current; ts.done = done;
 }
 
-template<int BLOCK, int STACK>
+template<int BLOCK, int STACK, class CNT>
 __device__ __forceinline__ void accel_intersect(const Lds &lds, const DPrim *prims, const V3 o, const V3 d, uint32_t ignore,
-                                                Hit &hit, uint32_t *cnt)
+                                                Hit &hit, CNT &cnt)
 { /* closest hit for one ray per lane; the wave iterates until every lane is done */
   TraceState ts;
   trace_begin(ts, d, cnt);
@@ -1552,6 +1570,22 @@ __device__ __forceinline__ uint32_t sample_cdf(const float *cdf, int num, float 
     t = (mn + mx)/2;
   }
   if(mx < (unsigned)num && cdf[t] <= rand) t = mx;
+  return t;
+}
+
+__device__ __forceinline__ uint32_t sample_cdf4(const float *c4, int num, float rand)
+{ /* sample_cdf over at most four entries held in scalar registers: the same search, no memory round trips */
+  unsigned int mn = 0, mx = num;
+  unsigned int t = mx/2;
+#define MI_CDF4(T) ((T) == 0 ? c4[0] : (T) == 1 ? c4[1] : (T) == 2 ? c4[2] : c4[3])
+  for(int it=0;it<3 && t != mn;it++)          /* mx - mn halves from at most 4: at most two steps */
+  {
+    if(MI_CDF4(t) <= rand) mn = t;
+    else mx = t;
+    t = (mn + mx)/2;
+  }
+  if(mx < (unsigned)num && MI_CDF4(t) <= rand) t = mx;
+#undef MI_CDF4
   return t;
 }
 

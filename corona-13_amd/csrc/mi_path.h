@@ -1,5 +1,4 @@
-/* mi_path.h -- per-path logic of the pt/ptdl hot path, shared by the two kernel organisations of mi_abi.hip
- * (persistent megakernel with path state in registers; wavefront pipeline with path state in HBM).
+/* mi_path.h -- per-path logic of the pt/ptdl hot path (the persistent megakernel of mi_abi.hip keeps the path state in registers).
  *
  *   path_generate   path_init + the length==0 half of path_extend: wavelength, time, thin-lens camera ray
  *                   (src/pathspace.c:13-28,210-249, src/camera.d/thinlens.c:68-128)
@@ -112,8 +111,8 @@ __device__ __forceinline__ void camera_frame_at(const mi_camera &cam, float time
 }
 
 /* start path `index`: afterwards ps holds the camera ray as the pending extension ray */
-template<bool RECORD, bool HALTON, bool MEDIA = false>
-__device__ __forceinline__ void path_generate(const DScene &sc, PathState &ps, unsigned long long index, mi_path_record *rec, uint32_t *cnt)
+template<bool RECORD, bool HALTON, bool MEDIA = false, class CNT>
+__device__ __forceinline__ void path_generate(const DScene &sc, PathState &ps, unsigned long long index, mi_path_record *rec, CNT &cnt)
 {
   /* path_init + first half of path_extend (length == 0), src/pathspace.c:13-28,210-249 */
   ps.index = index;
@@ -173,7 +172,7 @@ __device__ __forceinline__ void path_generate(const DScene &sc, PathState &ps, u
   ps.length = 1;
   ps.active = 1;
   ps.prev_material_modes = s_sensor;
-  cnt[6]++;                                  /* the sensor vertex */
+  MI_COUNT(cnt, 6, 1);                                  /* the sensor vertex */
   if(RECORD)
   {
     rec->index = ps.index; rec->pixel_i = ps.pixel_i; rec->pixel_j = ps.pixel_j; rec->lambda = ps.lambda;
@@ -184,12 +183,12 @@ __device__ __forceinline__ void path_generate(const DScene &sc, PathState &ps, u
 }
 
 /* the shadow ray of the pending next-event connection has been traced into `hit` */
-template<bool RECORD>
-__device__ __forceinline__ void shadow_resolve(const DScene &sc, PathState &ps, const Hit &hit, mi_path_record *rec, uint32_t *cnt, SplatReq &splat)
+template<bool RECORD, class CNT>
+__device__ __forceinline__ void shadow_resolve(const DScene &sc, PathState &ps, const Hit &hit, mi_path_record *rec, CNT &cnt, SplatReq &splat)
 {
    /* path_visible, src/pathspace.c:311-344: closest hit up to the emitter's primitive (all surfaces in scope are opaque) */
   ps.sh_pending = 0;
-  const bool visible = (hit.dist >= ps.sh_dist) || (hit.prim == MI_NOPRIM) || (hit.prim == ps.sh_light);
+  const bool visible = (hit.dist >= ps.sh_dist) || (hit.prim == MI_NOPRIM) || (hit.prim == (ps.sh_light & ~MI_LIGHT_ANYHIT));
   if(visible)
   {
     const float value = ps.sh_value;
@@ -207,7 +206,7 @@ __device__ __forceinline__ void shadow_resolve(const DScene &sc, PathState &ps, 
     }
     if(ok)
     {
-      cnt[5]++;
+      MI_COUNT(cnt, 5, 1);
       if(!RECORD) { splat.pending = true; splat.c0 = col[0]; splat.c1 = col[1]; splat.c2 = col[2]; }
     }
   }
@@ -241,8 +240,8 @@ __device__ __forceinline__ float media_pdf_to_surface(const Medium &m, float dis
 /* the extension ray ended at the sampled free-flight distance ps.clip before any geometry: a volume vertex
  * (path_propagate src/pathspace.c:745-751,771-776; shader_prepare src/shader.c:476-501; manifold_init manifold.h:236-246;
  * phase function src/shaders/medium_rgb.c:61-102; next event estimation as for surfaces) */
-template<bool RECORD, bool PTDL, bool HALTON, bool MB>
-__device__ __forceinline__ void path_shade_volume(const DScene &sc, PathState &ps, mi_path_record *rec, uint32_t *cnt)
+template<bool RECORD, bool PTDL, bool HALTON, bool MB, class CNT>
+__device__ __forceinline__ void path_shade_volume(const DScene &sc, PathState &ps, mi_path_record *rec, CNT &cnt)
 {
   const int v = ps.length;
   bool alive = true;
@@ -262,7 +261,7 @@ __device__ __forceinline__ void path_shade_volume(const DScene &sc, PathState &p
   const float vpdf = (ps.pdf*epdf)*G;
   ps.pdfprod *= (double)vpdf;
   ps.length++;
-  cnt[6]++;
+  MI_COUNT(cnt, 6, 1);
   const float vthr = ps.throughput*(eT/epdf);
   if(RECORD)
   {
@@ -282,7 +281,7 @@ __device__ __forceinline__ void path_shade_volume(const DScene &sc, PathState &p
       const float r2 = pts(MI_DIM_NEE_X);
       const float r1 = pts(MI_DIM_NEE_LIGHT2);
       const uint32_t t = sample_cdf(sc.light_cdf, (int)sc.num_lights, r1);
-      const uint32_t lp = sc.light_prim[t];
+      const uint32_t lpe = sc.light_prim[t], lp = lpe & ~MI_LIGHT_ANYHIT;   /* bit 31: any-hit shadow ray allowed (mi_device.h) */
       Surf ls;
       ls.x = prim_sample<MB>(sc.prims[lp], sc.primgeo[lp], r2, r3, ls.u, ls.v, MB ? sc.prims_t1 + lp : nullptr, ps.time);
       V3 ol = sub3(ls.x, sf.x);
@@ -331,7 +330,7 @@ __device__ __forceinline__ void path_shade_volume(const DScene &sc, PathState &p
             {
               ps.sh_pending = 1;
               ps.sh_org = ro; ps.sh_dir = rd; ps.sh_dist = total_dist;
-              ps.sh_light = lp; ps.sh_ignore = MI_NOPRIM;
+              ps.sh_light = lpe; ps.sh_ignore = MI_NOPRIM;
               ps.sh_value = (tn/1.0f)*wm;
               ps.sh_length = ps.length + 1;
             }
@@ -394,14 +393,14 @@ __device__ __forceinline__ void path_shade_volume(const DScene &sc, PathState &p
       ps.pdf = pdf;
     }
   }
-  if(!alive) { ps.active = 0; cnt[4]++; }
+  if(!alive) { ps.active = 0; cnt.c[4]++; }
 }
 
 /* the extension ray ps.org/ps.dir has been traced into `hit`: create vertex v = ps.length, then either end the path
  * (ps.active = 0) or leave the next extension ray (and, for ptdl, possibly a shadow ray) in ps */
-template<bool RECORD, bool PTDL, bool HALTON, bool MEDIA = false, bool MB = false>
+template<bool RECORD, bool PTDL, bool HALTON, bool MEDIA = false, bool MB = false, class CNT>
 __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, const Hit &hit, const uint32_t *shape_material, const float *shape_L,
-                                           mi_path_record *rec, uint32_t *cnt, SplatReq &splat)
+                                           mi_path_record *rec, CNT &cnt, SplatReq &splat)
 {
   if(MEDIA && hit.prim == MI_NOPRIM && ps.clip < FLT_MAX)
   {
@@ -420,7 +419,7 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
     const float vpdf = MEDIA ? (ps.pdf*1.0f)*G : ps.pdf*G;
     ps.pdfprod *= (double)vpdf;
     ps.length++;
-    cnt[6]++;
+    MI_COUNT(cnt, 6, 1);
     if(RECORD)
     {
       const V3 x = mk3(ps.prev_x.x + sc.far_dist*omega.x, ps.prev_x.y + sc.far_dist*omega.y, ps.prev_x.z + sc.far_dist*omega.z);
@@ -505,7 +504,7 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
       const double pp_before = ps.pdfprod;
       ps.pdfprod *= (double)vpdf;
       ps.length++;
-      cnt[6]++;
+      MI_COUNT(cnt, 6, 1);
       float path_throughput = 0.0f;
       if(mode & s_emit)
       { /* lights_eval_vertex, src/lights.d/list.c:242-275 */
@@ -558,7 +557,7 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
         }
         if(ok)
         {
-          cnt[5]++;
+          MI_COUNT(cnt, 5, 1);
           if(!RECORD) { splat.pending = true; splat.c0 = col[0]; splat.c1 = col[1]; splat.c2 = col[2]; }
         }
         if(!PTDL && ps.length > 3)
@@ -588,19 +587,62 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
             const float r3 = pts(MI_DIM_NEE_Y);
             const float r2 = pts(MI_DIM_NEE_X);
             const float r1 = pts(MI_DIM_NEE_LIGHT2);
-            const uint32_t t = sample_cdf(sc.light_cdf, (int)sc.num_lights, r1);
-            const uint32_t lp = sc.light_prim[t];
+            uint32_t lpe, lp;
             Surf ls;
-            ls.x = prim_sample<MB>(sc.prims[lp], sc.primgeo[lp], r2, r3, ls.u, ls.v, MB ? sc.prims_t1 + lp : nullptr, ps.time);
-            V3 ol = sub3(ls.x, sf.x);
-            const float ldist = sqrtf(dot3(ol, ol));
-            const double il = 1./(double)ldist;
-            ol = mk3((float)((double)ol.x*il), (float)((double)ol.y*il), (float)((double)ol.z*il));
-            const uint4 lhead = *(const uint4 *)&sc.primgeo[lp];
-            surface_setup<MB>(sc, lp, lhead, ol, ps.scramble, ls, ps.time);
             Shading lsh;
-            run_prepare_ops(sc, sc.materials[lhead.y], sc.materials[lhead.y].num_ops, ls, ps.lambda, lsh);
-            float lpdf = sc.light_L[t];
+            float lpdf, ldist;
+            V3 ol;
+            if(!MEDIA && !MB)
+            { /* plain kernels: every emitter primitive is a static triangle / quad with a colour-only material and has a DLight record
+                 (mi_scene_create sends every other scene to the extended kernels): one burst of ten 16-B loads instead of the chain
+                 emitter list -> primitive -> shading record -> material -> ops. Same arithmetic as the generic branch below. */
+              const uint32_t t = sc.num_lights <= 4 ? sample_cdf4(sc.light_cdf4, (int)sc.num_lights, r1) : sample_cdf(sc.light_cdf, (int)sc.num_lights, r1);
+              const float4 *lq = (const float4 *)(sc.lights + t);
+              const float4 q0 = lq[0], q1 = lq[1], q2 = lq[2], q3 = lq[3], q4 = lq[4], q5 = lq[5], q6 = lq[6], q7 = lq[7], q8 = lq[8], q9 = lq[9];
+              lpe = __float_as_uint(q9.x); lp = lpe & ~MI_LIGHT_ANYHIT;
+              const bool quad = __float_as_uint(q9.y) == MI_PRIM_QUAD;
+              const V3 v0 = mk3(q0.x, q0.y, q0.z), v1 = mk3(q0.w, q1.x, q1.y), v2 = mk3(q1.z, q1.w, q2.x), v3 = mk3(q2.y, q2.z, q2.w);
+              /* prims_sample + prims_retime, src/prims.c:178-252 */
+              float hu, hv;
+              if(quad) { hu = r2; hv = r3; }
+              else { const float a = sqrtf(r2); hu = r3*a; hv = (1.0f-r3)*a; }
+              const bool second = quad && !(hv >= hu);
+              const float u = second ? hu - hv : hu;
+              const float vv = !quad ? hv : second ? hv : hv - hu;
+              ls.x = second ? tri_retime(v0, v2, v3, u, vv) : tri_retime(v0, v1, v2, u, vv);
+              ls.u = hu; ls.v = hv;
+              ol = sub3(ls.x, sf.x);
+              ldist = sqrtf(dot3(ol, ol));
+              const double il = 1./(double)ldist;
+              ol = mk3((float)((double)ol.x*il), (float)((double)ol.y*il), (float)((double)ol.z*il));
+              /* prims_get_normal_time for triangles / quads (surface_setup); the flip towards the ray changes neither |n.omega| nor gn */
+              const V3 n0 = mk3(q3.x, q3.y, q3.z);
+              const V3 na = second ? mk3(q4.z, q4.w, q5.x) : mk3(q3.w, q4.x, q4.y);      /* n2 : n1 */
+              const V3 nb = second ? mk3(q5.y, q5.z, q5.w) : mk3(q4.z, q4.w, q5.x);      /* n3 : n2 */
+              ls.gn = second ? mk3(q6.w, q7.x, q7.y) : mk3(q6.x, q6.y, q6.z);
+              const float w = 1.0f - u - vv;
+              ls.n = normalise3(mk3(u*nb.x + vv*na.x + w*n0.x, u*nb.y + vv*na.y + w*n0.y, u*nb.z + vv*na.z + w*n0.z));
+              ls.flags = 0;
+              /* the material's prepare chain, all plain colours (run_prepare_ops): emission and the last line's roughness */
+              const float ec[3] = { q7.z, q7.w, q8.x };
+              lsh.em = q8.y*spectrum_eval(ec, ps.lambda);
+              lsh.roughness = q8.z;
+              lpdf = q8.w;
+            }
+            else
+            {
+              const uint32_t t = sample_cdf(sc.light_cdf, (int)sc.num_lights, r1);
+              lpe = sc.light_prim[t]; lp = lpe & ~MI_LIGHT_ANYHIT;   /* bit 31: any-hit shadow ray allowed (mi_device.h) */
+              ls.x = prim_sample<MB>(sc.prims[lp], sc.primgeo[lp], r2, r3, ls.u, ls.v, MB ? sc.prims_t1 + lp : nullptr, ps.time);
+              ol = sub3(ls.x, sf.x);
+              ldist = sqrtf(dot3(ol, ol));
+              const double il = 1./(double)ldist;
+              ol = mk3((float)((double)ol.x*il), (float)((double)ol.y*il), (float)((double)ol.z*il));
+              const uint4 lhead = *(const uint4 *)&sc.primgeo[lp];
+              surface_setup<MB>(sc, lp, lhead, ol, ps.scramble, ls, ps.time);
+              run_prepare_ops(sc, sc.materials[lhead.y], sc.materials[lhead.y].num_ops, ls, ps.lambda, lsh);
+              lpdf = sc.light_L[t];
+            }
             float edf = lsh.em/lpdf;
             if(lsh.roughness > 1.0f-1e-4f) edf = (float)((double)edf*((double)1.0f/MI_PI_D));
             else
@@ -655,7 +697,7 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
                   {
                     ps.sh_pending = 1;
                     ps.sh_org = ro; ps.sh_dir = rd; ps.sh_dist = total_dist;
-                    ps.sh_light = lp; ps.sh_ignore = hit.prim;
+                    ps.sh_light = lpe; ps.sh_ignore = hit.prim;
                     ps.sh_value = (tn/1.0f)*wm;
                     ps.sh_length = ps.length + 1;
                   }
@@ -724,7 +766,7 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
       }
     }
   }
-  if(!alive) { ps.active = 0; cnt[4]++; }
+  if(!alive) { ps.active = 0; cnt.c[4]++; }
 }
 
 #endif

@@ -130,8 +130,9 @@ int main(int argc, char *argv[])
     fprintf(f, "           cam 0 average image intensity (rgb): (%f %f %f)\n", mean[0]*gain/per, mean[1]*gain/per, mean[2]*gain/per);
     fprintf(f, "sampler  : %s\n", d->sampler == MI_SAMPLER_PTDL ? "pathtracer with next event estimation and mis" : "pathtracer");
     fprintf(f, "mutations: %s\n", d->pointsampler == MI_POINTS_HALTON ? "halton points" : "none");
-    fprintf(f, "work     : %.4f rays %.4f node visits %.4f prim tests %.5f splats per sample\n",
-        (double)cnt[0]/cnt[4], (double)cnt[1]/cnt[4], (double)cnt[3]/cnt[4], (double)cnt[5]/cnt[4]);
+    if(cnt[0])        /* the debug counters are only live under CORONA_MI_COUNTERS=1 (mi_scene_set_counters), like the reference's -DACCEL_DEBUG */
+      fprintf(f, "work     : %.4f rays %.4f node visits %.4f prim tests %.5f splats per sample\n",
+          (double)cnt[0]/cnt[4], (double)cnt[1]/cnt[4], (double)cnt[3]/cnt[4], (double)cnt[5]/cnt[4]);
     fclose(f);
   }
   printf("\n[main] rendered %lu spp in %.3f s (%.2f Msamples/s), saved %s%s_fb00.pfm\n", (unsigned long)overlays, t_prog,

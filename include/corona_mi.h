@@ -243,8 +243,12 @@ float *mi_fb_device_ptr(mi_scene *s);
 
 /* Work counters since creation, same four quantities as the reference's -DACCEL_DEBUG
  * (src/accel.d/qbvhmp.c:83-90): [0] rays (accel_intersect calls), [1] node visits with >=1 box hit,
- * [2] box hits, [3] primitive tests; plus [4] paths, [5] splats, [6] path vertices, [7] reserved. */
+ * [2] box hits, [3] primitive tests; plus [4] paths, [5] splats, [6] path vertices, [7] deepest traversal stack.
+ * Like the reference's, they are a debug facility: only [4] (paths) is counted by default; mi_scene_set_counters(s, 1)
+ * (or CORONA_MI_COUNTERS=1 in the environment when the scene is created) selects the counting kernels for the renders that
+ * follow -- same results, the ptdl kernel is about 10 % slower with them. mi_intersect and mi_trace_paths always count. */
 int  mi_counters(mi_scene *s, uint64_t out[8]);
+int  mi_scene_set_counters(mi_scene *s, int enable);
 
 /* Debug/test entry: trace `count` paths starting at `first` and write one mi_path_record per
  * path (no splatting into the framebuffer). Used by the parity tests to compare path by path. */

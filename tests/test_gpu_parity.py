@@ -66,25 +66,12 @@ CASES = [
 ]
 
 
-def megakernel_only():
-    """Halton, media and motion blur exist in the megakernel only; the developer switch CORONA_MI_MODE=wave (tools/nodes_check.sh runs
-    the suite under it) selects the wavefront pipeline, which refuses such scenes"""
-    import os
-    if os.environ.get("CORONA_MI_MODE") == "wave":
-        pytest.skip("CORONA_MI_MODE=wave: the wavefront pipeline has no Halton / media / motion blur")
-
-
-EXTENDED = ("halton", "media", "fog", "nested", "camera motion blur", "moving geometry")
-
-
 def points_of(name):
     return pkg.MI_POINTS_HALTON if name.startswith("halton") else pkg.MI_POINTS_RAND
 
 
 @pytest.mark.parametrize("name,scene_path,sampler,w,h,mv,n", CASES)
 def test_paths_match_oracle(name, scene_path, sampler, w, h, mv, n):
-    if name.startswith(EXTENDED):
-        megakernel_only()
     scene = make_scene(scene_path, width=w, height=h, max_verts=mv, sampler=sampler, pointsampler=points_of(name))
     be = pkg.Backend(scene)
     first = 12345
@@ -93,22 +80,28 @@ def test_paths_match_oracle(name, scene_path, sampler, w, h, mv, n):
     assert np.array_equal(gpu["index"], ora["index"])
     for f in ("pixel_i", "pixel_j", "lambda", "time", "scramble"):
         assert np.abs(gpu[f] - ora[f]).max() <= 1e-5, f
+    # what the build achieves (99.9995 % identical paths on 20 M-path soaks), not a loose bound: at most
+    # 2 paths in 100 000 may part ways with the oracle (grazing hits decided by the last ulp of the device libm's sinf / atan2f)
+    allowed = max(2, int(np.ceil(2e-5 * n)))
     same = gpu["length"] == ora["length"]
-    assert same.mean() >= 0.999
-    assert (gpu["num_splats"] == ora["num_splats"]).mean() >= 0.999
+    assert (~same).sum() <= allowed, (~same).sum()
+    # a path's splat count also changes when ONE of its next-event connections flips (a shadow ray grazing an edge, a weight at the
+    # float underflow limit): up to 7 connections per path at depth 8, 31 at depth 32, most of them in the media scenes
+    allowed_splats = allowed if sampler == pkg.MI_SAMPLER_PT else int(np.ceil((2e-4 if mv <= 8 else 1e-3) * n))
+    assert (gpu["num_splats"] != ora["num_splats"]).sum() <= allowed_splats
     for k in range(1, 8):
         m = same & (ora["length"] > k)
         if not m.sum():
             continue
-        assert (gpu["v"]["prim"][m, k] == ora["v"]["prim"][m, k]).mean() >= 0.999
+        assert (gpu["v"]["prim"][m, k] != ora["v"]["prim"][m, k]).sum() <= allowed
         dx = np.abs(gpu["v"]["x"][m, k] - ora["v"]["x"][m, k]).max(axis=1)
         # positions drift with every glossy bounce (libm sin/cos/atan2 differ in the last ulp between host and device)
         assert np.quantile(dx, 0.999) < (2e-3 if k <= 2 else 1e-2)
         # a moving camera's frame comes out of acosf / sinf per path: the last-ulp libm difference sits on every vertex from the start
         assert np.quantile(rel(gpu["v"]["throughput"][m, k], ora["v"]["throughput"][m, k]), 0.999) < (2e-2 if name.startswith(("camera motion blur", "moving geometry")) else 1e-3)
-        assert (gpu["v"]["flags"][m, k] == ora["v"]["flags"][m, k]).mean() >= 0.999
-        assert (gpu["v"]["mode"][m, k] == ora["v"]["mode"][m, k]).mean() >= 0.999
-        assert (gpu["v"]["shader"][m, k] == ora["v"]["shader"][m, k]).mean() >= 0.999
+        assert (gpu["v"]["flags"][m, k] != ora["v"]["flags"][m, k]).sum() <= allowed
+        assert (gpu["v"]["mode"][m, k] != ora["v"]["mode"][m, k]).sum() <= allowed
+        assert (gpu["v"]["shader"][m, k] != ora["v"]["shader"][m, k]).sum() <= allowed
         assert np.quantile(rel(gpu["v"]["pdf"][m, k], ora["v"]["pdf"][m, k]), 0.999) < (2e-2 if name.startswith(("camera motion blur", "moving geometry")) else 5e-3)
     m = same & (gpu["num_splats"] == ora["num_splats"]) & (ora["num_splats"] > 0)
     if m.sum():
@@ -117,6 +110,27 @@ def test_paths_match_oracle(name, scene_path, sampler, w, h, mv, n):
         assert np.array_equal(np.isnan(a), np.isnan(b))
         assert np.quantile(rel(a[fin], b[fin]), 0.99) < 1e-3
     be.close()
+
+
+def test_soak_two_million_paths():
+    """a 2 M-path slice of tests/dev/parity_soak.py inside the suite: cfg 2 (pt, depth 8) against the oracle, chunk by chunk --
+    primitive sequence, vertex count and splat count of every path; at most 2 in 100 000 may differ (measured: 5 in a million)"""
+    scene = make_scene(SCENE_0010, width=1280, height=720, max_verts=8)
+    be = pkg.Backend(scene)
+    total, chunk, bad = 2000000, 250000, 0
+    worst = 0.0
+    for first in range(777, 777 + total, chunk):
+        g = be.trace_paths(first, chunk)
+        o = oracle_records(scene, first, chunk)
+        k = np.arange(8)[None, :]
+        valid = k < np.minimum(o["length"], 8)[:, None]
+        ok = (g["length"] == o["length"]) & ((g["v"]["prim"] == o["v"]["prim"]) | ~valid).all(axis=1) & (g["num_splats"] == o["num_splats"])
+        bad += int((~ok).sum())
+        m = ok[:, None] & valid & (k >= 1)
+        worst = max(worst, float(np.quantile(rel(g["v"]["throughput"][m], o["v"]["throughput"][m]), 0.9999)))
+    be.close()
+    assert bad <= 2e-5 * total, bad
+    assert worst < 1e-3, worst
 
 
 def test_paths_match_reference_golden():
@@ -160,30 +174,41 @@ def test_image_matches_oracle_1spp():
     be.close()
 
 
-def test_ptdl_image_matches_oracle_1spp():
-    """BASELINE config 3 (0011_ptdl: next event estimation + shadow rays)"""
+def test_ptdl_image_matches_oracle_1spp(monkeypatch):
+    """BASELINE config 3 (0011_ptdl: next event estimation + shadow rays). Shadow rays towards the (planar quad) emitter stop at
+    the first occluder by default (MI_LIGHT_ANYHIT, mi_device.h): same image and splats as the oracle's closest-hit traversal,
+    fewer node visits; CORONA_MI_SHADOW=closest runs the reference's traversal, whose counters then equal the oracle's and,
+    through it, the reference's own -DACCEL_DEBUG totals."""
     scene = make_scene(SCENE_0010, width=1280, height=720, max_verts=8, sampler=pkg.MI_SAMPLER_PTDL)
-    be = pkg.Backend(scene)
     n = scene.width * scene.height
-    be.render(0, n)
-    fb = be.fb_read()
     ofb, ocnt, _ = oracle_render(scene, 0, n, threads=8)
     gain = scene.gain(1)
-    rmse = np.sqrt((((fb - ofb) * gain) ** 2).sum() / n)
-    assert rmse < 0.5, rmse                       # a handful of shadow rays grazing the emitter edge may flip
-    assert np.allclose(fb.sum(axis=(0, 1)), ofb.sum(axis=(0, 1)), rtol=2e-3)
-    cnt = be.counters()
-    for k in (0, 1, 2, 3, 5):
-        assert abs(cnt[k] - ocnt[k]) <= 2e-3 * ocnt[k], (k, cnt[k], ocnt[k])
     gold = json.loads((GOLDEN / "counters.json").read_text())["ptdl_mv8"]
-    for k, key in ((0, "rays"), (1, "node_visits"), (2, "box_hits"), (3, "prim_tests")):
-        assert abs(cnt[k] - gold[key]) <= 3e-3 * gold[key], (key, cnt[k], gold[key])
-    # 64 spp mean vs the reference's own 64-spp ptdl value (1.0743, 1.0716, 1.0624), BASELINE.md
-    be.fb_clear()
-    be.render(0, 64 * n)
-    mean = (be.fb_read() * scene.gain(64)).mean(axis=(0, 1))
-    assert np.all(np.abs(mean - np.array([1.0743, 1.0716, 1.0624])) < 0.01), mean
-    be.close()
+    counts = {}
+    for mode in ("anyhit", "closest"):
+        if mode == "closest":
+            monkeypatch.setenv("CORONA_MI_SHADOW", "closest")
+        be = pkg.Backend(scene)
+        be.render(0, n)
+        fb = be.fb_read()
+        rmse = np.sqrt((((fb - ofb) * gain) ** 2).sum() / n)
+        assert rmse < 0.5, rmse                       # a handful of shadow rays grazing the emitter edge may flip
+        assert np.allclose(fb.sum(axis=(0, 1)), ofb.sum(axis=(0, 1)), rtol=2e-3)
+        cnt = counts[mode] = be.counters()
+        for k in (0, 5) if mode == "anyhit" else (0, 1, 2, 3, 5):      # rays and splats always; the traversal work in closest-hit mode
+            assert abs(cnt[k] - ocnt[k]) <= 2e-3 * ocnt[k], (mode, k, cnt[k], ocnt[k])
+        if mode == "closest":
+            for k, key in ((0, "rays"), (1, "node_visits"), (2, "box_hits"), (3, "prim_tests")):
+                assert abs(cnt[k] - gold[key]) <= 3e-3 * gold[key], (key, cnt[k], gold[key])
+        else:
+            # 64 spp mean vs the reference's own 64-spp ptdl value (1.0743, 1.0716, 1.0624), BASELINE.md
+            be.fb_clear()
+            be.render(0, 64 * n)
+            mean = (be.fb_read() * scene.gain(64)).mean(axis=(0, 1))
+            assert np.all(np.abs(mean - np.array([1.0743, 1.0716, 1.0624])) < 0.01), mean
+        be.close()
+    assert counts["anyhit"][0] == counts["closest"][0] and counts["anyhit"][5] == counts["closest"][5]      # same rays, same splats
+    assert counts["anyhit"][1] < counts["closest"][1] and counts["anyhit"][3] < counts["closest"][3]        # ... for less traversal work
 
 
 def test_full_size_properties_cfg2():
@@ -374,26 +399,6 @@ def test_cfg5_film_3840x2160():
     for k in range(4):
         assert abs(cnt[k] - ocnt[k]) <= 1e-3 * ocnt[k], (k, cnt[k], ocnt[k])
     be.close()
-
-
-@pytest.mark.parametrize("sampler", [pkg.MI_SAMPLER_PT, pkg.MI_SAMPLER_PTDL])
-def test_wavefront_pipeline_equals_megakernel(sampler, monkeypatch):
-    """the two kernel organisations (CORONA_MI_MODE, read at mi_scene_create) trace the same paths: equal work counters,
-    equal images up to the order of the float atomics"""
-    scene = make_scene(SCENE_0010, width=640, height=352, max_verts=8, sampler=sampler)
-    n = 4 * scene.width * scene.height
-    out = {}
-    for mode in ("mega", "wave"):
-        monkeypatch.setenv("CORONA_MI_MODE", mode)
-        be = pkg.Backend(scene)
-        be.render(77, n)
-        out[mode] = (be.fb_read(), be.counters(), be.last_kernel_launches())
-        be.close()
-    assert out["mega"][2] == 1 and out["wave"][2] > 1
-    assert out["mega"][1][:7] == out["wave"][1][:7]
-    a, b = out["mega"][0], out["wave"][0]
-    assert np.abs(a - b).max() <= 1e-4 * np.abs(a).max()
-    assert np.allclose(a.sum(axis=(0, 1)), b.sum(axis=(0, 1)), rtol=1e-5)
 
 
 def test_tree_larger_than_lds_is_read_from_hbm():
@@ -595,7 +600,6 @@ def test_scene_stats():
 
 def test_halton_long_paths_against_reference_golden():
     """the reference's own 29..32-vertex ptdl paths (dimension >= 256 falls back to the per-path generator, halton.c:78-80)"""
-    megakernel_only()
     g = np.load(GOLDEN / "paths_halton_long_mv32.npz")
     ref = g["records"]
     scene = make_scene(SCENE_ROUGH, width=1280, height=720, max_verts=32, sampler=pkg.MI_SAMPLER_PTDL, pointsampler=pkg.MI_POINTS_HALTON)
@@ -614,7 +618,6 @@ def test_halton_long_paths_against_reference_golden():
 def test_halton_golden_and_reseeding():
     """the first reference paths directly; and a range whose end passes 2^32 indices is rendered with the permutations of
     seed frame + 1 (pointsampler_prepare_frame, halton.c:122-129) while the index itself is cut to 32 bits"""
-    megakernel_only()
     g = np.load(GOLDEN / "paths_halton_pt_mv8.npz")
     ref = g["records"]
     scene = make_scene(SCENE_0010, width=1280, height=720, max_verts=8, pointsampler=pkg.MI_POINTS_HALTON)
@@ -636,8 +639,7 @@ def test_halton_golden_and_reseeding():
     be.close()
 
 
-def test_halton_image_matches_oracle_and_differs_from_rand(monkeypatch):
-    megakernel_only()
+def test_halton_image_matches_oracle_and_differs_from_rand():
     scene = make_scene(SCENE_0010, width=256, height=256, max_verts=8, pointsampler=pkg.MI_POINTS_HALTON)
     npx = scene.width * scene.height
     be = pkg.Backend(scene)
@@ -655,15 +657,11 @@ def test_halton_image_matches_oracle_and_differs_from_rand(monkeypatch):
     fr = be.fb_read()
     be.close()
     assert abs(fr.sum() - fb.sum()) < 0.25 * fb.sum() and not np.allclose(fr, fb)      # same image in expectation (pt at 4 spp: noisy), other samples
-    monkeypatch.setenv("CORONA_MI_MODE", "wave")
-    with pytest.raises(RuntimeError, match="megakernel"):
-        pkg.Backend(scene)
 
 
 @pytest.mark.parametrize("scene_path,sampler", [(SCENE_MEDIA, pkg.MI_SAMPLER_PT), (SCENE_FOG, pkg.MI_SAMPLER_PTDL)])
 def test_media_image_matches_oracle(scene_path, sampler):
     """1-spp film through the MEDIA kernels (splats of paths with volume vertices included) against the oracle's"""
-    megakernel_only()
     scene = make_scene(scene_path, width=512, height=288, max_verts=8, sampler=sampler)
     npx = scene.width * scene.height
     be = pkg.Backend(scene)
@@ -679,16 +677,8 @@ def test_media_image_matches_oracle(scene_path, sampler):
     assert cnt[5] == ocnt[5] or abs(cnt[5] - ocnt[5]) <= 1e-3 * ocnt[5]                                            # splats
 
 
-def test_media_restrictions_are_reported(monkeypatch):
-    megakernel_only()
-    monkeypatch.setenv("CORONA_MI_MODE", "wave")
-    with pytest.raises(RuntimeError, match="megakernel"):
-        pkg.Backend(make_scene(SCENE_FOG, width=64, height=64, max_verts=4))
-
-
 def test_motion_blur_image_and_restrictions():
     """1-spp film of the moving-geometry scene against the oracle; what the backend cannot do with moving primitives is reported"""
-    megakernel_only()
     scene = make_scene(SCENE_MB, width=512, height=288, max_verts=8)
     npx = scene.width * scene.height
     be = pkg.Backend(scene)
