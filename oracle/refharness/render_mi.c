@@ -1,0 +1,379 @@
+/* oracle/refharness/render_mi.c -- the drop-in on the REFERENCE'S OWN HOST. TEST INFRASTRUCTURE, build-container only (our code).
+ *
+ * A MOD_render module for the real reference (hanatos/corona-13): it implements the reference's render interface
+ * (include/render.h:13-28) and is linked by oracle/Makefile with the reference's own sources -- its .nra2 / .geo / .cam loaders,
+ * its QBVH builder (src/accel.d/qbvhmp.c), its shader plugins, its emitter list, its progression loop (view_render,
+ * src/view.c:630-695), its PFM writer -- and with libcorona_mi.so through the C ABI (include/corona_mi.h) ONLY.
+ *
+ * Where src/render.d/gi.c:81-105 builds one path on the calling pool thread, this module lets the first worker that arrives
+ * in a progression claim the whole remaining index range [counter, end) of view_render's job counter (src/view.c:618-645,
+ * include/threads.h:22-37), renders it with mi_render on the GPU and adds the result to the reference's mmap'ed
+ * framebuffer (include/framebuffer.h:76-113) with mi_fb_read. The scene description handed to mi_scene_create is filled
+ * from the reference's LIVE globals, not from the scene files:
+ *
+ *   tree        rt.accel          the reference builder's qbvh_node_t array (src/accel.d/qbvhmp.c:62-81,175-193)
+ *   primitives  rt.prims          primid array in builder order, per-shape vtxidx / vtx arrays (include/prims.h:49-83)
+ *   materials   rt.shader         the dlopen'ed plugin chain of every shader line: plugin found by its symbols, parameters
+ *                                 read from the plugin's instance data (src/shaders/{color,mult,colorcheckersg,dielectric,
+ *                                 metal,medium_rgb,interior}.c) -> mi_material
+ *   emitters    rt.lights         primid / L arrays of src/lights.d/list.c:8-20 after lights_prepare_frame, cdf as in 76-104
+ *   camera      rt.view           camera_t (include/camera.h:13-35) + view_cam_init_frame (src/view.c:903-919)
+ *   film        rt.view           width, height, frame buffer 0
+ *
+ * The private structs of the reference that have no accessor are re-declared below to READ them (layout only). The sampler
+ * (MOD_sampler, compile time in the reference) arrives as -DMI_HOST_SAMPLER, the point sampler as -DMI_HOST_POINTS.
+ *
+ * tests/test_reference_host.py (-m gpu) runs this binary on scenes/0010_pt with the reference's own command line and compares
+ * its PFM with corona-mi's (our host): same paths, so equal up to the order of the float atomics.
+ */
+#include "corona_common.h"
+#include "render.h"
+#include "points.h"
+#include "pointsampler.h"
+#include "threads.h"
+#include "pathspace.h"
+#include "view.h"
+#include "spectrum.h"
+#include "prims.h"
+#include "accel.h"
+#include "shader.h"
+#include "lights.h"
+#include "camera.h"
+#include "framebuffer.h"
+#include <dlfcn.h>
+#include <float.h>
+#include <pthread.h>
+
+#include "corona_mi.h"
+
+#ifndef MI_HOST_SAMPLER
+#define MI_HOST_SAMPLER MI_SAMPLER_PT
+#endif
+#ifndef MI_HOST_POINTS
+#define MI_HOST_POINTS MI_POINTS_RAND
+#endif
+
+/* ---- layouts of reference-private structs (read only) -------------------------------------------------------------------- */
+/* src/accel.d/qbvhmp.c:62-81,175-193 */
+typedef struct { float4_t aabb0[6]; float4_t aabb1[6]; uint64_t child[4]; uint64_t parent; int64_t axis0, axis00, axis01; } ref_node_t;
+typedef struct { void *queue; uint64_t built; pthread_mutex_t mutex; float *prim_aabb; uint64_t num_nodes; uint64_t node_bufsize;
+                 float aabb[6]; ref_node_t *tree; struct prims_t *prims; } ref_accel_t;
+/* src/lights.d/list.c:8-20 */
+typedef struct { float *prim_area; float *L; primid_t *primid; uint32_t num_alloced_prims, num_prims, inited; float p_geo, p_sky, p_vol; void *vol; } ref_lights_t;
+/* src/view.c:29-67, up to the frame buffers */
+typedef struct { struct camera_t cam[2]; int num_cams; float eye_dist; float active_camid; uint64_t width, height; uint64_t overlays; float gain;
+                 double time_wallclock, time_overlays, time_user; double *stat_enery; uint64_t *stat_cnt; int num_fbs; framebuffer_t *fb; } ref_view_t;
+/* instance data of the shader plugins */
+typedef struct { float coeff[3]; float mul; float roughness; int slot; } ref_color_t;             /* src/shaders/color.c:27-34 */
+typedef struct { int num; int *pre; int host; } ref_mult_t;                                         /* src/shaders/mult.c:22-28 */
+typedef struct { int slot; float roughness; } ref_checker_t;                                        /* src/shaders/colorcheckersg.c:41-46 */
+typedef struct { int mat; } ref_metal_t;                                                            /* src/shaders/metal.c:37-41 */
+typedef struct { float mu_t_coeff[3]; float mul; float g; int mshader; } ref_medium_t;             /* src/shaders/medium_rgb.c:29-36 */
+typedef struct { int surface; int interior; } ref_interior_t;                                       /* src/shaders/interior.c:28-33 */
+
+typedef struct render_t
+{
+  pthread_mutex_t mutex;
+  mi_scene *scene;
+  /* storage behind the descriptor */
+  mi_node *nodes;
+  mi_shape *shapes;
+  mi_vtxidx *vtxidx;
+  mi_vtx *vtx;
+  mi_material *materials;
+  float *cdf, *cie, *checker, *metal;
+  double t_device;
+  uint64_t paths;
+  int failed;
+}
+render_t;
+
+typedef struct render_tls_t { int unused; } render_tls_t;
+
+render_t *render_init()
+{
+  render_t *r = (render_t *)common_alloc(256, sizeof(render_t));
+  memset(r, 0, sizeof(*r));
+  pthread_mutex_init(&r->mutex, 0);
+  return r;
+}
+
+void render_cleanup(render_t *r)
+{
+  if(r->scene)
+  {
+    fprintf(stderr, "[render_mi] %lu paths on the device in %.3f s (%.1f Msamples/s including read-back)\n", (unsigned long)r->paths, r->t_device,
+        r->t_device > 0 ? r->paths/r->t_device/1e6 : 0.0);
+    mi_scene_destroy(r->scene);
+    mi_shutdown();
+  }
+  free(r->nodes); free(r->shapes); free(r->vtxidx); free(r->vtx); free(r->materials); free(r->cdf); free(r->cie); free(r->checker); free(r->metal);
+  free(r);
+}
+
+render_tls_t *render_tls_init() { return (render_tls_t *)common_alloc(256, sizeof(render_tls_t)); }
+void render_tls_cleanup(render_tls_t *r) { free(r); }
+void render_clear() { if(rt.render->scene) mi_fb_clear(rt.render->scene); }
+void render_print_info(FILE *fd) { fprintf(fd, "render   : global illumination on the MI355X backend (libcorona_mi.so through the C ABI)\n"); }
+void render_splat(const path_t *p, const mf_t value) { view_splat(p, value); }
+
+/* ---- materials: the plugin chain of one shader line -> the backend's closed set -------------------------------------------- */
+static const char *plugin_of(int k)
+{ /* which lib<name>.so serves shader k: the one whose `init` symbol the loader stored (src/shader.c:727-757) */
+  const shader_so_t *s = rt.shader->shader + k;
+  for(int i=0;i<rt.shader->num_handles;i++)
+  {
+    void *init = dlsym(rt.shader->handle[i], "init");
+    if(init && (void *)s->init == init) return rt.shader->dlname[i];
+  }
+  return "diffuse";        /* the builtin (src/shader.c:157-257), also what an `exterior` line leaves behind */
+}
+
+static uint32_t slot_of(int ref_slot)
+{ /* tex_slot_t, src/shaders/texture.h:8-23 */
+  switch(ref_slot)
+  {
+    case 0: return MI_SLOT_DIFFUSE;  case 1: return MI_SLOT_SPECULAR; case 2: return MI_SLOT_EMISSION; case 3: return MI_SLOT_VOLUME;
+    case 4: return MI_SLOT_GLOSSY;   case 5: return MI_SLOT_ROUGHNESS; default: return MI_SLOT_UNUSED;
+  }
+}
+
+static int compile_material(int id, mi_material *m)
+{
+  memset(m, 0, sizeof(*m));
+  m->bsdf = MI_BSDF_NONE;
+  m->interior = -1;
+  if(id < 0 || id >= rt.shader->num_shaders) return 1;
+  const char *name = plugin_of(id);
+  const void *data = rt.shader->shader[id].data;
+  if(!strcmp(name, "interior"))
+  { /* src/shaders/interior.c:101-118: the surface's material, the shape filled with the medium */
+    const ref_interior_t *in = (const ref_interior_t *)data;
+    mi_material medium;
+    if(compile_material(in->interior, &medium) || medium.bsdf != MI_BSDF_MEDIUM) return 1;
+    if(!strcmp(plugin_of(in->surface), "interior") || compile_material(in->surface, m) || m->bsdf == MI_BSDF_MEDIUM) { m->bsdf = MI_BSDF_NONE; return 1; }
+    m->interior = in->interior;
+    return 0;
+  }
+  int host = id;
+  if(!strcmp(name, "mult"))
+  { /* src/shaders/mult.c:141-167: run the `pre` prepares, delegate to `host` */
+    const ref_mult_t *mu = (const ref_mult_t *)data;
+    host = mu->host;
+    if(mu->num > MI_MAX_OPS || host < 0 || host >= rt.shader->num_shaders) return 1;
+    for(int k=0;k<mu->num;k++)
+    {
+      const int p = mu->pre[k];
+      if(p < 0 || p >= rt.shader->num_shaders) return 1;
+      const char *pn = plugin_of(p);
+      mi_shade_op *op = m->op + m->num_ops;
+      if(!strcmp(pn, "color"))
+      {
+        const ref_color_t *c = (const ref_color_t *)rt.shader->shader[p].data;
+        op->kind = MI_OP_COLOR; op->slot = slot_of(c->slot);
+        memcpy(op->coeff, c->coeff, sizeof(op->coeff));
+        op->mul = c->mul; op->roughness = c->roughness;
+        /* black goes through NaN coefficients and NaN-swallowing clamps in the reference: value 0 for every slot */
+        if(!(c->coeff[0] == c->coeff[0])) { op->coeff[0] = op->coeff[1] = op->coeff[2] = 0.0f; op->mul = 0.0f; }
+      }
+      else if(!strcmp(pn, "colorcheckersg"))
+      {
+        const ref_checker_t *c = (const ref_checker_t *)rt.shader->shader[p].data;
+        op->kind = MI_OP_CHECKER; op->slot = slot_of(c->slot); op->mul = 1.0f; op->roughness = c->roughness;
+      }
+      else return 1;
+      m->num_ops++;
+    }
+  }
+  const char *hn = plugin_of(host);
+  const void *hd = rt.shader->shader[host].data;
+  if(!strcmp(hn, "diffuse")) m->bsdf = MI_BSDF_DIFFUSE;
+  else if(!strcmp(hn, "dielectric")) { m->bsdf = MI_BSDF_DIELECTRIC; m->param[0] = ((const float *)hd)[0]; m->param[1] = ((const float *)hd)[1]; }
+  else if(!strcmp(hn, "metal")) { m->bsdf = MI_BSDF_METAL; m->param[0] = (float)((const ref_metal_t *)hd)->mat; }
+  else if(!strcmp(hn, "medium_rgb"))
+  {
+    const ref_medium_t *md = (const ref_medium_t *)hd;
+    m->bsdf = MI_BSDF_MEDIUM; memcpy(m->param, md->mu_t_coeff, 12); m->param[3] = md->mul; m->mean_cos = md->g;
+  }
+  else return 1;
+  return 0;
+}
+
+static float *load_table(const char *name, size_t count)
+{ /* constant tables of the reference (CIE 1931, ColorChecker SG, metal IOR) as the package ships them (corona-13_amd/data) */
+  const char *dir = getenv("CORONA_MI_DATA");
+  char fn[2048];
+  snprintf(fn, sizeof(fn), "%s/%s", dir ? dir : "data", name);
+  FILE *f = fopen(fn, "rb");
+  if(!f) return 0;
+  float *d = (float *)malloc(count*sizeof(float));
+  if(d && fread(d, sizeof(float), count, f) != count) { free(d); d = 0; }
+  fclose(f);
+  return d;
+}
+
+/* ---- the descriptor from the live globals ---------------------------------------------------------------------------------- */
+static int setup(render_t *r)
+{
+  mi_scene_desc d;
+  memset(&d, 0, sizeof(d));
+  d.struct_size = sizeof(d);
+  d.abi_version = MI_ABI_VERSION;
+  const ref_view_t *view = (const ref_view_t *)rt.view;
+  d.width = (uint32_t)view->width; d.height = (uint32_t)view->height;
+  d.max_verts = PATHSPACE_MAX_VERTS;
+  d.sampler = MI_HOST_SAMPLER;
+  d.pointsampler = MI_HOST_POINTS;
+  d.frame = rt.anim_frame;
+
+  /* tree */
+  const ref_accel_t *a = (const ref_accel_t *)rt.accel;
+  d.num_nodes = (uint32_t)a->num_nodes;
+  r->nodes = (mi_node *)calloc(a->num_nodes, sizeof(mi_node));
+  for(uint64_t n=0;n<a->num_nodes;n++)
+  {
+    const ref_node_t *nd = a->tree + n;
+    for(int k=0;k<6;k++) for(int c=0;c<4;c++) r->nodes[n].aabb[k][c] = nd->aabb0[k].f[c];
+    for(int c=0;c<4;c++) r->nodes[n].child[c] = nd->child[c];      /* same encoding: bit 63 leaf | first << 5 | count, else node index */
+    r->nodes[n].axis0 = (int32_t)nd->axis0; r->nodes[n].axis00 = (int32_t)nd->axis00; r->nodes[n].axis01 = (int32_t)nd->axis01;
+    r->nodes[n].parent = (int32_t)nd->parent;
+  }
+  d.nodes = r->nodes;
+  memcpy(d.aabb, a->aabb, sizeof(d.aabb));
+
+  /* primitives: the reference's primid array as the builder left it; vertex arrays of all shapes behind one another */
+  const prims_t *p = rt.prims;
+  d.num_prims = p->num_prims;
+  d.primid = (const mi_primid *)p->primid;
+  d.num_shapes = p->num_shapes;
+  r->shapes = (mi_shape *)calloc(p->num_shapes + 1, sizeof(mi_shape));
+  uint64_t nvi = 0, nv = 0;
+  for(uint32_t s=0;s<p->num_shapes;s++)
+  {
+    const prims_header_t *h = (const prims_header_t *)p->shape[s].data;
+    nvi += (h->vertex_offset - h->vtxidx_offset)/sizeof(prims_vtxidx_t);
+    nv  += (p->shape[s].data_size - h->vertex_offset)/sizeof(prims_vtx_t);
+  }
+  r->vtxidx = (mi_vtxidx *)malloc((nvi + 1)*sizeof(mi_vtxidx));
+  r->vtx = (mi_vtx *)malloc((nv + 1)*sizeof(mi_vtx));
+  nvi = nv = 0;
+  for(uint32_t s=0;s<p->num_shapes;s++)
+  {
+    const prims_header_t *h = (const prims_header_t *)p->shape[s].data;
+    const uint64_t ci = (h->vertex_offset - h->vtxidx_offset)/sizeof(prims_vtxidx_t), cv = (p->shape[s].data_size - h->vertex_offset)/sizeof(prims_vtx_t);
+    r->shapes[s].material = (int32_t)p->shape[s].material;
+    r->shapes[s].num_prims = (uint32_t)p->shape[s].num_prims;
+    r->shapes[s].vtxidx_base = (uint32_t)nvi; r->shapes[s].vtx_base = (uint32_t)nv;
+    memcpy(r->vtxidx + nvi, p->shape[s].vtxidx, ci*sizeof(mi_vtxidx));
+    memcpy(r->vtx + nv, p->shape[s].vtx, cv*sizeof(mi_vtx));
+    nvi += ci; nv += cv;
+  }
+  d.shapes = r->shapes; d.num_vtxidx = nvi; d.vtxidx = r->vtxidx; d.num_vtx = nv; d.vtx = r->vtx;
+
+  /* materials */
+  d.num_materials = rt.shader->num_shaders;
+  r->materials = (mi_material *)calloc(rt.shader->num_shaders + 1, sizeof(mi_material));
+  for(int k=0;k<rt.shader->num_shaders;k++) compile_material(k, r->materials + k);
+  d.materials = r->materials;
+  d.exterior = rt.shader->exterior_medium_shader >= 0 ? (uint32_t)rt.shader->exterior_medium_shader + 1 : 0;
+
+  /* emitters: lights_prepare_frame (src/lights.d/list.c:76-104) has normalised L and the type probabilities; the cdf over
+     area * L it samples with (sample_cdf over prim_area, 130-174) */
+  const ref_lights_t *l = (const ref_lights_t *)rt.lights;
+  d.lights.num_prims = l->num_prims;
+  d.lights.primid = (const mi_primid *)l->primid;
+  d.lights.L = l->L;
+  r->cdf = (float *)calloc(l->num_prims + 1, sizeof(float));
+  for(uint32_t k=0;k<l->num_prims;k++) r->cdf[k] = l->prim_area[k];
+  d.lights.cdf = r->cdf;
+  d.lights.p_sky = l->p_sky; d.lights.p_geo = l->p_geo; d.lights.p_vol = l->p_vol;
+
+  /* camera */
+  const camera_t *c = view->cam;
+  hit_t frame;
+  memset(&frame, 0, sizeof(frame));
+  view_cam_init_frame(0, &frame);                     /* the frame at shutter open, src/view.c:903-919 */
+  mi_camera *mc = &d.cam;
+  memcpy(mc->pos, c->pos, 12); memcpy(mc->pos_t1, c->pos_t1, 12);
+  memcpy(mc->a, frame.a, 12); memcpy(mc->b, frame.b, 12); memcpy(mc->n, frame.n, 12);
+  mc->orient[0] = c->orient.w; memcpy(mc->orient + 1, c->orient.x, 12);
+  mc->orient_t1[0] = c->orient_t1.w; memcpy(mc->orient_t1 + 1, c->orient_t1.x, 12);
+  mc->moving = (memcmp(c->pos, c->pos_t1, 12) || memcmp(&c->orient, &c->orient_t1, sizeof(c->orient))) ? 1 : 0;
+  mc->focus = c->focus; mc->focal_length = c->focal_length;
+  mc->film_width = c->film_width; mc->film_height = c->film_height;
+  mc->f_stop = view_av2fstop(c->aperture_value);
+  mc->exposure_time = view_tv2time(c->exposure_value);
+  mc->iso = c->iso;
+  mc->time_scale = fminf(1.0f, mc->exposure_time/(1.0f/30.0f));      /* view_sample_time, src/view.c:881-891 */
+
+  r->cie = load_table("cie1931_xyz.f32", 96*3);
+  r->checker = load_table("colorchecker_sg.f32", 140*36);
+  r->metal = load_table("metal_ior.f32", 5*95*2);
+  if(!r->cie) { fprintf(stderr, "[render_mi] cannot read cie1931_xyz.f32 (set CORONA_MI_DATA to corona-13_amd/data)\n"); return 1; }
+  d.cie_xyz = r->cie; d.checker = r->checker; d.metal_ior = r->metal;
+
+  if(getenv("CORONA_MI_DESC_DUMP"))
+  { /* what was handed over, for the field-by-field comparison with our own host's descriptor (tests/test_reference_host.py) */
+    FILE *f = fopen(getenv("CORONA_MI_DESC_DUMP"), "wb");
+    if(f)
+    {
+      fprintf(f, "film %u %u %u %u %lu\n", d.width, d.height, d.max_verts, d.sampler, (unsigned long)d.frame);
+      fprintf(f, "aabb %.9g %.9g %.9g %.9g %.9g %.9g\n", d.aabb[0], d.aabb[1], d.aabb[2], d.aabb[3], d.aabb[4], d.aabb[5]);
+      fprintf(f, "cam");
+      for(size_t k=0;k<sizeof(mi_camera)/4;k++) fprintf(f, k == 20 ? " %.0f" : " %.9g", k == 20 ? (float)d.cam.moving : ((const float *)&d.cam)[k]);
+      fprintf(f, "\nlights %u %.9g %.9g %.9g", d.lights.num_prims, d.lights.p_sky, d.lights.p_geo, d.lights.p_vol);
+      for(uint32_t k=0;k<d.lights.num_prims;k++) fprintf(f, " %lu %.9g %.9g", (unsigned long)d.lights.primid[k], d.lights.cdf[k], d.lights.L[k]);
+      fprintf(f, "\n");
+      for(uint32_t k=0;k<d.num_materials;k++)
+      {
+        const mi_material *m = d.materials + k;
+        fprintf(f, "material %u %u %u %d %.9g %.9g %.9g %.9g %.9g", k, m->bsdf, m->num_ops, m->interior, m->param[0], m->param[1], m->param[2], m->param[3], m->mean_cos);
+        for(uint32_t o=0;o<m->num_ops;o++) fprintf(f, " | %u %u %.9g %.9g %.9g %.9g %.9g", m->op[o].kind, m->op[o].slot, m->op[o].coeff[0], m->op[o].coeff[1], m->op[o].coeff[2], m->op[o].mul, m->op[o].roughness);
+        fprintf(f, "\n");
+      }
+      for(uint32_t k=0;k<d.num_shapes;k++) fprintf(f, "shape %u %d %u %u %u\n", k, d.shapes[k].material, d.shapes[k].num_prims, d.shapes[k].vtxidx_base, d.shapes[k].vtx_base);
+      uint64_t hp = 1469598103934665603ull;       /* FNV-1a over the primid array; the nodes go to <dump>.nodes as they are */
+      for(uint64_t k=0;k<d.num_prims*8;k++) hp = (hp ^ ((const uint8_t *)d.primid)[k])*1099511628211ull;
+      fprintf(f, "tree %u %lu %016lx %lu %lu\n", d.num_nodes, (unsigned long)d.num_prims, (unsigned long)hp, (unsigned long)d.num_vtxidx, (unsigned long)d.num_vtx);
+      fclose(f);
+      char fn[2048];
+      snprintf(fn, sizeof(fn), "%s.nodes", getenv("CORONA_MI_DESC_DUMP"));
+      if((f = fopen(fn, "wb"))) { fwrite(d.nodes, sizeof(mi_node), d.num_nodes, f); fclose(f); }
+    }
+  }
+  if(mi_init(-1)) return 1;
+  if(mi_scene_create(&d, &r->scene)) return 1;
+  fprintf(stderr, "[render_mi] scene handed to the device: %u nodes, %lu primitives, %u shapes, %u shaders, %u emitter primitives, film %ux%u\n",
+      d.num_nodes, (unsigned long)d.num_prims, d.num_shapes, d.num_materials, d.lights.num_prims, d.width, d.height);
+  return 0;
+}
+
+/* ---- the progression ------------------------------------------------------------------------------------------------------- */
+void render_sample_path(uint64_t index)
+{
+  render_t *r = rt.render;
+  threads_t *t = rt.threads;
+  pthread_mutex_lock(&r->mutex);
+  if(!r->scene && !r->failed && setup(r)) { r->failed = 1; fprintf(stderr, "[render_mi] no device scene: nothing will be rendered\n"); }
+  if(!r->failed)
+  {
+    /* claim the rest of this progression: the other workers of the pool find the counter at `end` and return (src/view.c:618-628) */
+    const uint64_t next = __sync_lock_test_and_set(&t->counter, t->end);
+    const uint64_t end = t->end;
+    const ref_view_t *view = (const ref_view_t *)rt.view;
+    const double t0 = common_time_wallclock();
+    mi_fb_clear(r->scene);
+    uint64_t n = 1;
+    if(next == index + 1 && next < end) { mi_render(r->scene, index, end - index); n = end - index; }
+    else
+    { /* another worker had drawn an index in between: this path, then the unclaimed rest */
+      mi_render(r->scene, index, 1);
+      if(next < end) { mi_render(r->scene, next, end - next); n += end - next; }
+    }
+    /* the progression's contract: after the pool's barrier fb[] has received all splats of [counter, end) */
+    mi_fb_read(r->scene, view->fb[0].fb, 1);
+    r->t_device += common_time_wallclock() - t0;
+    r->paths += n;
+  }
+  pthread_mutex_unlock(&r->mutex);
+}
