@@ -38,7 +38,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
                                                            uint2 *stack_overflow)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const Lds lds = lds_setup<MI_BLOCK, NODES_LDS>(sc, smem, stack_overflow);
+  const Lds lds = lds_setup<MI_BLOCK, NODES_LDS, HALTON>(sc, smem, stack_overflow);
 
   /* every workgroup owns a contiguous part of the path index range and hands it out through an LDS counter: the
      wave-level refill below then needs no global atomic at all (one shared counter costs ~11 ns per wave refill) */
@@ -240,8 +240,8 @@ static bool path_kernel_valid(unsigned which)
 {
   if((which & 32u) && !(which & 16u)) return false;
   if((which & 1u) && !(which & 64u)) return false;
-#ifdef MI_DEV_FAST
-  if((which & (8u | 16u | 32u)) || !(which & 4u)) return false;
+#ifdef MI_DEV_FAST       /* 2: with the Halton kernels */
+  if((which & (16u | 32u)) || !(which & 4u) || ((which & 8u) && MI_DEV_FAST != 2)) return false;
 #endif
   return true;
 }
@@ -255,7 +255,7 @@ template<bool R, bool P, bool N, bool H, bool M, bool MBk, bool C> static const 
 {
   constexpr bool valid = !(MBk && !M) && !(R && !C)
 #ifdef MI_DEV_FAST
-                         && !H && !M && !MBk && N
+                         && (!H || MI_DEV_FAST == 2) && !M && !MBk && N
 #endif
                          ;
   if constexpr(valid) return path_kernel_go<R, P, N, H, M, MBk, C>(L);
@@ -823,8 +823,9 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   /* the tree lives in LDS next to the traversal stacks when it fits (0010_pt: 50 KB + 96 KB of 160 KB); larger trees are
      read from HBM / L2 by the NODES_LDS = false instantiations (CORONA_MI_NODES=global forces that, for tests) */
   const char *nodes_env = getenv("CORONA_MI_NODES");
-  s->nodes_lds = node_bytes + stack_bytes <= 160*1024 && !(nodes_env && !strcmp(nodes_env, "global"));
-  s->lds_bytes = (s->nodes_lds ? node_bytes : 0) + stack_bytes;
+  const size_t halton_bytes = h->pointsampler == MI_POINTS_HALTON ? (size_t)2*MI_HALTON_LDS : 0;     /* staged head of the permutation tables */
+  s->nodes_lds = halton_bytes + node_bytes + stack_bytes <= 160*1024 && !(nodes_env && !strcmp(nodes_env, "global"));
+  s->lds_bytes = halton_bytes + (s->nodes_lds ? node_bytes : 0) + stack_bytes;
   s->device_built = device_build; s->stack_need = stack_need;
   { const char *ce = getenv("CORONA_MI_COUNTERS"); s->counting = ce && atoi(ce) ? 1 : 0; }
   {

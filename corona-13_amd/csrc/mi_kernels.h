@@ -107,12 +107,27 @@ enum { MI_DIM_IMAGE_X = 0, MI_DIM_IMAGE_Y = 1, MI_DIM_LAMBDA = 2, MI_DIM_TIME = 
        MI_DIM_OMEGA_X = 1, MI_DIM_OMEGA_Y = 2, MI_DIM_SCATTER_MODE = 3, MI_DIM_RUSSIAN_R = 4,
        MI_DIM_NEE_LIGHT1 = 0, MI_DIM_NEE_LIGHT2 = 1, MI_DIM_NEE_X = 2, MI_DIM_NEE_Y = 3 };      /* include/pathspace.h:16-53 */
 
+/* The first MI_HALTON_LDS entries of the concatenated permutation tables (dimensions 1 .. ~17: the camera's five and the first
+ * two or three path vertices' -- the dimensions every path draws) are staged into LDS at the start of the workgroup's dynamic
+ * LDS by the HALTON instantiations (lds_setup); the rest of the 387 KB stays in L2. 0 = everything from L2 (A/B switch). */
+#ifndef MI_HALTON_LDS
+#define MI_HALTON_LDS 4096
+#endif
+__device__ __forceinline__ const unsigned short *halton_lds()
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char mi_dynamic_lds[];
+  return (const unsigned short *)mi_dynamic_lds;
+}
+
 __device__ __forceinline__ float halton_sample(const DScene &sc, uint32_t dim, uint32_t index)
 {
   if(dim == 0) return __uint_as_float(0x3f800000u | (__brev(index) >> 9)) - 1.0f;            /* halton2, ext/halton/halton.h:291-306 */
   const uint4 d = sc.halton_dim[dim];
   const uint32_t P = d.x, recip = d.y, groups = d.z >> 24;
-  const unsigned short *perm = sc.halton_perm + (d.z & 0xffffffu);
+  const uint32_t off = d.z & 0xffffffu;
+  const unsigned short *perm = sc.halton_perm + off;
+  const bool staged = MI_HALTON_LDS && off + P <= MI_HALTON_LDS;                              /* this dimension's table is in LDS */
+  const unsigned short *lperm = halton_lds() + off;
   /* at most 7 groups (P = 23: 23^7 < 2^32). First all remainders, then all look-ups (in flight together instead of one
      load latency per group), then the sum; groups beyond the dimension's own read entry 0 and are left out of the sum */
   uint32_t rem[7], digit[7];
@@ -125,8 +140,16 @@ __device__ __forceinline__ float halton_sample(const DScene &sc, uint32_t dim, u
     rem[g] = (uint32_t)g < groups ? r : 0u;
     index = q;
   }
+  if(staged)
+  {
 #pragma unroll
-  for(int g=0;g<7;g++) digit[g] = perm[rem[g]];
+    for(int g=0;g<7;g++) digit[g] = lperm[rem[g]];
+  }
+  else
+  {
+#pragma unroll
+    for(int g=0;g<7;g++) digit[g] = perm[rem[g]];
+  }
   uint32_t sum = 0;
 #pragma unroll
   for(int g=0;g<7;g++) if((uint32_t)g < groups) sum = sum*P + digit[g];
@@ -138,7 +161,7 @@ __device__ __forceinline__ float halton_sample(const DScene &sc, uint32_t dim, u
 template<uint32_t P, uint32_t G, uint32_t OFF>
 __device__ __forceinline__ float halton_const(const DScene &sc, uint32_t index)
 {
-  const unsigned short *perm = sc.halton_perm + OFF;
+  const unsigned short *perm = (MI_HALTON_LDS && OFF + P <= MI_HALTON_LDS) ? halton_lds() + OFF : sc.halton_perm + OFF;
   uint32_t digit[G];
 #pragma unroll
   for(uint32_t g=0;g<G;g++) { digit[g] = perm[index % P]; index /= P; }
@@ -532,12 +555,20 @@ __device__ __forceinline__ uint2 stack_top(const Lds &lds, const lds_uint2 *lsta
 /* Workgroup prologue shared by all traversal kernels. NODES_LDS: the BVH is staged into LDS once per workgroup
  * (coalesced 16-B loads) in front of the traversal stacks; otherwise it does not fit next to the stacks and is read from
  * HBM / L2 through the same SoA layout (mi_device.h), LDS holds the stacks only. Call from all threads (barrier inside). */
-template<int BLOCK, bool NODES_LDS>
+template<int BLOCK, bool NODES_LDS, bool HALTON = false>
 __device__ __forceinline__ Lds lds_setup(const DScene &sc, unsigned char *smem, uint2 *stack_overflow)
 {
   const uint32_t N = sc.num_nodes;
   Lds lds;
   uint2 *lds_stack;
+  if(HALTON && MI_HALTON_LDS)
+  { /* the hot head of the Halton permutation tables first (halton_lds()), tree and stacks behind it */
+    uint32_t *dst = (uint32_t *)smem;
+    const uint32_t *src = (const uint32_t *)sc.halton_perm;
+    for(uint32_t i=threadIdx.x;i<MI_HALTON_LDS/2;i+=BLOCK) dst[i] = src[i];
+    smem += 2*MI_HALTON_LDS;
+    if(!NODES_LDS) __syncthreads();
+  }
   if(NODES_LDS)
   {
     float4 *lds_nodes = (float4 *)smem;

@@ -8,6 +8,6 @@ cd "$(dirname "$0")/../corona-13_amd"
 tag=$1; shift
 mkdir -p csrc/variants
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -ffp-contract=off -fno-slp-vectorize \
-  -mllvm -enable-post-misched=0 -Wall -Wno-unused-function -I../include -Ihost -Icsrc -DMI_DEV_FAST "$@" \
+  -mllvm -enable-post-misched=0 -Wall -Wno-unused-function -I../include -Ihost -Icsrc ${MI_DEV_FAST_FLAG:--DMI_DEV_FAST} "$@" \
   -shared csrc/mi_abi.hip -o csrc/variants/libcorona_mi_$tag.so
 echo "built csrc/variants/libcorona_mi_$tag.so ($*)"
