@@ -45,6 +45,42 @@ enum { s_tech_extend = 1, s_tech_nee = 2 };
 
 struct V3 { float x, y, z; };
 #define MI_HD __host__ __device__ __forceinline__   /* per-primitive constants are precomputed on the host with the very same code */
+/* 1.0f/x. On the device: v_rcp_f32 + two Newton steps + v_div_fixup_f32 (6 instructions) instead of the compiler's IEEE division
+ * (11: two v_div_scale, v_rcp, five fma, v_div_fmas, v_div_fixup). Bit-identical to the correctly rounded 1.0f/x for every
+ * x in {+-0, +-inf, NaN} and every normal x with |x| < 2^126 -- checked over all 2^32 bit patterns by tools/micro/rcp_exact.hip;
+ * what the scaling steps of the long form are for, a denormal x or |x| >= 2^126 (no length, determinant or cosine of this
+ * geometry), can come out one ulp off. The host (per-primitive constants at upload) divides. */
+MI_HD float mi_rcp(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MI_IEEE_DIV)
+  float y = __builtin_amdgcn_rcpf(x);
+  float e = __builtin_fmaf(-x, y, 1.0f);
+  y = __builtin_fmaf(y, e, y);
+  e = __builtin_fmaf(-x, y, 1.0f);
+  y = __builtin_fmaf(y, e, y);
+  return __builtin_amdgcn_div_fixupf(y, x, 1.0f);
+#else
+  return 1.0f/x;
+#endif
+}
+/* sqrtf(x). On the device: v_sqrt_f32 (within one ulp) and the choice among its two neighbours by the sign of the exact
+ * residuals x - s*(s -+ 1ulp) -- the core of the compiler's correctly rounded expansion without the scaling it wraps around
+ * it for denormal arguments (9 instead of 16 instructions). Bit-identical to sqrtf for +-0, inf, NaN, negative x and every
+ * x >= 2^-104 (4.9e-32), over all 2^32 bit patterns (tools/micro/rcp_exact.hip); smaller positive x (no squared length or
+ * discriminant here) can come out one ulp off. */
+MI_HD float mi_sqrt(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MI_IEEE_DIV)
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float lo = __uint_as_float(__float_as_uint(s) - 1u), hi = __uint_as_float(__float_as_uint(s) + 1u);
+  const float rlo = __builtin_fmaf(-lo, s, x), rhi = __builtin_fmaf(-hi, s, x);
+  float r = rlo <= 0.0f ? lo : s;
+  r = rhi > 0.0f ? hi : r;
+  return r;
+#else
+  return sqrtf(x);
+#endif
+}
 MI_HD V3 mk3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
 MI_HD float dot3(const V3 a, const V3 b) { return a.x*b.x + a.y*b.y + a.z*b.z; }
 MI_HD V3 cross3(const V3 a, const V3 b)
@@ -56,7 +92,7 @@ MI_HD V3 scale3(const V3 a, float s) { return mk3(a.x*s, a.y*s, a.z*s); }
 MI_HD V3 neg3(const V3 a) { return mk3(-a.x, -a.y, -a.z); }
 MI_HD V3 normalise3(const V3 a)
 { /* normalise, include/corona_common.h:172-176 */
-  const float len = 1.0f/sqrtf(dot3(a, a));
+  const float len = mi_rcp(mi_sqrt(dot3(a, a)));
   return scale3(a, len);
 }
 MI_HD V3 ld3(const float *p) { return mk3(p[0], p[1], p[2]); }
@@ -262,7 +298,7 @@ __device__ __forceinline__ float sphere_t(const V3 c, float radius, const V3 ro,
   }
   const float discrim = b*b - 4.0f*a*cc;
   if(discrim < 0) return -FLT_MAX;
-  const float sq = sqrtf(discrim);
+  const float sq = mi_sqrt(discrim);
   const float temp = b < 0 ? -0.5f*(b - sq) : -0.5f*(b + sq);
   const float x0 = temp/a, x1 = cc/temp;
   if(x0 <= 0.0f) return x1;
@@ -301,7 +337,7 @@ __device__ __forceinline__ void line_intersect(const DPrim &p, const V3 ro, cons
     const float C = o1*o1 + o2*o2 - r0*r0;
     const float discr = (float)((double)(B*B) - 4.0*(double)A*(double)C);
     if(discr < 0.0) return;
-    const float sq = sqrtf(discr);
+    const float sq = mi_sqrt(discr);
     const float temp = B < 0 ? -0.5f*(B - sq) : -0.5f*(B + sq);
     const float t0 = temp/A, t1 = C/temp;
     float t, out0, out1, out2;
@@ -348,7 +384,7 @@ __device__ __forceinline__ void line_intersect(const DPrim &p, const V3 ro, cons
     {
       const float discr = c1*c1 - c0*c2;
       if(discr < 0.0f) return;
-      const float root = sqrtf(discr);
+      const float root = mi_sqrt(discr);
 #pragma unroll
       for(int i=-1;i<2;i+=2)
       {
@@ -389,7 +425,7 @@ __device__ __forceinline__ void triquad_intersect(const PrimRegs &r, uint32_t ty
   const V3 tv = sub3(o, v0);
   /* triangle A: edge1 = v1-v0, edge2 = v2-v0 */
   const V3 pA = cross3(d, e02);
-  const float invA = 1.0f/dot3(eA1, pA);
+  const float invA = mi_rcp(dot3(eA1, pA));
   const float vA = dot3(tv, pA)*invA;
   const V3 qA = cross3(tv, eA1);
   const float uA = dot3(d, qA)*invA;
@@ -397,7 +433,7 @@ __device__ __forceinline__ void triquad_intersect(const PrimRegs &r, uint32_t ty
   const bool hitA = !(vA < 0.0f || vA > 1.0f) && !(uA < 0.0f || uA + vA > 1.0f) && (tA > 0.0f && tA <= hit.dist);
   /* triangle B: edge1 = v2-v0, edge2 = v3-v0 */
   const V3 pB = cross3(d, eB2);
-  const float invB = 1.0f/dot3(e02, pB);
+  const float invB = mi_rcp(dot3(e02, pB));
   const float vB = dot3(tv, pB)*invB;
   const V3 qB = cross3(tv, e02);
   const float uB = dot3(d, qB)*invB;
@@ -420,7 +456,7 @@ MI_HD void pack_line(DPrim &p, const V3 v0, const V3 v1, float r0, float r1)
 {
   float *f = &p.v[0][0];
   float d[3] = {v1.x-v0.x, v1.y-v0.y, v1.z-v0.z};
-  const float dlen = sqrtf(d[0]*d[0] + d[1]*d[1] + d[2]*d[2]);
+  const float dlen = mi_sqrt(d[0]*d[0] + d[1]*d[1] + d[2]*d[2]);
   for(int k=0;k<16;k++) f[k] = 0.0f;
   f[0] = v0.x; f[1] = v0.y; f[2] = v0.z; f[3] = r0; f[4] = r1; f[5] = dlen;
   if(fabsf(r1-r0) < 1e-3)
@@ -430,7 +466,7 @@ MI_HD void pack_line(DPrim &p, const V3 v0, const V3 v1, float r0, float r1)
     float a[3], b[3];
     if(fabsf(d[1]) < 0.5) { a[0] = d[1]*0.0f - 1.0f*d[2]; a[1] = d[2]*0.0f - 0.0f*d[0]; a[2] = d[0]*1.0f - 0.0f*d[1]; }   /* d x (0,1,0) */
     else                  { a[0] = d[1]*0.0f - 0.0f*d[2]; a[1] = d[2]*1.0f - 0.0f*d[0]; a[2] = d[0]*0.0f - 1.0f*d[1]; }   /* d x (1,0,0) */
-    const float il = 1.0f/sqrtf(a[0]*a[0] + a[1]*a[1] + a[2]*a[2]);
+    const float il = 1.0f/mi_sqrt(a[0]*a[0] + a[1]*a[1] + a[2]*a[2]);
     for(int k=0;k<3;k++) a[k] *= il;
     b[0] = d[1]*a[2] - a[1]*d[2]; b[1] = d[2]*a[0] - a[2]*d[0]; b[2] = d[0]*a[1] - a[0]*d[1];
     f[6] = d[0]; f[7] = d[1]; f[8] = d[2];
@@ -452,7 +488,7 @@ MI_HD void pack_line(DPrim &p, const V3 v0, const V3 v1, float r0, float r1)
 MI_HD void line_shading_consts(float *g, const DPrim &p, const V3 v0, const V3 v1)
 {
   V3 d = sub3(v1, v0);
-  const float ilen_d = 1.0f/sqrtf(dot3(d, d));
+  const float ilen_d = 1.0f/mi_sqrt(dot3(d, d));
   d = scale3(d, ilen_d);
   V3 a, b; get_onb(d, a, b);
   V3 ac, bc; get_onb(mk3(p.v[2][0], p.v[2][1], p.v[2][2]), ac, bc);    /* dwords 6..8: the intersection's unit axis */
@@ -611,7 +647,7 @@ template<class CNT>
 __device__ __forceinline__ void trace_begin(TraceState &ts, const V3 d, CNT &cnt)
 {
   MI_COUNT(cnt, 0, 1);
-  ts.idx = 1.0f/d.x; ts.idy = 1.0f/d.y; ts.idz = 1.0f/d.z;
+  ts.idx = mi_rcp(d.x); ts.idy = mi_rcp(d.y); ts.idz = mi_rcp(d.z);
   ts.sp = 0;
   ts.current = 0;      /* node 0 = root */
   ts.done = false;
@@ -966,7 +1002,7 @@ struct Shading { float roughness, rs, rd, rg, em; };
 __device__ __forceinline__ float spectrum_eval(const float *coeff, float lambda)
 { /* rgb2spec_eval_fast, include/rgb2spec.h:145-149 (exact rsqrt instead of rsqrtss) */
   const float x = (coeff[0]*lambda + coeff[1])*lambda + coeff[2];
-  const float y = 1.0f/sqrtf(x*x + 1.0f);
+  const float y = mi_rcp(mi_sqrt(x*x + 1.0f));
   return .5f*x*y + .5f;
 }
 
@@ -1115,22 +1151,22 @@ __device__ __forceinline__ float ggx_G1(const V3 w, const V3 n, float roughness)
 { /* ggx.h:29-36 */
   const float r2 = roughness*roughness;
   const float cos_th = fabsf(dot3(w, n));
-  const float sin_th = sqrtf(fmaxf(0.0f, 1.0f - cos_th*cos_th));
+  const float sin_th = mi_sqrt(fmaxf(0.0f, 1.0f - cos_th*cos_th));
   const float tan_th = sin_th/cos_th;
-  return 2.0f/(1.0f + sqrtf(1.0f + r2*tan_th*tan_th));
+  return 2.0f*mi_rcp(1.0f + mi_sqrt(1.0f + r2*tan_th*tan_th));     /* 2/x == 2*RN(1/x): scaling by two commutes with rounding */
 }
 __device__ __forceinline__ float ggx_G1_cos(float cos_wn, float roughness)
 { /* ggx.h:38-46 */
   const float r2 = roughness*roughness;
-  const float sin_wn = sqrtf(DCLAMP(1.0f - cos_wn*cos_wn, 0.0f, 1.0f));
+  const float sin_wn = mi_sqrt(DCLAMP(1.0f - cos_wn*cos_wn, 0.0f, 1.0f));
   const float tan_th = sin_wn/cos_wn;
-  return 2.0f/(1.0f + sqrtf(1.0f + r2*tan_th*tan_th));
+  return 2.0f*mi_rcp(1.0f + mi_sqrt(1.0f + r2*tan_th*tan_th));     /* 2/x == 2*RN(1/x): scaling by two commutes with rounding */
 }
 __device__ __forceinline__ void ggx_sample11(float tan_theta_i, float U1, float U2, float &slope_x, float &slope_y)
 { /* ggx.h:59-110 */
   if(tan_theta_i < 0.0001f)
   {
-    const float r = sqrtf(U1/fmaxf(1e-8f, 1-U1));
+    const float r = mi_sqrt(U1/fmaxf(1e-8f, 1-U1));
     const float phi = (float)(2.0f*MI_PI_D*(double)U2);
     float sn, cs;
     sincosf(phi, &sn, &cs);
@@ -1138,12 +1174,12 @@ __device__ __forceinline__ void ggx_sample11(float tan_theta_i, float U1, float 
     slope_y = r*sn;
     return;
   }
-  const float a = 1.0f/tan_theta_i;
-  const float G1 = 2.0f/(1.0f + sqrtf(1.0f + 1.0f/(a*a)));
+  const float a = mi_rcp(tan_theta_i);
+  const float G1 = 2.0f*mi_rcp(1.0f + mi_sqrt(1.0f + mi_rcp(a*a)));
   const float A = 2.0f*U1/G1 - 1.0f;
-  const float tmp = 1.0f/(A*A - 1.0f);
+  const float tmp = mi_rcp(A*A - 1.0f);
   const float B = tan_theta_i;
-  const float D = sqrtf(fmaxf(0.0f, B*B*tmp*tmp - (A*A - B*B)*tmp));
+  const float D = mi_sqrt(fmaxf(0.0f, B*B*tmp*tmp - (A*A - B*B)*tmp));
   float sx1 = B*tmp - D, sx2 = B*tmp + D;
   if(!(fabsf(sx1) < FLT_MAX)) sx1 = 0.0f;
   if(!(fabsf(sx2) < FLT_MAX)) sx2 = 0.0f;
@@ -1153,7 +1189,7 @@ __device__ __forceinline__ void ggx_sample11(float tan_theta_i, float U1, float 
   else          { S = -1.0f; U2 = 2.0f*(0.5f - U2); }
   const float z = (U2*(U2*(U2*(-0.365728915865723f) + 0.790235037209296f) - 0.424965825137544f) + 0.000152998850436920f) /
                   (U2*(U2*(U2*(U2*0.169507819808272f - 0.397203533833404f) - 0.232500544458471f) + 1.0f) - 0.539825872510702f);
-  slope_y = S*z*sqrtf((float)(1.0 + (double)(slope_x*slope_x)));
+  slope_y = S*z*mi_sqrt((float)(1.0 + (double)(slope_x*slope_x)));
 }
 __device__ __forceinline__ V3 ggx_sample_h(const V3 wi, float rx, float ry, float U1, float U2)
 { /* ggx.h:115-162 */
@@ -1161,7 +1197,7 @@ __device__ __forceinline__ V3 ggx_sample_h(const V3 wi, float rx, float ry, floa
   float tan_theta = 0.0f, sin_phi = 0.0f, cos_phi = 1.0f;
   if(wi_.z < 0.99999)
   {
-    const float len = sqrtf(wi_.x*wi_.x + wi_.y*wi_.y);
+    const float len = mi_sqrt(wi_.x*wi_.x + wi_.y*wi_.y);
     tan_theta = len/wi_.z;
     sin_phi = wi_.y/len;
     cos_phi = wi_.x/len;
@@ -1173,7 +1209,7 @@ __device__ __forceinline__ V3 ggx_sample_h(const V3 wi, float rx, float ry, floa
   slope_x = tmp;
   slope_x = rx*slope_x;
   slope_y = ry*slope_y;
-  const float inv_h = sqrtf((float)((double)(slope_x*slope_x + slope_y*slope_y) + 1.0));
+  const float inv_h = mi_sqrt((float)((double)(slope_x*slope_x + slope_y*slope_y) + 1.0));
   V3 h = mk3(-slope_x/inv_h, -slope_y/inv_h, (float)(1.0/(double)inv_h));
   if(!(inv_h > 0.0)) h = mk3(0.0f, 1.0f, 0.0f);
   return h;
@@ -1182,7 +1218,7 @@ __device__ __forceinline__ float ggx_pdf_h(const V3 wi, const V3 h, const V3 n, 
 { /* ggx.h:167-182 */
   const float r2 = roughness*roughness;
   const float cos_th = fabsf(dot3(h, n));
-  const float sin_th = sqrtf(fmaxf(0.0f, 1.0f - cos_th*cos_th));
+  const float sin_th = mi_sqrt(fmaxf(0.0f, 1.0f - cos_th*cos_th));
   const float tan_th = sin_th/cos_th;
   const double A2 = (double)(r2 + tan_th*tan_th);
   const float D_h = (float)((double)r2/(MI_PI_D*(double)cos_th*(double)cos_th*(double)cos_th*(double)cos_th*A2*A2));
@@ -1193,7 +1229,7 @@ __device__ __forceinline__ float ggx_pdf_h_cos(float cosh, float cos_in, float c
 { /* ggx.h:184-201 */
   const float r2 = roughness*roughness;
   const float cosh2 = cosh*cosh;
-  const float sin_th = sqrtf(DCLAMP(1.0f - cosh2, 0.0f, 1.0f));
+  const float sin_th = mi_sqrt(DCLAMP(1.0f - cosh2, 0.0f, 1.0f));
   const float tan_th = sin_th/fabsf(cosh);
   const float den = tan_th*tan_th + r2;
   const float ct4 = cosh2*cosh2;
@@ -1223,9 +1259,9 @@ __device__ __forceinline__ float fresnel_metal(float n1, float n2, float k2, flo
   const float sinr = 1.0f - cosr*cosr;
   const float cost2r = 1.0f - eta2r*sinr;
   const float cost2i = eta2i*(-sinr);
-  const float len = sqrtf(cost2r*cost2r + cost2i*cost2i);
-  const float costr = sqrtf(0.5f*(cost2r + len));
-  float costi = sqrtf(0.5f*(len - cost2r));
+  const float len = mi_sqrt(cost2r*cost2r + cost2i*cost2i);
+  const float costr = mi_sqrt(0.5f*(cost2r + len));
+  float costi = mi_sqrt(0.5f*(len - cost2r));
   if(cost2i < 0.0f) costi = -costi;
   const float n1cosr = n1*cosr, n2cosrr = n2*cosr, n2cosri = k2*cosr;
   const float n1costr = n1*costr, n1costi = n1*costi;
@@ -1252,8 +1288,8 @@ __device__ __forceinline__ void sample_diffuse(PS &pts, const Surf &sf, const Sh
 { /* sample_d, src/shader.c:165-205 */
   const float x1 = pts(MI_DIM_OMEGA_X);
   const float x2 = pts(MI_DIM_OMEGA_Y);
-  const float sq = sqrtf(x1);
-  const float c0 = sqrtf((float)(1.0 - (double)x1));
+  const float sq = mi_sqrt(x1);
+  const float c0 = mi_sqrt((float)(1.0 - (double)x1));
   const float ang = (float)(2*MI_PI_D*(double)x2);
   float sn, cs;
   sincosf(ang, &sn, &cs);                 /* one range reduction for both (same values as sinf/cosf) */
@@ -1303,14 +1339,14 @@ __device__ __forceinline__ void sample_dielectric(PS &pts, const Surf &sf, const
   const float n1 = eta_ratio, n2 = 1.0f;
   const float nr = n1/n2;
   const float cost2 = 1.0f - (nr*nr)*(1.0f - cosr*cosr);
-  const float cost = cost2 <= 0.0f ? 0.0f : sqrtf(cost2);
+  const float cost = cost2 <= 0.0f ? 0.0f : mi_sqrt(cost2);
   const float R = fresnel_dielectric(n1, n2, cosr, cost);
   if(pts(MI_DIM_SCATTER_MODE) <= R)
   {
     bs.mode = s_reflect;
     bs.omega = mk3(wi.x + 2.0f*cosr*h.x, wi.y + 2.0f*cosr*h.y, wi.z + 2.0f*cosr*h.z);
     if(dot3(bs.omega, n) <= 0.0f) return;
-    pdf *= 1.0f/(4.0f*cosr);
+    pdf *= mi_rcp(4.0f*cosr);
     if(r > GLOSSY_THR)
     {
       bs.pdf = R*(pdf/fabsf(dot3(bs.omega, n)));
@@ -1371,7 +1407,7 @@ __device__ __forceinline__ void sample_metal(const DScene &sc, PS &pts, const Su
   bs.mode = s_reflect;
   bs.omega = mk3(wi.x + 2.0f*cosr*h.x, wi.y + 2.0f*cosr*h.y, wi.z + 2.0f*cosr*h.z);
   if(dot3(bs.omega, n) <= 0.0f) return;
-  pdf *= 1.0f/(4.0f*cosr);
+  pdf *= mi_rcp(4.0f*cosr);
   if(r > 1e-4f)
   {
     bs.pdf = pdf/fabsf(dot3(bs.omega, n));
@@ -1435,7 +1471,7 @@ __device__ __forceinline__ BsdfEval brdf_dielectric(const Surf &sf, const Shadin
     if(cosr < 0.0f) return res;
     const float nr = n1/n2;
     const float cost2 = 1.0f - (nr*nr)*(1.0f - cosr*cosr);
-    const float cost = cost2 <= 0.0f ? 0.0f : sqrtf(cost2);
+    const float cost = cost2 <= 0.0f ? 0.0f : mi_sqrt(cost2);
     const float R = fresnel_dielectric(n1, n2, cosr, cost);
     const float G1 = ggx_G1(wo, n, r);
     if(res.mode & s_glossy) { res.value = (sh.rg*R)*(DG1*G1/(4.0f*fabsf(cosr*cos_out))); return res; }
@@ -1447,7 +1483,7 @@ __device__ __forceinline__ BsdfEval brdf_dielectric(const Surf &sf, const Shadin
   {
     bool mask = false;
     float h0 = n1*wi.x - n2*wo.x, h1 = n1*wi.y - n2*wo.y, h2 = n1*wi.z - n2*wo.z;
-    const float hilen = 1.0f/sqrtf(h0*h0 + (h1*h1 + h2*h2));
+    const float hilen = mi_rcp(mi_sqrt(h0*h0 + (h1*h1 + h2*h2)));
     h0 *= hilen; h1 *= hilen; h2 *= hilen;
     float cosh2 = h0*n.x + (h1*n.y + h2*n.z);
     const bool cosh_lt0 = cosh2 < 0.0f;
@@ -1458,7 +1494,7 @@ __device__ __forceinline__ BsdfEval brdf_dielectric(const Surf &sf, const Shadin
     mask |= cosr2 <= 0.0f;
     const float nr = n1/n2;
     const float cost2 = 1.0f - (nr*nr)*(1.0f - cosr2*cosr2);
-    const float cost = cost2 <= 0.0f ? 0.0f : sqrtf(cost2);
+    const float cost = cost2 <= 0.0f ? 0.0f : mi_sqrt(cost2);
     const float R2 = fresnel_dielectric(n1, n2, cosr2, cost);
     const float DG1 = ggx_pdf_h_cos(cosh2, cos_in, cosr2, r);
     const float G1 = ggx_G1_cos(cos_in, r);
@@ -1509,7 +1545,7 @@ __device__ __forceinline__ float pdf_dielectric(const Surf &sf, const Shading &s
   else
   {
     float h0 = n1*wi.x - n2*wo.x, h1 = n1*wi.y - n2*wo.y, h2 = n1*wi.z - n2*wo.z;
-    const float hilen = 1.0f/sqrtf(h0*h0 + (h1*h1 + h2*h2));
+    const float hilen = mi_rcp(mi_sqrt(h0*h0 + (h1*h1 + h2*h2)));
     h0 *= hilen; h1 *= hilen; h2 *= hilen;
     if(n2 < n1) { h0 = -h0; h1 = -h1; h2 = -h2; }
     h = mk3(h0, h1, h2);
@@ -1520,13 +1556,13 @@ __device__ __forceinline__ float pdf_dielectric(const Surf &sf, const Shading &s
   }
   const float nr = n1/n2;
   const float cost2 = 1.0f - (nr*nr)*(1.0f - cosr*cosr);
-  const float cost = cost2 <= 0.0f ? 0.0f : sqrtf(cost2);
+  const float cost = cost2 <= 0.0f ? 0.0f : mi_sqrt(cost2);
   const float R = fresnel_dielectric(n1, n2, cosr, cost);
   float pdf = 1.0f;
   if(mode & s_reflect)
   {
     if(mode & s_specular) { mask |= cosh < HALFVEC_COS_THR; return mask ? 0.0f : R; }
-    pdf = pdf*(1.0f/(4.0f*fabsf(dot3(wo, h))));
+    pdf = pdf*mi_rcp(4.0f*fabsf(dot3(wo, h)));
     pdf = pdf*R;
   }
   else
@@ -1582,7 +1618,7 @@ __device__ __forceinline__ float pdf_metal(const Surf &sf, const Shading &sh, co
     if(cosh < HALFVEC_COS_THR) return 0.0f;
     return 1.0f;
   }
-  float pdf = 1.0f/(4.0f*fabsf(dot3(wo, h)));
+  float pdf = mi_rcp(4.0f*fabsf(dot3(wo, h)));
   pdf *= ggx_pdf_h(wi, h, n, sh.roughness);
   pdf /= fabsf(cos_out);
   if(!(pdf > 0.0f)) return 0.0f;
@@ -1642,7 +1678,7 @@ __device__ __forceinline__ V3 prim_sample(const DPrim &p, const DPrimGeo &geo, f
       if(hv >= hu) return tri_retime(vt[0], vt[1], vt[2], hu, hv - hu);
       return tri_retime(vt[0], vt[2], vt[3], hu - hv, hv);
     }
-    const float a = sqrtf(r0);
+    const float a = mi_sqrt(r0);
     hu = r1*a; hv = (1.0f-r1)*a;
     return tri_retime(vt[0], vt[1], vt[2], hu, hv);
   }
@@ -1656,7 +1692,7 @@ __device__ __forceinline__ V3 prim_sample(const DPrim &p, const DPrimGeo &geo, f
   }
   if(type == MI_PRIM_TRI)
   {
-    const float a = sqrtf(r0);
+    const float a = mi_sqrt(r0);
     hu = r1*a; hv = (1.0f-r1)*a;
     return tri_retime(ld3(p.v[0]), ld3(gv), ld3(gv + 3), hu, hv);
   }
@@ -1664,7 +1700,7 @@ __device__ __forceinline__ V3 prim_sample(const DPrim &p, const DPrimGeo &geo, f
   { /* geo_sphere_retime, include/geo/sphere.h:38-49 */
     hu = r0; hv = (float)((double)acosf(r1)/MI_PI_D);
     const float x1 = (float)((double)(-(cosf((float)((double)hv*MI_PI_D))-1.f))/2.0), x2 = hu;
-    const float z = 1.f - 2.f*x1, rr = sqrtf(1.f - z*z);
+    const float z = 1.f - 2.f*x1, rr = mi_sqrt(1.f - z*z);
     const float phi = (float)(2.f*MI_PI_D*(double)x2);
     const float radius = p.v[1][0];
     return mk3(p.v[0][0] + radius*(rr*cosf(phi)), p.v[0][1] + radius*(rr*sinf(phi)), p.v[0][2] + radius*z);
@@ -1676,11 +1712,11 @@ __device__ __forceinline__ V3 prim_sample(const DPrim &p, const DPrimGeo &geo, f
   const float lr0 = f[3], lr1 = f[4];
   float y;
   if(fabsf(lr1-lr0) < 1e-3f) y = hu;
-  else y = (sqrtf((lr1*lr1 - lr0*lr0)*hu + lr0*lr0) - lr0)/(lr1-lr0);
+  else y = (mi_sqrt((lr1*lr1 - lr0*lr0)*hu + lr0*lr0) - lr0)/(lr1-lr0);
   const float phi = (float)(2.0*MI_PI_D*(double)hv);
   float sinphi, cosphi; sincosf(phi, &sinphi, &cosphi);
   V3 d = sub3(v1, v0);
-  d = scale3(d, 1.0f/sqrtf(dot3(d, d)));
+  d = scale3(d, mi_rcp(mi_sqrt(dot3(d, d))));
   V3 a, b; get_onb(d, a, b);
   return mk3(v0.x + (v1.x - v0.x)*y + a.x*sinphi + b.x*cosphi, v0.y + (v1.y - v0.y)*y + a.y*sinphi + b.y*cosphi,
              v0.z + (v1.z - v0.z)*y + a.z*sinphi + b.z*cosphi);
@@ -1741,14 +1777,14 @@ __device__ __forceinline__ void splat_wave(const DScene &sc, bool pending, float
     if(inside)
     {
       const float uu = (x0 + u + .5f) - spi, vv = (y0 + v + .5f) - spj;
-      f = bh_w(sqrtf(uu*uu + vv*vv) + 1.5f);
+      f = bh_w(mi_sqrt(uu*uu + vv*vv) + 1.5f);
     }
     float weight = 0.0f;
 #pragma unroll
     for(int k=0;k<16;k++) weight += __shfl(f, base + k);     /* taps outside the image contribute exactly 0, as if skipped */
     if(inside && weight > 0)
     {
-      const float g = (1.0f/weight)*f;
+      const float g = mi_rcp(weight)*f;
       float *px = sc.fb + 3*((size_t)(x0+u) + (size_t)wd*(y0+v));
       atomicAdd(px+0, s0*g);
       atomicAdd(px+1, s1*g);

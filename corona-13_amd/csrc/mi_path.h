@@ -95,7 +95,7 @@ __device__ __forceinline__ void camera_frame_at(const mi_camera &cam, float time
   else
   {
     const float theta_2 = acosf(cos_theta_2);
-    const float sin_theta_2 = sqrtf(1.0f - cos_theta_2*cos_theta_2);
+    const float sin_theta_2 = mi_sqrt(1.0f - cos_theta_2*cos_theta_2);
     if(fabsf(sin_theta_2) < 1e-10f) for(int k=0;k<4;k++) r[k] = (q[k] + p[k])*.5f;
     else
     {
@@ -135,8 +135,8 @@ __device__ __forceinline__ void path_generate(const DScene &sc, PathState &ps, u
   const float ang = (float)(2*MI_PI_D*(double)r1);
   float sn, cs;
   sincosf(ang, &sn, &cs);                 /* one range reduction for both (same values as sinf/cosf) */
-  const float lu = cs*sqrtf(r2)*cc.lens_radius;
-  const float lv = sn*sqrtf(r2)*cc.lens_radius;
+  const float lu = cs*mi_sqrt(r2)*cc.lens_radius;
+  const float lv = sn*mi_sqrt(r2)*cc.lens_radius;
   V3 ca = ld3(cam.a), cb = ld3(cam.b), cn = ld3(cam.n), cpos = ld3(cam.pos);
   /* camera motion blur, src/view.c:903-919. Only in the MEDIA ("extended") instantiations: even as a never-taken uniform branch
      it cost the plain kernels 0.9 % (A/B on one box: 2722 vs 2746 Msamples/s), so scenes with a moving camera run those */
@@ -285,7 +285,7 @@ __device__ __forceinline__ void path_shade_volume(const DScene &sc, PathState &p
       Surf ls;
       ls.x = prim_sample<MB>(sc.prims[lp], sc.primgeo[lp], r2, r3, ls.u, ls.v, MB ? sc.prims_t1 + lp : nullptr, ps.time);
       V3 ol = sub3(ls.x, sf.x);
-      const float ldist = sqrtf(dot3(ol, ol));
+      const float ldist = mi_sqrt(dot3(ol, ol));
       const double il = 1./(double)ldist;
       ol = mk3((float)((double)ol.x*il), (float)((double)ol.y*il), (float)((double)ol.z*il));
       const uint4 lhead = *(const uint4 *)&sc.primgeo[lp];
@@ -310,10 +310,10 @@ __device__ __forceinline__ void path_shade_volume(const DScene &sc, PathState &p
         { /* prims_get_ray, src/prims.c:390-492: no offset at a volume vertex, the usual one at the emitter */
           const float eps = 1e-4f*DMAX(DMAX(.5f, fabsf(sf.x.x)), DMAX(fabsf(sf.x.y), fabsf(sf.x.z)));
           V3 rd = sub3(ls.x, sf.x);
-          rd = scale3(rd, 1.0f/sqrtf(dot3(rd, rd)));
+          rd = scale3(rd, mi_rcp(mi_sqrt(dot3(rd, rd))));
           const V3 ro = sf.x;
           const V3 dv = mk3(ls.x.x - eps*rd.x - ro.x, ls.x.y - eps*rd.y - ro.y, ls.x.z - eps*rd.z - ro.z);
-          const float total_dist = sqrtf(dot3(dv, dv));
+          const float total_dist = mi_sqrt(dot3(dv, dv));
           if(!(dot3(ls.gn, rd) >= 0) && total_dist > 0.0f)
           {
             const float Gn = 1.0f*fabsf(dot3(ls.n, ol))/(ldist*ldist);
@@ -355,7 +355,7 @@ __device__ __forceinline__ void path_shade_volume(const DScene &sc, PathState &p
     if(g == 0.0f)
     { /* sample_sphere */
       const float z = 1.f - 2.f*r1;
-      const float r = sqrtf(1.f - z*z);
+      const float r = mi_sqrt(1.f - z*z);
       const float phi = (float)(2.f*MI_PI_D*(double)r2);
       float sn, cs;
       sincosf(phi, &sn, &cs);
@@ -367,7 +367,7 @@ __device__ __forceinline__ void path_shade_volume(const DScene &sc, PathState &p
       const float sqr = (1.0f-g*g)/(1.0f+g*(2.0f*r1-1.0f));
       const float cos_theta = 1.0f/(2.0f*g)*(1.0f + g*g - sqr*sqr);
       const float phi = (float)(2.0f*MI_PI_D*(double)r2);
-      const float l = sqrtf(fmaxf(0.0f, 1.0f-cos_theta*cos_theta));
+      const float l = mi_sqrt(fmaxf(0.0f, 1.0f-cos_theta*cos_theta));
       float sn, cs;
       sincosf(phi, &sn, &cs);
       o0 = cos_theta; o1 = cs*l; o2 = sn*l;
@@ -565,8 +565,8 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
           const float p_survival = DMIN(1.0f, vthr/ps.prev_throughput);
           PointSampler<HALTON> pts(sc, ps.rng, ps.index, rand_beg_extend<PTDL>(v));   /* the last vertex's dimensions, src/pathspace.c:278-281 */
           const float rr = pts(MI_DIM_RUSSIAN_R);
-          if(rr >= p_survival) { vthr = vthr*(1.0f/(1.0f-p_survival)); alive = false; }
-          else vthr = vthr*(1.0f/p_survival);
+          if(rr >= p_survival) { vthr = vthr*mi_rcp(1.0f-p_survival); alive = false; }
+          else vthr = vthr*mi_rcp(p_survival);
           if(RECORD && v < MI_REC_MAX_VERTS)
           {
             rec->v[v].throughput = vthr;
@@ -605,14 +605,14 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
               /* prims_sample + prims_retime, src/prims.c:178-252 */
               float hu, hv;
               if(quad) { hu = r2; hv = r3; }
-              else { const float a = sqrtf(r2); hu = r3*a; hv = (1.0f-r3)*a; }
+              else { const float a = mi_sqrt(r2); hu = r3*a; hv = (1.0f-r3)*a; }
               const bool second = quad && !(hv >= hu);
               const float u = second ? hu - hv : hu;
               const float vv = !quad ? hv : second ? hv : hv - hu;
               ls.x = second ? tri_retime(v0, v2, v3, u, vv) : tri_retime(v0, v1, v2, u, vv);
               ls.u = hu; ls.v = hv;
               ol = sub3(ls.x, sf.x);
-              ldist = sqrtf(dot3(ol, ol));
+              ldist = mi_sqrt(dot3(ol, ol));
               const double il = 1./(double)ldist;
               ol = mk3((float)((double)ol.x*il), (float)((double)ol.y*il), (float)((double)ol.z*il));
               /* prims_get_normal_time for triangles / quads (surface_setup); the flip towards the ray changes neither |n.omega| nor gn */
@@ -635,7 +635,7 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
               lpe = sc.light_prim[t]; lp = lpe & ~MI_LIGHT_ANYHIT;   /* bit 31: any-hit shadow ray allowed (mi_device.h) */
               ls.x = prim_sample<MB>(sc.prims[lp], sc.primgeo[lp], r2, r3, ls.u, ls.v, MB ? sc.prims_t1 + lp : nullptr, ps.time);
               ol = sub3(ls.x, sf.x);
-              ldist = sqrtf(dot3(ol, ol));
+              ldist = mi_sqrt(dot3(ol, ol));
               const double il = 1./(double)ldist;
               ol = mk3((float)((double)ol.x*il), (float)((double)ol.y*il), (float)((double)ol.z*il));
               const uint4 lhead = *(const uint4 *)&sc.primgeo[lp];
@@ -672,10 +672,10 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
               { /* prims_get_ray, src/prims.c:390-492 */
                 const float eps = 1e-4f*DMAX(DMAX(.5f, fabsf(sf.x.x)), DMAX(fabsf(sf.x.y), fabsf(sf.x.z)));
                 V3 rd = sub3(ls.x, sf.x);
-                rd = scale3(rd, 1.0f/sqrtf(dot3(rd, rd)));
+                rd = scale3(rd, mi_rcp(mi_sqrt(dot3(rd, rd))));
                 const V3 ro = mk3(sf.x.x + eps*rd.x, sf.x.y + eps*rd.y, sf.x.z + eps*rd.z);
                 const V3 dv = mk3(ls.x.x - eps*rd.x - ro.x, ls.x.y - eps*rd.y - ro.y, ls.x.z - eps*rd.z - ro.z);
-                const float total_dist = sqrtf(dot3(dv, dv));
+                const float total_dist = mi_sqrt(dot3(dv, dv));
                 if(!(dot3(ls.gn, rd) >= 0) && total_dist > 0.0f)
                 {
                   const float Gn = fabsf(dot3(sf.n, ol))*fabsf(dot3(ls.n, ol))/(ldist*ldist);
