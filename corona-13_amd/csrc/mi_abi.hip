@@ -38,7 +38,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
                                                            uint2 *stack_overflow)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const Lds lds = lds_setup<MI_BLOCK, NODES_LDS, HALTON>(sc, smem, stack_overflow);
+  const Lds lds = lds_setup<MI_BLOCK, NODES_LDS, HALTON, PTDL && !MEDIA>(sc, smem, stack_overflow);
 
   /* every workgroup owns a contiguous part of the path index range and hands it out through an LDS counter: the
      wave-level refill below then needs no global atomic at all (one shared counter costs ~11 ns per wave refill) */
@@ -824,8 +824,9 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
      read from HBM / L2 by the NODES_LDS = false instantiations (CORONA_MI_NODES=global forces that, for tests) */
   const char *nodes_env = getenv("CORONA_MI_NODES");
   const size_t halton_bytes = h->pointsampler == MI_POINTS_HALTON ? (size_t)2*MI_HALTON_LDS : 0;     /* staged head of the permutation tables */
-  s->nodes_lds = halton_bytes + node_bytes + stack_bytes <= 160*1024 && !(nodes_env && !strcmp(nodes_env, "global"));
-  s->lds_bytes = halton_bytes + (s->nodes_lds ? node_bytes : 0) + stack_bytes;
+  const size_t lights_bytes = h->sampler == MI_SAMPLER_PTDL ? (size_t)MI_LIGHTS_LDS*sizeof(DLight) : 0;  /* ptdl: emitter records in LDS */
+  s->nodes_lds = halton_bytes + lights_bytes + node_bytes + stack_bytes <= 160*1024 && !(nodes_env && !strcmp(nodes_env, "global"));
+  s->lds_bytes = halton_bytes + lights_bytes + (s->nodes_lds ? node_bytes : 0) + stack_bytes;
   s->device_built = device_build; s->stack_need = stack_need;
   { const char *ce = getenv("CORONA_MI_COUNTERS"); s->counting = ce && atoi(ce) ? 1 : 0; }
   {

@@ -591,7 +591,18 @@ __device__ __forceinline__ uint2 stack_top(const Lds &lds, const lds_uint2 *lsta
 /* Workgroup prologue shared by all traversal kernels. NODES_LDS: the BVH is staged into LDS once per workgroup
  * (coalesced 16-B loads) in front of the traversal stacks; otherwise it does not fit next to the stacks and is read from
  * HBM / L2 through the same SoA layout (mi_device.h), LDS holds the stacks only. Call from all threads (barrier inside). */
-template<int BLOCK, bool NODES_LDS, bool HALTON = false>
+/* ptdl: the one-burst emitter records (DLight) of up to MI_LIGHTS_LDS emitter primitives sit in LDS, behind the Halton head */
+#ifndef MI_LIGHTS_LDS
+#define MI_LIGHTS_LDS 16
+#endif
+template<bool HALTON>
+__device__ __forceinline__ const float4 *lights_lds()
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char mi_dynamic_lds[];
+  return (const float4 *)(mi_dynamic_lds + (HALTON ? 2*MI_HALTON_LDS : 0));
+}
+
+template<int BLOCK, bool NODES_LDS, bool HALTON = false, bool LIGHTS = false>
 __device__ __forceinline__ Lds lds_setup(const DScene &sc, unsigned char *smem, uint2 *stack_overflow)
 {
   const uint32_t N = sc.num_nodes;
@@ -603,6 +614,13 @@ __device__ __forceinline__ Lds lds_setup(const DScene &sc, unsigned char *smem, 
     const uint32_t *src = (const uint32_t *)sc.halton_perm;
     for(uint32_t i=threadIdx.x;i<MI_HALTON_LDS/2;i+=BLOCK) dst[i] = src[i];
     smem += 2*MI_HALTON_LDS;
+    if(!NODES_LDS) __syncthreads();
+  }
+  if(LIGHTS && MI_LIGHTS_LDS)
+  {
+    if(sc.lights && sc.num_lights <= MI_LIGHTS_LDS)
+      for(uint32_t i=threadIdx.x;i<sc.num_lights*(uint32_t)(sizeof(DLight)/16);i+=BLOCK) ((float4 *)smem)[i] = ((const float4 *)sc.lights)[i];
+    smem += MI_LIGHTS_LDS*sizeof(DLight);
     if(!NODES_LDS) __syncthreads();
   }
   if(NODES_LDS)
@@ -690,7 +708,7 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
       const uint4 child = *(const uint4 *)&lds.nodes[6*N + node];
       const uint32_t ax = lds.axes[node];       /* with the other loads of this node, not after the slab test */
       float tm0, tm1, tm2, tm3;
-      uint32_t mask = 0;
+      bool m0, m1, m2, m3;      /* child c is hit: lane masks in scalar registers, combined by scalar instructions below */
       if(!slow)
       { /* 4 child slabs, qbvhmp.c:1188-1246. The ray's sign bits pick the entry / exit plane of every slab, which is what
            the reference's min(t0,t1) / max(t0,t1) evaluate to for finite 1/dir and b_min <= b_max (rounding is monotonic;
@@ -702,8 +720,8 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
 #define SLAB(J, C, TM) { \
         const float lo = fmaxf(fmaxf(fmaxf((nx.C - o.x)*idx, (ny.C - o.y)*idy), (nz.C - o.z)*idz), 0.0f); \
         const float hi = fminf(fminf(fminf((fx.C - o.x)*idx, (fy.C - o.y)*idy), (fz.C - o.z)*idz), hit.dist); \
-        TM = lo; mask |= (lo <= hi ? 1u : 0u) << (J); }
-        SLAB(0, x, tm0) SLAB(1, y, tm1) SLAB(2, z, tm2) SLAB(3, w, tm3)
+        TM = lo; J = lo <= hi; }
+        SLAB(m0, x, tm0) SLAB(m1, y, tm1) SLAB(m2, z, tm2) SLAB(m3, w, tm3)
 #undef SLAB
       }
       else
@@ -722,17 +740,17 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
         t0 = ((Z0) - o.z)*idz; t1 = ((Z1) - o.z)*idz; \
         mn = t0 < t1 ? t0 : t1; mx = t0 > t1 ? t0 : t1; \
         lo = lo > mn ? lo : mn; hi = hi < mx ? hi : mx; \
-        TM = lo; mask |= (lo <= hi ? 1u : 0u) << (J); }
-        SLAB(0, mnx.x, mxx.x, mny.x, mxy.x, mnz.x, mxz.x, tm0)
-        SLAB(1, mnx.y, mxx.y, mny.y, mxy.y, mnz.y, mxz.y, tm1)
-        SLAB(2, mnx.z, mxx.z, mny.z, mxy.z, mnz.z, mxz.z, tm2)
-        SLAB(3, mnx.w, mxx.w, mny.w, mxy.w, mnz.w, mxz.w, tm3)
+        TM = lo; J = lo <= hi; }
+        SLAB(m0, mnx.x, mxx.x, mny.x, mxy.x, mnz.x, mxz.x, tm0)
+        SLAB(m1, mnx.y, mxx.y, mny.y, mxy.y, mnz.y, mxz.y, tm1)
+        SLAB(m2, mnx.z, mxx.z, mny.z, mxy.z, mnz.z, mxz.z, tm2)
+        SLAB(m3, mnx.w, mxx.w, mny.w, mxy.w, mnz.w, mxz.w, tm3)
 #undef SLAB
       }
-      if(mask)
+      if(m0 || m1 || m2 || m3)
       {
         MI_COUNT(cnt, 1, 1);
-        MI_COUNT(cnt, 2, __popc(mask));
+        MI_COUNT(cnt, 2, (uint32_t)m0 + (uint32_t)m1 + (uint32_t)m2 + (uint32_t)m3);
         /* front-to-back order from split axes and ray signs, qbvhmp.c:1313-1320: the near half is children
            {2*near0, 2*near0+1}, ordered by the sign along its own split axis; likewise the far half */
         const uint32_t axis0 = ax & 3u;
@@ -740,7 +758,8 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
         const uint32_t axis1n = near0 ? ((ax >> 4) & 3u) : ((ax >> 2) & 3u);
         const uint32_t axis1f = near0 ? ((ax >> 2) & 3u) : ((ax >> 4) & 3u);
         const bool near1n = (nearbits >> axis1n) & 1u, near1f = (nearbits >> axis1f) & 1u;
-        const uint32_t mh = near0 ? ((mask >> 2) | (mask << 2)) : mask;   /* bits 0,1 near half; 2,3 far half */
+        const bool ha0 = near0 ? m2 : m0, ha1 = near0 ? m3 : m1;          /* hit flags of the near half, of the far half */
+        const bool hb0 = near0 ? m0 : m2, hb1 = near0 ? m1 : m3;
         const uint32_t ca0 = near0 ? child.z : child.x, ca1 = near0 ? child.w : child.y;
         const uint32_t cb0 = near0 ? child.x : child.z, cb1 = near0 ? child.y : child.w;
         const float ta0 = near0 ? tm2 : tm0, ta1 = near0 ? tm3 : tm1;
@@ -749,8 +768,8 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
         const uint32_t c10 = near1f ? cb1 : cb0, c11 = near1f ? cb0 : cb1;
         const float t01 = near1n ? ta0 : ta1;
         const float t10 = near1f ? tb1 : tb0, t11 = near1f ? tb0 : tb1;
-        const bool h00 = (mh >> (near1n ? 1 : 0)) & 1u, h01 = (mh >> (near1n ? 0 : 1)) & 1u;
-        const bool h10 = (mh >> (near1f ? 3 : 2)) & 1u, h11 = (mh >> (near1f ? 2 : 3)) & 1u;
+        const bool h00 = near1n ? ha1 : ha0, h01 = near1n ? ha0 : ha1;
+        const bool h10 = near1f ? hb1 : hb0, h11 = near1f ? hb0 : hb1;
         /* the first hit child in order n00,n01,n10,n11 becomes current; later ones are pushed far-first (qbvhmp.c:1336-1354) */
         const bool p11 = h11 && (h00 || h01 || h10);
         const bool p10 = h10 && (h00 || h01);

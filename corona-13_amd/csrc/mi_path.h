@@ -597,8 +597,17 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
                  (mi_scene_create sends every other scene to the extended kernels): one burst of ten 16-B loads instead of the chain
                  emitter list -> primitive -> shading record -> material -> ops. Same arithmetic as the generic branch below. */
               const uint32_t t = sc.num_lights <= 4 ? sample_cdf4(sc.light_cdf4, (int)sc.num_lights, r1) : sample_cdf(sc.light_cdf, (int)sc.num_lights, r1);
-              const float4 *lq = (const float4 *)(sc.lights + t);
-              const float4 q0 = lq[0], q1 = lq[1], q2 = lq[2], q3 = lq[3], q4 = lq[4], q5 = lq[5], q6 = lq[6], q7 = lq[7], q8 = lq[8], q9 = lq[9];
+              float4 q0, q1, q2, q3, q4, q5, q6, q7, q8, q9;
+              if(MI_LIGHTS_LDS && sc.num_lights <= MI_LIGHTS_LDS)
+              { /* from LDS (staged by lds_setup): short latency, the compiler places each read next to its use */
+                const float4 *lq = lights_lds<HALTON>() + t*(uint32_t)(sizeof(DLight)/16);
+                q0 = lq[0]; q1 = lq[1]; q2 = lq[2]; q3 = lq[3]; q4 = lq[4]; q5 = lq[5]; q6 = lq[6]; q7 = lq[7]; q8 = lq[8]; q9 = lq[9];
+              }
+              else
+              {
+                const float4 *lq = (const float4 *)(sc.lights + t);
+                q0 = lq[0]; q1 = lq[1]; q2 = lq[2]; q3 = lq[3]; q4 = lq[4]; q5 = lq[5]; q6 = lq[6]; q7 = lq[7]; q8 = lq[8]; q9 = lq[9];
+              }
               lpe = __float_as_uint(q9.x); lp = lpe & ~MI_LIGHT_ANYHIT;
               const bool quad = __float_as_uint(q9.y) == MI_PRIM_QUAD;
               const V3 v0 = mk3(q0.x, q0.y, q0.z), v1 = mk3(q0.w, q1.x, q1.y), v2 = mk3(q1.z, q1.w, q2.x), v3 = mk3(q2.y, q2.z, q2.w);
