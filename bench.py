@@ -345,12 +345,13 @@ def main():
         cfg = r["cfg"]
         inst = ("false", "true" if cfg["sampler"] == "ptdl" else "false", "true" if r["nodes_in_lds"] else "false",
                 "true" if args.points == "halton" else "false",
-                "true" if cfg["scene"] in ("0055_media", "0056_fog", "0058_cam_mb", "0059_mb") else "false", "true" if cfg["scene"] == "0059_mb" else "false")
+                "true" if cfg["scene"] in ("0055_media", "0056_fog", "0058_cam_mb", "0059_mb") else "false", "true" if cfg["scene"] == "0059_mb" else "false", "false")
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": prof_name if traffic is not None else None,
                 "hbm_measured_gbs": traffic / (r["kms"] * 1e-3) / 1e9 if traffic is not None else None,
-                "limiter": "valu issue, not HBM: the 0.5 MB scene is LDS/L2 resident (see roofline_valu)",
-                "kernel": "mi_path_kernel<%s> (RECORD, PTDL, NODES_LDS, HALTON, MEDIA, MB)" % ",".join(inst), "kernel_ms": r["kms"],
+                "limiter": "valu issue, not HBM: the 0.5 MB scene is LDS/L2 resident, so the algorithmic figure is a work rate (it may exceed the "
+                           "HBM peak) and hbm_measured_gbs is what DRAM actually sees; the physical roofline is roofline_valu",
+                "kernel": "mi_path_kernel<%s> (RECORD, PTDL, NODES_LDS, HALTON, MEDIA, MB, COUNT)" % ",".join(inst), "kernel_ms": r["kms"],
                 "algorithmic_bytes_per_sample": bytes_per_sample, "work_counts": src,
                 "work_per_sample": {"node_visits": work["node_visits"], "prim_tests": work["prim_tests"], "splats": work["splats"]},
                 "live_work_per_sample": dict(live, rays=dc[0] / paths)}

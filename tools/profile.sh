@@ -8,9 +8,9 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py --steps 5 > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 5 --no-cpu-baseline > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 5 --no-cpu-baseline --no-secondary > $OUT/trace.log 2>&1
 cp $OUT/trace/*/*_kernel_stats.csv $OUT/kernel_stats.csv
-pmc() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_$name -- python3 $R/bench.py --steps 2 --warmup 0 --no-cpu-baseline > $OUT/pmc_$name.log 2>&1; cp $OUT/pmc_$name/*/*_counter_collection.csv $OUT/pmc_$name.csv; }
+pmc() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_$name -- python3 $R/bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-secondary > $OUT/pmc_$name.log 2>&1; cp $OUT/pmc_$name/*/*_counter_collection.csv $OUT/pmc_$name.csv; }
 pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE
 pmc sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_ANY
@@ -26,12 +26,18 @@ res = {}
 for f in glob.glob(out + "/pmc_*.csv"):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "mi_path_kernel" in r["Kernel_Name"]:
+        # the timed kernel only: pt, tree in LDS, no debug counters (bench.py also launches the counting instantiation once, outside its timed region)
+        if "mi_path_kernel<false, false, true, false, false, false, false>" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
             res["VGPR_Count"] = r.get("VGPR_Count"); res["LDS_Block_Size"] = r.get("LDS_Block_Size"); res["Scratch_Size"] = r.get("Scratch_Size")
             res["Grid_Size"] = r.get("Grid_Size"); res["Workgroup_Size"] = r.get("Workgroup_Size")
     for k, v in agg.items():
         res[k] = sum(v) / len(v)
+res["paths_per_launch"] = 64 * 1280 * 736
+for r in csv.DictReader(open(out + "/kernel_stats.csv")):
+    if "mi_path_kernel<false, false, true, false, false, false, false>" in r["Name"]:
+        res["kernel_ms"] = float(r["AverageNs"]) * 1e-6
+        res["kernel_calls"] = int(r["Calls"])
 try:
     res.update(json.load(open(out + "/hbm_copy.json")))
 except Exception:
