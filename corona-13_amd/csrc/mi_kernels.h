@@ -820,7 +820,7 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
       for(uint32_t i=0;i<num;i+=2)
       {
 #ifdef MI_PROFILE_LOOPS
-        if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) cnt.c[9] += MI_PROFILE_LOOPS == 2 ? 2*__popcll(__ballot(1)) : 2;   /* wave-level leaf slots (2: lane slots of lanes with a leaf) */
+        { const unsigned nl = __popcll(__ballot(1)); if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) cnt.c[9] += MI_PROFILE_LOOPS == 2 ? 2*nl : 2; }   /* wave-level leaf slots (2: lane slots of lanes still in their leaf) */
 #endif
         if(i + 1 < num) rb = prim_load(prims, idxp + i + 1);
         MI_LEAF_STEP(ra, i)
@@ -834,7 +834,7 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
       while(analytic)
       {
 #ifdef MI_PROFILE_LOOPS
-        if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) cnt.c[10]++;   /* wave-level analytic passes */
+        { const unsigned nl = __popcll(__ballot(1)); if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) cnt.c[10] += MI_PROFILE_LOOPS == 2 ? nl : 1; }   /* wave-level analytic passes (2: lanes in them) */
 #endif
         const uint32_t i = __ffs(analytic) - 1;
         analytic &= analytic - 1;
