@@ -296,6 +296,28 @@ def test_errors_are_reported():
     assert m.mi_scene_create(d, C.byref(out)) < 0
     d.contents.pointsampler = 0
     assert m.mi_render(None, 0, 1) < 0
+    # a tree that is not one: a child link back to the root (cycle) and a node reached twice (shared subtree) are both found in O(N)
+    nodes = d.contents.nodes
+    inner = [(n, c) for n in range(d.contents.num_nodes) for c in range(4) if not (nodes[n].child[c] >> 63)]
+    (n0, c0), (n1, c1) = inner[5], inner[6]
+    keep = nodes[n0].child[c0]
+    nodes[n0].child[c0] = 0
+    assert m.mi_scene_create(d, C.byref(out)) < 0 and b"not a tree" in m.mi_last_error()
+    nodes[n0].child[c0] = nodes[n1].child[c1]
+    assert m.mi_scene_create(d, C.byref(out)) < 0 and b"not a tree" in m.mi_last_error()
+    nodes[n0].child[c0] = keep
+    # a shape whose material index lies outside the material list (checked for every shape, also those without primitives)
+    shapes = d.contents.shapes
+    mat = shapes[d.contents.num_shapes - 1].material
+    shapes[d.contents.num_shapes - 1].material = d.contents.num_materials
+    assert m.mi_scene_create(d, C.byref(out)) < 0 and b"material" in m.mi_last_error()
+    shapes[d.contents.num_shapes - 1].material = -1
+    assert m.mi_scene_create(d, C.byref(out)) < 0
+    shapes[d.contents.num_shapes - 1].material = mat
+    assert m.mi_scene_create(d, C.byref(out)) == 0            # and the untouched descriptor still loads
+    m.mi_scene_destroy(out)
+    assert m.mi_init(4096) < 0 and b"no such device" in m.mi_last_error()      # a device index is not wrapped around any more
+    assert m.mi_init(0) == 0
 
 
 def _compare_hits(scene, be, pos, direction, ignore=None, max_dist=None):

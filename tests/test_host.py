@@ -256,6 +256,13 @@ def test_cli_info_validates_scene_files(tmp_path):
     geo.write_bytes(geo.read_bytes()[:40])
     bad = subprocess.run([str(cli), str(tmp_path / "scenes" / "0010_pt" / "test.nra2"), "--info"], capture_output=True, text=True)
     assert "sphere" in bad.stderr and ("spheres 0" in bad.stdout or bad.returncode != 0)
+    # a .geo header that promises 2^61 primitives (the products in the bounds checks would wrap around): rejected, shape skipped
+    geo = tmp_path / "scenes" / "geo" / "cone.geo"
+    raw = bytearray(geo.read_bytes())
+    raw[8:16] = struct.pack("<Q", 1 << 61)
+    geo.write_bytes(bytes(raw))
+    bad = subprocess.run([str(cli), str(tmp_path / "scenes" / "0010_pt" / "test.nra2"), "--info"], capture_output=True, text=True)
+    assert "cone" in bad.stderr and "bad magic/version/offsets" in bad.stderr and bad.returncode in (0, 2)
     # a missing scene file is an error
     assert subprocess.run([str(cli), str(tmp_path / "nothing.nra2"), "--info"], capture_output=True, text=True).returncode != 0
 
