@@ -102,8 +102,8 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
        MI_TAIL_LANES rays is still under way. Those lanes keep their traversal state (registers + LDS stack) and go on in the
        next iteration next to the fresh rays of the lanes that shade now, so one long ray does not hold 63 lanes idle. */
     {
-      const V3 o = tr_shadow ? ps.sh_org : ps.org, d = tr_shadow ? ps.sh_dir : ps.dir;
-      const uint32_t ignore = tr_shadow ? ps.sh_ignore : ps.ignore;
+      const V3 o = ray_origin<PTDL>(ps, tr_shadow), d = tr_shadow ? ps.sh_dir : ps.dir;
+      const uint32_t ignore = ps.ignore;     /* the shadow ray of a vertex starts on the same primitive as its extension ray */
       const unsigned tail = exhausted_wave ? 1u : (unsigned)(PTDL ? MI_TAIL_LANES_PTDL : MI_TAIL_LANES);
       while(true)
       {

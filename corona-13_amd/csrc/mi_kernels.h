@@ -568,7 +568,8 @@ struct Lds
   const float4 *nodes;      /* [MI_NODE_FIELDS][num_nodes] in LDS (or in HBM when the tree does not fit, see lds_setup) */
   const uint32_t *axes;     /* [num_nodes], same place */
   uint2 *stack;             /* [STACK][BLOCK] in LDS, this thread's column */
-  uint2 *overflow;          /* [extra][total threads] in HBM, this thread's column: entries beyond STACK (rare) */
+  uint2 *overflow;          /* [extra][total threads] in HBM: entries beyond STACK (rare). The workgroup's row; the thread's column is
+                               added where it is used, so that no per-thread 64-bit pointer lives in registers through the kernel */
   uint32_t overflow_stride;
   uint32_t num_nodes;
 };
@@ -577,7 +578,7 @@ template<int BLOCK, int STACK>
 __device__ __forceinline__ void stack_push(const Lds &lds, int sp, uint2 e)
 {
   if(sp < STACK) lds.stack[sp*BLOCK] = e;
-  else lds.overflow[(size_t)(sp - STACK)*lds.overflow_stride] = e;
+  else lds.overflow[(size_t)(sp - STACK)*lds.overflow_stride + threadIdx.x] = e;
 }
 typedef unsigned int mi_u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) mi_u32x2 lds_uint2;   /* typed LDS pointer: ds_read/ds_write instead of flat */
@@ -585,7 +586,7 @@ template<int BLOCK, int STACK>
 __device__ __forceinline__ uint2 stack_top(const Lds &lds, const lds_uint2 *lstack, int sp)
 {
   if(sp < STACK) { const mi_u32x2 v = lstack[sp*BLOCK]; return make_uint2(v.x, v.y); }
-  return lds.overflow[(size_t)(sp - STACK)*lds.overflow_stride];
+  return lds.overflow[(size_t)(sp - STACK)*lds.overflow_stride + threadIdx.x];
 }
 
 /* Workgroup prologue shared by all traversal kernels. NODES_LDS: the BVH is staged into LDS once per workgroup
@@ -641,7 +642,7 @@ __device__ __forceinline__ Lds lds_setup(const DScene &sc, unsigned char *smem, 
   }
   lds.stack = lds_stack + threadIdx.x; lds.num_nodes = N;
   lds.overflow_stride = gridDim.x*BLOCK;
-  lds.overflow = stack_overflow + (size_t)blockIdx.x*BLOCK + threadIdx.x;
+  lds.overflow = stack_overflow + (size_t)blockIdx.x*BLOCK;
   return lds;
 }
 
@@ -1012,7 +1013,8 @@ __device__ __forceinline__ void surface_setup(const DScene &sc, uint32_t prim, c
   /* flip towards the ray, tangent frame */
   sf.flags = s_none;
   if(dot3(omega, sf.gn) > 0.0f) { sf.n = neg3(sf.n); sf.flags |= s_inside; }
-  get_scrambled_onb(scramble, sf.n, sf.a, sf.b);
+  /* the tangent frame get_scrambled_onb(scramble, n) (manifold.h:226-232) is formed by the caller where it is first needed -- the
+     bsdf sample at the end of path_shade -- instead of living through next event estimation (six registers of the ptdl kernel) */
 }
 
 /* ------------------------------------------------------------------------------------------ spectra, shading inputs */

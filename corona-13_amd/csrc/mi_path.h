@@ -15,13 +15,14 @@
 struct PathState
 {
   /* ray to trace next */
-  V3 org, dir;
+  V3 org, dir;              /* ptdl does not keep `org` (nor an origin of the shadow ray): both rays of a vertex start at
+                               prev_x + org_eps * direction, formed when the ray is started (ray_origin) -- two registers less */
+  float org_eps;            /* prims_offset_ray's epsilon at the vertex the rays leave (0: camera, volume vertex) */
   uint32_t ignore;          /* primitive the ray starts on */
   /* vertex v-1 (the one the ray leaves) */
   V3 prev_x;
   float prev_cos;           /* path_lambert(v-1, omega): |n.omega| or 1 */
   float prev_throughput;    /* v[v-1].throughput */
-  uint32_t prev_mode;
   /* vertex v being created */
   float throughput;         /* v[v].throughput (after the bsdf sample at v-1) */
   float pdf;                /* v[v].pdf as left by the bsdf sample (projected solid angle) */
@@ -30,16 +31,19 @@ struct PathState
   Media media;
   /* per path */
   float lambda, pixel_i, pixel_j, scramble;
-  int length;               /* number of complete vertices */
   Rng rng;
   unsigned long long index;
+  int length;               /* number of complete vertices */
   uint32_t active;          /* path alive: an extension ray is waiting to be traced */
-  /* ptdl: pending shadow ray of the next-event estimate made at the last vertex */
+  uint32_t prev_mode;
+  /* ptdl: pending shadow ray of the next-event estimate made at the last vertex (bit fields for these small words were tried:
+     pt -0.7 %, ptdl +0.3 %) */
   uint32_t sh_pending;
   uint32_t prev_material_modes;
-  V3 sh_org, sh_dir;
+  /* ptdl: pending shadow ray of the next-event estimate made at the last vertex */
+  V3 sh_dir;
   float sh_dist, sh_value;
-  uint32_t sh_light, sh_ignore;
+  uint32_t sh_light;         /* the shadow ray starts on ps.ignore, like the extension ray of the same vertex */
   int sh_length;
   /* homogeneous media (MEDIA instantiations only): the volume of the edge under way (e[v].vol) and the free-flight distance
      sampled for it (FLT_MAX: none) */
@@ -47,6 +51,15 @@ struct PathState
   float clip;
   float time;               /* the path's time in the shutter interval (motion-blurred primitives) */
 };
+
+/* origin of the extension ray (shadow = false) or of the pending shadow ray of the vertex at ps.prev_x */
+template<bool PTDL>
+__device__ __forceinline__ V3 ray_origin(const PathState &ps, bool shadow)
+{
+  if(!PTDL) return ps.org;
+  const V3 d = shadow ? ps.sh_dir : ps.dir;
+  return mk3(ps.prev_x.x + ps.org_eps*d.x, ps.prev_x.y + ps.org_eps*d.y, ps.prev_x.z + ps.org_eps*d.z);
+}
 
 /* a splat to be carried out by the wave (splat_wave) after the divergent part of the iteration */
 struct SplatReq { bool pending; float c0, c1, c2; };
@@ -159,7 +172,7 @@ __device__ __forceinline__ void path_generate(const DScene &sc, PathState &ps, u
   const V3 x0 = mk3(cpos.x + aoff.x, cpos.y + aoff.y, cpos.z + aoff.z);
   const float thr0 = sensor*G/cc.pdf_av;
   ps.org = x0; ps.dir = om; ps.ignore = MI_NOPRIM;
-  ps.prev_x = x0;
+  ps.prev_x = x0; ps.org_eps = 0.0f;
   ps.prev_cos = fabsf(dot3(cn, om));        /* path_lambert on the sensor vertex */
   ps.prev_throughput = thr0;
   ps.prev_mode = s_sensor;
@@ -249,7 +262,8 @@ __device__ __forceinline__ void path_shade_volume(const DScene &sc, PathState &p
   const float dist = ps.clip;
   const Medium med = ps.cur;
   Surf sf;
-  sf.x = mk3(ps.org.x + dist*ps.dir.x, ps.org.y + dist*ps.dir.y, ps.org.z + dist*ps.dir.z);
+  const V3 rorg = ray_origin<PTDL>(ps, false);
+  sf.x = mk3(rorg.x + dist*ps.dir.x, rorg.y + dist*ps.dir.y, rorg.z + dist*ps.dir.z);
   sf.n = omega; sf.gn = omega;                               /* the frame looks along the incoming direction */
   get_scrambled_onb(ps.scramble, sf.n, sf.a, sf.b);
   sf.u = sf.v = sf.s = sf.t = 0.0f; sf.flags = 0;
@@ -329,8 +343,9 @@ __device__ __forceinline__ void path_shade_volume(const DScene &sc, PathState &p
             if(tn/1.0f > 0.0f)
             {
               ps.sh_pending = 1;
-              ps.sh_org = ro; ps.sh_dir = rd; ps.sh_dist = total_dist;
-              ps.sh_light = lpe; ps.sh_ignore = MI_NOPRIM;
+              ps.prev_x = sf.x; ps.org_eps = 0.0f;                  /* = ro: no offset at a volume vertex */
+              ps.sh_dir = rd; ps.sh_dist = total_dist;
+              ps.sh_light = lpe; ps.ignore = MI_NOPRIM;
               ps.sh_value = (tn/1.0f)*wm;
               ps.sh_length = ps.length + 1;
             }
@@ -384,7 +399,7 @@ __device__ __forceinline__ void path_shade_volume(const DScene &sc, PathState &p
       ps.org = sf.x;
       ps.dir = wo;
       ps.ignore = MI_NOPRIM;
-      ps.prev_x = sf.x;
+      ps.prev_x = sf.x; ps.org_eps = 0.0f;
       ps.prev_cos = 1.0f;                                      /* path_lambert at a volume vertex */
       ps.prev_throughput = vthr;
       ps.prev_mode = vmode;
@@ -434,7 +449,8 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
   {
     /* shader_prepare, src/shader.c:462-542 */
     Surf sf;
-    sf.x = mk3(ps.org.x + hit.dist*ps.dir.x, ps.org.y + hit.dist*ps.dir.y, ps.org.z + hit.dist*ps.dir.z);
+    const V3 rorg = ray_origin<PTDL>(ps, false);
+    sf.x = mk3(rorg.x + hit.dist*ps.dir.x, rorg.y + hit.dist*ps.dir.y, rorg.z + hit.dist*ps.dir.z);
     sf.u = hit.u; sf.v = hit.v;
     /* the record's header first (one 16-B load): it names the material, whose fetch is then under way while the
        surface is set up */
@@ -705,8 +721,9 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
                   if(tn/1.0f > 0.0f)
                   {
                     ps.sh_pending = 1;
-                    ps.sh_org = ro; ps.sh_dir = rd; ps.sh_dist = total_dist;
-                    ps.sh_light = lpe; ps.sh_ignore = hit.prim;
+                    ps.prev_x = sf.x; ps.org_eps = eps;                 /* ro = sf.x + eps*rd is formed again when the ray starts */
+                    ps.sh_dir = rd; ps.sh_dist = total_dist;
+                    ps.sh_light = lpe; ps.ignore = hit.prim;
                     ps.sh_value = (tn/1.0f)*wm;
                     ps.sh_length = ps.length + 1;
                   }
@@ -727,6 +744,7 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
       if(alive)
       {
         BsdfSample bs;
+        get_scrambled_onb(ps.scramble, sf.n, sf.a, sf.b);              /* the vertex's tangent frame, see surface_setup */
         PointSampler<HALTON> pts(sc, ps.rng, ps.index, rand_beg_extend<PTDL>(v + 1));   /* the vertex the sample leads to */
         if(mat_bsdf == MI_BSDF_DIFFUSE) sample_diffuse(pts, sf, sh, mode, bs);
         else if(mat_bsdf == MI_BSDF_DIELECTRIC) sample_dielectric(pts, sf, sh, omega, eta_ratio, mode, bs);
@@ -764,7 +782,7 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
           ps.org = mk3(sf.x.x + eps*bs.omega.x, sf.x.y + eps*bs.omega.y, sf.x.z + eps*bs.omega.z);
           ps.dir = bs.omega;
           ps.ignore = hit.prim;
-          ps.prev_x = sf.x;
+          ps.prev_x = sf.x; ps.org_eps = eps;
           ps.prev_cos = fabsf(dot3(sf.n, bs.omega));
           ps.prev_throughput = vthr;
           ps.prev_mode = vmode;
