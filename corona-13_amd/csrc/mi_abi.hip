@@ -27,8 +27,15 @@
 #ifndef MI_ANYHIT
 #define MI_ANYHIT 1      /* shadow rays towards flagged emitters stop at the first occluder (MI_LIGHT_ANYHIT, mi_device.h) */
 #endif
+#ifndef MI_LEAF_JOBS
+#define MI_LEAF_JOBS 1
+#endif
 #ifndef MI_STACK
-#define MI_STACK 12      /* LDS traversal stack entries per lane; deeper entries overflow to HBM (mi_device.h) */
+#if MI_LEAF_JOBS
+#define MI_STACK (MI_STACK_LDS - 3)   /* the top three entries of a lane's column hold the results of the distributed leaf phase (leaf_jobs) */
+#else
+#define MI_STACK MI_STACK_LDS         /* LDS traversal stack entries per lane; deeper entries overflow to HBM (mi_device.h) */
+#endif
 #endif
 
 /* ======================================================================================= persistent megakernel */
@@ -49,6 +56,10 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
   const unsigned long long blk_lo = count/nb*blockIdx.x + (blockIdx.x < count%nb ? blockIdx.x : count%nb);
   const unsigned long long blk_hi = blk_lo + count/nb + (blockIdx.x < count%nb ? 1 : 0);
 
+  /* pt: the primitive tests of a traversal round are dealt out over all lanes of the wave (leaf_jobs); ptdl and the extended kernels
+     keep the per-lane leaf loop -- there the extra live registers of the job loop spill (A/B in DESIGN.md) */
+  constexpr bool JOBS = MI_LEAF_JOBS && !PTDL && !MEDIA && !MB;
+  constexpr int STACK = JOBS ? MI_STACK_LDS - 3 : MI_STACK_LDS;
   Counters<COUNT || RECORD> cnt;        /* COUNT = false: only the path count (see Counters, mi_kernels.h) */
   PathState ps;
   ps.active = 0;
@@ -111,7 +122,8 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
         const unsigned nbusy = __popcll(__ballot(busy));
         if(!nbusy) break;
         if(nbusy < tail && __any(tracing && ts.done)) break;
-        if(busy) trace_round<MI_BLOCK, MI_STACK, MB, PTDL && MI_ANYHIT>(lds, sc.prims, o, d, ignore, hit, ts, cnt);
+        if(busy) trace_round<MI_BLOCK, STACK, MB, PTDL && MI_ANYHIT, JOBS>(lds, sc.prims, o, d, ignore, hit, ts, cnt);
+        if(JOBS) leaf_jobs<MI_BLOCK, STACK, MB, PTDL && MI_ANYHIT>(lds, sc.prims, o, d, ignore, hit, ts, busy, cnt);   /* every lane of the wave takes part */
       }
     }
     MI_PHASE(cnt, 1)
@@ -169,12 +181,13 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_intersect_kernel(DScene sc, const
   for(unsigned long long base=(unsigned long long)blockIdx.x*MI_BLOCK; base<n; base+=(unsigned long long)gridDim.x*MI_BLOCK)
   {
     const unsigned long long i = base + threadIdx.x;
-    if(i < n)
+    const bool live = i < n;                     /* the lanes behind the last ray still take part in the traversal's wave-level steps */
+    const mi_ray r = rays[live ? i : n - 1];
+    Hit hit;
+    hit.prim = MI_NOPRIM; hit.dist = r.max_dist; hit.u = hit.v = 0.0f;
+    accel_intersect<MI_BLOCK, MI_STACK>(lds, sc.prims, mk3(r.pos[0], r.pos[1], r.pos[2]), mk3(r.dir[0], r.dir[1], r.dir[2]), r.ignore, hit, cnt, live);
+    if(live)
     {
-      const mi_ray r = rays[i];
-      Hit hit;
-      hit.prim = MI_NOPRIM; hit.dist = r.max_dist; hit.u = hit.v = 0.0f;
-      accel_intersect<MI_BLOCK, MI_STACK>(lds, sc.prims, mk3(r.pos[0], r.pos[1], r.pos[2]), mk3(r.dir[0], r.dir[1], r.dir[2]), r.ignore, hit, cnt);
       mi_hit h;
       h.prim = hit.prim; h.primid = hit.prim == MI_NOPRIM ? MI_PRIMID_INVALID : MI_GEO_PRIMID(sc.primgeo[hit.prim]);
       h.dist = hit.dist; h.u = hit.u; h.v = hit.v; h.pad[0] = h.pad[1] = 0;
@@ -819,7 +832,7 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   d.counters = (unsigned long long *)s->d_counters;
 
   const size_t node_bytes = (((size_t)MI_NODE_FIELDS*N*16 + (size_t)N*4) + 15) & ~(size_t)15;
-  const size_t stack_bytes = (size_t)MI_STACK*MI_BLOCK*sizeof(uint2);
+  const size_t stack_bytes = (size_t)MI_STACK_LDS*MI_BLOCK*sizeof(uint2) + (MI_LEAF_JOBS ? (size_t)(MI_BLOCK/64)*MI_JOBS_MAX : 0);   /* + the waves' job lists */
   /* the tree lives in LDS next to the traversal stacks when it fits (0010_pt: 50 KB + 96 KB of 160 KB); larger trees are
      read from HBM / L2 by the NODES_LDS = false instantiations (CORONA_MI_NODES=global forces that, for tests) */
   const char *nodes_env = getenv("CORONA_MI_NODES");

@@ -416,7 +416,8 @@ __device__ __forceinline__ PrimRegs prim_load(const DPrim *prims, uint32_t prim)
   return r;
 }
 
-__device__ __forceinline__ void triquad_intersect(const PrimRegs &r, uint32_t type, const V3 o, const V3 d, Hit &hit, uint32_t prim)
+template<bool BOTH = false>
+__device__ __forceinline__ bool triquad_intersect(const PrimRegs &r, uint32_t type, const V3 o, const V3 d, Hit &hit, uint32_t prim)
 { /* prims_intersect for tris and quads, src/prims.c:645-663: quad = tri(v0,v1,v2), and only if that misses tri(v0,v2,v3).
      Both triangles are evaluated without branches (same arithmetic as geo_tri_intersect, include/geo/triangle.h:263-305)
      and the reference's priority is applied afterwards, so a wave does not diverge on which half was hit. */
@@ -439,6 +440,11 @@ __device__ __forceinline__ void triquad_intersect(const PrimRegs &r, uint32_t ty
   const float uB = dot3(d, qB)*invB;
   const float tB = dot3(eB2, qB)*invB;
   const bool hitB = (type == MI_PRIM_QUAD) && !(vB < 0.0f || vB > 1.0f) && !(uB < 0.0f || uB + vB > 1.0f) && (tB > 0.0f && tB <= hit.dist);
+  /* BOTH (distributed leaf phase, leaf_jobs): both halves of a quad are crossed in front of the ray -- only a folded (non-planar)
+     quad seen edge-on. Which half the reference then reports depends on the running closest hit (src/prims.c:654-663), so such a
+     test is handed back to the sequential loop. */
+  const bool both = BOTH && (type == MI_PRIM_QUAD) && !(vA < 0.0f || vA > 1.0f) && !(uA < 0.0f || uA + vA > 1.0f) && tA > 0.0f &&
+                    !(vB < 0.0f || vB > 1.0f) && !(uB < 0.0f || uB + vB > 1.0f) && tB > 0.0f;
   if(hitA)
   {
     hit.dist = tA; hit.prim = prim; hit.u = uA;
@@ -448,6 +454,7 @@ __device__ __forceinline__ void triquad_intersect(const PrimRegs &r, uint32_t ty
   {
     hit.dist = tB; hit.prim = prim; hit.u = uB + vB; hit.v = vB;  /* tri (v0 v2 v3) uv => quad uv = (u+v, v) */
   }
+  return both;
 }
 
 /* the 64-byte record of a line segment (truncated cone / cylinder) as line_intersect reads it, from its two end points and
@@ -563,6 +570,9 @@ __device__ __forceinline__ void analytic_intersect(const DPrim *prims, uint32_t 
 }
 
 /* ------------------------------------------------------------------------------------------ traversal */
+#ifndef MI_STACK_LDS
+#define MI_STACK_LDS 12  /* entries per lane of the LDS stack area (mi_abi.hip: MI_STACK = what traversal may use of them) */
+#endif
 struct Lds
 {
   const float4 *nodes;      /* [MI_NODE_FIELDS][num_nodes] in LDS (or in HBM when the tree does not fit, see lds_setup) */
@@ -572,7 +582,10 @@ struct Lds
                                added where it is used, so that no per-thread 64-bit pointer lives in registers through the kernel */
   uint32_t overflow_stride;
   uint32_t num_nodes;
+  unsigned char *jobs;      /* leaf_jobs: this wave's list of MI_JOBS_MAX source lanes, in LDS behind the stacks */
 };
+#define MI_JOBS_MAX 256     /* primitive tests one wave deals out per round at most (64 lanes x 4); more: sequential leaf loop */
+#define MI_JOB_SLOTS 3      /* stack entries of a lane's LDS column that leaf_jobs uses for results: best (8 B), uv (8 B), analytic mask */
 
 template<int BLOCK, int STACK>
 __device__ __forceinline__ void stack_push(const Lds &lds, int sp, uint2 e)
@@ -641,6 +654,7 @@ __device__ __forceinline__ Lds lds_setup(const DScene &sc, unsigned char *smem, 
     lds.nodes = sc.nodes; lds.axes = sc.node_axes;
   }
   lds.stack = lds_stack + threadIdx.x; lds.num_nodes = N;
+  lds.jobs = (unsigned char *)(lds_stack + (size_t)MI_STACK_LDS*BLOCK) + (threadIdx.x >> 6)*MI_JOBS_MAX;
   lds.overflow_stride = gridDim.x*BLOCK;
   lds.overflow = stack_overflow + (size_t)blockIdx.x*BLOCK;
   return lds;
@@ -649,6 +663,10 @@ __device__ __forceinline__ Lds lds_setup(const DScene &sc, unsigned char *smem, 
 #ifndef MI_TAIL_INNER
 #define MI_TAIL_INNER 4
 #endif
+#ifndef MI_LEAF_JOBS
+#define MI_LEAF_JOBS 1   /* 1: the primitive tests of a round are dealt out over all 64 lanes of the wave (leaf_jobs) */
+#endif
+
 
 struct TraceState
 { /* resumable traversal of one ray: survives between rounds so that a wave can re-fill idle lanes in between */
@@ -673,9 +691,217 @@ __device__ __forceinline__ void trace_begin(TraceState &ts, const V3 d, CNT &cnt
   ts.anyhit = false;
 }
 
+/* what follows a leaf in accel_intersect: pop the next subtree that starts in front of the closest hit (qbvhmp.c:1357-1364,1380-1386) */
+template<int BLOCK, int STACK, bool ANYHIT>
+__device__ __forceinline__ void leaf_finish(const Lds &lds, const Hit &hit, TraceState &ts)
+{
+  lds_uint2 *lstack = (lds_uint2 *)lds.stack;
+  int sp = ts.sp;
+  uint32_t current = MI_LEAF32;
+  bool done = true;
+  if(ANYHIT && ts.anyhit && hit.prim != MI_NOPRIM) sp = 0;   /* an occluder is all a shadow ray needs to know (MI_LIGHT_ANYHIT) */
+  while(sp > 0)
+  {
+    sp--;
+    const uint2 e = stack_top<BLOCK, STACK>(lds, lstack, sp);
+    if(!(__uint_as_float(e.y) > hit.dist)) { current = e.x; done = false; break; }
+  }
+  ts.sp = sp; ts.current = current; ts.done = done;
+}
+
+/* the leaf a lane holds (ts.current), primitive by primitive on that lane (qbvhmp.c:1366-1379), then the pop */
+template<int BLOCK, int STACK, bool MB, bool ANYHIT, class CNT>
+__device__ __forceinline__ void leaf_sequential(const Lds &lds, const DPrim *prims, const V3 o, const V3 d, uint32_t ignore,
+                                                Hit &hit, TraceState &ts, CNT &cnt)
+{
+  const uint32_t current = ts.current;
+  {
+    {
+      uint32_t idxp = (current ^ MI_LEAF32) >> 5;
+      const uint32_t num = current & 31u;
+      /* triangles and quads first (software pipelined: the next primitive's 64 B are in flight while this one is
+         intersected); spheres / cones / cylinders of this leaf are remembered and intersected afterwards, so that the
+         wave runs that rare, long code once per leaf round instead of once per primitive slot. Every primitive of the
+         leaf is still tested exactly once against the running closest hit (prims_intersect, src/prims.c:638-672). */
+      uint32_t analytic = 0;
+      /* two record buffers in ping-pong: the load of primitive i+1 is in flight while i is intersected, and no
+         16-register copy is needed per iteration */
+#define MI_LEAF_STEP(R, I) { MI_COUNT(cnt, 3, 1); \
+        const uint32_t type = __float_as_uint((R).q3.x); \
+        if(type >= MI_PRIM_TRI) { if(idxp + (I) != ignore) triquad_intersect((R), type, o, d, hit, idxp + (I)); }   /* triangle.h:271 */ \
+        else analytic |= 1u << (I); }
+      PrimRegs ra = prim_load(prims, num ? idxp : 0), rb;      /* rb is loaded before each use (same condition) */
+      for(uint32_t i=0;i<num;i+=2)
+      {
+#ifdef MI_PROFILE_LOOPS
+        { const unsigned nl = __popcll(__ballot(1)); if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) cnt.c[9] += MI_PROFILE_LOOPS == 2 ? 2*nl : 2; }   /* wave-level leaf slots (2: lane slots of lanes still in their leaf) */
+#endif
+        if(i + 1 < num) rb = prim_load(prims, idxp + i + 1);
+        MI_LEAF_STEP(ra, i)
+        if(i + 1 < num)
+        {
+          if(i + 2 < num) ra = prim_load(prims, idxp + i + 2);
+          MI_LEAF_STEP(rb, i + 1)
+        }
+      }
+#undef MI_LEAF_STEP
+      while(analytic)
+      {
+#ifdef MI_PROFILE_LOOPS
+        { const unsigned nl = __popcll(__ballot(1)); if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) cnt.c[10] += MI_PROFILE_LOOPS == 2 ? nl : 1; }   /* wave-level analytic passes (2: lanes in them) */
+#endif
+        const uint32_t i = __ffs(analytic) - 1;
+        analytic &= analytic - 1;
+        analytic_intersect<MB>(prims, idxp + i, o, d, ignore, hit, MB ? ts.time : 0.0f, MB ? ts.prims_t1 : nullptr);
+      }
+    }
+  }
+  leaf_finish<BLOCK, STACK, ANYHIT>(lds, hit, ts);
+}
+
+/* Distributed leaf phase (MI_LEAF_JOBS). In the sequential leaf loop a round costs the wave as many test slots as its LONGEST leaf
+ * has primitives (6 in the reference's trees), while the average lane holds 1.8 -- 31 % of the slots test something. Here every
+ * (lane, primitive) pair of the round becomes a job and the jobs are dealt out over ALL 64 lanes, also those whose own ray is
+ * finished or still at an inner node:
+ *   owners        lanes that hold a leaf: num = primitives in it, exclusive prefix sum over the wave (ballots of the bits of num)
+ *   job list      jobs[prefix + k] = owner lane, one byte per job, in the wave's LDS list
+ *   worker lane j takes job j: fetches the owner's ray (ds_bpermute: origin, direction, closest distance at the start of the leaf,
+ *                 ignored primitive, leaf link), the primitive's record, runs the same triquad_intersect
+ *   results       a hit goes to the owner's slot `best` with ds_min_u64 on (distance bits << 32 | 31 - k): the closest wins and,
+ *                 at equal distance, the later primitive -- what the sequential `t <= hit.dist` does; the winner leaves u, v
+ *   owners        read best / uv, run the sphere / cone / cylinder tests of the leaf (mask gathered by the workers), pop.
+ * Per ray the same primitives are tested against the same ray with the same arithmetic; the closest hit a leaf yields is that of
+ * the sequential loop except where its result depends on the ORDER of the running distance: a quad both of whose halves are
+ * crossed (triquad_intersect<true>) -- such a test poisons the owner's slot and the owner runs the sequential loop.
+ * Counters are unchanged (every primitive of the leaf counts once). */
+typedef unsigned long long mi_u64;
+typedef __attribute__((address_space(3))) mi_u64 lds_u64;
+typedef __attribute__((address_space(3))) unsigned int lds_u32;
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+
+template<int BLOCK, int STACK, bool MB, bool ANYHIT, class CNT>
+__device__ __forceinline__ void leaf_jobs(const Lds &lds, const DPrim *prims, const V3 o, const V3 d, uint32_t ignore,
+                                          Hit &hit, TraceState &ts, bool busy, CNT &cnt)
+{
+  const unsigned lane = __lane_id();
+  const bool own = busy && !ts.done && (ts.current & MI_LEAF32);
+  if(!__any(own)) return;
+  const uint32_t cur = ts.current;
+  const uint32_t num = own ? cur & 31u : 0u;
+  /* exclusive prefix sum of num over the wave from the ballots of its bits (leaves of the reference's trees hold <= 6) */
+  const mi_u64 b0 = __ballot(num & 1u), b1 = __ballot(num & 2u), b2 = __ballot(num & 4u);
+  const uint32_t J = __popcll(b0) + 2u*__popcll(b1) + 4u*__popcll(b2);
+  if(__any(num > 7u) || J > MI_JOBS_MAX)
+  { /* leaves longer than the prefix sum covers, or more jobs than the list holds: the sequential loop */
+    if(own) leaf_sequential<BLOCK, STACK, MB, ANYHIT>(lds, prims, o, d, ignore, hit, ts, cnt);
+    return;
+  }
+#define MI_MBCNT(M) __builtin_amdgcn_mbcnt_hi((uint32_t)((M) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(M), 0u))
+  const uint32_t prefix = MI_MBCNT(b0) + 2u*MI_MBCNT(b1) + 4u*MI_MBCNT(b2);
+#undef MI_MBCNT
+  lds_u8 *jobs = (lds_u8 *)lds.jobs;
+  lds_uint2 *col = (lds_uint2 *)lds.stack;                    /* this lane's LDS column; lane s of the wave: col + (s - lane) */
+  lds_u64 *best = (lds_u64 *)(col + (STACK + 0)*BLOCK);
+  lds_uint2 *uvs = col + (STACK + 1)*BLOCK;
+  lds_u32 *anl = (lds_u32 *)(col + (STACK + 2)*BLOCK);
+  if(own)
+  {
+    for(uint32_t k=0;k<num;k++) jobs[prefix + k] = (unsigned char)lane;
+    *best = ((mi_u64)__float_as_uint(hit.dist) << 32) | 0xffffffffull;
+    *anl = 0u;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#define MI_JOB_FETCH(JJ, VALID, SRC, PRIM, K, REC) \
+    const uint32_t SRC##_j = (JJ); \
+    const bool VALID = SRC##_j < J; \
+    const int SRC = VALID ? (int)jobs[SRC##_j] : (int)lane; \
+    const uint32_t SRC##_cur = (uint32_t)__shfl((int)cur, SRC), SRC##_pre = (uint32_t)__shfl((int)prefix, SRC); \
+    const uint32_t K = SRC##_j - SRC##_pre, PRIM = ((SRC##_cur ^ MI_LEAF32) >> 5) + K; \
+    const PrimRegs REC = prim_load(prims, VALID ? PRIM : 0u);
+#define MI_JOB_TEST(VALID, SRC, PRIM, K, REC, CAND, KEY, H) \
+    bool CAND = false; \
+    mi_u64 KEY = 0; \
+    Hit H; \
+    H.prim = MI_NOPRIM; H.u = H.v = 0.0f; \
+    { \
+      const V3 so = mk3(__shfl(o.x, SRC), __shfl(o.y, SRC), __shfl(o.z, SRC)), sd = mk3(__shfl(d.x, SRC), __shfl(d.y, SRC), __shfl(d.z, SRC)); \
+      H.dist = __shfl(hit.dist, SRC); \
+      const uint32_t sign = (uint32_t)__shfl((int)ignore, SRC); \
+      const int off = SRC - (int)lane; \
+      if(VALID) \
+      { \
+        const uint32_t type = __float_as_uint(REC.q3.x); \
+        if(type >= MI_PRIM_TRI) \
+        { \
+          if(PRIM != sign) \
+          { \
+            const bool both = triquad_intersect<true>(REC, type, so, sd, H, PRIM); \
+            if(both) __hip_atomic_fetch_min(best + off, (mi_u64)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   /* poison: sequential */ \
+            else if(H.prim != MI_NOPRIM) \
+            { \
+              KEY = ((mi_u64)__float_as_uint(H.dist) << 32) | (mi_u64)(31u - K); \
+              __hip_atomic_fetch_min(best + off, KEY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); \
+              CAND = true; \
+            } \
+          } \
+        } \
+        else __hip_atomic_fetch_or(anl + 2*off, 1u << K, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); \
+      } \
+    }
+  for(uint32_t base=0;base<J;base+=64u)
+  {
+#ifdef MI_PROFILE_LOOPS
+    if(lane == 0) cnt.c[9] += MI_PROFILE_LOOPS == 2 ? (J - base < 64u ? J - base : 64u) : 1;   /* wave-level test slots (2: jobs in them) */
+#endif
+    MI_JOB_FETCH(base + lane, valid, src, prim, k, rec)
+    MI_JOB_TEST(valid, src, prim, k, rec, cand, key, h)
+    if(__any(cand))
+    { /* the job that holds the owner's minimum so far leaves its u, v (a later, closer one overwrites them) */
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if(cand && best[src - (int)lane] == key) uvs[src - (int)lane] = mi_u32x2{__float_as_uint(h.u), __float_as_uint(h.v)};
+    }
+  }
+#undef MI_JOB_FETCH
+#undef MI_JOB_TEST
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if(own)
+  {
+    const mi_u64 res = *best;
+    if(res == 0)
+    { /* a folded quad crossed twice: what it yields depends on the running distance -- this lane's leaf in the reference's order */
+      leaf_sequential<BLOCK, STACK, MB, ANYHIT>(lds, prims, o, d, ignore, hit, ts, cnt);
+    }
+    else
+    {
+      MI_COUNT(cnt, 3, num);
+      const uint32_t idxp = (cur ^ MI_LEAF32) >> 5;
+      if((uint32_t)res != 0xffffffffu)
+      {
+        const mi_u32x2 uv = *uvs;
+        hit.dist = __uint_as_float((uint32_t)(res >> 32)); hit.prim = idxp + (31u - (uint32_t)res);
+        hit.u = __uint_as_float(uv.x); hit.v = __uint_as_float(uv.y);
+      }
+      uint32_t analytic = *anl;
+      while(analytic)
+      {
+#ifdef MI_PROFILE_LOOPS
+        { const unsigned nl = __popcll(__ballot(1)); if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) cnt.c[10] += MI_PROFILE_LOOPS == 2 ? nl : 1; }
+#endif
+        const uint32_t i = __ffs(analytic) - 1;
+        analytic &= analytic - 1;
+        analytic_intersect<MB>(prims, idxp + i, o, d, ignore, hit, MB ? ts.time : 0.0f, MB ? ts.prims_t1 : nullptr);
+      }
+      leaf_finish<BLOCK, STACK, ANYHIT>(lds, hit, ts);
+    }
+  }
+}
+
 /* one "while-while" round of accel_intersect (src/accel.d/qbvhmp.c:1262-1390, static boxes): descend inner nodes until this
  * lane holds a leaf (or runs out of work), then intersect that leaf and pop the next subtree */
-template<int BLOCK, int STACK, bool MB = false, bool ANYHIT = false, class CNT>
+template<int BLOCK, int STACK, bool MB = false, bool ANYHIT = false, bool JOBS = false, class CNT>
 __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, const V3 o, const V3 d, uint32_t ignore,
                                             Hit &hit, TraceState &ts, CNT &cnt)
 {
@@ -802,66 +1028,29 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
         }
       }
     }
-    if(!done && (current & MI_LEAF32))
-    { /* leaf: intersect its primitives (qbvhmp.c:1366-1379), then pop */
-      uint32_t idxp = (current ^ MI_LEAF32) >> 5;
-      const uint32_t num = current & 31u;
-      /* triangles and quads first (software pipelined: the next primitive's 64 B are in flight while this one is
-         intersected); spheres / cones / cylinders of this leaf are remembered and intersected afterwards, so that the
-         wave runs that rare, long code once per leaf round instead of once per primitive slot. Every primitive of the
-         leaf is still tested exactly once against the running closest hit (prims_intersect, src/prims.c:638-672). */
-      uint32_t analytic = 0;
-      /* two record buffers in ping-pong: the load of primitive i+1 is in flight while i is intersected, and no
-         16-register copy is needed per iteration */
-#define MI_LEAF_STEP(R, I) { MI_COUNT(cnt, 3, 1); \
-        const uint32_t type = __float_as_uint((R).q3.x); \
-        if(type >= MI_PRIM_TRI) { if(idxp + (I) != ignore) triquad_intersect((R), type, o, d, hit, idxp + (I)); }   /* triangle.h:271 */ \
-        else analytic |= 1u << (I); }
-      PrimRegs ra = prim_load(prims, num ? idxp : 0), rb;      /* rb is loaded before each use (same condition) */
-      for(uint32_t i=0;i<num;i+=2)
-      {
-#ifdef MI_PROFILE_LOOPS
-        { const unsigned nl = __popcll(__ballot(1)); if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) cnt.c[9] += MI_PROFILE_LOOPS == 2 ? 2*nl : 2; }   /* wave-level leaf slots (2: lane slots of lanes still in their leaf) */
-#endif
-        if(i + 1 < num) rb = prim_load(prims, idxp + i + 1);
-        MI_LEAF_STEP(ra, i)
-        if(i + 1 < num)
-        {
-          if(i + 2 < num) ra = prim_load(prims, idxp + i + 2);
-          MI_LEAF_STEP(rb, i + 1)
-        }
-      }
-#undef MI_LEAF_STEP
-      while(analytic)
-      {
-#ifdef MI_PROFILE_LOOPS
-        { const unsigned nl = __popcll(__ballot(1)); if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) cnt.c[10] += MI_PROFILE_LOOPS == 2 ? nl : 1; }   /* wave-level analytic passes (2: lanes in them) */
-#endif
-        const uint32_t i = __ffs(analytic) - 1;
-        analytic &= analytic - 1;
-        analytic_intersect<MB>(prims, idxp + i, o, d, ignore, hit, MB ? ts.time : 0.0f, MB ? ts.prims_t1 : nullptr);
-      }
-      current = MI_LEAF32;
-      done = true;
-      if(ANYHIT && ts.anyhit && hit.prim != MI_NOPRIM) sp = 0;   /* an occluder is all a shadow ray needs to know (MI_LIGHT_ANYHIT) */
-      while(sp > 0)
-      {
-        sp--;
-        const uint2 e = stack_top<BLOCK, STACK>(lds, lstack, sp);
-        if(!(__uint_as_float(e.y) > hit.dist)) { current = e.x; done = false; break; }
-      }
-    }
   }
   ts.sp = sp; ts.current = current; ts.done = done;
+  if(!JOBS && !done && (current & MI_LEAF32)) leaf_sequential<BLOCK, STACK, MB, ANYHIT>(lds, prims, o, d, ignore, hit, ts, cnt);   /* JOBS: the caller runs leaf_jobs with all lanes */
 }
 
 template<int BLOCK, int STACK, class CNT>
 __device__ __forceinline__ void accel_intersect(const Lds &lds, const DPrim *prims, const V3 o, const V3 d, uint32_t ignore,
-                                                Hit &hit, CNT &cnt)
-{ /* closest hit for one ray per lane; the wave iterates until every lane is done */
+                                                Hit &hit, CNT &cnt, bool live = true)
+{ /* closest hit for one ray per lane; the wave iterates until every lane is done. Call from ALL lanes of the wave (live = false:
+     this lane has no ray): the distributed leaf phase deals work out to every lane */
   TraceState ts;
   trace_begin(ts, d, cnt);
+  if(!live) { ts.done = true; MI_COUNT(cnt, 0, (uint32_t)-1); }
+#if MI_LEAF_JOBS
+  while(__any(!ts.done))
+  {
+    const bool busy = !ts.done;
+    if(busy) trace_round<BLOCK, STACK, false, false, true>(lds, prims, o, d, ignore, hit, ts, cnt);
+    leaf_jobs<BLOCK, STACK, false, false>(lds, prims, o, d, ignore, hit, ts, busy, cnt);
+  }
+#else
   while(!ts.done) trace_round<BLOCK, STACK>(lds, prims, o, d, ignore, hit, ts, cnt);
+#endif
 }
 
 /* ------------------------------------------------------------------------------------------ geometry at the hit */
