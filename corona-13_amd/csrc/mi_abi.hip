@@ -30,6 +30,9 @@
 #ifndef MI_LEAF_JOBS
 #define MI_LEAF_JOBS 1
 #endif
+#ifndef MI_LEAF_JOBS_PTDL
+#define MI_LEAF_JOBS_PTDL 0   /* A/B switch: the distributed leaf phase in the ptdl kernels too */
+#endif
 #ifndef MI_STACK
 #if MI_LEAF_JOBS
 #define MI_STACK (MI_STACK_LDS - 3)   /* the top three entries of a lane's column hold the results of the distributed leaf phase (leaf_jobs) */
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
 
   /* pt: the primitive tests of a traversal round are dealt out over all lanes of the wave (leaf_jobs); ptdl and the extended kernels
      keep the per-lane leaf loop -- there the extra live registers of the job loop spill (A/B in DESIGN.md) */
-  constexpr bool JOBS = MI_LEAF_JOBS && !PTDL && !MEDIA && !MB;
+  constexpr bool JOBS = MI_LEAF_JOBS && (!PTDL || MI_LEAF_JOBS_PTDL) && !MEDIA && !MB;
   constexpr int STACK = JOBS ? MI_STACK_LDS - 3 : MI_STACK_LDS;
   Counters<COUNT || RECORD> cnt;        /* COUNT = false: only the path count (see Counters, mi_kernels.h) */
   PathState ps;

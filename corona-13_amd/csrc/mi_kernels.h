@@ -663,6 +663,9 @@ __device__ __forceinline__ Lds lds_setup(const DScene &sc, unsigned char *smem, 
 #ifndef MI_TAIL_INNER
 #define MI_TAIL_INNER 4
 #endif
+#ifndef MI_LEAF_EXIT
+#define MI_LEAF_EXIT 48   /* leaf_jobs kernels: the node loop of a round ends once this many lanes wait with a leaf (a full pass of jobs); 64 = never. A/B 24..56 */
+#endif
 #ifndef MI_LEAF_JOBS
 #define MI_LEAF_JOBS 1   /* 1: the primitive tests of a round are dealt out over all 64 lanes of the wave (leaf_jobs) */
 #endif
@@ -812,59 +815,39 @@ __device__ __forceinline__ void leaf_jobs(const Lds &lds, const DPrim *prims, co
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-#define MI_JOB_FETCH(JJ, VALID, SRC, PRIM, K, REC) \
-    const uint32_t SRC##_j = (JJ); \
-    const bool VALID = SRC##_j < J; \
-    const int SRC = VALID ? (int)jobs[SRC##_j] : (int)lane; \
-    const uint32_t SRC##_cur = (uint32_t)__shfl((int)cur, SRC), SRC##_pre = (uint32_t)__shfl((int)prefix, SRC); \
-    const uint32_t K = SRC##_j - SRC##_pre, PRIM = ((SRC##_cur ^ MI_LEAF32) >> 5) + K; \
-    const PrimRegs REC = prim_load(prims, VALID ? PRIM : 0u);
-#define MI_JOB_TEST(VALID, SRC, PRIM, K, REC, CAND, KEY, H) \
-    bool CAND = false; \
-    mi_u64 KEY = 0; \
-    Hit H; \
-    H.prim = MI_NOPRIM; H.u = H.v = 0.0f; \
-    { \
-      const V3 so = mk3(__shfl(o.x, SRC), __shfl(o.y, SRC), __shfl(o.z, SRC)), sd = mk3(__shfl(d.x, SRC), __shfl(d.y, SRC), __shfl(d.z, SRC)); \
-      H.dist = __shfl(hit.dist, SRC); \
-      const uint32_t sign = (uint32_t)__shfl((int)ignore, SRC); \
-      const int off = SRC - (int)lane; \
-      if(VALID) \
-      { \
-        const uint32_t type = __float_as_uint(REC.q3.x); \
-        if(type >= MI_PRIM_TRI) \
-        { \
-          if(PRIM != sign) \
-          { \
-            const bool both = triquad_intersect<true>(REC, type, so, sd, H, PRIM); \
-            if(both) __hip_atomic_fetch_min(best + off, (mi_u64)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   /* poison: sequential */ \
-            else if(H.prim != MI_NOPRIM) \
-            { \
-              KEY = ((mi_u64)__float_as_uint(H.dist) << 32) | (mi_u64)(31u - K); \
-              __hip_atomic_fetch_min(best + off, KEY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); \
-              CAND = true; \
-            } \
-          } \
-        } \
-        else __hip_atomic_fetch_or(anl + 2*off, 1u << K, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); \
-      } \
-    }
   for(uint32_t base=0;base<J;base+=64u)
   {
 #ifdef MI_PROFILE_LOOPS
     if(lane == 0) cnt.c[9] += MI_PROFILE_LOOPS == 2 ? (J - base < 64u ? J - base : 64u) : 1;   /* wave-level test slots (2: jobs in them) */
 #endif
-    MI_JOB_FETCH(base + lane, valid, src, prim, k, rec)
-    MI_JOB_TEST(valid, src, prim, k, rec, cand, key, h)
+    const uint32_t j = base + lane;
+    const bool valid = j < J;
+    const int src = valid ? (int)jobs[j] : (int)lane;
+    const uint32_t scur = (uint32_t)__shfl((int)cur, src), spre = (uint32_t)__shfl((int)prefix, src);
+    const uint32_t k = j - spre, prim = valid ? ((scur ^ MI_LEAF32) >> 5) + k : 0u;
+    /* the record is needed whatever its type turns out to be: all four 16-byte loads are issued at once, and the owner's ray
+       arrives (ds_bpermute) while they are in flight. The test itself is branch-free; what it found counts if the job is real. */
+    const PrimRegs rec = prim_load(prims, prim);
+    const V3 so = mk3(__shfl(o.x, src), __shfl(o.y, src), __shfl(o.z, src)), sd = mk3(__shfl(d.x, src), __shfl(d.y, src), __shfl(d.z, src));
+    Hit h;
+    h.prim = MI_NOPRIM; h.u = h.v = 0.0f;
+    h.dist = __shfl(hit.dist, src);
+    const uint32_t sign = (uint32_t)__shfl((int)ignore, src);
+    const int off = src - (int)lane;
+    const uint32_t type = __float_as_uint(rec.q3.x);
+    const bool both = triquad_intersect<true>(rec, type, so, sd, h, prim);
+    const bool tq = valid && type >= MI_PRIM_TRI && prim != sign;       /* triangle.h:271 */
+    const bool cand = tq && !both && h.prim != MI_NOPRIM;
+    const mi_u64 key = ((mi_u64)__float_as_uint(h.dist) << 32) | (mi_u64)(31u - k);
+    if(tq && (both || cand)) __hip_atomic_fetch_min(best + off, both ? (mi_u64)0 : key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   /* 0: poison, the owner goes sequential */
+    if(valid && type < MI_PRIM_TRI) __hip_atomic_fetch_or(anl + 2*off, 1u << k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     if(__any(cand))
     { /* the job that holds the owner's minimum so far leaves its u, v (a later, closer one overwrites them) */
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      if(cand && best[src - (int)lane] == key) uvs[src - (int)lane] = mi_u32x2{__float_as_uint(h.u), __float_as_uint(h.v)};
+      if(cand && best[off] == key) uvs[off] = mi_u32x2{__float_as_uint(h.u), __float_as_uint(h.v)};
     }
   }
-#undef MI_JOB_FETCH
-#undef MI_JOB_TEST
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
   if(own)
@@ -885,6 +868,9 @@ __device__ __forceinline__ void leaf_jobs(const Lds &lds, const DPrim *prims, co
         hit.u = __uint_as_float(uv.x); hit.v = __uint_as_float(uv.y);
       }
       uint32_t analytic = *anl;
+#ifdef MI_EXPERIMENT_ANALYTIC_TWICE
+      for(uint32_t a2 = analytic; a2; a2 &= a2 - 1) analytic_intersect<MB>(prims, idxp + __ffs(a2) - 1, o, d, ignore, hit, MB ? ts.time : 0.0f, MB ? ts.prims_t1 : nullptr);
+#endif
       while(analytic)
       {
 #ifdef MI_PROFILE_LOOPS
@@ -924,6 +910,7 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
       const unsigned ninner = __popcll(__ballot(inner));
       if(!ninner) break;
       if(ninner < MI_TAIL_INNER && __any((current & MI_LEAF32) && !done)) break;
+      if(JOBS && MI_LEAF_EXIT < 64 && __popcll(__ballot((current & MI_LEAF32) && !done)) >= MI_LEAF_EXIT) break;   /* enough leaves wait to fill the lanes of a job pass */
 #ifdef MI_PROFILE_LOOPS
       const unsigned nround = __popcll(__ballot(!done));    /* lanes of this round whose ray is still under way */
 #endif
@@ -935,7 +922,7 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
       const uint4 child = *(const uint4 *)&lds.nodes[6*N + node];
       const uint32_t ax = lds.axes[node];       /* with the other loads of this node, not after the slab test */
       float tm0, tm1, tm2, tm3;
-      bool m0, m1, m2, m3;      /* child c is hit: lane masks in scalar registers, combined by scalar instructions below */
+      mi_u64 M0, M1, M2, M3;    /* child c is hit: lane masks (the compares' own results) in scalar registers, combined by scalar instructions below */
       if(!slow)
       { /* 4 child slabs, qbvhmp.c:1188-1246. The ray's sign bits pick the entry / exit plane of every slab, which is what
            the reference's min(t0,t1) / max(t0,t1) evaluate to for finite 1/dir and b_min <= b_max (rounding is monotonic;
@@ -947,8 +934,8 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
 #define SLAB(J, C, TM) { \
         const float lo = fmaxf(fmaxf(fmaxf((nx.C - o.x)*idx, (ny.C - o.y)*idy), (nz.C - o.z)*idz), 0.0f); \
         const float hi = fminf(fminf(fminf((fx.C - o.x)*idx, (fy.C - o.y)*idy), (fz.C - o.z)*idz), hit.dist); \
-        TM = lo; J = lo <= hi; }
-        SLAB(m0, x, tm0) SLAB(m1, y, tm1) SLAB(m2, z, tm2) SLAB(m3, w, tm3)
+        TM = lo; J = __ballot(lo <= hi); }
+        SLAB(M0, x, tm0) SLAB(M1, y, tm1) SLAB(M2, z, tm2) SLAB(M3, w, tm3)
 #undef SLAB
       }
       else
@@ -967,26 +954,26 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
         t0 = ((Z0) - o.z)*idz; t1 = ((Z1) - o.z)*idz; \
         mn = t0 < t1 ? t0 : t1; mx = t0 > t1 ? t0 : t1; \
         lo = lo > mn ? lo : mn; hi = hi < mx ? hi : mx; \
-        TM = lo; J = lo <= hi; }
-        SLAB(m0, mnx.x, mxx.x, mny.x, mxy.x, mnz.x, mxz.x, tm0)
-        SLAB(m1, mnx.y, mxx.y, mny.y, mxy.y, mnz.y, mxz.y, tm1)
-        SLAB(m2, mnx.z, mxx.z, mny.z, mxy.z, mnz.z, mxz.z, tm2)
-        SLAB(m3, mnx.w, mxx.w, mny.w, mxy.w, mnz.w, mxz.w, tm3)
+        TM = lo; J = __ballot(lo <= hi); }
+        SLAB(M0, mnx.x, mxx.x, mny.x, mxy.x, mnz.x, mxz.x, tm0)
+        SLAB(M1, mnx.y, mxx.y, mny.y, mxy.y, mnz.y, mxz.y, tm1)
+        SLAB(M2, mnx.z, mxx.z, mny.z, mxy.z, mnz.z, mxz.z, tm2)
+        SLAB(M3, mnx.w, mxx.w, mny.w, mxy.w, mnz.w, mxz.w, tm3)
 #undef SLAB
       }
-      if(m0 || m1 || m2 || m3)
+      if(__builtin_amdgcn_inverse_ballot_w64(M0 | M1 | M2 | M3))
       {
         MI_COUNT(cnt, 1, 1);
-        MI_COUNT(cnt, 2, (uint32_t)m0 + (uint32_t)m1 + (uint32_t)m2 + (uint32_t)m3);
+        MI_COUNT(cnt, 2, (uint32_t)__builtin_amdgcn_inverse_ballot_w64(M0) + (uint32_t)__builtin_amdgcn_inverse_ballot_w64(M1) + (uint32_t)__builtin_amdgcn_inverse_ballot_w64(M2) + (uint32_t)__builtin_amdgcn_inverse_ballot_w64(M3));
         /* front-to-back order from split axes and ray signs, qbvhmp.c:1313-1320: the near half is children
            {2*near0, 2*near0+1}, ordered by the sign along its own split axis; likewise the far half */
         const uint32_t axis0 = ax & 3u;
-        const bool near0 = (nearbits >> axis0) & 1u;
+        const mi_u64 N0 = __ballot((nearbits >> axis0) & 1u);
+        const bool near0 = __builtin_amdgcn_inverse_ballot_w64(N0);
         const uint32_t axis1n = near0 ? ((ax >> 4) & 3u) : ((ax >> 2) & 3u);
         const uint32_t axis1f = near0 ? ((ax >> 2) & 3u) : ((ax >> 4) & 3u);
-        const bool near1n = (nearbits >> axis1n) & 1u, near1f = (nearbits >> axis1f) & 1u;
-        const bool ha0 = near0 ? m2 : m0, ha1 = near0 ? m3 : m1;          /* hit flags of the near half, of the far half */
-        const bool hb0 = near0 ? m0 : m2, hb1 = near0 ? m1 : m3;
+        const mi_u64 N1N = __ballot((nearbits >> axis1n) & 1u), N1F = __ballot((nearbits >> axis1f) & 1u);
+        const bool near1n = __builtin_amdgcn_inverse_ballot_w64(N1N), near1f = __builtin_amdgcn_inverse_ballot_w64(N1F);
         const uint32_t ca0 = near0 ? child.z : child.x, ca1 = near0 ? child.w : child.y;
         const uint32_t cb0 = near0 ? child.x : child.z, cb1 = near0 ? child.y : child.w;
         const float ta0 = near0 ? tm2 : tm0, ta1 = near0 ? tm3 : tm1;
@@ -995,12 +982,18 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
         const uint32_t c10 = near1f ? cb1 : cb0, c11 = near1f ? cb0 : cb1;
         const float t01 = near1n ? ta0 : ta1;
         const float t10 = near1f ? tb1 : tb0, t11 = near1f ? tb0 : tb1;
-        const bool h00 = near1n ? ha1 : ha0, h01 = near1n ? ha0 : ha1;
-        const bool h10 = near1f ? hb1 : hb0, h11 = near1f ? hb0 : hb1;
+        /* the hit flags go through the same two selections as lane masks in scalar registers (s_and / s_andn2 / s_or on the
+           ballots: the scalar unit, not the vector pipes this kernel is bound by) and come back as predicates */
+        /* conditional swaps: (X, Y) = N ? (B, A) : (A, B), lane by lane, four scalar instructions each */
+        const mi_u64 D0 = (M0 ^ M2) & N0, D1 = (M1 ^ M3) & N0;
+        const mi_u64 HA0 = M0 ^ D0, HB0 = M2 ^ D0, HA1 = M1 ^ D1, HB1 = M3 ^ D1;          /* hit flags of the near half (A), of the far half (B) */
+        const mi_u64 DN = (HA0 ^ HA1) & N1N, DF = (HB0 ^ HB1) & N1F;
+        const mi_u64 H00 = HA0 ^ DN, H01 = HA1 ^ DN, H10 = HB0 ^ DF, H11 = HB1 ^ DF;
         /* the first hit child in order n00,n01,n10,n11 becomes current; later ones are pushed far-first (qbvhmp.c:1336-1354) */
-        const bool p11 = h11 && (h00 || h01 || h10);
-        const bool p10 = h10 && (h00 || h01);
-        const bool p01 = h01 && h00;
+        const bool h00 = __builtin_amdgcn_inverse_ballot_w64(H00), h01 = __builtin_amdgcn_inverse_ballot_w64(H01), h10 = __builtin_amdgcn_inverse_ballot_w64(H10);
+        const bool p11 = __builtin_amdgcn_inverse_ballot_w64(H11 & (H00 | H01 | H10));
+        const bool p10 = __builtin_amdgcn_inverse_ballot_w64(H10 & (H00 | H01));
+        const bool p01 = __builtin_amdgcn_inverse_ballot_w64(H01 & H00);
         if(sp + 3 <= STACK)
         { /* all three slots are in LDS */
           if(p11) { lstack[sp*BLOCK] = mi_u32x2{c11, __float_as_uint(t11)}; sp++; }
