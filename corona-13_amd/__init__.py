@@ -26,6 +26,7 @@ MI_LIB = Path(os.environ.get("CORONA_MI_LIB", PKG_DIR / "csrc" / "libcorona_mi.s
 MI_SAMPLER_PT, MI_SAMPLER_PTDL = 0, 1
 MI_POINTS_RAND, MI_POINTS_HALTON = 0, 1
 MI_REC_MAX_VERTS, MI_REC_MAX_SPLATS = 8, 8
+MI_NODE_LEAF = 1 << 63          # mi_node.child: leaf link = MI_NODE_LEAF | first_prim << 5 | count (corona_mi.h)
 
 
 # ---------------------------------------------------------------- ctypes mirrors of corona_mi.h

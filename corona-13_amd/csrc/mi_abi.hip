@@ -750,6 +750,12 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
     e = build_on_device(s, h, &N, &stack_need);
     d.num_nodes = N;
   }
+  if(!e && N)
+  { /* tree and primitive records are in their final order: leaves in which the order of the tests matters (a folded quad behind a
+       primitive the leaf loops put off) are marked, see mi_mark_ordered_kernel */
+    hipLaunchKernelGGL(mi_mark_ordered_kernel, dim3((4*N + 255)/256), dim3(256), 0, 0, (const float4 *)s->d_nodes, N, (DPrim *)s->d_prims);
+    if(hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) e = fail(MI_ERR_DEVICE, "cannot mark the leaves");
+  }
   if(!e && h->lights.num_prims)
   { /* the list is in its final (builder or device-sorted) order now: set the any-hit flags */
     std::vector<uint32_t> cur(h->lights.num_prims);

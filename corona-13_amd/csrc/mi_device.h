@@ -32,9 +32,10 @@ struct DPrim                       /* 64 B */
 {
   float v[4][3];                   /* tri/quad: v[0] = v0, v[1..3] = edges v1-v0, v2-v0, v3-v0. sphere: v[0] centre, v[1][0] radius.
                                       line: see line_intersect (mi_kernels.h) */
-  uint32_t type;                   /* vcnt: 1 sphere, 2 line, 3 tri, 4 quad */
-  uint32_t pad[3];
+  uint32_t type;                   /* vcnt: 1 sphere, 2 line, 3 tri, 4 quad; 0: tested after the leaf's plain triangles / quads, in leaf order, kind in pad[] */
+  uint32_t pad[3];                 /* type 0: pad[0] = vcnt; pad[1] = MI_PRIM_ORDERED for a STATIC triangle / quad (same record as type 3 / 4), else moving */
 };
+#define MI_PRIM_ORDERED 1u         /* set by mi_mark_ordered_kernel (mi_kernels.h) */
 
 struct DPrimT1                     /* 96 B, motion-blurred triangles / quads only: the shutter-close state of a primitive whose DPrim (type 0,
                                       pad[0] = vertex count) holds the four shutter-open VERTICES instead of v0 + edges. Vertices and normals

@@ -431,7 +431,7 @@ __device__ __forceinline__ bool triquad_intersect(const PrimRegs &r, uint32_t ty
   const V3 qA = cross3(tv, eA1);
   const float uA = dot3(d, qA)*invA;
   const float tA = dot3(e02, qA)*invA;
-  const bool hitA = !(vA < 0.0f || vA > 1.0f) && !(uA < 0.0f || uA + vA > 1.0f) && (tA > 0.0f && tA <= hit.dist);
+  const bool preA = !(vA < 0.0f || vA > 1.0f) && !(uA < 0.0f || uA + vA > 1.0f) && tA > 0.0f;     /* crossed in front of the ray */
   /* triangle B: edge1 = v2-v0, edge2 = v3-v0 */
   const V3 pB = cross3(d, eB2);
   const float invB = mi_rcp(dot3(e02, pB));
@@ -439,12 +439,14 @@ __device__ __forceinline__ bool triquad_intersect(const PrimRegs &r, uint32_t ty
   const V3 qB = cross3(tv, e02);
   const float uB = dot3(d, qB)*invB;
   const float tB = dot3(eB2, qB)*invB;
-  const bool hitB = (type == MI_PRIM_QUAD) && !(vB < 0.0f || vB > 1.0f) && !(uB < 0.0f || uB + vB > 1.0f) && (tB > 0.0f && tB <= hit.dist);
-  /* BOTH (distributed leaf phase, leaf_jobs): both halves of a quad are crossed in front of the ray -- only a folded (non-planar)
-     quad seen edge-on. Which half the reference then reports depends on the running closest hit (src/prims.c:654-663), so such a
-     test is handed back to the sequential loop. */
-  const bool both = BOTH && (type == MI_PRIM_QUAD) && !(vA < 0.0f || vA > 1.0f) && !(uA < 0.0f || uA + vA > 1.0f) && tA > 0.0f &&
-                    !(vB < 0.0f || vB > 1.0f) && !(uB < 0.0f || uB + vB > 1.0f) && tB > 0.0f;
+  const bool preB = (type == MI_PRIM_QUAD) && !(vB < 0.0f || vB > 1.0f) && !(uB < 0.0f || uB + vB > 1.0f) && tB > 0.0f;
+  /* BOTH: both halves of a quad are crossed in front of the ray -- only a folded (non-planar) quad. Which half the reference then
+     reports depends on the running closest hit (src/prims.c:654-663: the second half is tested iff the first one is not accepted),
+     i.e. on the primitives of the leaf tested BEFORE it: leaf_jobs, which tests all of a leaf's primitives against the distance the
+     leaf started with, hands such a leaf to the per-lane loop. (The per-lane loop works in order except that it puts off spheres,
+     lines and moving primitives; a quad that this could affect is marked at upload, see mi_mark_ordered_kernel.) */
+  const bool both = BOTH && preA && preB;
+  const bool hitA = preA && tA <= hit.dist, hitB = preB && tB <= hit.dist;
   if(hitA)
   {
     hit.dist = tA; hit.prim = prim; hit.u = uA;
@@ -529,7 +531,7 @@ struct TraceState;
 template<bool MB>
 __device__ __forceinline__ void analytic_intersect(const DPrim *prims, uint32_t prim, const V3 o, const V3 d, uint32_t ignore, Hit &hit,
                                                    float time, const DPrimT1 *prims_t1)
-{ /* prims_intersect for spheres and lines, src/prims.c:665-668 */
+{ /* prims_intersect for spheres and lines, src/prims.c:665-668; and for every primitive the leaf loops put off (DPrim.type 0) */
   /* the whole 64-B record in four 16-B loads up front (one memory round trip), then registers only */
   const float4 *q = (const float4 *)(prims + prim);
   const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
@@ -538,6 +540,14 @@ __device__ __forceinline__ void analytic_intersect(const DPrim *prims, uint32_t 
   p.v[1][1] = q1.x; p.v[1][2] = q1.y; p.v[2][0] = q1.z; p.v[2][1] = q1.w;
   p.v[2][2] = q2.x; p.v[3][0] = q2.y; p.v[3][1] = q2.z; p.v[3][2] = q2.w;
   p.type = __float_as_uint(q3.x); p.pad[0] = __float_as_uint(q3.y); p.pad[1] = __float_as_uint(q3.z); p.pad[2] = __float_as_uint(q3.w);
+  if(p.type == 0 && p.pad[1] == MI_PRIM_ORDERED)
+  { /* a static triangle / quad that has to wait for the primitives put off before it in its leaf (mi_mark_ordered_kernel) */
+    if(prim == ignore) return;
+    PrimRegs r;
+    r.q0 = q0; r.q1 = q1; r.q2 = q2; r.q3 = q3;
+    triquad_intersect(r, p.pad[0], o, d, hit, prim);
+    return;
+  }
   if(MB && p.type == 0 && p.pad[0] < MI_PRIM_TRI)
   { /* moving sphere / cone / cylinder: the static record at the ray's time, then the usual tests below */
     V3 a0, a1;
@@ -718,48 +728,85 @@ __device__ __forceinline__ void leaf_sequential(const Lds &lds, const DPrim *pri
                                                 Hit &hit, TraceState &ts, CNT &cnt)
 {
   const uint32_t current = ts.current;
-  {
-    {
-      uint32_t idxp = (current ^ MI_LEAF32) >> 5;
-      const uint32_t num = current & 31u;
-      /* triangles and quads first (software pipelined: the next primitive's 64 B are in flight while this one is
-         intersected); spheres / cones / cylinders of this leaf are remembered and intersected afterwards, so that the
-         wave runs that rare, long code once per leaf round instead of once per primitive slot. Every primitive of the
-         leaf is still tested exactly once against the running closest hit (prims_intersect, src/prims.c:638-672). */
-      uint32_t analytic = 0;
-      /* two record buffers in ping-pong: the load of primitive i+1 is in flight while i is intersected, and no
-         16-register copy is needed per iteration */
+  const uint32_t idxp = (current ^ MI_LEAF32) >> 5;
+  const uint32_t num = current & 31u;
+  /* triangles and quads first (software pipelined: the next primitive's 64 B are in flight while this one is
+     intersected); spheres / cones / cylinders of this leaf are remembered and intersected afterwards, so that the
+     wave runs that rare, long code once per leaf round instead of once per primitive slot. Every primitive of the
+     leaf is still tested exactly once against the running closest hit (prims_intersect, src/prims.c:638-672), and the
+     closest hit does not depend on that order (at equal distance a triangle's `<=` beats a sphere's / line's `<` from
+     either side) -- with one exception: a folded quad crossed in both halves reports the half the RUNNING distance lets
+     through (src/prims.c:654-663). Where that can matter -- a non-planar quad behind a primitive that is put off -- the
+     quad and everything behind it in the leaf is put off as well (type 0 + MI_PRIM_ORDERED, set at upload by
+     mi_mark_ordered_kernel), so that leaf is worked through in the reference's order. */
+  uint32_t analytic = 0;
+  /* two record buffers in ping-pong: the load of primitive i+1 is in flight while i is intersected, and no
+     16-register copy is needed per iteration */
 #define MI_LEAF_STEP(R, I) { MI_COUNT(cnt, 3, 1); \
-        const uint32_t type = __float_as_uint((R).q3.x); \
-        if(type >= MI_PRIM_TRI) { if(idxp + (I) != ignore) triquad_intersect((R), type, o, d, hit, idxp + (I)); }   /* triangle.h:271 */ \
-        else analytic |= 1u << (I); }
-      PrimRegs ra = prim_load(prims, num ? idxp : 0), rb;      /* rb is loaded before each use (same condition) */
-      for(uint32_t i=0;i<num;i+=2)
-      {
+    const uint32_t type = __float_as_uint((R).q3.x); \
+    if(type >= MI_PRIM_TRI) { if(idxp + (I) != ignore) triquad_intersect((R), type, o, d, hit, idxp + (I)); }   /* triangle.h:271 */ \
+    else analytic |= 1u << (I); }
+  PrimRegs ra = prim_load(prims, num ? idxp : 0), rb;      /* rb is loaded before each use (same condition) */
+  for(uint32_t i=0;i<num;i+=2)
+  {
 #ifdef MI_PROFILE_LOOPS
-        { const unsigned nl = __popcll(__ballot(1)); if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) cnt.c[9] += MI_PROFILE_LOOPS == 2 ? 2*nl : 2; }   /* wave-level leaf slots (2: lane slots of lanes still in their leaf) */
+    { const unsigned nl = __popcll(__ballot(1)); if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) cnt.c[9] += MI_PROFILE_LOOPS == 2 ? 2*nl : 2; }   /* wave-level leaf slots (2: lane slots of lanes still in their leaf) */
 #endif
-        if(i + 1 < num) rb = prim_load(prims, idxp + i + 1);
-        MI_LEAF_STEP(ra, i)
-        if(i + 1 < num)
-        {
-          if(i + 2 < num) ra = prim_load(prims, idxp + i + 2);
-          MI_LEAF_STEP(rb, i + 1)
-        }
-      }
-#undef MI_LEAF_STEP
-      while(analytic)
-      {
-#ifdef MI_PROFILE_LOOPS
-        { const unsigned nl = __popcll(__ballot(1)); if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) cnt.c[10] += MI_PROFILE_LOOPS == 2 ? nl : 1; }   /* wave-level analytic passes (2: lanes in them) */
-#endif
-        const uint32_t i = __ffs(analytic) - 1;
-        analytic &= analytic - 1;
-        analytic_intersect<MB>(prims, idxp + i, o, d, ignore, hit, MB ? ts.time : 0.0f, MB ? ts.prims_t1 : nullptr);
-      }
+    if(i + 1 < num) rb = prim_load(prims, idxp + i + 1);
+    MI_LEAF_STEP(ra, i)
+    if(i + 1 < num)
+    {
+      if(i + 2 < num) ra = prim_load(prims, idxp + i + 2);
+      MI_LEAF_STEP(rb, i + 1)
     }
   }
+#undef MI_LEAF_STEP
+  while(analytic)
+  {
+#ifdef MI_PROFILE_LOOPS
+    { const unsigned nl = __popcll(__ballot(1)); if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) cnt.c[10] += MI_PROFILE_LOOPS == 2 ? nl : 1; }   /* wave-level analytic passes (2: lanes in them) */
+#endif
+    const uint32_t i = __ffs(analytic) - 1;
+    analytic &= analytic - 1;
+    analytic_intersect<MB>(prims, idxp + i, o, d, ignore, hit, MB ? ts.time : 0.0f, MB ? ts.prims_t1 : nullptr);
+  }
   leaf_finish<BLOCK, STACK, ANYHIT>(lds, hit, ts);
+}
+
+/* Upload-time pass over the leaves (one thread per child link of the tree, after the primitive records are in place -- for a
+ * device-built tree after the build): the leaf loops test a leaf's triangles and quads first and put off its spheres, lines and
+ * moving primitives. That changes nothing (see leaf_sequential) unless a quad can be crossed in both halves, which takes a folded
+ * quad: a static quad whose fourth vertex leaves the plane of the first three by more than 1e-5 of its size and which follows a
+ * primitive that is put off, or anything that follows a moving quad. From there to the end of its leaf every triangle / quad
+ * is put off too (type 0, pad[0] = vertex count, pad[1] = MI_PRIM_ORDERED): the put-off tests run in the leaf's order. */
+__global__ void mi_mark_ordered_kernel(const float4 *nodes, uint32_t N, DPrim *prims)
+{
+  const uint32_t i = blockIdx.x*blockDim.x + threadIdx.x;
+  if(i >= 4u*N) return;
+  const uint32_t link = ((const uint32_t *)(nodes + (size_t)6*N))[i];
+  if(!(link & MI_LEAF32)) return;
+  const uint32_t first = (link ^ MI_LEAF32) >> 5, num = link & 31u;
+  bool deferred = false, ordered = false;
+  for(uint32_t k=0;k<num;k++)
+  {
+    DPrim &p = prims[first + k];
+    if(p.type >= MI_PRIM_TRI)
+    {
+      if(!ordered && deferred && p.type == MI_PRIM_QUAD)
+      {
+        const V3 e1 = ld3(p.v[1]), e2 = ld3(p.v[2]), e3 = ld3(p.v[3]);
+        const V3 n = cross3(e1, e2);
+        const float vol = fabsf(dot3(n, e3)), ref = sqrtf(dot3(n, n))*sqrtf(dot3(e3, e3));
+        if(!(vol <= 1e-5f*ref)) ordered = true;
+      }
+      if(ordered) { p.pad[0] = p.type; p.pad[1] = MI_PRIM_ORDERED; p.type = 0; }
+    }
+    else
+    {
+      deferred = true;
+      if(p.type == 0 && p.pad[0] == MI_PRIM_QUAD) ordered = true;       /* a moving quad: its shape changes with time */
+    }
+  }
 }
 
 /* Distributed leaf phase (MI_LEAF_JOBS). In the sequential leaf loop a round costs the wave as many test slots as its LONGEST leaf
@@ -794,11 +841,8 @@ __device__ __forceinline__ void leaf_jobs(const Lds &lds, const DPrim *prims, co
   /* exclusive prefix sum of num over the wave from the ballots of its bits (leaves of the reference's trees hold <= 6) */
   const mi_u64 b0 = __ballot(num & 1u), b1 = __ballot(num & 2u), b2 = __ballot(num & 4u);
   const uint32_t J = __popcll(b0) + 2u*__popcll(b1) + 4u*__popcll(b2);
-  if(__any(num > 7u) || J > MI_JOBS_MAX)
-  { /* leaves longer than the prefix sum covers, or more jobs than the list holds: the sequential loop */
-    if(own) leaf_sequential<BLOCK, STACK, MB, ANYHIT>(lds, prims, o, d, ignore, hit, ts, cnt);
-    return;
-  }
+  /* leaves longer than the prefix sum covers, or more jobs than the list holds: every owner runs the per-lane loop (below) */
+  const bool fits = !__any(num > 7u) && J <= MI_JOBS_MAX;
 #define MI_MBCNT(M) __builtin_amdgcn_mbcnt_hi((uint32_t)((M) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(M), 0u))
   const uint32_t prefix = MI_MBCNT(b0) + 2u*MI_MBCNT(b1) + 4u*MI_MBCNT(b2);
 #undef MI_MBCNT
@@ -807,7 +851,7 @@ __device__ __forceinline__ void leaf_jobs(const Lds &lds, const DPrim *prims, co
   lds_u64 *best = (lds_u64 *)(col + (STACK + 0)*BLOCK);
   lds_uint2 *uvs = col + (STACK + 1)*BLOCK;
   lds_u32 *anl = (lds_u32 *)(col + (STACK + 2)*BLOCK);
-  if(own)
+  if(own && fits)
   {
     for(uint32_t k=0;k<num;k++) jobs[prefix + k] = (unsigned char)lane;
     *best = ((mi_u64)__float_as_uint(hit.dist) << 32) | 0xffffffffull;
@@ -815,7 +859,7 @@ __device__ __forceinline__ void leaf_jobs(const Lds &lds, const DPrim *prims, co
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  for(uint32_t base=0;base<J;base+=64u)
+  for(uint32_t base=0;fits && base<J;base+=64u)
   {
 #ifdef MI_PROFILE_LOOPS
     if(lane == 0) cnt.c[9] += MI_PROFILE_LOOPS == 2 ? (J - base < 64u ? J - base : 64u) : 1;   /* wave-level test slots (2: jobs in them) */
@@ -852,7 +896,7 @@ __device__ __forceinline__ void leaf_jobs(const Lds &lds, const DPrim *prims, co
   __builtin_amdgcn_wave_barrier();
   if(own)
   {
-    const mi_u64 res = *best;
+    const mi_u64 res = fits ? *best : 0;
     if(res == 0)
     { /* a folded quad crossed twice: what it yields depends on the running distance -- this lane's leaf in the reference's order */
       leaf_sequential<BLOCK, STACK, MB, ANYHIT>(lds, prims, o, d, ignore, hit, ts, cnt);
@@ -868,9 +912,6 @@ __device__ __forceinline__ void leaf_jobs(const Lds &lds, const DPrim *prims, co
         hit.u = __uint_as_float(uv.x); hit.v = __uint_as_float(uv.y);
       }
       uint32_t analytic = *anl;
-#ifdef MI_EXPERIMENT_ANALYTIC_TWICE
-      for(uint32_t a2 = analytic; a2; a2 &= a2 - 1) analytic_intersect<MB>(prims, idxp + __ffs(a2) - 1, o, d, ignore, hit, MB ? ts.time : 0.0f, MB ? ts.prims_t1 : nullptr);
-#endif
       while(analytic)
       {
 #ifdef MI_PROFILE_LOOPS
@@ -1869,7 +1910,8 @@ template<bool MB = false>
 __device__ __forceinline__ V3 prim_sample(const DPrim &p, const DPrimGeo &geo, float r0, float r1, float &hu, float &hv,
                                           const DPrimT1 *t1 = nullptr, float time = 0.0f)
 { /* prims_sample + prims_retime, src/prims.c:178-252 */
-  if(MB && p.type == 0)
+  const bool ordered = p.type == 0 && p.pad[1] == MI_PRIM_ORDERED;     /* a static triangle / quad under its leaf-order mark (mi_mark_ordered_kernel) */
+  if(MB && p.type == 0 && !ordered)
   { /* moving emitter (triangle / quad): the record holds the shutter-open vertices, *t1 the shutter-close ones; sample the
        primitive as it is at the path's time */
     const float w0 = 1.0f - time, w1 = time;
@@ -1885,7 +1927,7 @@ __device__ __forceinline__ V3 prim_sample(const DPrim &p, const DPrimGeo &geo, f
     hu = r1*a; hv = (1.0f-r1)*a;
     return tri_retime(vt[0], vt[1], vt[2], hu, hv);
   }
-  const uint32_t type = p.type;
+  const uint32_t type = ordered ? p.pad[0] : p.type;
   const float *gv = geo.f + 26;             /* v1, v2, v3 of a triangle / quad (DPrim keeps v0 and the edges) */
   if(type == MI_PRIM_QUAD)
   {

@@ -7,6 +7,7 @@ Tolerances (float32, fp contraction off on both sides, libm differences in sin/c
   * 1-spp image vs the oracle image: per-pixel L2 (pfmdiff RMSE on gain-scaled XYZ) < 0.05
     (noise floor between two independent 64-spp renders of the reference itself: 4.34)
 """
+import ctypes as C
 import json
 
 import numpy as np
@@ -766,3 +767,107 @@ def test_frame_reducer_on_device_matches_plain_render():
         be.close()
     finally:
         dist.destroy_process_group()
+
+
+def _chunk_tree(desc, leaf_size):
+    """a valid 4-wide tree over the descriptor's primitive list whose leaves hold `leaf_size` primitives each (the last one the rest):
+    every child box is the scene's box, so a ray that meets the scene visits every leaf in link order"""
+    P = int(desc.num_prims)
+    links = [pkg.MI_NODE_LEAF | (first << 5) | min(leaf_size, P - first) for first in range(0, P, leaf_size)]
+    nodes = []                                   # (children links, parent); node 0 is appended last and moved to the front below
+
+    def group(level):                            # -> links of the level above
+        out = []
+        for i in range(0, len(level), 4):
+            nodes.append(level[i:i + 4])
+            out.append(len(nodes) - 1)
+        return out
+    level = links
+    while True:
+        level = group(level)
+        if len(level) == 1:
+            break
+    n = len(nodes)
+    remap = lambda k: n - 1 - k                  # the root was made last: reverse the numbering so that it becomes node 0
+    arr = (pkg.MiNode * n)()
+    for k, ch in enumerate(nodes):
+        nd = arr[remap(k)]
+        nd.axis0, nd.axis00, nd.axis01, nd.parent = 0, 1, 2, -1
+        for c in range(4):
+            if c < len(ch):
+                link = ch[c]
+                nd.child[c] = link if link & pkg.MI_NODE_LEAF else remap(link)
+                if not link & pkg.MI_NODE_LEAF:
+                    arr[remap(link)].parent = remap(k)
+                for a in range(3):
+                    nd.aabb[a][c], nd.aabb[a + 3][c] = desc.aabb[a], desc.aabb[a + 3]
+            else:
+                nd.child[c] = pkg.MI_NODE_LEAF       # empty child: no primitives, inverted box (qbvhmp.c:1095-1112)
+                for a in range(3):
+                    nd.aabb[a][c], nd.aabb[a + 3][c] = 3.4028234663852886e38, -3.4028234663852886e38
+    arr[0].parent = -1
+    return arr
+
+
+def test_leaf_phase_corner_cases(tmp_path):
+    """the distributed leaf phase (leaf_jobs, mi_kernels.h) hands three cases back to the per-lane loop: a folded quad crossed in
+    both halves (what it reports depends on the running closest hit, src/prims.c:654-663), leaves of more than 7 primitives, and
+    rounds with more jobs than the wave's list holds. All three against the oracle's accel_intersect, bit for bit, counters included:
+    a stack of folded quads seen edge-on, under the builder's tree and under trees with leaves of 3 / 7 / 20 / 31 primitives."""
+    import shutil, sys
+    from helpers import REPO
+    sys.path.insert(0, str(REPO / "tools"))
+    from make_geo import read_geo, write_geo, VTXIDX, VTX
+    shutil.copytree(REPO / "scenes", tmp_path / "scenes")
+    # 40 quads v0 v1 v2 v3 folded along the diagonal v0-v2 into a V (v1 and v3 lifted): a ray across the diagonal meets both halves
+    Q = 40
+    _, tvi, tv = read_geo(REPO / "scenes" / "geo" / "emitter.geo")
+    primid = (np.uint64(4) << np.uint64(61)) | (np.arange(Q, dtype=np.uint64) * np.uint64(4) << np.uint64(32))
+    vtxidx = np.zeros(4 * Q, dtype=VTXIDX)
+    vtxidx["v"] = np.arange(4 * Q)
+    vtxidx["uv"] = np.tile(tvi["uv"][:4], Q)
+    vtx = np.zeros(4 * Q, dtype=VTX)
+    vtx["n"] = tv["n"][0]
+    for q in range(Q):
+        z = np.float32(0.5 + 0.05 * q)
+        vtx["p"][4 * q:4 * q + 4] = np.float32([[-1, -1, z], [1, -1, z + 0.6], [1, 1, z], [-1, 1, z + 0.6]])
+    write_geo(tmp_path / "scenes" / "geo" / "folded.geo", primid, vtxidx, vtx)
+    nra = tmp_path / "scenes" / "0010_pt" / "test.nra2"
+    lines = nra.read_text().splitlines()
+    k = lines.index("6")
+    nra.write_text("\n".join(lines[:k] + ["5", "5 ../geo/emitter", "10 ../geo/folded", "10 ../geo/cone", "10 ../geo/sphere", "10 ../geo/cylinder"]) + "\n")
+    scene = make_scene(nra, width=64, height=64, max_verts=4)
+    P = int(scene.desc.num_prims)
+    assert P == Q + 6
+    rng = np.random.default_rng(5)
+    n = 64 * 700
+    # half of the rays cross the valleys nearly horizontally, across the fold; the rest come from anywhere
+    pos = np.zeros((n, 3), dtype=np.float32)
+    d = np.zeros((n, 3), dtype=np.float32)
+    h = n // 2
+    ang = rng.uniform(0, 2 * np.pi, size=h)
+    pos[:h] = np.stack([4 * np.cos(ang), 4 * np.sin(ang), rng.uniform(0.4, 3.2, size=h)], axis=1)
+    tgt = np.stack([rng.uniform(-.8, .8, size=h), rng.uniform(-.8, .8, size=h), rng.uniform(0.5, 3.0, size=h)], axis=1)
+    d[:h] = tgt - pos[:h]
+    pos[h:] = rng.uniform(-4, 4, size=(n - h, 3)) + [0, 0, 2]
+    d[h:] = rng.normal(size=(n - h, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    ignore = rng.integers(0, P, size=n).astype(np.uint32)
+    ignore[::2] = 0xffffffff
+    be = pkg.Backend(scene)
+    gpu = _compare_hits(scene, be, pos, d)
+    assert (gpu["primid"] != 0xffffffffffffffff).mean() > 0.5
+    _compare_hits(scene, be, pos, d, ignore=ignore, max_dist=rng.uniform(0.5, 30, size=n).astype(np.float32))
+    be.close()
+    desc = scene.desc
+    keep_nodes, keep_n = desc.nodes, desc.num_nodes
+    try:
+        for leaf_size in (3, 7, 20, 31):
+            arr = _chunk_tree(desc, leaf_size)
+            desc.nodes, desc.num_nodes = C.cast(arr, C.POINTER(pkg.MiNode)), len(arr)
+            be = pkg.Backend(scene)
+            _compare_hits(scene, be, pos[:64 * 200], d[:64 * 200])
+            _compare_hits(scene, be, pos[:64 * 200], d[:64 * 200], ignore=ignore[:64 * 200])
+            be.close()
+    finally:
+        desc.nodes, desc.num_nodes = keep_nodes, keep_n
