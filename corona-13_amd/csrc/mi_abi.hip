@@ -33,6 +33,12 @@
 #ifndef MI_LEAF_JOBS_PTDL
 #define MI_LEAF_JOBS_PTDL 0   /* A/B switch: the distributed leaf phase in the ptdl kernels too */
 #endif
+#ifndef MI_LEAF_JOBS_MEDIA
+#define MI_LEAF_JOBS_MEDIA 1  /* ... in the extended (media / moving camera) pt kernels: +7 % (0055_media, 0056_fog, 0058_cam_mb) */
+#endif
+#ifndef MI_LEAF_JOBS_MB
+#define MI_LEAF_JOBS_MB 0     /* ... in the motion-blur pt kernels: parity green, but 1748 against 1923 Msamples/s on 0059_mb (every moving primitive is a put-off test) */
+#endif
 #ifndef MI_STACK
 #if MI_LEAF_JOBS
 #define MI_STACK (MI_STACK_LDS - 3)   /* the top three entries of a lane's column hold the results of the distributed leaf phase (leaf_jobs) */
@@ -59,9 +65,9 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
   const unsigned long long blk_lo = count/nb*blockIdx.x + (blockIdx.x < count%nb ? blockIdx.x : count%nb);
   const unsigned long long blk_hi = blk_lo + count/nb + (blockIdx.x < count%nb ? 1 : 0);
 
-  /* pt: the primitive tests of a traversal round are dealt out over all lanes of the wave (leaf_jobs); ptdl and the extended kernels
-     keep the per-lane leaf loop -- there the extra live registers of the job loop spill (A/B in DESIGN.md) */
-  constexpr bool JOBS = MI_LEAF_JOBS && (!PTDL || MI_LEAF_JOBS_PTDL) && !MEDIA && !MB;
+  /* pt: the primitive tests of a traversal round are dealt out over all lanes of the wave (leaf_jobs); the ptdl kernels keep the
+     per-lane leaf loop -- there the extra live registers of the job loop spill (A/B in DESIGN.md) */
+  constexpr bool JOBS = MI_LEAF_JOBS && (!PTDL || MI_LEAF_JOBS_PTDL) && (!MEDIA || MI_LEAF_JOBS_MEDIA) && (!MB || MI_LEAF_JOBS_MB);
   constexpr int STACK = JOBS ? MI_STACK_LDS - 3 : MI_STACK_LDS;
   Counters<COUNT || RECORD> cnt;        /* COUNT = false: only the path count (see Counters, mi_kernels.h) */
   PathState ps;
