@@ -63,6 +63,56 @@ MI_HD float mi_rcp(float x)
   return 1.0f/x;
 #endif
 }
+/* sincosf(y). Default: the device libm's. With -DMI_HOST_SINCOS: as the HOST computes it -- the reference (and the oracle) call glibc's
+ * sincosf / sinf / cosf, the device libm's results differ from those in the last ulp now and then, and that decides about half of the
+ * paths that part ways with the oracle (grazing hits): 4 M-path soaks, paths with a different primitive sequence, device libm / this:
+ * cfg 2 12 / 6, cfg 3 13 / 6, cfg 4 64 / 33, metal ptdl 35 / 1. glibc's float routines (sysdeps/ieee754/flt-32/s_sincosf.c, 2.35: quadrant
+ * by a scaled conversion, a degree-4 and a degree-3 polynomial in x^2, all in double, one rounding to float at the end) are restated here
+ * operation by operation in device doubles; the coefficients are the table in libm.so's data (`__sincosf_table`). Bit-identical to the
+ * host's sincosf for every float in [-2 pi, 2 pi] -- 2 x 1 086 918 620 arguments, checked on the host (the restatement against glibc) and on
+ * the device (tools/micro/sincos_exact.hip); between 17 and 120, where the host's FMA build of glibc rounds the reduction once less, 1 in
+ * 10^6 differs by an ulp. Arguments of 120 and beyond (none here: every angle is 2 pi u or a multiple of pi below 6 pi) go to the device
+ * libm. Not the default because a double operation costs 4.7 cycles against 2.8 (tools/micro/valu_cost.hip): cfg 2 +1.8 %, cfg 3 +3.9 %
+ * kernel time. */
+MI_HD void mi_sincosf(float y, float *sinp, float *cosp)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && defined(MI_HOST_SINCOS)
+  const uint32_t top = (__float_as_uint(y) >> 20) & 0x7ffu;            /* abstop12 */
+  if(top >= ((0x42f00000u >> 20) & 0x7ffu)) { sincosf(y, sinp, cosp); return; }     /* |y| >= 120, inf, NaN */
+  double x = (double)y;
+  int n = 0;
+  if(top < ((0x3f490fdbu >> 20) & 0x7ffu))
+  { /* |y| < pi/4 */
+    if(top < ((0x39800000u >> 20) & 0x7ffu)) { *sinp = y; *cosp = 1.0f; return; }   /* |y| < 2^-12 */
+  }
+  else
+  { /* reduce_fast: hpi_inv is 2/pi * 2^24, the quadrant ends up in bits 24..31 */
+    const double r = x*0x1.45f306dc9c883p+23;
+    n = ((int)r + 0x800000) >> 24;
+    x = x - (double)n*0x1.921fb54442d18p+0;
+    if(((n ^ (n >> 1)) & 1) != 0) x = -x;                             /* sign[n & 3] = {1, -1, -1, 1} */
+  }
+  const double x2 = x*x;
+  /* sincosf_poly; for n & 2 glibc switches to a table with the cosine coefficients negated: the same sums with the sign flipped */
+  const double x4 = x2*x2, x3 = x2*x;
+  const double c2 = -0x1.6c087e89a359dp-10 + x2*0x1.99343027bf8c3p-16;
+  const double s1 = 0x1.1107605230bc4p-7 + x2*-0x1.994eb3774cf24p-13;
+  const double c1 = 0x1p0 + x2*-0x1.ffffffd0c621cp-2;
+  const double x5 = x3*x2, x6 = x4*x2;
+  const double s = x + x3*-0x1.555545995a603p-3;
+  const double c = c1 + x4*0x1.55553e1068f19p-5;
+  const float fs = (float)(s + x5*s1);
+  float fc = (float)(c + x6*c2);
+  if(n & 2) fc = -fc;
+  *sinp = (n & 1) ? fc : fs;
+  *cosp = (n & 1) ? fs : fc;
+#else
+  sincosf(y, sinp, cosp);
+#endif
+}
+MI_HD float mi_sinf(float y) { float s, c; mi_sincosf(y, &s, &c); return s; }
+MI_HD float mi_cosf(float y) { float s, c; mi_sincosf(y, &s, &c); return c; }
+
 /* sqrtf(x). On the device: v_sqrt_f32 (within one ulp) and the choice among its two neighbours by the sign of the exact
  * residuals x - s*(s -+ 1ulp) -- the core of the compiler's correctly rounded expansion without the scaling it wraps around
  * it for denormal arguments (9 instead of 16 instructions). Bit-identical to sqrtf for +-0, inf, NaN, negative x and every
@@ -1181,7 +1231,7 @@ __device__ __forceinline__ void surface_setup(const DScene &sc, uint32_t prim, c
       {
         const float phi = (float)(2.0*MI_PI_D*(double)sf.v);
         float sinphi, cosphi;
-        sincosf(phi, &sinphi, &cosphi);
+        mi_sincosf(phi, &sinphi, &cosphi);
         const V3 n = mk3(a.x*sinphi + b.x*cosphi, a.y*sinphi + b.y*cosphi, a.z*sinphi + b.z*cosphi);
         const float rr = r1 - r0;
         if(fabsf(rr) < 1e-3) sf.n = n;
@@ -1413,7 +1463,7 @@ __device__ __forceinline__ void ggx_sample11(float tan_theta_i, float U1, float 
     const float r = mi_sqrt(U1/fmaxf(1e-8f, 1-U1));
     const float phi = (float)(2.0f*MI_PI_D*(double)U2);
     float sn, cs;
-    sincosf(phi, &sn, &cs);
+    mi_sincosf(phi, &sn, &cs);
     slope_x = r*cs;
     slope_y = r*sn;
     return;
@@ -1536,7 +1586,7 @@ __device__ __forceinline__ void sample_diffuse(PS &pts, const Surf &sf, const Sh
   const float c0 = mi_sqrt((float)(1.0 - (double)x1));
   const float ang = (float)(2*MI_PI_D*(double)x2);
   float sn, cs;
-  sincosf(ang, &sn, &cs);                 /* one range reduction for both (same values as sinf/cosf) */
+  mi_sincosf(ang, &sn, &cs);                 /* one range reduction for both (same values as sinf/cosf) */
   const float c1 = sq*cs, c2 = sq*sn;
   bs.omega = mk3(c0*sf.n.x + c1*sf.a.x + c2*sf.b.x, c0*sf.n.y + c1*sf.a.y + c2*sf.b.y, c0*sf.n.z + c1*sf.a.z + c2*sf.b.z);
   bs.pdf = (float)(1.0f/MI_PI_D);
@@ -1944,11 +1994,11 @@ __device__ __forceinline__ V3 prim_sample(const DPrim &p, const DPrimGeo &geo, f
   if(type == MI_PRIM_SPHERE)
   { /* geo_sphere_retime, include/geo/sphere.h:38-49 */
     hu = r0; hv = (float)((double)acosf(r1)/MI_PI_D);
-    const float x1 = (float)((double)(-(cosf((float)((double)hv*MI_PI_D))-1.f))/2.0), x2 = hu;
+    const float x1 = (float)((double)(-(mi_cosf((float)((double)hv*MI_PI_D))-1.f))/2.0), x2 = hu;
     const float z = 1.f - 2.f*x1, rr = mi_sqrt(1.f - z*z);
     const float phi = (float)(2.f*MI_PI_D*(double)x2);
     const float radius = p.v[1][0];
-    return mk3(p.v[0][0] + radius*(rr*cosf(phi)), p.v[0][1] + radius*(rr*sinf(phi)), p.v[0][2] + radius*z);
+    return mk3(p.v[0][0] + radius*(rr*mi_cosf(phi)), p.v[0][1] + radius*(rr*mi_sinf(phi)), p.v[0][2] + radius*z);
   }
   /* line: geo_line_retime, include/geo/line.h:88-121 */
   hu = r0; hv = r1;
@@ -1959,7 +2009,7 @@ __device__ __forceinline__ V3 prim_sample(const DPrim &p, const DPrimGeo &geo, f
   if(fabsf(lr1-lr0) < 1e-3f) y = hu;
   else y = (mi_sqrt((lr1*lr1 - lr0*lr0)*hu + lr0*lr0) - lr0)/(lr1-lr0);
   const float phi = (float)(2.0*MI_PI_D*(double)hv);
-  float sinphi, cosphi; sincosf(phi, &sinphi, &cosphi);
+  float sinphi, cosphi; mi_sincosf(phi, &sinphi, &cosphi);
   V3 d = sub3(v1, v0);
   d = scale3(d, mi_rcp(mi_sqrt(dot3(d, d))));
   V3 a, b; get_onb(d, a, b);
@@ -1974,9 +2024,9 @@ __device__ __forceinline__ float bh_w(float n)
   if(n > NN-1.0f || n < 0.0f) return 0.0f;
   const float a0 = 0.35875, a1 = 0.48829, a2 = 0.14128, a3 = 0.01168;
   const float N_1 = 1.0f/(NN-1.0f);
-  const float cos1 = cosf((float)(2.0f*MI_PI_D*(double)n*(double)N_1));
-  const float cos2 = cosf((float)(4.0f*MI_PI_D*(double)n*(double)N_1));
-  const float cos3 = cosf((float)(6.0f*MI_PI_D*(double)n*(double)N_1));
+  const float cos1 = mi_cosf((float)(2.0f*MI_PI_D*(double)n*(double)N_1));
+  const float cos2 = mi_cosf((float)(4.0f*MI_PI_D*(double)n*(double)N_1));
+  const float cos3 = mi_cosf((float)(6.0f*MI_PI_D*(double)n*(double)N_1));
   return a0 - a1*cos1 + a2*cos2 - a3*cos3;
 }
 

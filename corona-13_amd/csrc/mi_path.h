@@ -112,8 +112,8 @@ __device__ __forceinline__ void camera_frame_at(const mi_camera &cam, float time
     if(fabsf(sin_theta_2) < 1e-10f) for(int k=0;k<4;k++) r[k] = (q[k] + p[k])*.5f;
     else
     {
-      const float wa = sinf((1.0f - time)*theta_2)/sin_theta_2;
-      const float wb = sinf(time*theta_2)/sin_theta_2;
+      const float wa = mi_sinf((1.0f - time)*theta_2)/sin_theta_2;
+      const float wb = mi_sinf(time*theta_2)/sin_theta_2;
       for(int k=0;k<4;k++) r[k] = q[k]*wa + p[k]*wb;
     }
   }
@@ -147,7 +147,7 @@ __device__ __forceinline__ void path_generate(const DScene &sc, PathState &ps, u
   const float r2 = pts.template camera<MI_DIM_APERTURE_Y>();
   const float ang = (float)(2*MI_PI_D*(double)r1);
   float sn, cs;
-  sincosf(ang, &sn, &cs);                 /* one range reduction for both (same values as sinf/cosf) */
+  mi_sincosf(ang, &sn, &cs);                 /* one range reduction for both (same values as sinf/cosf) */
   const float lu = cs*mi_sqrt(r2)*cc.lens_radius;
   const float lv = sn*mi_sqrt(r2)*cc.lens_radius;
   V3 ca = ld3(cam.a), cb = ld3(cam.b), cn = ld3(cam.n), cpos = ld3(cam.pos);
@@ -373,7 +373,7 @@ __device__ __forceinline__ void path_shade_volume(const DScene &sc, PathState &p
       const float r = mi_sqrt(1.f - z*z);
       const float phi = (float)(2.f*MI_PI_D*(double)r2);
       float sn, cs;
-      sincosf(phi, &sn, &cs);
+      mi_sincosf(phi, &sn, &cs);
       o0 = r*cs; o1 = r*sn; o2 = z;
       pdf = (float)(1.0/(4.0*MI_PI_D));
     }
@@ -384,7 +384,7 @@ __device__ __forceinline__ void path_shade_volume(const DScene &sc, PathState &p
       const float phi = (float)(2.0f*MI_PI_D*(double)r2);
       const float l = mi_sqrt(fmaxf(0.0f, 1.0f-cos_theta*cos_theta));
       float sn, cs;
-      sincosf(phi, &sn, &cs);
+      mi_sincosf(phi, &sn, &cs);
       o0 = cos_theta; o1 = cs*l; o2 = sn*l;
       pdf = (float)(1.0/(4.0*MI_PI_D)*(double)(1.0f-g*g)/(double)powf(1.0f + g*g - 2.0f*g*cos_theta, 3.0f/2.0f));
     }

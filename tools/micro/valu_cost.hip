@@ -67,6 +67,22 @@ BODY(k_cmpclass, "v_cmp_class_f32 vcc, %0, %8\n v_cmp_class_f32 vcc, %1, %8\n v_
 BODY(k_cmpu, "v_cmp_eq_u32 vcc, %0, %8\n v_cmp_eq_u32 vcc, %1, %8\n v_cmp_eq_u32 vcc, %2, %8\n v_cmp_eq_u32 vcc, %3, %8\n v_cmp_eq_u32 vcc, %4, %8\n v_cmp_eq_u32 vcc, %5, %8\n v_cmp_eq_u32 vcc, %6, %8\n v_cmp_eq_u32 vcc, %7, %8\n")
 BODY(k_movdpp, "v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %4, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %6, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n")
 
+
+// double precision (the glibc-exact sincos of mi_kernels.h is made of these)
+#define BODY64(NAME, ASM) \
+__global__ void __launch_bounds__(256) NAME(float *out, int iters) \
+{ \
+  double a0 = threadIdx.x*1e-3, a1 = a0 + 1.0, a2 = a0 + 2.0, a3 = a0 + 3.0, a4 = a0 + 4.0, a5 = a0 + 5.0, a6 = a0 + 6.0, a7 = a0 + 7.0, b0 = 0.999, b1 = 1e-3; \
+  for(int i=0;i<iters;i++) \
+  { \
+    REP8(asm volatile(ASM : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b0), "v"(b1));) \
+  } \
+  out[blockIdx.x*blockDim.x + threadIdx.x] = (float)(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7); \
+}
+BODY64(k_mul64, "v_mul_f64 %0, %0, %8\n v_mul_f64 %1, %1, %8\n v_mul_f64 %2, %2, %8\n v_mul_f64 %3, %3, %8\n v_mul_f64 %4, %4, %8\n v_mul_f64 %5, %5, %8\n v_mul_f64 %6, %6, %8\n v_mul_f64 %7, %7, %8\n")
+BODY64(k_add64, "v_add_f64 %0, %0, %8\n v_add_f64 %1, %1, %8\n v_add_f64 %2, %2, %8\n v_add_f64 %3, %3, %8\n v_add_f64 %4, %4, %8\n v_add_f64 %5, %5, %8\n v_add_f64 %6, %6, %8\n v_add_f64 %7, %7, %8\n")
+BODY64(k_fma64, "v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %1, %1, %8, %9\n v_fma_f64 %2, %2, %8, %9\n v_fma_f64 %3, %3, %8, %9\n v_fma_f64 %4, %4, %8, %9\n v_fma_f64 %5, %5, %8, %9\n v_fma_f64 %6, %6, %8, %9\n v_fma_f64 %7, %7, %8, %9\n")
+
 template<class K> static void run(const char *name, K kern, float *d, int per_asm)
 {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -92,5 +108,6 @@ int main()
   run("cnd_e64", k_cnd_e64, d, 8); run("cnd_ab", k_cnd_ab, d, 8); run("cmp vcc", k_cmp, d, 8); run("cmp sgpr", k_cmp64, d, 8);
   run("4cmp+4sel", k_cmp4sel4, d, 8); run("min", k_min, d, 8); run("med3", k_med3, d, 8); run("fma 3 vgpr", k_fma3, d, 8); run("sqrt", k_sqrt, d, 8);
   run("bfi", k_bfi, d, 8); run("bfeu", k_bfeu, d, 8); run("bfei", k_bfei, d, 8); run("and", k_and, d, 8); run("lshr", k_lshr, d, 8); run("or3", k_or3, d, 8); run("andor", k_andor, d, 8); run("lshlor", k_lshlor, d, 8); run("perm", k_perm, d, 8); run("add3", k_add3, d, 8); run("sub", k_sub, d, 8); run("xor", k_xor, d, 8); run("mad24", k_mad24, d, 8); run("lshladd", k_lshladd, d, 8); run("bcnt", k_bcnt, d, 8); run("cvt", k_cvt, d, 8); run("maxu", k_maxu, d, 8); run("fmac", k_fmac, d, 8); run("mule64", k_mule64, d, 8); run("cmpclass", k_cmpclass, d, 8); run("cmpu", k_cmpu, d, 8); run("movdpp", k_movdpp, d, 8);
+  run("mul_f64", k_mul64, d, 8); run("add_f64", k_add64, d, 8); run("fma_f64", k_fma64, d, 8);
   return 0;
 }
