@@ -25,6 +25,7 @@ MI_LIB = Path(os.environ.get("CORONA_MI_LIB", PKG_DIR / "csrc" / "libcorona_mi.s
 
 MI_SAMPLER_PT, MI_SAMPLER_PTDL = 0, 1
 MI_POINTS_RAND, MI_POINTS_HALTON = 0, 1
+MI_TRAVERSAL_EXACT, MI_TRAVERSAL_FAST = 0, 1
 MI_REC_MAX_VERTS, MI_REC_MAX_SPLATS = 8, 8
 MI_NODE_LEAF = 1 << 63          # mi_node.child: leaf link = MI_NODE_LEAF | first_prim << 5 | count (corona_mi.h)
 
@@ -285,6 +286,7 @@ def mi_lib():
         m.mi_fb_device_ptr.restype = C.c_void_p
         m.mi_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         m.mi_scene_set_counters.argtypes = [C.c_void_p, C.c_int]
+        m.mi_scene_set_traversal.argtypes = [C.c_void_p, C.c_int]
         m.mi_trace_paths.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
         m.mi_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         m.mi_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
@@ -299,7 +301,7 @@ def mi_lib():
 
 
 MI_SYMBOLS = ["mi_init", "mi_scene_create", "mi_scene_set_framebuffer", "mi_scene_set_stream", "mi_render",
-              "mi_sync", "mi_fb_read", "mi_fb_clear", "mi_fb_device_ptr", "mi_counters", "mi_scene_set_counters", "mi_trace_paths", "mi_intersect",
+              "mi_sync", "mi_fb_read", "mi_fb_clear", "mi_fb_device_ptr", "mi_counters", "mi_scene_set_counters", "mi_scene_set_traversal", "mi_trace_paths", "mi_intersect",
               "mi_last_kernel_ms", "mi_last_kernel_launches", "mi_scene_stats", "mi_scene_destroy", "mi_shutdown", "mi_last_error"]
 
 
@@ -314,7 +316,7 @@ def ray_dtypes():
 class Backend:
     """Device-resident scene on one MI355X, driven through the C ABI."""
 
-    def __init__(self, scene: Scene, device: int = -1, device_build: bool = False, counters: bool = True):
+    def __init__(self, scene: Scene, device: int = -1, device_build: bool = False, counters: bool = True, traversal: str | None = None):
         """device_build: hand the scene over WITHOUT the host-built tree (mi_scene_desc.nodes = NULL); the backend then
         builds its own 4-wide BVH on the GPU (csrc/mi_build.h).
         counters: render with the counting kernels (mi_scene_set_counters) so that counters() reports the traversal work --
@@ -332,9 +334,16 @@ class Backend:
         self._check(self.m.mi_scene_create(desc_ptr, C.byref(self._ptr)), "mi_scene_create")
         self.scene = scene
         self.set_counters(counters)
+        if traversal is not None:
+            self.set_traversal(traversal)
 
     def set_counters(self, enable):
         self._check(self.m.mi_scene_set_counters(self._ptr, 1 if enable else 0), "mi_scene_set_counters")
+
+    def set_traversal(self, mode):
+        """'exact': the reference's order of operations per ray (counters equal its -DACCEL_DEBUG totals); 'fast' (the library's
+        default): leaves put aside while the lane descends on -- same hits, other work counters (corona_mi.h)"""
+        self._check(self.m.mi_scene_set_traversal(self._ptr, {"exact": 0, "fast": 1}[mode]), "mi_scene_set_traversal")
 
     def _check(self, err, what):
         if err:

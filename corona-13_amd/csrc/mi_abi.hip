@@ -4,7 +4,7 @@
  * Replaces everything the reference reaches from work_sample() (src/view.c:618-628): one launch
  * traces path indices [first, first+count) and splats them into the device framebuffer.
  */
-#include "mi_path.h"
+#include "mi_megakernel.h"
 #include "mi_build.h"
 #include "mi_halton.h"
 #include <cstring>
@@ -15,197 +15,53 @@
 #include <string.h>
 #include <vector>
 
-#ifndef MI_BLOCK
-#define MI_BLOCK 1024    /* threads per workgroup: 16 waves/CU = 4 per SIMD (128 VGPRs each) */
-#endif
-#ifndef MI_TAIL_LANES
-#define MI_TAIL_LANES 16       /* a traversal slice ends when fewer rays than this are still under way */
-#endif
-#ifndef MI_TAIL_LANES_PTDL
-#define MI_TAIL_LANES_PTDL 12  /* ptdl shades more per vertex (next event estimation); A/B 6 / 8 / 10 / 12 / 16: 38.67 / 38.44 / 38.22 / 38.14 / 38.19 ms */
-#endif
-#ifndef MI_ANYHIT
-#define MI_ANYHIT 1      /* shadow rays towards flagged emitters stop at the first occluder (MI_LIGHT_ANYHIT, mi_device.h) */
-#endif
-#ifndef MI_LEAF_JOBS
-#define MI_LEAF_JOBS 1
-#endif
-#ifndef MI_LEAF_JOBS_PTDL
-#define MI_LEAF_JOBS_PTDL 0   /* A/B switch: the distributed leaf phase in the ptdl kernels too */
-#endif
-#ifndef MI_LEAF_JOBS_MEDIA
-#define MI_LEAF_JOBS_MEDIA 1  /* ... in the extended (media / moving camera) pt kernels: +7 % (0055_media, 0056_fog, 0058_cam_mb) */
-#endif
-#ifndef MI_LEAF_JOBS_MB
-#define MI_LEAF_JOBS_MB 0     /* ... in the motion-blur pt kernels: parity green, but 1748 against 1923 Msamples/s on 0059_mb (every moving primitive is a put-off test) */
-#endif
-#ifndef MI_STACK
-#if MI_LEAF_JOBS
-#define MI_STACK (MI_STACK_LDS - 3)   /* the top three entries of a lane's column hold the results of the distributed leaf phase (leaf_jobs) */
-#else
-#define MI_STACK MI_STACK_LDS         /* LDS traversal stack entries per lane; deeper entries overflow to HBM (mi_device.h) */
-#endif
-#endif
-
-/* ======================================================================================= persistent megakernel */
-template<bool RECORD, bool PTDL, bool NODES_LDS, bool HALTON = false, bool MEDIA = false, bool MB = false, bool COUNT = true>
-__global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned long long first, unsigned long long count,
-                                                           const uint32_t *shape_material, const float *shape_L, mi_path_record *records,
-                                                           uint2 *stack_overflow)
+/* ======================================================================================= upload-time kernels */
+/* Upload-time pass over the child links (one thread per link): an inner link takes the split axes of the node it points to into
+ * bits 25..30, so that a node visit needs no separate look-up of its axes (one LDS read less per visit, and no second round trip in
+ * front of the box reads). `axes` = axis0 | axis00 << 2 | axis01 << 4 per node, as the host builder / the device build leave them. */
+__global__ void mi_fold_axes_kernel(float4 *nodes, const uint32_t *axes, uint32_t N)
 {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const Lds lds = lds_setup<MI_BLOCK, NODES_LDS, HALTON, PTDL && !MEDIA>(sc, smem, stack_overflow);
-
-  /* every workgroup owns a contiguous part of the path index range and hands it out through an LDS counter: the
-     wave-level refill below then needs no global atomic at all (one shared counter costs ~11 ns per wave refill) */
-  __shared__ unsigned int blk_next;
-  if(threadIdx.x == 0) blk_next = 0;
-  __syncthreads();
-  const unsigned long long nb = gridDim.x;
-  const unsigned long long blk_lo = count/nb*blockIdx.x + (blockIdx.x < count%nb ? blockIdx.x : count%nb);
-  const unsigned long long blk_hi = blk_lo + count/nb + (blockIdx.x < count%nb ? 1 : 0);
-
-  /* pt: the primitive tests of a traversal round are dealt out over all lanes of the wave (leaf_jobs); the ptdl kernels keep the
-     per-lane leaf loop -- there the extra live registers of the job loop spill (A/B in DESIGN.md) */
-  constexpr bool JOBS = MI_LEAF_JOBS && (!PTDL || MI_LEAF_JOBS_PTDL) && (!MEDIA || MI_LEAF_JOBS_MEDIA) && (!MB || MI_LEAF_JOBS_MB);
-  constexpr int STACK = JOBS ? MI_STACK_LDS - 3 : MI_STACK_LDS;
-  Counters<COUNT || RECORD> cnt;        /* COUNT = false: only the path count (see Counters, mi_kernels.h) */
-  PathState ps;
-  ps.active = 0;
-  ps.sh_pending = 0;
-  bool exhausted = false;
-  const unsigned lane = __lane_id();
-  TraceState ts;
-  ts.done = true;
-  Hit hit;
-  hit.prim = MI_NOPRIM; hit.dist = FLT_MAX; hit.u = hit.v = 0.0f;
-  bool tracing = false, tr_shadow = false;
-
-  MI_PHASE_INIT(cnt)
-  while(true)
-  {
-    /* ------------------------------------------------------------ refill idle lanes (wave-level compaction of the work queue) */
-    if(!exhausted)
-    {
-      const bool want = !ps.active && !ps.sh_pending;
-      const unsigned long long m = __ballot(want);
-      if(m)
-      {
-        const unsigned n = __popcll(m);
-        unsigned int base = 0;
-        if(lane == (unsigned)(__ffsll((long long)m) - 1)) base = atomicAdd(&blk_next, n);     /* LDS atomic: this block's own range */
-        base = __shfl(base, __ffsll((long long)m) - 1);
-        if(want)
-        {
-          const unsigned rank = __popcll(m & ((1ull << lane) - 1ull));
-          const unsigned long long i = blk_lo + base + rank;
-          if(i < blk_hi) path_generate<RECORD, HALTON, MEDIA>(sc, ps, first + i, RECORD ? records + i : nullptr, cnt);
-          else exhausted = true;
-        }
-      }
-    }
-    if(!__any(ps.active || ps.sh_pending)) break;
-    const bool exhausted_wave = __any(exhausted);   /* this block's index range has run dry */
-    MI_PHASE(cnt, 0)
-
-    /* ------------------------------------------------------------ one ray per busy lane: a pending shadow ray first, else the extension ray */
-    if(!tracing && (ps.active || ps.sh_pending))
-    {
-      tr_shadow = PTDL && ps.sh_pending;
-      hit.prim = MI_NOPRIM; hit.dist = tr_shadow ? ps.sh_dist : (MEDIA ? media_free_flight<PTDL, HALTON>(sc, ps) : FLT_MAX); hit.u = hit.v = 0.0f;
-      trace_begin(ts, tr_shadow ? ps.sh_dir : ps.dir, cnt);
-      if(PTDL && MI_ANYHIT) ts.anyhit = tr_shadow && (ps.sh_light & MI_LIGHT_ANYHIT);
-      if(MB) { ts.time = ps.time; ts.prims_t1 = sc.prims_t1; }      /* motion-blurred primitives are tested at the path's time */
-      tracing = true;
-    }
-    /* ------------------------------------------------------------ a slice of traversal: while-while rounds until only a tail of
-       MI_TAIL_LANES rays is still under way. Those lanes keep their traversal state (registers + LDS stack) and go on in the
-       next iteration next to the fresh rays of the lanes that shade now, so one long ray does not hold 63 lanes idle. */
-    {
-      const V3 o = ray_origin<PTDL>(ps, tr_shadow), d = tr_shadow ? ps.sh_dir : ps.dir;
-      const uint32_t ignore = ps.ignore;     /* the shadow ray of a vertex starts on the same primitive as its extension ray */
-      const unsigned tail = exhausted_wave ? 1u : (unsigned)(PTDL ? MI_TAIL_LANES_PTDL : MI_TAIL_LANES);
-      while(true)
-      {
-        const bool busy = tracing && !ts.done;
-        const unsigned nbusy = __popcll(__ballot(busy));
-        if(!nbusy) break;
-        if(nbusy < tail && __any(tracing && ts.done)) break;
-        if(busy) trace_round<MI_BLOCK, STACK, MB, PTDL && MI_ANYHIT, JOBS>(lds, sc.prims, o, d, ignore, hit, ts, cnt);
-        if(JOBS) leaf_jobs<MI_BLOCK, STACK, MB, PTDL && MI_ANYHIT>(lds, sc.prims, o, d, ignore, hit, ts, busy, cnt);   /* every lane of the wave takes part */
-      }
-    }
-    MI_PHASE(cnt, 1)
-    SplatReq splat;
-    splat.pending = false; splat.c0 = splat.c1 = splat.c2 = 0.0f;
-    if(tracing && ts.done)
-    {
-      tracing = false;
-      mi_path_record *rec = RECORD ? records + (ps.index - first) : nullptr;
-      if(tr_shadow) shadow_resolve<RECORD>(sc, ps, hit, rec, cnt, splat);
-      else path_shade<RECORD, PTDL, HALTON, MEDIA, MB>(sc, ps, hit, shape_material, shape_L, rec, cnt, splat);
-    }
-
-    /* ------------------------------------------------------------ splats of this iteration, cooperatively */
-    MI_PHASE(cnt, 5)
-    if(!RECORD) splat_wave(sc, splat.pending, ps.pixel_i, ps.pixel_j, splat.c0, splat.c1, splat.c2);
-    MI_PHASE(cnt, 6)
-  }
-
-#ifdef MI_PROFILE_LOOPS    /* development build: box hits / splats / vertices become wave-level inner iterations / leaf slots / analytic passes */
-  cnt.c[2] = cnt.c[8]; cnt.c[5] = cnt.c[9]; cnt.c[6] = cnt.c[10];
-#endif
-#ifdef MI_PROFILE_PHASES   /* development build: the 8 counters become lane 0's phase ticks | occurrences << 36 (tools/phase_probe.py) */
-  unsigned long long phase_out[8];
-  for(int k=0;k<8;k++) phase_out[k] = lane ? 0ull : ((unsigned long long)cnt.c[8 + k] | ((unsigned long long)cnt.c[16 + k] << 36));
-#endif
-  unsigned long long *shard = sc.counters + (size_t)(blockIdx.x % MI_COUNTER_SHARDS)*8;
-#ifndef MI_PROFILE_PHASES
-  if(cnt.on) atomicMax(shard + 7, (unsigned long long)cnt.c[7]);     /* deepest traversal stack use */
-#endif
-  /* ------------------------------------------------------------ flush work counters: wave reduction, one atomic per wave */
-#pragma unroll
-  for(int k=0;k<8;k++)
-  {
-    if(!cnt.on && k != 4) continue;         /* the plain kernels only count paths */
-    unsigned long long c = cnt.c[k];
-#ifdef MI_PROFILE_PHASES
-    c = phase_out[k];
-    if(k == 7) { if(lane == 0 && c) atomicAdd(shard + 7, c); continue; }
-#endif
-    for(int off=32;off>0;off>>=1) c += __shfl_down(c, off);
-    if(k == 7) continue;                    /* slot 7 is a maximum, flushed above */
-    if(lane == 0 && c) atomicAdd(shard + k, c);
-  }
+  const uint32_t i = blockIdx.x*blockDim.x + threadIdx.x;
+  if(i >= 4u*N) return;
+  uint32_t *link = (uint32_t *)(nodes + (size_t)6*N) + i;
+  const uint32_t l = *link;
+  if(!(l & MI_LEAF32)) *link = (l & MI_NODE_MASK) | (axes[l & MI_NODE_MASK] << MI_AXES_SHIFT);
 }
 
-/* ======================================================================================= unit hook: rays in, hits out */
-template<bool NODES_LDS>
-__global__ __launch_bounds__(MI_BLOCK) void mi_intersect_kernel(DScene sc, const mi_ray *rays, unsigned long long n, mi_hit *out,
-                                                                uint2 *stack_overflow)
+/* Upload-time pass over the leaves (one thread per child link of the tree, after the primitive records are in place -- for a
+ * device-built tree after the build): the leaf loops test a leaf's triangles and quads first and put off its spheres, lines and
+ * moving primitives. That changes nothing (see leaf_sequential) unless a quad can be crossed in both halves, which takes a folded
+ * quad: a static quad whose fourth vertex leaves the plane of the first three by more than 1e-5 of its size and which follows a
+ * primitive that is put off, or anything that follows a moving quad. From there to the end of its leaf every triangle / quad
+ * is put off too (type 0, pad[0] = vertex count, pad[1] = MI_PRIM_ORDERED): the put-off tests run in the leaf's order. */
+__global__ void mi_mark_ordered_kernel(const float4 *nodes, uint32_t N, DPrim *prims)
 {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const Lds lds = lds_setup<MI_BLOCK, NODES_LDS>(sc, smem, stack_overflow);
-  Counters<true> cnt;
-  for(unsigned long long base=(unsigned long long)blockIdx.x*MI_BLOCK; base<n; base+=(unsigned long long)gridDim.x*MI_BLOCK)
+  const uint32_t i = blockIdx.x*blockDim.x + threadIdx.x;
+  if(i >= 4u*N) return;
+  const uint32_t link = ((const uint32_t *)(nodes + (size_t)6*N))[i];
+  if(!(link & MI_LEAF32)) return;
+  const uint32_t first = (link ^ MI_LEAF32) >> 5, num = link & 31u;
+  bool deferred = false, ordered = false;
+  for(uint32_t k=0;k<num;k++)
   {
-    const unsigned long long i = base + threadIdx.x;
-    const bool live = i < n;                     /* the lanes behind the last ray still take part in the traversal's wave-level steps */
-    const mi_ray r = rays[live ? i : n - 1];
-    Hit hit;
-    hit.prim = MI_NOPRIM; hit.dist = r.max_dist; hit.u = hit.v = 0.0f;
-    accel_intersect<MI_BLOCK, MI_STACK>(lds, sc.prims, mk3(r.pos[0], r.pos[1], r.pos[2]), mk3(r.dir[0], r.dir[1], r.dir[2]), r.ignore, hit, cnt, live);
-    if(live)
+    DPrim &p = prims[first + k];
+    if(p.type >= MI_PRIM_TRI)
     {
-      mi_hit h;
-      h.prim = hit.prim; h.primid = hit.prim == MI_NOPRIM ? MI_PRIMID_INVALID : MI_GEO_PRIMID(sc.primgeo[hit.prim]);
-      h.dist = hit.dist; h.u = hit.u; h.v = hit.v; h.pad[0] = h.pad[1] = 0;
-      out[i] = h;
+      if(!ordered && deferred && p.type == MI_PRIM_QUAD)
+      {
+        const V3 e1 = ld3(p.v[1]), e2 = ld3(p.v[2]), e3 = ld3(p.v[3]);
+        const V3 n = cross3(e1, e2);
+        const float vol = fabsf(dot3(n, e3)), ref = sqrtf(dot3(n, n))*sqrtf(dot3(e3, e3));
+        if(!(vol <= 1e-5f*ref)) ordered = true;
+      }
+      if(ordered) { p.pad[0] = p.type; p.pad[1] = MI_PRIM_ORDERED; p.type = 0; }
+    }
+    else
+    {
+      deferred = true;
+      if(p.type == 0 && p.pad[0] == MI_PRIM_QUAD) ordered = true;       /* a moving quad: its shape changes with time */
     }
   }
-  unsigned long long *shard = sc.counters + (size_t)(blockIdx.x % MI_COUNTER_SHARDS)*8;
-  atomicMax(shard + 7, (unsigned long long)cnt.c[7]);
-  for(int k=0;k<4;k++) if(cnt.c[k]) atomicAdd(shard + k, (unsigned long long)cnt.c[k]);
 }
 
 /* ======================================================================================= host side */
@@ -245,6 +101,7 @@ struct mi_scene
   uint64_t launches;
   uint64_t kernel_launches_last;
   int counting;                     /* launch the COUNT instantiations (mi_scene_set_counters / CORONA_MI_COUNTERS) */
+  int fast;                         /* launch the FAST instantiations (mi_scene_set_traversal / CORONA_MI_TRAVERSAL): same hits, other work counters */
   bool media;                       /* some shape is filled with a homogeneous medium: MEDIA instantiations */
   void *d_shape_medium, *d_prims_t1, *d_lights;
   /* Halton point sampler */
@@ -255,38 +112,31 @@ struct mi_scene
 };
 
 /* ---------------------------------------------------------------------------------------- kernel table
- * bit 0 RECORD, 1 PTDL, 2 NODES_LDS, 3 HALTON, 4 MEDIA, 5 MB, 6 COUNT. MB implies MEDIA; the RECORD kernels always count.
- * MI_DEV_FAST (development builds, tools/variants.sh): only the plain tree-in-LDS kernels, 20 s instead of minutes to compile. */
-struct PathLaunch { mi_scene *s; int grid; uint64_t first, n; mi_path_record *rec; };
-static bool path_kernel_valid(unsigned which)
+ * The megakernel's instantiations live in ten parts (mi_megakernel.h, mi_part.hip), one translation unit each. */
+extern template const void *mi_path_part<false, false, false, false>(unsigned, const PathLaunch *);
+extern template const void *mi_path_part<true,  false, false, false>(unsigned, const PathLaunch *);
+extern template const void *mi_path_part<false, true,  false, false>(unsigned, const PathLaunch *);
+extern template const void *mi_path_part<true,  true,  false, false>(unsigned, const PathLaunch *);
+extern template const void *mi_path_part<false, true,  true,  false>(unsigned, const PathLaunch *);
+extern template const void *mi_path_part<true,  true,  true,  false>(unsigned, const PathLaunch *);
+extern template const void *mi_path_part<false, false, false, true>(unsigned, const PathLaunch *);
+extern template const void *mi_path_part<true,  false, false, true>(unsigned, const PathLaunch *);
+extern template const void *mi_path_part<false, true,  false, true>(unsigned, const PathLaunch *);
+extern template const void *mi_path_part<true,  true,  false, true>(unsigned, const PathLaunch *);
+
+static const void *path_kernel(bool ptdl, bool media, bool mb, bool fast, unsigned which, const PathLaunch *L)
 {
-  if((which & 32u) && !(which & 16u)) return false;
-  if((which & 1u) && !(which & 64u)) return false;
-#ifdef MI_DEV_FAST       /* 2: with the Halton kernels */
-  if((which & (16u | 32u)) || !(which & 4u) || ((which & 8u) && MI_DEV_FAST != 2)) return false;
-#endif
-  return true;
-}
-template<bool... B> static const void *path_kernel_go(PathLaunch *L)
-{
-  if(L) hipLaunchKernelGGL((mi_path_kernel<B...>), dim3(L->grid), dim3(MI_BLOCK), L->s->lds_bytes, L->s->stream, L->s->d, (unsigned long long)L->first,
-                           (unsigned long long)L->n, (const uint32_t *)L->s->d_shape_material, (const float *)L->s->d_shape_L, L->rec, (uint2 *)L->s->d_overflow);
-  return (const void *)mi_path_kernel<B...>;
-}
-template<bool R, bool P, bool N, bool H, bool M, bool MBk, bool C> static const void *path_kernel_leaf(PathLaunch *L)
-{
-  constexpr bool valid = !(MBk && !M) && !(R && !C)
 #ifdef MI_DEV_FAST
-                         && (!H || MI_DEV_FAST == 2) && !M && !MBk && N
+  if(media || mb) { fprintf(stderr, "[mi] internal: development build without the extended kernels\n"); abort(); }
 #endif
-                         ;
-  if constexpr(valid) return path_kernel_go<R, P, N, H, M, MBk, C>(L);
-  else { fprintf(stderr, "[mi] internal: kernel variant not built\n"); abort(); }
-}
-template<int LEFT, bool... B> static const void *path_kernel_dispatch(unsigned which, PathLaunch *L)
-{
-  if constexpr(LEFT == 0) return path_kernel_leaf<B...>(L);
-  else return (which & 1u) ? path_kernel_dispatch<LEFT - 1, B..., true>(which >> 1, L) : path_kernel_dispatch<LEFT - 1, B..., false>(which >> 1, L);
+  if(mb) return ptdl ? mi_path_part<true, true, true, false>(which, L) : mi_path_part<false, true, true, false>(which, L);   /* no FAST rounds with moving primitives */
+  if(media)
+  {
+    if(fast) return ptdl ? mi_path_part<true, true, false, true>(which, L) : mi_path_part<false, true, false, true>(which, L);
+    return ptdl ? mi_path_part<true, true, false, false>(which, L) : mi_path_part<false, true, false, false>(which, L);
+  }
+  if(fast) return ptdl ? mi_path_part<true, false, false, true>(which, L) : mi_path_part<false, false, false, true>(which, L);
+  return ptdl ? mi_path_part<true, false, false, false>(which, L) : mi_path_part<false, false, false, false>(which, L);
 }
 
 extern "C" const char *mi_last_error(void) { return g_err; }
@@ -756,6 +606,14 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
     e = build_on_device(s, h, &N, &stack_need);
     d.num_nodes = N;
   }
+  if(!e && N >= (1u << MI_AXES_SHIFT)) e = fail(MI_ERR_UNSUPPORTED, "more than 2^25 nodes");
+  if(!e && N)
+  { /* the split axes of every node move into the links that point to it (mi_fold_axes_kernel); the root's go into the scene */
+    uint32_t root_axes = 0;
+    hipLaunchKernelGGL(mi_fold_axes_kernel, dim3((4*N + 255)/256), dim3(256), 0, 0, (float4 *)s->d_nodes, (const uint32_t *)s->d_axes, N);
+    if(hipGetLastError() != hipSuccess || hipMemcpy(&root_axes, s->d_axes, 4, hipMemcpyDeviceToHost) != hipSuccess) e = fail(MI_ERR_DEVICE, "cannot fold the split axes into the links");
+    d.root_link = root_axes << MI_AXES_SHIFT;
+  }
   if(!e && N)
   { /* tree and primitive records are in their final order: leaves in which the order of the tests matters (a folded quad behind a
        primitive the leaf loops put off) are marked, see mi_mark_ordered_kernel */
@@ -813,7 +671,7 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   { mi_scene_destroy(s); return fail(MI_ERR_DEVICE, "cannot create stream/events"); }
   s->stream = s->stream_own;
 
-  d.nodes = (const float4 *)s->d_nodes; d.node_axes = (const uint32_t *)s->d_axes;
+  d.nodes = (const float4 *)s->d_nodes;
   d.prims = (const DPrim *)s->d_prims; d.primgeo = (const DPrimGeo *)s->d_primgeo;
   d.materials = (const DMaterial *)s->d_materials;
   d.shape_medium = (const DShapeMedium *)s->d_shape_medium;
@@ -846,8 +704,8 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   d.fb = s->d_fb;
   d.counters = (unsigned long long *)s->d_counters;
 
-  const size_t node_bytes = (((size_t)MI_NODE_FIELDS*N*16 + (size_t)N*4) + 15) & ~(size_t)15;
-  const size_t stack_bytes = (size_t)MI_STACK_LDS*MI_BLOCK*sizeof(uint2) + (MI_LEAF_JOBS ? (size_t)(MI_BLOCK/64)*MI_JOBS_MAX : 0);   /* + the waves' job lists */
+  const size_t node_bytes = (size_t)MI_NODE_FIELDS*N*16;
+  const size_t stack_bytes = (size_t)MI_STACK_LDS*MI_BLOCK*sizeof(uint2) + (size_t)(MI_BLOCK/64)*MI_JOBS_LDS;   /* + the waves' job lists */
   /* the tree lives in LDS next to the traversal stacks when it fits (0010_pt: 50 KB + 96 KB of 160 KB); larger trees are
      read from HBM / L2 by the NODES_LDS = false instantiations (CORONA_MI_NODES=global forces that, for tests) */
   const char *nodes_env = getenv("CORONA_MI_NODES");
@@ -857,9 +715,17 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   s->lds_bytes = halton_bytes + lights_bytes + (s->nodes_lds ? node_bytes : 0) + stack_bytes;
   s->device_built = device_build; s->stack_need = stack_need;
   { const char *ce = getenv("CORONA_MI_COUNTERS"); s->counting = ce && atoi(ce) ? 1 : 0; }
-  {
-    std::vector<const void *> kernels = { (const void *)mi_intersect_kernel<true>, (const void *)mi_intersect_kernel<false> };
-    for(unsigned which=0;which<128;which++) if(path_kernel_valid(which)) kernels.push_back(path_kernel_dispatch<7>(which, nullptr));
+  { const char *te = getenv("CORONA_MI_TRAVERSAL"); s->fast = !(te && !strcmp(te, "exact")); }
+  { /* the kernels this scene can launch (record / counting / traversal variants of its configuration) may use the whole LDS */
+    std::vector<const void *> kernels = { (const void *)mi_intersect_kernel<true, false>, (const void *)mi_intersect_kernel<false, false>,
+                                          (const void *)mi_intersect_kernel<true, true>, (const void *)mi_intersect_kernel<false, true> };
+    for(unsigned k=0;k<8;k++)
+    {
+      const unsigned which = ((k & 1u) ? MI_WHICH_RECORD | MI_WHICH_COUNT : 0u) | ((k & 2u) ? MI_WHICH_COUNT : 0u) | (s->nodes_lds ? MI_WHICH_NODES_LDS : 0u) |
+                             (h->pointsampler == MI_POINTS_HALTON ? MI_WHICH_HALTON : 0u);
+      if(mi_path_which_valid(which))
+        kernels.push_back(path_kernel(h->sampler == MI_SAMPLER_PTDL, s->media, s->d_prims_t1 != nullptr, (k & 4u) != 0, which, nullptr));
+    }
     for(const void *k : kernels)
       if(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess)
       { mi_scene_destroy(s); return fail(MI_ERR_DEVICE, "cannot raise the dynamic LDS limit"); }
@@ -910,6 +776,14 @@ extern "C" int mi_scene_set_counters(mi_scene *s, int enable)
   return MI_OK;
 }
 
+extern "C" int mi_scene_set_traversal(mi_scene *s, int mode)
+{
+  MI_ENTER(s, "null scene");
+  if(mode != MI_TRAVERSAL_EXACT && mode != MI_TRAVERSAL_FAST) return fail(MI_ERR_ARG, "mi_scene_set_traversal: unknown mode");
+  s->fast = mode == MI_TRAVERSAL_FAST;
+  return MI_OK;
+}
+
 extern "C" int mi_scene_set_stream(mi_scene *s, void *hip_stream)
 {
   MI_ENTER(s, "null scene");
@@ -932,12 +806,14 @@ static int ensure_halton(mi_scene *s, uint64_t end_index)
 }
 
 static void launch_path_kernel(mi_scene *s, bool record, int grid, uint64_t first, uint64_t n, mi_path_record *rec)
-{ /* pick the instantiation: RECORD (test hook) x PTDL (sampler) x NODES_LDS (tree fits LDS) x HALTON (point sampler) x MEDIA
-     ("extended": media, moving camera, emitters without a one-burst record) x MB (moving primitives) x COUNT (debug counters) */
-  const unsigned which = (record ? 1u : 0u) | (s->d.sampler == MI_SAMPLER_PTDL ? 2u : 0u) | (s->nodes_lds ? 4u : 0u) | (s->halton ? 8u : 0u) |
-                         (s->media ? 16u : 0u) | (s->d_prims_t1 ? 48u : 0u) | ((s->counting || record) ? 64u : 0u);
-  PathLaunch L = { s, grid, first, n, rec };
-  (void)path_kernel_dispatch<7>(which, &L);
+{ /* pick the instantiation: the part by PTDL (sampler) x MEDIA ("extended": media, moving camera, emitters without a one-burst
+     record) x MB (moving primitives) x FAST (traversal rounds), inside it RECORD (test hook) x NODES_LDS (tree fits LDS) x HALTON
+     (point sampler) x COUNT (debug counters) */
+  const unsigned which = (record ? MI_WHICH_RECORD : 0u) | (s->nodes_lds ? MI_WHICH_NODES_LDS : 0u) | (s->halton ? MI_WHICH_HALTON : 0u) |
+                         ((s->counting || record) ? MI_WHICH_COUNT : 0u);
+  PathLaunch L = { s->d, grid, s->lds_bytes, s->stream, (unsigned long long)first, (unsigned long long)n, (const uint32_t *)s->d_shape_material,
+                   (const float *)s->d_shape_L, rec, (uint2 *)s->d_overflow };
+  (void)path_kernel(s->d.sampler == MI_SAMPLER_PTDL, s->media, s->d_prims_t1 != nullptr, s->fast != 0, which, &L);
 }
 
 extern "C" int mi_render(mi_scene *s, uint64_t first_index, uint64_t count)
@@ -1005,7 +881,7 @@ extern "C" int mi_counters(mi_scene *s, uint64_t out[8])
   for(int sh=0;sh<MI_COUNTER_SHARDS;sh++)
   {
     for(int k=0;k<7;k++) out[k] += tmp[(size_t)sh*8 + k];
-#ifdef MI_PROFILE_PHASES
+#if defined(MI_PROFILE_PHASES) || defined(MI_PROFILE_TRAV)
     out[7] += tmp[(size_t)sh*8 + 7];
 #else
     if(tmp[(size_t)sh*8 + 7] > out[7]) out[7] = tmp[(size_t)sh*8 + 7];
@@ -1053,10 +929,11 @@ extern "C" int mi_intersect(mi_scene *s, const mi_ray *rays, uint64_t n, mi_hit 
     int grid = s->grid;
     const uint64_t need = (n + MI_BLOCK - 1)/MI_BLOCK;
     if((uint64_t)grid > need) grid = (int)need;
-    if(s->nodes_lds) hipLaunchKernelGGL(mi_intersect_kernel<true>, dim3(grid), dim3(MI_BLOCK), s->lds_bytes, s->stream, s->d, (const mi_ray *)d_rays,
-                                        (unsigned long long)n, (mi_hit *)d_hits, (uint2 *)s->d_overflow);
-    else             hipLaunchKernelGGL(mi_intersect_kernel<false>, dim3(grid), dim3(MI_BLOCK), s->lds_bytes, s->stream, s->d, (const mi_ray *)d_rays,
-                                        (unsigned long long)n, (mi_hit *)d_hits, (uint2 *)s->d_overflow);
+#define MI_ISECT(N, F) hipLaunchKernelGGL((mi_intersect_kernel<N, F>), dim3(grid), dim3(MI_BLOCK), s->lds_bytes, s->stream, s->d, (const mi_ray *)d_rays, \
+                                        (unsigned long long)n, (mi_hit *)d_hits, (uint2 *)s->d_overflow)
+    if(s->nodes_lds) { if(s->fast) MI_ISECT(true, true); else MI_ISECT(true, false); }
+    else             { if(s->fast) MI_ISECT(false, true); else MI_ISECT(false, false); }
+#undef MI_ISECT
     e = hipGetLastError();
   }
   if(e == hipSuccess) e = hipStreamSynchronize(s->stream);

@@ -3,9 +3,10 @@
  *  nodes      SoA of 16-byte lanes, node-major inside each field (stage to LDS; a wave whose lanes sit in
  *             different nodes then spreads over all sixteen 16-B LDS slots instead of two):
  *               field 0..2  min x,y,z of the 4 children       field 3..5  max x,y,z
- *               field 6     4 child links: bit31 leaf | first_prim<<5 | count, else node index
- *             + one dword per node: axis0 | axis00<<2 | axis01<<4
- *             = 116 B per node (reference qbvh_node_t: 256 B, src/accel.d/qbvhmp.c:62-81)
+ *               field 6     4 child links: bit31 leaf | first_prim<<5 | count, else node index | the CHILD's split axes << 25
+ *                           (axis0 | axis00<<2 | axis01<<4, MI_AXES_SHIFT: a visit knows its node's axes from the link it arrived
+ *                           by -- no second LDS read per visit, folded in at upload by mi_fold_axes_kernel)
+ *             = 112 B per node (reference qbvh_node_t: 256 B, src/accel.d/qbvhmp.c:62-81)
  *  prims      one 64-B record per primitive in builder (leaf) order, pre-resolved at upload so an
  *             intersection test is ONE aligned fetch instead of primid -> vtxidx -> vtx
  *             (src/prims.c:638-672, include/geo.h:120-138)
@@ -17,6 +18,8 @@
 #include "corona_mi.h"
 
 #define MI_LEAF32 0x80000000u
+#define MI_AXES_SHIFT 25           /* inner link: node index in bits 0..24, the node's split axes in bits 25..30 */
+#define MI_NODE_MASK 0x01ffffffu
 #define MI_NODE_FIELDS 7
 #define MI_COUNTER_SHARDS 256
 /* light_prim[] bit 31: a shadow ray towards this emitter primitive may stop at the FIRST occluder it finds (any-hit) instead of
@@ -111,7 +114,7 @@ struct DScene
   /* accel */
   uint32_t num_nodes, num_prims;
   const float4  *nodes;            /* [MI_NODE_FIELDS][num_nodes] */
-  const uint32_t *node_axes;       /* [num_nodes] */
+  uint32_t root_link;              /* link of node 0: its split axes << MI_AXES_SHIFT */
   const DPrim  *prims;
   const DPrimGeo *primgeo;
   float aabb[6];

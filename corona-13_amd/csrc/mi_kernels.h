@@ -301,7 +301,7 @@ struct PointSampler
  * 10 % through register pressure, the pt kernel 1 %); mi_scene_set_counters() selects the counting kernels.
  * Development builds append more: -DMI_PROFILE_LOOPS wave-level loop iterations (c[8..10]), -DMI_PROFILE_PHASES lane-0 clock
  * ticks per phase (c[8+k]), their occurrences (c[16+k]), the last marker (c[30]) and time stamp (c[31]). */
-#if defined(MI_PROFILE_PHASES) || defined(MI_PROFILE_LOOPS)
+#if defined(MI_PROFILE_PHASES) || defined(MI_PROFILE_LOOPS) || defined(MI_PROFILE_TRAV)
 #define MI_CNT 32
 #else
 #define MI_CNT 8
@@ -324,6 +324,14 @@ template<bool ON> struct Counters
 #else
 #define MI_PHASE_INIT(cnt)
 #define MI_PHASE(cnt, k)
+#endif
+/* -DMI_PROFILE_TRAV (development build, tools/trav_probe.py): lane 0's clock ticks per part of a wave iteration, summed over the
+ * launch into counters 0..6: 0 node loop, 1 job list set-up, 2 job passes, 3 owners' epilogue (results, sphere / line tests, pop),
+ * 4 rest of the slice loop, 5 refill + ray start + shading, 6 splat. MI_TT adds the time since the previous mark to part k. */
+#ifdef MI_PROFILE_TRAV
+#define MI_TT(cnt, k) { const uint32_t t_ = (uint32_t)clock64(); (cnt).c[8 + (k)] += t_ - (cnt).c[31]; (cnt).c[31] = t_; }
+#else
+#define MI_TT(cnt, k)
 #endif
 
 /* ------------------------------------------------------------------------------------------ hit */
@@ -636,7 +644,7 @@ __device__ __forceinline__ void analytic_intersect(const DPrim *prims, uint32_t 
 struct Lds
 {
   const float4 *nodes;      /* [MI_NODE_FIELDS][num_nodes] in LDS (or in HBM when the tree does not fit, see lds_setup) */
-  const uint32_t *axes;     /* [num_nodes], same place */
+  uint32_t root;            /* link of node 0 (its split axes << MI_AXES_SHIFT) */
   uint2 *stack;             /* [STACK][BLOCK] in LDS, this thread's column */
   uint2 *overflow;          /* [extra][total threads] in HBM: entries beyond STACK (rare). The workgroup's row; the thread's column is
                                added where it is used, so that no per-thread 64-bit pointer lives in registers through the kernel */
@@ -645,6 +653,7 @@ struct Lds
   unsigned char *jobs;      /* leaf_jobs: this wave's list of MI_JOBS_MAX source lanes, in LDS behind the stacks */
 };
 #define MI_JOBS_MAX 256     /* primitive tests one wave deals out per round at most (64 lanes x 4); more: sequential leaf loop */
+#define MI_JOBS_LDS 512     /* bytes of a wave's job list in LDS (the FAST rounds deal out up to MI_SPEC_JOBS_MAX = 512 tests) */
 #define MI_JOB_SLOTS 3      /* stack entries of a lane's LDS column that leaf_jobs uses for results: best (8 B), uv (8 B), analytic mask */
 
 template<int BLOCK, int STACK>
@@ -700,21 +709,19 @@ __device__ __forceinline__ Lds lds_setup(const DScene &sc, unsigned char *smem, 
   if(NODES_LDS)
   {
     float4 *lds_nodes = (float4 *)smem;
-    uint32_t *lds_axes = (uint32_t *)(smem + (size_t)MI_NODE_FIELDS*N*16);
-    const size_t stack_off = (((size_t)MI_NODE_FIELDS*N*16 + (size_t)N*4) + 15) & ~(size_t)15;
+    const size_t stack_off = (size_t)MI_NODE_FIELDS*N*16;
     lds_stack = (uint2 *)(smem + stack_off);
     for(uint32_t i=threadIdx.x;i<MI_NODE_FIELDS*N;i+=BLOCK) lds_nodes[i] = sc.nodes[i];
-    for(uint32_t i=threadIdx.x;i<N;i+=BLOCK) lds_axes[i] = sc.node_axes[i];
     __syncthreads();
-    lds.nodes = lds_nodes; lds.axes = lds_axes;
+    lds.nodes = lds_nodes;
   }
   else
   {
     lds_stack = (uint2 *)smem;
-    lds.nodes = sc.nodes; lds.axes = sc.node_axes;
+    lds.nodes = sc.nodes;
   }
-  lds.stack = lds_stack + threadIdx.x; lds.num_nodes = N;
-  lds.jobs = (unsigned char *)(lds_stack + (size_t)MI_STACK_LDS*BLOCK) + (threadIdx.x >> 6)*MI_JOBS_MAX;
+  lds.stack = lds_stack + threadIdx.x; lds.num_nodes = N; lds.root = sc.root_link;
+  lds.jobs = (unsigned char *)(lds_stack + (size_t)MI_STACK_LDS*BLOCK) + (threadIdx.x >> 6)*MI_JOBS_LDS;
   lds.overflow_stride = gridDim.x*BLOCK;
   lds.overflow = stack_overflow + (size_t)blockIdx.x*BLOCK;
   return lds;
@@ -744,12 +751,12 @@ struct TraceState
 };
 
 template<class CNT>
-__device__ __forceinline__ void trace_begin(TraceState &ts, const V3 d, CNT &cnt)
+__device__ __forceinline__ void trace_begin(const Lds &lds, TraceState &ts, const V3 d, CNT &cnt)
 {
   MI_COUNT(cnt, 0, 1);
   ts.idx = mi_rcp(d.x); ts.idy = mi_rcp(d.y); ts.idz = mi_rcp(d.z);
   ts.sp = 0;
-  ts.current = 0;      /* node 0 = root */
+  ts.current = lds.root;      /* node 0 = root, with its split axes */
   ts.done = false;
   ts.anyhit = false;
 }
@@ -772,12 +779,11 @@ __device__ __forceinline__ void leaf_finish(const Lds &lds, const Hit &hit, Trac
   ts.sp = sp; ts.current = current; ts.done = done;
 }
 
-/* the leaf a lane holds (ts.current), primitive by primitive on that lane (qbvhmp.c:1366-1379), then the pop */
-template<int BLOCK, int STACK, bool MB, bool ANYHIT, class CNT>
-__device__ __forceinline__ void leaf_sequential(const Lds &lds, const DPrim *prims, const V3 o, const V3 d, uint32_t ignore,
-                                                Hit &hit, TraceState &ts, CNT &cnt)
+/* the leaf `current`, primitive by primitive on this lane (qbvhmp.c:1366-1379) */
+template<bool MB, class CNT>
+__device__ __forceinline__ void leaf_tests(const DPrim *prims, uint32_t current, const V3 o, const V3 d, uint32_t ignore,
+                                           Hit &hit, const TraceState &ts, CNT &cnt)
 {
-  const uint32_t current = ts.current;
   const uint32_t idxp = (current ^ MI_LEAF32) >> 5;
   const uint32_t num = current & 31u;
   /* triangles and quads first (software pipelined: the next primitive's 64 B are in flight while this one is
@@ -820,43 +826,15 @@ __device__ __forceinline__ void leaf_sequential(const Lds &lds, const DPrim *pri
     analytic &= analytic - 1;
     analytic_intersect<MB>(prims, idxp + i, o, d, ignore, hit, MB ? ts.time : 0.0f, MB ? ts.prims_t1 : nullptr);
   }
-  leaf_finish<BLOCK, STACK, ANYHIT>(lds, hit, ts);
 }
 
-/* Upload-time pass over the leaves (one thread per child link of the tree, after the primitive records are in place -- for a
- * device-built tree after the build): the leaf loops test a leaf's triangles and quads first and put off its spheres, lines and
- * moving primitives. That changes nothing (see leaf_sequential) unless a quad can be crossed in both halves, which takes a folded
- * quad: a static quad whose fourth vertex leaves the plane of the first three by more than 1e-5 of its size and which follows a
- * primitive that is put off, or anything that follows a moving quad. From there to the end of its leaf every triangle / quad
- * is put off too (type 0, pad[0] = vertex count, pad[1] = MI_PRIM_ORDERED): the put-off tests run in the leaf's order. */
-__global__ void mi_mark_ordered_kernel(const float4 *nodes, uint32_t N, DPrim *prims)
+/* the leaf a lane holds (ts.current) on that lane, then the pop */
+template<int BLOCK, int STACK, bool MB, bool ANYHIT, class CNT>
+__device__ __forceinline__ void leaf_sequential(const Lds &lds, const DPrim *prims, const V3 o, const V3 d, uint32_t ignore,
+                                                Hit &hit, TraceState &ts, CNT &cnt)
 {
-  const uint32_t i = blockIdx.x*blockDim.x + threadIdx.x;
-  if(i >= 4u*N) return;
-  const uint32_t link = ((const uint32_t *)(nodes + (size_t)6*N))[i];
-  if(!(link & MI_LEAF32)) return;
-  const uint32_t first = (link ^ MI_LEAF32) >> 5, num = link & 31u;
-  bool deferred = false, ordered = false;
-  for(uint32_t k=0;k<num;k++)
-  {
-    DPrim &p = prims[first + k];
-    if(p.type >= MI_PRIM_TRI)
-    {
-      if(!ordered && deferred && p.type == MI_PRIM_QUAD)
-      {
-        const V3 e1 = ld3(p.v[1]), e2 = ld3(p.v[2]), e3 = ld3(p.v[3]);
-        const V3 n = cross3(e1, e2);
-        const float vol = fabsf(dot3(n, e3)), ref = sqrtf(dot3(n, n))*sqrtf(dot3(e3, e3));
-        if(!(vol <= 1e-5f*ref)) ordered = true;
-      }
-      if(ordered) { p.pad[0] = p.type; p.pad[1] = MI_PRIM_ORDERED; p.type = 0; }
-    }
-    else
-    {
-      deferred = true;
-      if(p.type == 0 && p.pad[0] == MI_PRIM_QUAD) ordered = true;       /* a moving quad: its shape changes with time */
-    }
-  }
+  leaf_tests<MB>(prims, ts.current, o, d, ignore, hit, ts, cnt);
+  leaf_finish<BLOCK, STACK, ANYHIT>(lds, hit, ts);
 }
 
 /* Distributed leaf phase (MI_LEAF_JOBS). In the sequential leaf loop a round costs the wave as many test slots as its LONGEST leaf
@@ -909,6 +887,7 @@ __device__ __forceinline__ void leaf_jobs(const Lds &lds, const DPrim *prims, co
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
+  MI_TT(cnt, 1)
   for(uint32_t base=0;fits && base<J;base+=64u)
   {
 #ifdef MI_PROFILE_LOOPS
@@ -944,6 +923,7 @@ __device__ __forceinline__ void leaf_jobs(const Lds &lds, const DPrim *prims, co
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
+  MI_TT(cnt, 2)
   if(own)
   {
     const mi_u64 res = fits ? *best : 0;
@@ -974,6 +954,129 @@ __device__ __forceinline__ void leaf_jobs(const Lds &lds, const DPrim *prims, co
       leaf_finish<BLOCK, STACK, ANYHIT>(lds, hit, ts);
     }
   }
+  MI_TT(cnt, 3)
+}
+
+/* the ray geometry a node visit needs, fixed for the length of a round */
+struct RayBox
+{
+  uint32_t nearbits, offx, offy, offz;   /* sign bits of the direction; near-plane field of each axis: max planes (fields 3..5) for negative directions */
+  float idx, idy, idz;
+  bool slow;                             /* a lane of the wave has an infinite 1/dir: literal SSE-semantics slab test for the whole wave */
+};
+__device__ __forceinline__ RayBox raybox_setup(const V3 d, const TraceState &ts, uint32_t N)
+{
+  RayBox rb;
+  const uint32_t near_x = __float_as_uint(d.x) >> 31, near_y = __float_as_uint(d.y) >> 31, near_z = __float_as_uint(d.z) >> 31;
+  rb.nearbits = near_x | (near_y << 1) | (near_z << 2);
+  rb.idx = ts.idx; rb.idy = ts.idy; rb.idz = ts.idz;
+  rb.offx = near_x ? 3u*N : 0u; rb.offy = near_y ? 3u*N : 0u; rb.offz = near_z ? 3u*N : 0u;
+  rb.slow = __any(isinf(rb.idx) || isinf(rb.idy) || isinf(rb.idz));
+  return rb;
+}
+
+/* one inner node of accel_intersect (src/accel.d/qbvhmp.c:1188-1246,1313-1354): the four child boxes against the ray clipped to
+ * `dist`, front-to-back order from split axes and ray signs; the nearest hit child becomes `current`, the others are pushed
+ * far-first. Returns false if no child is hit (the caller pops). */
+template<int BLOCK, int STACK, class CNT>
+__device__ __forceinline__ bool node_visit(const Lds &lds, lds_uint2 *lstack, const RayBox &rb, const V3 o, float dist, uint32_t &current, int &sp, CNT &cnt)
+{
+  const uint32_t N = lds.num_nodes;
+  const uint32_t nearbits = rb.nearbits, offx = rb.offx, offy = rb.offy, offz = rb.offz;
+  const float idx = rb.idx, idy = rb.idy, idz = rb.idz;
+  const bool slow = rb.slow;
+  const uint32_t node = current & MI_NODE_MASK;
+  const uint32_t ax = current >> MI_AXES_SHIFT;        /* the node's split axes travel in the link (mi_fold_axes_kernel) */
+  const uint4 child = *(const uint4 *)&lds.nodes[6*N + node];
+  float tm0, tm1, tm2, tm3;
+  mi_u64 M0, M1, M2, M3;    /* child c is hit: lane masks (the compares' own results) in scalar registers, combined by scalar instructions below */
+  if(!slow)
+  { /* 4 child slabs, qbvhmp.c:1188-1246. The ray's sign bits pick the entry / exit plane of every slab, which is what
+       the reference's min(t0,t1) / max(t0,t1) evaluate to for finite 1/dir and b_min <= b_max (rounding is monotonic;
+       empty children are uploaded as [-FLT_MAX, FLT_MAX], see upload_nodes). That leaves v_max3/v_min3 chains
+       instead of 48 compare+select pairs (each pair costs a VCC hazard nop on gfx950). */
+    const float4 nx = lds.nodes[offx + node],       fx = lds.nodes[3*N - offx + node];
+    const float4 ny = lds.nodes[N + offy + node],   fy = lds.nodes[4*N - offy + node];
+    const float4 nz = lds.nodes[2*N + offz + node], fz = lds.nodes[5*N - offz + node];
+#define SLAB(J, C, TM) { \
+    const float lo = fmaxf(fmaxf(fmaxf((nx.C - o.x)*idx, (ny.C - o.y)*idy), (nz.C - o.z)*idz), 0.0f); \
+    const float hi = fminf(fminf(fminf((fx.C - o.x)*idx, (fy.C - o.y)*idy), (fz.C - o.z)*idz), dist); \
+    TM = lo; J = __ballot(lo <= hi); }
+    SLAB(M0, x, tm0) SLAB(M1, y, tm1) SLAB(M2, z, tm2) SLAB(M3, w, tm3)
+#undef SLAB
+  }
+  else
+  { /* a lane of this wave has a zero direction component (1/dir infinite): 0*inf NaNs are possible and the reference's
+       SSE min/max semantics (second operand on NaN) decide; evaluate them literally with ordered compares */
+    const float4 mnx = lds.nodes[0*N + node], mny = lds.nodes[1*N + node], mnz = lds.nodes[2*N + node];
+    const float4 mxx = lds.nodes[3*N + node], mxy = lds.nodes[4*N + node], mxz = lds.nodes[5*N + node];
+#define SLAB(J, X0, X1, Y0, Y1, Z0, Z1, TM) { \
+    float lo = 0.0f, hi = dist; \
+    float t0 = ((X0) - o.x)*idx, t1 = ((X1) - o.x)*idx; \
+    float mn = t0 < t1 ? t0 : t1, mx = t0 > t1 ? t0 : t1; \
+    lo = lo > mn ? lo : mn; hi = hi < mx ? hi : mx; \
+    t0 = ((Y0) - o.y)*idy; t1 = ((Y1) - o.y)*idy; \
+    mn = t0 < t1 ? t0 : t1; mx = t0 > t1 ? t0 : t1; \
+    lo = lo > mn ? lo : mn; hi = hi < mx ? hi : mx; \
+    t0 = ((Z0) - o.z)*idz; t1 = ((Z1) - o.z)*idz; \
+    mn = t0 < t1 ? t0 : t1; mx = t0 > t1 ? t0 : t1; \
+    lo = lo > mn ? lo : mn; hi = hi < mx ? hi : mx; \
+    TM = lo; J = __ballot(lo <= hi); }
+    SLAB(M0, mnx.x, mxx.x, mny.x, mxy.x, mnz.x, mxz.x, tm0)
+    SLAB(M1, mnx.y, mxx.y, mny.y, mxy.y, mnz.y, mxz.y, tm1)
+    SLAB(M2, mnx.z, mxx.z, mny.z, mxy.z, mnz.z, mxz.z, tm2)
+    SLAB(M3, mnx.w, mxx.w, mny.w, mxy.w, mnz.w, mxz.w, tm3)
+#undef SLAB
+  }
+  if(!__builtin_amdgcn_inverse_ballot_w64(M0 | M1 | M2 | M3)) return false;
+  {
+    MI_COUNT(cnt, 1, 1);
+    MI_COUNT(cnt, 2, (uint32_t)__builtin_amdgcn_inverse_ballot_w64(M0) + (uint32_t)__builtin_amdgcn_inverse_ballot_w64(M1) + (uint32_t)__builtin_amdgcn_inverse_ballot_w64(M2) + (uint32_t)__builtin_amdgcn_inverse_ballot_w64(M3));
+    /* front-to-back order from split axes and ray signs, qbvhmp.c:1313-1320: the near half is children
+       {2*near0, 2*near0+1}, ordered by the sign along its own split axis; likewise the far half */
+    const uint32_t axis0 = ax & 3u;
+    const mi_u64 N0 = __ballot((nearbits >> axis0) & 1u);
+    const bool near0 = __builtin_amdgcn_inverse_ballot_w64(N0);
+    const uint32_t axis1n = near0 ? ((ax >> 4) & 3u) : ((ax >> 2) & 3u);
+    const uint32_t axis1f = near0 ? ((ax >> 2) & 3u) : ((ax >> 4) & 3u);
+    const mi_u64 N1N = __ballot((nearbits >> axis1n) & 1u), N1F = __ballot((nearbits >> axis1f) & 1u);
+    const bool near1n = __builtin_amdgcn_inverse_ballot_w64(N1N), near1f = __builtin_amdgcn_inverse_ballot_w64(N1F);
+    const uint32_t ca0 = near0 ? child.z : child.x, ca1 = near0 ? child.w : child.y;
+    const uint32_t cb0 = near0 ? child.x : child.z, cb1 = near0 ? child.y : child.w;
+    const float ta0 = near0 ? tm2 : tm0, ta1 = near0 ? tm3 : tm1;
+    const float tb0 = near0 ? tm0 : tm2, tb1 = near0 ? tm1 : tm3;
+    const uint32_t c00 = near1n ? ca1 : ca0, c01 = near1n ? ca0 : ca1;
+    const uint32_t c10 = near1f ? cb1 : cb0, c11 = near1f ? cb0 : cb1;
+    const float t01 = near1n ? ta0 : ta1;
+    const float t10 = near1f ? tb1 : tb0, t11 = near1f ? tb0 : tb1;
+    /* the hit flags go through the same two selections as lane masks in scalar registers (s_and / s_andn2 / s_or on the
+       ballots: the scalar unit, not the vector pipes this kernel is bound by) and come back as predicates */
+    /* conditional swaps: (X, Y) = N ? (B, A) : (A, B), lane by lane, four scalar instructions each */
+    const mi_u64 D0 = (M0 ^ M2) & N0, D1 = (M1 ^ M3) & N0;
+    const mi_u64 HA0 = M0 ^ D0, HB0 = M2 ^ D0, HA1 = M1 ^ D1, HB1 = M3 ^ D1;          /* hit flags of the near half (A), of the far half (B) */
+    const mi_u64 DN = (HA0 ^ HA1) & N1N, DF = (HB0 ^ HB1) & N1F;
+    const mi_u64 H00 = HA0 ^ DN, H01 = HA1 ^ DN, H10 = HB0 ^ DF, H11 = HB1 ^ DF;
+    /* the first hit child in order n00,n01,n10,n11 becomes current; later ones are pushed far-first (qbvhmp.c:1336-1354) */
+    const bool h00 = __builtin_amdgcn_inverse_ballot_w64(H00), h01 = __builtin_amdgcn_inverse_ballot_w64(H01), h10 = __builtin_amdgcn_inverse_ballot_w64(H10);
+    const bool p11 = __builtin_amdgcn_inverse_ballot_w64(H11 & (H00 | H01 | H10));
+    const bool p10 = __builtin_amdgcn_inverse_ballot_w64(H10 & (H00 | H01));
+    const bool p01 = __builtin_amdgcn_inverse_ballot_w64(H01 & H00);
+    if(sp + 3 <= STACK)
+    { /* all three slots are in LDS */
+      if(p11) { lstack[sp*BLOCK] = mi_u32x2{c11, __float_as_uint(t11)}; sp++; }
+      if(p10) { lstack[sp*BLOCK] = mi_u32x2{c10, __float_as_uint(t10)}; sp++; }
+      if(p01) { lstack[sp*BLOCK] = mi_u32x2{c01, __float_as_uint(t01)}; sp++; }
+    }
+    else
+    {
+      if(p11) { stack_push<BLOCK, STACK>(lds, sp, make_uint2(c11, __float_as_uint(t11))); sp++; }
+      if(p10) { stack_push<BLOCK, STACK>(lds, sp, make_uint2(c10, __float_as_uint(t10))); sp++; }
+      if(p01) { stack_push<BLOCK, STACK>(lds, sp, make_uint2(c01, __float_as_uint(t01))); sp++; }
+    }
+    current = h00 ? c00 : h01 ? c01 : h10 ? c10 : c11;
+    MI_COUNT_MAX(cnt, 7, (uint32_t)sp);
+  }
+  return true;
 }
 
 /* one "while-while" round of accel_intersect (src/accel.d/qbvhmp.c:1262-1390, static boxes): descend inner nodes until this
@@ -982,17 +1085,11 @@ template<int BLOCK, int STACK, bool MB = false, bool ANYHIT = false, bool JOBS =
 __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, const V3 o, const V3 d, uint32_t ignore,
                                             Hit &hit, TraceState &ts, CNT &cnt)
 {
-  const uint32_t near_x = __float_as_uint(d.x) >> 31, near_y = __float_as_uint(d.y) >> 31, near_z = __float_as_uint(d.z) >> 31;
-  const uint32_t nearbits = near_x | (near_y << 1) | (near_z << 2);
-  const float idx = ts.idx, idy = ts.idy, idz = ts.idz;
-  const uint32_t N = lds.num_nodes;
+  const RayBox rb = raybox_setup(d, ts, lds.num_nodes);
   int sp = ts.sp;
   uint32_t current = ts.done ? MI_LEAF32 : ts.current;
   bool done = ts.done;
   lds_uint2 *lstack = (lds_uint2 *)lds.stack;
-  /* near-plane field of each axis: max planes (fields 3..5) for negative directions */
-  const uint32_t offx = near_x ? 3u*N : 0u, offy = near_y ? 3u*N : 0u, offz = near_z ? 3u*N : 0u;
-  const bool slow = __any(isinf(idx) || isinf(idy) || isinf(idz));
   {
     while(true)
     { /* descend until every lane holds a leaf -- or only a tail of MI_TAIL_INNER lanes is still descending while others
@@ -1009,97 +1106,7 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
 #ifdef MI_PROFILE_LOOPS
       if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) cnt.c[8] += MI_PROFILE_LOOPS == 2 ? nround : 1;   /* wave-level inner iterations (2: lanes still under way) */
 #endif
-      const uint32_t node = current;
-      const uint4 child = *(const uint4 *)&lds.nodes[6*N + node];
-      const uint32_t ax = lds.axes[node];       /* with the other loads of this node, not after the slab test */
-      float tm0, tm1, tm2, tm3;
-      mi_u64 M0, M1, M2, M3;    /* child c is hit: lane masks (the compares' own results) in scalar registers, combined by scalar instructions below */
-      if(!slow)
-      { /* 4 child slabs, qbvhmp.c:1188-1246. The ray's sign bits pick the entry / exit plane of every slab, which is what
-           the reference's min(t0,t1) / max(t0,t1) evaluate to for finite 1/dir and b_min <= b_max (rounding is monotonic;
-           empty children are uploaded as [-FLT_MAX, FLT_MAX], see upload_nodes). That leaves v_max3/v_min3 chains
-           instead of 48 compare+select pairs (each pair costs a VCC hazard nop on gfx950). */
-        const float4 nx = lds.nodes[offx + node],       fx = lds.nodes[3*N - offx + node];
-        const float4 ny = lds.nodes[N + offy + node],   fy = lds.nodes[4*N - offy + node];
-        const float4 nz = lds.nodes[2*N + offz + node], fz = lds.nodes[5*N - offz + node];
-#define SLAB(J, C, TM) { \
-        const float lo = fmaxf(fmaxf(fmaxf((nx.C - o.x)*idx, (ny.C - o.y)*idy), (nz.C - o.z)*idz), 0.0f); \
-        const float hi = fminf(fminf(fminf((fx.C - o.x)*idx, (fy.C - o.y)*idy), (fz.C - o.z)*idz), hit.dist); \
-        TM = lo; J = __ballot(lo <= hi); }
-        SLAB(M0, x, tm0) SLAB(M1, y, tm1) SLAB(M2, z, tm2) SLAB(M3, w, tm3)
-#undef SLAB
-      }
-      else
-      { /* a lane of this wave has a zero direction component (1/dir infinite): 0*inf NaNs are possible and the reference's
-           SSE min/max semantics (second operand on NaN) decide; evaluate them literally with ordered compares */
-        const float4 mnx = lds.nodes[0*N + node], mny = lds.nodes[1*N + node], mnz = lds.nodes[2*N + node];
-        const float4 mxx = lds.nodes[3*N + node], mxy = lds.nodes[4*N + node], mxz = lds.nodes[5*N + node];
-#define SLAB(J, X0, X1, Y0, Y1, Z0, Z1, TM) { \
-        float lo = 0.0f, hi = hit.dist; \
-        float t0 = ((X0) - o.x)*idx, t1 = ((X1) - o.x)*idx; \
-        float mn = t0 < t1 ? t0 : t1, mx = t0 > t1 ? t0 : t1; \
-        lo = lo > mn ? lo : mn; hi = hi < mx ? hi : mx; \
-        t0 = ((Y0) - o.y)*idy; t1 = ((Y1) - o.y)*idy; \
-        mn = t0 < t1 ? t0 : t1; mx = t0 > t1 ? t0 : t1; \
-        lo = lo > mn ? lo : mn; hi = hi < mx ? hi : mx; \
-        t0 = ((Z0) - o.z)*idz; t1 = ((Z1) - o.z)*idz; \
-        mn = t0 < t1 ? t0 : t1; mx = t0 > t1 ? t0 : t1; \
-        lo = lo > mn ? lo : mn; hi = hi < mx ? hi : mx; \
-        TM = lo; J = __ballot(lo <= hi); }
-        SLAB(M0, mnx.x, mxx.x, mny.x, mxy.x, mnz.x, mxz.x, tm0)
-        SLAB(M1, mnx.y, mxx.y, mny.y, mxy.y, mnz.y, mxz.y, tm1)
-        SLAB(M2, mnx.z, mxx.z, mny.z, mxy.z, mnz.z, mxz.z, tm2)
-        SLAB(M3, mnx.w, mxx.w, mny.w, mxy.w, mnz.w, mxz.w, tm3)
-#undef SLAB
-      }
-      if(__builtin_amdgcn_inverse_ballot_w64(M0 | M1 | M2 | M3))
-      {
-        MI_COUNT(cnt, 1, 1);
-        MI_COUNT(cnt, 2, (uint32_t)__builtin_amdgcn_inverse_ballot_w64(M0) + (uint32_t)__builtin_amdgcn_inverse_ballot_w64(M1) + (uint32_t)__builtin_amdgcn_inverse_ballot_w64(M2) + (uint32_t)__builtin_amdgcn_inverse_ballot_w64(M3));
-        /* front-to-back order from split axes and ray signs, qbvhmp.c:1313-1320: the near half is children
-           {2*near0, 2*near0+1}, ordered by the sign along its own split axis; likewise the far half */
-        const uint32_t axis0 = ax & 3u;
-        const mi_u64 N0 = __ballot((nearbits >> axis0) & 1u);
-        const bool near0 = __builtin_amdgcn_inverse_ballot_w64(N0);
-        const uint32_t axis1n = near0 ? ((ax >> 4) & 3u) : ((ax >> 2) & 3u);
-        const uint32_t axis1f = near0 ? ((ax >> 2) & 3u) : ((ax >> 4) & 3u);
-        const mi_u64 N1N = __ballot((nearbits >> axis1n) & 1u), N1F = __ballot((nearbits >> axis1f) & 1u);
-        const bool near1n = __builtin_amdgcn_inverse_ballot_w64(N1N), near1f = __builtin_amdgcn_inverse_ballot_w64(N1F);
-        const uint32_t ca0 = near0 ? child.z : child.x, ca1 = near0 ? child.w : child.y;
-        const uint32_t cb0 = near0 ? child.x : child.z, cb1 = near0 ? child.y : child.w;
-        const float ta0 = near0 ? tm2 : tm0, ta1 = near0 ? tm3 : tm1;
-        const float tb0 = near0 ? tm0 : tm2, tb1 = near0 ? tm1 : tm3;
-        const uint32_t c00 = near1n ? ca1 : ca0, c01 = near1n ? ca0 : ca1;
-        const uint32_t c10 = near1f ? cb1 : cb0, c11 = near1f ? cb0 : cb1;
-        const float t01 = near1n ? ta0 : ta1;
-        const float t10 = near1f ? tb1 : tb0, t11 = near1f ? tb0 : tb1;
-        /* the hit flags go through the same two selections as lane masks in scalar registers (s_and / s_andn2 / s_or on the
-           ballots: the scalar unit, not the vector pipes this kernel is bound by) and come back as predicates */
-        /* conditional swaps: (X, Y) = N ? (B, A) : (A, B), lane by lane, four scalar instructions each */
-        const mi_u64 D0 = (M0 ^ M2) & N0, D1 = (M1 ^ M3) & N0;
-        const mi_u64 HA0 = M0 ^ D0, HB0 = M2 ^ D0, HA1 = M1 ^ D1, HB1 = M3 ^ D1;          /* hit flags of the near half (A), of the far half (B) */
-        const mi_u64 DN = (HA0 ^ HA1) & N1N, DF = (HB0 ^ HB1) & N1F;
-        const mi_u64 H00 = HA0 ^ DN, H01 = HA1 ^ DN, H10 = HB0 ^ DF, H11 = HB1 ^ DF;
-        /* the first hit child in order n00,n01,n10,n11 becomes current; later ones are pushed far-first (qbvhmp.c:1336-1354) */
-        const bool h00 = __builtin_amdgcn_inverse_ballot_w64(H00), h01 = __builtin_amdgcn_inverse_ballot_w64(H01), h10 = __builtin_amdgcn_inverse_ballot_w64(H10);
-        const bool p11 = __builtin_amdgcn_inverse_ballot_w64(H11 & (H00 | H01 | H10));
-        const bool p10 = __builtin_amdgcn_inverse_ballot_w64(H10 & (H00 | H01));
-        const bool p01 = __builtin_amdgcn_inverse_ballot_w64(H01 & H00);
-        if(sp + 3 <= STACK)
-        { /* all three slots are in LDS */
-          if(p11) { lstack[sp*BLOCK] = mi_u32x2{c11, __float_as_uint(t11)}; sp++; }
-          if(p10) { lstack[sp*BLOCK] = mi_u32x2{c10, __float_as_uint(t10)}; sp++; }
-          if(p01) { lstack[sp*BLOCK] = mi_u32x2{c01, __float_as_uint(t01)}; sp++; }
-        }
-        else
-        {
-          if(p11) { stack_push<BLOCK, STACK>(lds, sp, make_uint2(c11, __float_as_uint(t11))); sp++; }
-          if(p10) { stack_push<BLOCK, STACK>(lds, sp, make_uint2(c10, __float_as_uint(t10))); sp++; }
-          if(p01) { stack_push<BLOCK, STACK>(lds, sp, make_uint2(c01, __float_as_uint(t01))); sp++; }
-        }
-        current = h00 ? c00 : h01 ? c01 : h10 ? c10 : c11;
-        MI_COUNT_MAX(cnt, 7, (uint32_t)sp);
-      }
+      if(node_visit<BLOCK, STACK>(lds, lstack, rb, o, hit.dist, current, sp, cnt)) {}
       else
       { /* pop, skipping entries that start behind the current hit (qbvhmp.c:1357-1364) */
         current = MI_LEAF32;          /* empty leaf: falls out of this loop; `done` if the stack runs dry */
@@ -1114,17 +1121,227 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
     }
   }
   ts.sp = sp; ts.current = current; ts.done = done;
+  MI_TT(cnt, 0)
   if(!JOBS && !done && (current & MI_LEAF32)) leaf_sequential<BLOCK, STACK, MB, ANYHIT>(lds, prims, o, d, ignore, hit, ts, cnt);   /* JOBS: the caller runs leaf_jobs with all lanes */
 }
 
-template<int BLOCK, int STACK, class CNT>
+/* ------------------------------------------------------------------------------------------ FAST traversal rounds
+ * The rounds above keep the reference's order of operations ray by ray (that is what makes the node / box / primitive counters
+ * equal its -DACCEL_DEBUG totals): a lane that reaches a leaf waits until the wave's leaf phase has tested it, because the next
+ * node it may enter depends on the distance that leaf leaves. 53 % of the node loop's lane-slots were such waits.
+ * trace_round_spec lets the lane go on instead: the leaf is PUT ASIDE (up to MI_SPEC_K of them per round, plus the one it holds
+ * when the node loop ends), the next subtree is popped against the unchanged distance, and the leaf phase tests the put-aside
+ * leaves of all lanes together -- more jobs per pass, fewer rounds, fewer idle slots. What it yields:
+ *   - the same closest hit, bit for bit: the nodes visited are a SUPERSET of the reference's (a subtree is entered iff its box
+ *     is hit in front of the distance known at that time, which is never shorter than the reference's at the same point of
+ *     its traversal), the order in which a ray reaches its leaves is the reference's (same stack discipline), every primitive
+ *     is tested against the distance the round started with and the results are merged by (distance, position in that order):
+ *     closest wins, later wins a tie -- what the running `t <= dist` of the sequential loop does. A subtree pushed during the
+ *     round that the shorter distance would have culled at its box test is culled when it is popped (same comparison).
+ *   - different work counters: speculative node visits and primitive tests are real work and are counted as such.
+ * Leaves in which the order of the tests matters (a folded quad crossed in both halves) poison the lane's result slot as in
+ * leaf_jobs and the lane works through its leaves sequentially, in order. */
+#ifndef MI_SPEC_K
+#define MI_SPEC_K 1           /* leaves a lane may put aside per round; one more can wait in `current`. A/B on cfg 2, 1 / 2 / 3: 18.68 / 18.92 / 20.25 ms */
+#endif
+#ifndef MI_SPEC_BLOCKED
+#define MI_SPEC_BLOCKED 16    /* the node loop of a round ends once this many lanes hold a leaf they can no longer put aside */
+#endif
+#define MI_SPEC_JOBS_MAX 512  /* job list entries per wave (one byte each: owner lane | slot << 6) */
+
+template<int BLOCK, int STACK>
+__device__ __forceinline__ void stack_pop(const Lds &lds, lds_uint2 *lstack, float dist, int &sp, uint32_t &current, bool &done)
+{ /* pop, skipping entries that start behind the current hit (qbvhmp.c:1357-1364) */
+  current = MI_LEAF32;
+  done = true;
+  while(sp > 0)
+  {
+    sp--;
+    const uint2 e = stack_top<BLOCK, STACK>(lds, lstack, sp);
+    if(!(__uint_as_float(e.y) > dist)) { current = e.x; done = false; break; }
+  }
+}
+
+template<int BLOCK, int STACK, bool MB, bool ANYHIT, class CNT>
+__device__ __forceinline__ void trace_round_spec(const Lds &lds, const DPrim *prims, const V3 o, const V3 d, uint32_t ignore,
+                                                 Hit &hit, TraceState &ts, bool busy, CNT &cnt)
+{ /* call from ALL lanes of the wave; busy = this lane has a ray under way */
+  constexpr int K = MI_SPEC_K;
+  static_assert(K >= 1 && K <= 3, "slots are two bits of a job byte");
+  const unsigned lane = __lane_id();
+  const RayBox rb = raybox_setup(d, ts, lds.num_nodes);
+  lds_uint2 *lstack = (lds_uint2 *)lds.stack;
+  int sp = ts.sp;
+  bool done = ts.done || !busy;
+  uint32_t current = done ? MI_LEAF32 : ts.current;
+  uint32_t lf[K + 1];                                   /* the leaves of this round in the order the ray reached them; 0 = none */
+#pragma unroll
+  for(int k=0;k<=K;k++) lf[k] = 0u;
+  /* -------- node loop */
+  while(true)
+  {
+    const bool inner = !(current & MI_LEAF32);          /* finished lanes carry MI_LEAF32 */
+    const bool leaf = (current & MI_LEAF32) && !done;
+    /* room to put it aside (an empty leaf needs none). Not in a wave with a degenerate ray (1/dir infinite): there the box tests
+       can yield NaN, the reference's verdict then depends on the distance it happened to know (SSE operand order), and "tested
+       against a longer distance = superset" no longer holds -- such waves wait with their leaves like the exact rounds do */
+    const bool advance = leaf && (!(current & 31u) || (!rb.slow && lf[K-1] == 0u));
+    const mi_u64 mmove = __ballot(inner || advance);
+    if(!mmove) break;
+    const mi_u64 mwait = __ballot(leaf && !advance);
+    if(__popcll(mmove) < MI_TAIL_INNER && (mwait || __any(lf[0] != 0u))) break;
+    if(__popcll(mwait) >= MI_SPEC_BLOCKED) break;
+#ifdef MI_PROFILE_LOOPS
+    { const unsigned nround = __popcll(__ballot(!done)); if(lane == 0) cnt.c[8] += MI_PROFILE_LOOPS == 2 ? nround : 1; }
+#endif
+    bool pop = false;
+    if(inner) pop = !node_visit<BLOCK, STACK>(lds, lstack, rb, o, hit.dist, current, sp, cnt);
+    else if(advance)
+    {
+      if(current & 31u)
+      {
+#pragma unroll
+        for(int k=0;k<K;k++) if(lf[k] == 0u) { lf[k] = current; break; }
+      }
+      pop = true;
+    }
+    if(pop) stack_pop<BLOCK, STACK>(lds, lstack, hit.dist, sp, current, done);
+  }
+  MI_TT(cnt, 0)
+  /* -------- leaf phase: the (lane, slot, primitive) tests of all put-aside leaves dealt out over the 64 lanes */
+  const bool holds = (current & MI_LEAF32) && !done;    /* the leaf the lane still holds is tested too, then popped */
+  if(holds) lf[K] = current;
+  uint32_t n[K + 1], num = 0;
+#pragma unroll
+  for(int k=0;k<=K;k++) { n[k] = lf[k] & 31u; num += n[k]; }
+  if(__any(num != 0u || holds))
+  {
+    bool big = false;
+#pragma unroll
+    for(int k=0;k<=K;k++) big = big || n[k] > 7u;
+    /* exclusive prefix sum of num (<= 7 (K + 1) <= 28) over the wave from the ballots of its bits */
+    const mi_u64 b0 = __ballot(num & 1u), b1 = __ballot(num & 2u), b2 = __ballot(num & 4u), b3 = __ballot(num & 8u), b4 = __ballot(num & 16u);
+    const uint32_t J = __popcll(b0) + 2u*__popcll(b1) + 4u*__popcll(b2) + 8u*__popcll(b3) + 16u*__popcll(b4);
+    const bool fits = !__any(big) && J <= MI_SPEC_JOBS_MAX;
+#define MI_MBCNT(M) __builtin_amdgcn_mbcnt_hi((uint32_t)((M) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(M), 0u))
+    const uint32_t prefix = MI_MBCNT(b0) + 2u*MI_MBCNT(b1) + 4u*MI_MBCNT(b2) + 8u*MI_MBCNT(b3) + 16u*MI_MBCNT(b4);
+#undef MI_MBCNT
+    lds_u8 *jobs = (lds_u8 *)lds.jobs;
+    lds_uint2 *col = (lds_uint2 *)lds.stack;
+    lds_u64 *best = (lds_u64 *)(col + (STACK + 0)*BLOCK);
+    lds_uint2 *uvs = col + (STACK + 1)*BLOCK;
+    lds_u32 *anl = (lds_u32 *)(col + (STACK + 2)*BLOCK);
+    if(num && fits)
+    {
+      uint32_t at = prefix;
+#pragma unroll
+      for(int k=0;k<=K;k++) { for(uint32_t i=0;i<n[k];i++) jobs[at + i] = (unsigned char)(lane | ((unsigned)k << 6)); at += n[k]; }
+      *best = ((mi_u64)__float_as_uint(hit.dist) << 32) | 0xffffffffull;
+      *anl = 0u;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    MI_TT(cnt, 1)
+    for(uint32_t base=0;fits && base<J;base+=64u)
+    {
+#ifdef MI_PROFILE_LOOPS
+      if(lane == 0) cnt.c[9] += MI_PROFILE_LOOPS == 2 ? (J - base < 64u ? J - base : 64u) : 1;
+#endif
+      const uint32_t j = base + lane;
+      const bool valid = j < J;
+      const uint32_t e = valid ? (uint32_t)jobs[j] : lane;
+      const int src = (int)(e & 63u);
+      const uint32_t slot = e >> 6;
+      uint32_t sl[K + 1];
+#pragma unroll
+      for(int k=0;k<=K;k++) sl[k] = (uint32_t)__shfl((int)lf[k], src);
+      const uint32_t spre = (uint32_t)__shfl((int)prefix, src);
+      uint32_t link = sl[0], off = 0u, acc = 0u;
+#pragma unroll
+      for(int k=1;k<=K;k++) { acc += sl[k-1] & 31u; if(slot == (uint32_t)k) { link = sl[k]; off = acc; } }
+      const uint32_t kk = j - spre - off;
+      const uint32_t prim = valid ? ((link ^ MI_LEAF32) >> 5) + kk : 0u;
+      const uint32_t pos = (slot << 3) | kk;             /* order of the tests on the owner's ray: slot, then position in the leaf */
+      const PrimRegs rec = prim_load(prims, prim);
+      const V3 so = mk3(__shfl(o.x, src), __shfl(o.y, src), __shfl(o.z, src)), sd = mk3(__shfl(d.x, src), __shfl(d.y, src), __shfl(d.z, src));
+      Hit h;
+      h.prim = MI_NOPRIM; h.u = h.v = 0.0f;
+      h.dist = __shfl(hit.dist, src);
+      const uint32_t sign = (uint32_t)__shfl((int)ignore, src);
+      const int offl = src - (int)lane;
+      const uint32_t type = __float_as_uint(rec.q3.x);
+      const bool both = triquad_intersect<true>(rec, type, so, sd, h, prim);
+      const bool tq = valid && type >= MI_PRIM_TRI && prim != sign;       /* triangle.h:271 */
+      const bool cand = tq && !both && h.prim != MI_NOPRIM;
+      const mi_u64 key = ((mi_u64)__float_as_uint(h.dist) << 32) | (mi_u64)(31u - pos);
+      if(tq && (both || cand)) __hip_atomic_fetch_min(best + offl, both ? (mi_u64)0 : key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   /* 0: poison, the owner goes sequential */
+      if(valid && type < MI_PRIM_TRI) __hip_atomic_fetch_or(anl + 2*offl, 1u << pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      if(__any(cand))
+      { /* the job that holds the owner's minimum so far leaves its u, v (a later, closer one overwrites them) */
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if(cand && best[offl] == key) uvs[offl] = mi_u32x2{__float_as_uint(h.u), __float_as_uint(h.v)};
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    MI_TT(cnt, 2)
+    if(num)
+    {
+      const mi_u64 res = fits ? *best : 0;
+      if(res == 0)
+      { /* order matters in one of the leaves (or the list does not fit): this lane's leaves one after the other, each in order */
+#pragma unroll
+        for(int k=0;k<=K;k++) if(n[k]) leaf_tests<MB>(prims, lf[k], o, d, ignore, hit, ts, cnt);
+      }
+      else
+      {
+        MI_COUNT(cnt, 3, num);
+        if((uint32_t)res != 0xffffffffu)
+        {
+          const uint32_t pos = 31u - (uint32_t)res;
+          uint32_t link = lf[0];
+#pragma unroll
+          for(int k=1;k<=K;k++) if((pos >> 3) == (uint32_t)k) link = lf[k];
+          const mi_u32x2 uv = *uvs;
+          hit.dist = __uint_as_float((uint32_t)(res >> 32)); hit.prim = ((link ^ MI_LEAF32) >> 5) + (pos & 7u);
+          hit.u = __uint_as_float(uv.x); hit.v = __uint_as_float(uv.y);
+        }
+        uint32_t analytic = *anl;
+        while(analytic)
+        {
+#ifdef MI_PROFILE_LOOPS
+          { const unsigned nl = __popcll(__ballot(1)); if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) cnt.c[10] += MI_PROFILE_LOOPS == 2 ? nl : 1; }
+#endif
+          const uint32_t pos = __ffs(analytic) - 1;
+          analytic &= analytic - 1;
+          uint32_t link = lf[0];
+#pragma unroll
+          for(int k=1;k<=K;k++) if((pos >> 3) == (uint32_t)k) link = lf[k];
+          analytic_intersect<MB>(prims, ((link ^ MI_LEAF32) >> 5) + (pos & 7u), o, d, ignore, hit, MB ? ts.time : 0.0f, MB ? ts.prims_t1 : nullptr);
+        }
+      }
+    }
+    if(ANYHIT && ts.anyhit && hit.prim != MI_NOPRIM && !done) { sp = 0; current = MI_LEAF32; done = true; }   /* an occluder is all such a shadow ray needs */
+    else if(holds) stack_pop<BLOCK, STACK>(lds, lstack, hit.dist, sp, current, done);
+    MI_TT(cnt, 3)
+  }
+  if(busy) { ts.sp = sp; ts.current = current; ts.done = done; }
+}
+
+template<int BLOCK, int STACK, bool FAST = false, class CNT>
 __device__ __forceinline__ void accel_intersect(const Lds &lds, const DPrim *prims, const V3 o, const V3 d, uint32_t ignore,
                                                 Hit &hit, CNT &cnt, bool live = true)
 { /* closest hit for one ray per lane; the wave iterates until every lane is done. Call from ALL lanes of the wave (live = false:
      this lane has no ray): the distributed leaf phase deals work out to every lane */
   TraceState ts;
-  trace_begin(ts, d, cnt);
+  trace_begin(lds, ts, d, cnt);
   if(!live) { ts.done = true; MI_COUNT(cnt, 0, (uint32_t)-1); }
+  if(FAST)
+  {
+    while(__any(!ts.done)) trace_round_spec<BLOCK, STACK, false, false>(lds, prims, o, d, ignore, hit, ts, !ts.done, cnt);
+    return;
+  }
 #if MI_LEAF_JOBS
   while(__any(!ts.done))
   {

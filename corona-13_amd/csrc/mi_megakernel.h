@@ -1,0 +1,321 @@
+/* mi_megakernel.h -- the persistent path tracing kernel (mi_path_kernel) and the ray-level test kernel (mi_intersect_kernel) of
+ * libcorona_mi.so for gfx950, and the table of their instantiations.
+ *
+ * The megakernel has eight template switches (RECORD, PTDL, NODES_LDS, HALTON, MEDIA, MB, COUNT, FAST); the valid combinations are
+ * compiled in PARTS -- one translation unit per (PTDL, MEDIA, MB, FAST), csrc/mi_part.hip with -DMI_PART=k -- so that the library
+ * builds in parallel (make -j), and each part dispatches over its remaining four switches (mi_path_part). mi_abi.hip holds the
+ * host side and picks the part.
+ */
+#ifndef MI_MEGAKERNEL_H
+#define MI_MEGAKERNEL_H
+
+#include "mi_path.h"
+#include <stdio.h>
+#include <stdlib.h>
+
+#ifndef MI_BLOCK
+#define MI_BLOCK 1024    /* threads per workgroup: 16 waves/CU = 4 per SIMD (128 VGPRs each) */
+#endif
+#ifndef MI_TAIL_LANES
+#define MI_TAIL_LANES 16       /* a traversal slice ends when fewer rays than this are still under way */
+#endif
+#ifndef MI_TAIL_LANES_PTDL
+#define MI_TAIL_LANES_PTDL 12  /* ptdl shades more per vertex (next event estimation); A/B 6 / 8 / 10 / 12 / 16: 38.67 / 38.44 / 38.22 / 38.14 / 38.19 ms */
+#endif
+#ifndef MI_ANYHIT
+#define MI_ANYHIT 1      /* shadow rays towards flagged emitters stop at the first occluder (MI_LIGHT_ANYHIT, mi_device.h) */
+#endif
+#ifndef MI_LEAF_JOBS
+#define MI_LEAF_JOBS 1
+#endif
+#ifndef MI_LEAF_JOBS_PTDL
+#define MI_LEAF_JOBS_PTDL 0   /* A/B switch: the distributed leaf phase in the ptdl kernels too */
+#endif
+#ifndef MI_LEAF_JOBS_MEDIA
+#define MI_LEAF_JOBS_MEDIA 1  /* ... in the extended (media / moving camera) pt kernels: +7 % (0055_media, 0056_fog, 0058_cam_mb) */
+#endif
+#ifndef MI_LEAF_JOBS_MB
+#define MI_LEAF_JOBS_MB 0     /* ... in the motion-blur pt kernels: parity green, but 1748 against 1923 Msamples/s on 0059_mb (every moving primitive is a put-off test) */
+#endif
+#ifndef MI_PARK_TRACE
+#define MI_PARK_TRACE 1   /* the tail lanes' traversal state waits in LDS while the others shade (kernels with a distributed leaf phase) */
+#endif
+#ifndef MI_STACK
+#if MI_LEAF_JOBS
+#define MI_STACK (MI_STACK_LDS - 3)   /* the top three entries of a lane's column hold the results of the distributed leaf phase (leaf_jobs) */
+#else
+#define MI_STACK MI_STACK_LDS         /* LDS traversal stack entries per lane; deeper entries overflow to HBM (mi_device.h) */
+#endif
+#endif
+
+/* ======================================================================================= persistent megakernel */
+template<bool RECORD, bool PTDL, bool NODES_LDS, bool HALTON = false, bool MEDIA = false, bool MB = false, bool COUNT = true, bool FAST = false>
+__global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned long long first, unsigned long long count,
+                                                           const uint32_t *shape_material, const float *shape_L, mi_path_record *records,
+                                                           uint2 *stack_overflow)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const Lds lds = lds_setup<MI_BLOCK, NODES_LDS, HALTON, PTDL && !MEDIA>(sc, smem, stack_overflow);
+
+  /* every workgroup owns a contiguous part of the path index range and hands it out through an LDS counter: the
+     wave-level refill below then needs no global atomic at all (one shared counter costs ~11 ns per wave refill) */
+  __shared__ unsigned int blk_next;
+  if(threadIdx.x == 0) blk_next = 0;
+  __syncthreads();
+  const unsigned long long nb = gridDim.x;
+  const unsigned long long blk_lo = count/nb*blockIdx.x + (blockIdx.x < count%nb ? blockIdx.x : count%nb);
+  const unsigned long long blk_hi = blk_lo + count/nb + (blockIdx.x < count%nb ? 1 : 0);
+
+  /* pt: the primitive tests of a traversal round are dealt out over all lanes of the wave (leaf_jobs); the ptdl kernels keep the
+     per-lane leaf loop -- there the extra live registers of the job loop spill (A/B in DESIGN.md) */
+  constexpr bool JOBS = !FAST && MI_LEAF_JOBS && (!PTDL || MI_LEAF_JOBS_PTDL) && (!MEDIA || MI_LEAF_JOBS_MEDIA) && (!MB || MI_LEAF_JOBS_MB);
+  constexpr int STACK = (JOBS || FAST) ? MI_STACK_LDS - 3 : MI_STACK_LDS;     /* FAST: the rounds of trace_round_spec (mi_kernels.h), same result slots */
+  Counters<COUNT || RECORD> cnt;        /* COUNT = false: only the path count (see Counters, mi_kernels.h) */
+  PathState ps;
+  ps.active = 0;
+  ps.sh_pending = 0;
+  bool exhausted = false;
+  const unsigned lane = __lane_id();
+  TraceState ts;
+  ts.done = true;
+  Hit hit;
+  hit.prim = MI_NOPRIM; hit.dist = FLT_MAX; hit.u = hit.v = 0.0f;
+  bool tracing = false, tr_shadow = false;
+
+  MI_PHASE_INIT(cnt)
+#ifdef MI_PROFILE_TRAV
+  cnt.c[31] = (uint32_t)clock64();
+#endif
+  while(true)
+  {
+    /* ------------------------------------------------------------ refill idle lanes (wave-level compaction of the work queue) */
+    if(!exhausted)
+    {
+      const bool want = !ps.active && !ps.sh_pending;
+      const unsigned long long m = __ballot(want);
+      if(m)
+      {
+        const unsigned n = __popcll(m);
+        unsigned int base = 0;
+        if(lane == (unsigned)(__ffsll((long long)m) - 1)) base = atomicAdd(&blk_next, n);     /* LDS atomic: this block's own range */
+        base = __shfl(base, __ffsll((long long)m) - 1);
+        if(want)
+        {
+          const unsigned rank = __popcll(m & ((1ull << lane) - 1ull));
+          const unsigned long long i = blk_lo + base + rank;
+          if(i < blk_hi) path_generate<RECORD, HALTON, MEDIA>(sc, ps, first + i, RECORD ? records + i : nullptr, cnt);
+          else exhausted = true;
+        }
+      }
+    }
+    if(!__any(ps.active || ps.sh_pending)) break;
+    const bool exhausted_wave = __any(exhausted);   /* this block's index range has run dry */
+    MI_PHASE(cnt, 0)
+
+    /* ------------------------------------------------------------ one ray per busy lane: a pending shadow ray first, else the extension ray */
+    if(!tracing && (ps.active || ps.sh_pending))
+    {
+      tr_shadow = PTDL && ps.sh_pending;
+      hit.prim = MI_NOPRIM; hit.dist = tr_shadow ? ps.sh_dist : (MEDIA ? media_free_flight<PTDL, HALTON>(sc, ps) : FLT_MAX); hit.u = hit.v = 0.0f;
+      trace_begin(lds, ts, tr_shadow ? ps.sh_dir : ps.dir, cnt);
+      if(PTDL && MI_ANYHIT) ts.anyhit = tr_shadow && (ps.sh_light & MI_LIGHT_ANYHIT);
+      if(MB) { ts.time = ps.time; ts.prims_t1 = sc.prims_t1; }      /* motion-blurred primitives are tested at the path's time */
+      tracing = true;
+    }
+    MI_TT(cnt, 5)
+    /* ------------------------------------------------------------ a slice of traversal: while-while rounds until only a tail of
+       MI_TAIL_LANES rays is still under way. Those lanes keep their traversal state (registers + LDS stack) and go on in the
+       next iteration next to the fresh rays of the lanes that shade now, so one long ray does not hold 63 lanes idle. */
+    {
+      const V3 o = ray_origin<PTDL>(ps, tr_shadow), d = tr_shadow ? ps.sh_dir : ps.dir;
+      const uint32_t ignore = ps.ignore;     /* the shadow ray of a vertex starts on the same primitive as its extension ray */
+      const unsigned tail = exhausted_wave ? 1u : (unsigned)(PTDL ? MI_TAIL_LANES_PTDL : MI_TAIL_LANES);
+      while(true)
+      {
+        const bool busy = tracing && !ts.done;
+        const unsigned nbusy = __popcll(__ballot(busy));
+        if(!nbusy) break;
+        if(nbusy < tail && __any(tracing && ts.done)) break;
+        if(FAST) { trace_round_spec<MI_BLOCK, STACK, MB, PTDL && MI_ANYHIT>(lds, sc.prims, o, d, ignore, hit, ts, busy, cnt); continue; }
+        if(busy) trace_round<MI_BLOCK, STACK, MB, PTDL && MI_ANYHIT, JOBS>(lds, sc.prims, o, d, ignore, hit, ts, cnt);
+        if(JOBS) leaf_jobs<MI_BLOCK, STACK, MB, PTDL && MI_ANYHIT>(lds, sc.prims, o, d, ignore, hit, ts, busy, cnt);   /* every lane of the wave takes part */
+      }
+    }
+    MI_PHASE(cnt, 1)
+    MI_TT(cnt, 4)
+    /* The lanes of the tail keep their ray. Its traversal state (closest hit so far, node, stack pointer: 6 dwords; the three 1/dir
+       are formed again) would sit in eleven registers through the shading of the other lanes, where the kernel's register pressure
+       peaks -- between two rounds the three result slots of the lane's LDS column (leaf phase) are free and take it instead. */
+    constexpr bool PARK = MI_PARK_TRACE && (FAST || JOBS) && !MB;
+    const bool keep = tracing && !ts.done;
+    if(PARK && keep)
+    {
+      lds_uint2 *col = (lds_uint2 *)lds.stack + STACK*MI_BLOCK;
+      col[0] = mi_u32x2{hit.prim, __float_as_uint(hit.dist)};
+      col[MI_BLOCK] = mi_u32x2{__float_as_uint(hit.u), __float_as_uint(hit.v)};
+      col[2*MI_BLOCK] = mi_u32x2{ts.current, (uint32_t)ts.sp | (ts.anyhit ? 0x10000u : 0u)};
+    }
+    SplatReq splat;
+    splat.pending = false; splat.c0 = splat.c1 = splat.c2 = 0.0f;
+    if(tracing && ts.done)
+    {
+      tracing = false;
+      mi_path_record *rec = RECORD ? records + (ps.index - first) : nullptr;
+      if(tr_shadow) shadow_resolve<RECORD>(sc, ps, hit, rec, cnt, splat);
+      else path_shade<RECORD, PTDL, HALTON, MEDIA, MB>(sc, ps, hit, shape_material, shape_L, rec, cnt, splat);
+    }
+
+    if(PARK)
+    {
+      if(keep)
+      {
+        const lds_uint2 *col = (const lds_uint2 *)lds.stack + STACK*MI_BLOCK;
+        const mi_u32x2 a = col[0], b = col[MI_BLOCK], c = col[2*MI_BLOCK];
+        hit.prim = a.x; hit.dist = __uint_as_float(a.y); hit.u = __uint_as_float(b.x); hit.v = __uint_as_float(b.y);
+        ts.current = c.x; ts.sp = (int)(c.y & 0xffffu); ts.anyhit = (c.y & 0x10000u) != 0; ts.done = false;
+        const V3 d = tr_shadow ? ps.sh_dir : ps.dir;
+        ts.idx = mi_rcp(d.x); ts.idy = mi_rcp(d.y); ts.idz = mi_rcp(d.z);
+      }
+      else
+      {
+        hit.prim = MI_NOPRIM; hit.dist = FLT_MAX; hit.u = hit.v = 0.0f;
+        ts.current = MI_LEAF32; ts.sp = 0; ts.anyhit = false; ts.done = true; ts.idx = ts.idy = ts.idz = 0.0f;
+      }
+    }
+    /* ------------------------------------------------------------ splats of this iteration, cooperatively */
+    MI_PHASE(cnt, 5)
+    MI_TT(cnt, 5)
+    if(!RECORD) splat_wave(sc, splat.pending, ps.pixel_i, ps.pixel_j, splat.c0, splat.c1, splat.c2);
+    MI_PHASE(cnt, 6)
+    MI_TT(cnt, 6)
+#ifdef MI_PROFILE_TRAV
+    cnt.c[15]++;            /* wave iterations */
+#endif
+  }
+
+#ifdef MI_PROFILE_LOOPS    /* development build: box hits / splats / vertices become wave-level inner iterations / leaf slots / analytic passes */
+  cnt.c[2] = cnt.c[8]; cnt.c[5] = cnt.c[9]; cnt.c[6] = cnt.c[10];
+#endif
+#ifdef MI_PROFILE_TRAV     /* development build: counters 0..6 become lane 0's ticks per part of the wave iteration (tools/trav_probe.py); 7 stays */
+  for(int k=0;k<8;k++) cnt.c[k] = lane ? 0u : cnt.c[8 + k];
+#endif
+#ifdef MI_PROFILE_PHASES   /* development build: the 8 counters become lane 0's phase ticks | occurrences << 36 (tools/phase_probe.py) */
+  unsigned long long phase_out[8];
+  for(int k=0;k<8;k++) phase_out[k] = lane ? 0ull : ((unsigned long long)cnt.c[8 + k] | ((unsigned long long)cnt.c[16 + k] << 36));
+#endif
+  unsigned long long *shard = sc.counters + (size_t)(blockIdx.x % MI_COUNTER_SHARDS)*8;
+#if !defined(MI_PROFILE_PHASES) && !defined(MI_PROFILE_TRAV)
+  if(cnt.on) atomicMax(shard + 7, (unsigned long long)cnt.c[7]);     /* deepest traversal stack use */
+#endif
+  /* ------------------------------------------------------------ flush work counters: wave reduction, one atomic per wave */
+#pragma unroll
+  for(int k=0;k<8;k++)
+  {
+#ifndef MI_PROFILE_TRAV
+    if(!cnt.on && k != 4) continue;         /* the plain kernels only count paths */
+#endif
+    unsigned long long c = cnt.c[k];
+#ifdef MI_PROFILE_PHASES
+    c = phase_out[k];
+    if(k == 7) { if(lane == 0 && c) atomicAdd(shard + 7, c); continue; }
+#endif
+    for(int off=32;off>0;off>>=1) c += __shfl_down(c, off);
+#ifndef MI_PROFILE_TRAV
+    if(k == 7) continue;                    /* slot 7 is a maximum, flushed above */
+#endif
+    if(lane == 0 && c) atomicAdd(shard + k, c);
+  }
+}
+
+/* ======================================================================================= unit hook: rays in, hits out */
+template<bool NODES_LDS, bool FAST>
+__global__ __launch_bounds__(MI_BLOCK) void mi_intersect_kernel(DScene sc, const mi_ray *rays, unsigned long long n, mi_hit *out,
+                                                                uint2 *stack_overflow)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const Lds lds = lds_setup<MI_BLOCK, NODES_LDS>(sc, smem, stack_overflow);
+  Counters<true> cnt;
+  for(unsigned long long base=(unsigned long long)blockIdx.x*MI_BLOCK; base<n; base+=(unsigned long long)gridDim.x*MI_BLOCK)
+  {
+    const unsigned long long i = base + threadIdx.x;
+    const bool live = i < n;                     /* the lanes behind the last ray still take part in the traversal's wave-level steps */
+    const mi_ray r = rays[live ? i : n - 1];
+    Hit hit;
+    hit.prim = MI_NOPRIM; hit.dist = r.max_dist; hit.u = hit.v = 0.0f;
+    accel_intersect<MI_BLOCK, MI_STACK, FAST>(lds, sc.prims, mk3(r.pos[0], r.pos[1], r.pos[2]), mk3(r.dir[0], r.dir[1], r.dir[2]), r.ignore, hit, cnt, live);
+    if(live)
+    {
+      mi_hit h;
+      h.prim = hit.prim; h.primid = hit.prim == MI_NOPRIM ? MI_PRIMID_INVALID : MI_GEO_PRIMID(sc.primgeo[hit.prim]);
+      h.dist = hit.dist; h.u = hit.u; h.v = hit.v; h.pad[0] = h.pad[1] = 0;
+      out[i] = h;
+    }
+  }
+  unsigned long long *shard = sc.counters + (size_t)(blockIdx.x % MI_COUNTER_SHARDS)*8;
+  atomicMax(shard + 7, (unsigned long long)cnt.c[7]);
+  for(int k=0;k<4;k++) if(cnt.c[k]) atomicAdd(shard + k, (unsigned long long)cnt.c[k]);
+}
+
+
+/* ---------------------------------------------------------------------------------------- kernel table
+ * A part = one (PTDL, MEDIA, MB, FAST); inside it `which` selects bit 0 RECORD, 1 NODES_LDS, 2 HALTON, 3 COUNT. MB implies MEDIA and
+ * has no FAST rounds (its leaf phase stays per lane); the RECORD kernels always count.
+ * MI_DEV_FAST (development builds, tools/variants.sh): only the plain tree-in-LDS kernels (2: with the Halton ones) -- the other
+ * parts compile to stubs. L = NULL: return the kernel's address without launching (hipFuncSetAttribute). */
+struct PathLaunch
+{
+  DScene d;
+  int grid;
+  size_t lds_bytes;
+  hipStream_t stream;
+  unsigned long long first, n;
+  const uint32_t *shape_material;
+  const float *shape_L;
+  mi_path_record *rec;
+  uint2 *overflow;
+};
+#define MI_WHICH_RECORD 1u
+#define MI_WHICH_NODES_LDS 2u
+#define MI_WHICH_HALTON 4u
+#define MI_WHICH_COUNT 8u
+
+template<bool PTDL, bool MEDIA, bool MB, bool FAST> const void *mi_path_part(unsigned which, const PathLaunch *L);
+
+static inline bool mi_path_which_valid(unsigned which)
+{
+  if((which & MI_WHICH_RECORD) && !(which & MI_WHICH_COUNT)) return false;
+#ifdef MI_DEV_FAST
+  if(!(which & MI_WHICH_NODES_LDS) || ((which & MI_WHICH_HALTON) && MI_DEV_FAST != 2)) return false;
+#endif
+  return true;
+}
+
+#ifdef MI_PART_DEFINE
+template<bool PTDL, bool MEDIA, bool MB, bool FAST, bool R, bool N, bool H, bool C> static const void *mi_path_go(const PathLaunch *L)
+{
+  constexpr bool valid = !(MB && !MEDIA) && !(MB && FAST) && !(R && !C)
+#ifdef MI_DEV_FAST
+                         && (!H || MI_DEV_FAST == 2) && !MEDIA && !MB && N
+#endif
+                         ;
+  if constexpr(valid)
+  {
+    if(L) hipLaunchKernelGGL((mi_path_kernel<R, PTDL, N, H, MEDIA, MB, C, FAST>), dim3(L->grid), dim3(MI_BLOCK), L->lds_bytes, L->stream, L->d, L->first, L->n,
+                             L->shape_material, L->shape_L, L->rec, L->overflow);
+    return (const void *)mi_path_kernel<R, PTDL, N, H, MEDIA, MB, C, FAST>;
+  }
+  else { fprintf(stderr, "[mi] internal: kernel variant not built\n"); abort(); }
+}
+template<bool PTDL, bool MEDIA, bool MB, bool FAST, int LEFT, bool... B> static const void *mi_path_pick(unsigned which, const PathLaunch *L)
+{
+  if constexpr(LEFT == 0) return mi_path_go<PTDL, MEDIA, MB, FAST, B...>(L);
+  else return (which & 1u) ? mi_path_pick<PTDL, MEDIA, MB, FAST, LEFT - 1, B..., true>(which >> 1, L)
+                           : mi_path_pick<PTDL, MEDIA, MB, FAST, LEFT - 1, B..., false>(which >> 1, L);
+}
+template<bool PTDL, bool MEDIA, bool MB, bool FAST> const void *mi_path_part(unsigned which, const PathLaunch *L)
+{
+  return mi_path_pick<PTDL, MEDIA, MB, FAST, 4>(which, L);
+}
+#endif
+
+#endif

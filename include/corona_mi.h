@@ -250,6 +250,20 @@ float *mi_fb_device_ptr(mi_scene *s);
 int  mi_counters(mi_scene *s, uint64_t out[8]);
 int  mi_scene_set_counters(mi_scene *s, int enable);
 
+/* How a ray walks the tree. Both modes return the same closest hit, bit for bit (distance, primitive, u, v), hence the same paths
+ * and images; they differ in the WORK they do for it:
+ *   MI_TRAVERSAL_EXACT  the reference's order of operations ray by ray (accel_intersect, src/accel.d/qbvhmp.c:1262-1390): a leaf is
+ *                       tested before the next subtree is chosen, so node visits / box hits / primitive tests equal the
+ *                       reference's -DACCEL_DEBUG totals. For counter parity and as the yardstick of the fast mode.
+ *   MI_TRAVERSAL_FAST   (default) a lane that reaches a leaf puts it aside and goes on descending against the distance known so
+ *                       far; the put-aside leaves of the whole wave are tested together. A few per cent more node visits and
+ *                       primitive tests (they are counted), far fewer idle lane-slots (csrc/mi_kernels.h, trace_round_spec).
+ * CORONA_MI_TRAVERSAL=exact|fast in the environment sets the mode a scene is created with. Scenes with motion-blurred
+ * primitives always run the exact rounds. No reference counterpart. */
+#define MI_TRAVERSAL_EXACT 0
+#define MI_TRAVERSAL_FAST  1
+int  mi_scene_set_traversal(mi_scene *s, int mode);
+
 /* Debug/test entry: trace `count` paths starting at `first` and write one mi_path_record per
  * path (no splatting into the framebuffer). Used by the parity tests to compare path by path. */
 #define MI_REC_MAX_VERTS 8

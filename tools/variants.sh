@@ -1,13 +1,13 @@
 #!/bin/bash
-# development helper (build container): compile kernel variants for an A/B run on the GPU box.
+# development helper (build container): compile a kernel variant for an A/B run on the GPU box.
 #   tools/variants.sh <tag> [extra hipcc flags...]   ->  corona-13_amd/csrc/variants/libcorona_mi_<tag>.so
-# -DMI_DEV_FAST: only the plain tree-in-LDS kernels (pt / ptdl, with and without RECORD) -- 20 s per variant.
-# The variants travel to the GPU box with the snapshot; tests/dev/ab.sh runs parity + timing for each.
+# -DMI_DEV_FAST: only the plain tree-in-LDS kernels (pt / ptdl, exact and FAST rounds, with and without RECORD / COUNT) -- 12 s per
+# variant on 8 cores. MI_DEV_FAST_FLAG= (empty) builds everything. The variants travel to the GPU box with the snapshot;
+# tests/dev/ab.sh runs parity + timing for each. Prints the registers / spills of the variant's kernels (tools/kstat.py).
 set -e
-cd "$(dirname "$0")/../corona-13_amd"
+cd "$(dirname "$0")/.."
 tag=$1; shift
-mkdir -p csrc/variants
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -ffp-contract=off -fno-slp-vectorize \
-  -mllvm -enable-post-misched=0 -Wall -Wno-unused-function -I../include -Ihost -Icsrc ${MI_DEV_FAST_FLAG:--DMI_DEV_FAST} "$@" \
-  -shared csrc/mi_abi.hip -o csrc/variants/libcorona_mi_$tag.so
-echo "built csrc/variants/libcorona_mi_$tag.so ($*)"
+mkdir -p corona-13_amd/csrc/variants
+make -s -C corona-13_amd -j8 MI_DEFS="${MI_DEV_FAST_FLAG--DMI_DEV_FAST} $*" BUILD=/tmp/mi_variants/$tag MI_LIB=csrc/variants/libcorona_mi_$tag.so csrc/variants/libcorona_mi_$tag.so
+echo "built corona-13_amd/csrc/variants/libcorona_mi_$tag.so ($*)"
+python3 tools/kstat.py corona-13_amd/csrc/variants/libcorona_mi_$tag.so mi_path_kernel | grep -v "kernel<true"
