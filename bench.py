@@ -55,6 +55,11 @@ CONFIGS = {
     "fog_ptdl": dict(scene="0056_fog", sampler="ptdl", w=1280, h=720, spp=64, mv=8, name="scenes/0056_fog, ptdl, 1280x720, 64 spp"),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+LDS_PEAK_TBS = 150.0           # MI355X_MICROARCH.md, LDS section: ds_read_b64 / b128 streaming, all 256 CUs (~2.4 GHz)
+# mean of the finished image (gain-scaled XYZ over the padded film) as the REFERENCE renders it at 64 spp (BASELINE.md section 2,
+# sidecar "average image intensity"); the run fails if the last frame is further off than the tolerance
+REFERENCE_IMAGE_MEAN = {"cfg2": (1.0675, 1.0683, 1.0539), "cfg3": (1.0743, 1.0716, 1.0624)}
+IMAGE_MEAN_TOL = 0.02
 CUS, SIMDS_PER_CU = 256, 4     # MI355X_MICROARCH.md: 256 CUs in 8 XCDs, 4 SIMD-32 per CU (a wave64 f32 VALU op issues over 2 cycles)
 # Work per sample of the REFERENCE's traversal on the REFERENCE's tree (its own -DACCEL_DEBUG counters, tests/golden/counters.json:
 # node visits, primitive tests per path; splats per path from SURVEY 8(d)). The algorithmic-bytes figure of SURVEY 8(d),
@@ -120,10 +125,18 @@ def cpu_baseline(width, height):
             "sample": f"4 spp of the same 1280x736 frame ({n} paths), oracle/liboracle.so, {secs:.2f} s"}
 
 
-def committed_profile():
+def library_build_id():
+    """first 16 hex digits of the sha256 of the loaded libcorona_mi.so: ties a committed PMC summary to the build it was taken from"""
+    import hashlib
+    from __graft_entry__ import load_package
+    lib = Path(load_package().MI_LIB)
+    return hashlib.sha256(lib.read_bytes()).hexdigest()[:16] if lib.exists() else None
+
+
+def committed_profile(kernel="pt"):
     """per-launch PMC averages of the committed rocprofv3 passes of this same command (tools/profile.sh ->
-    profiles/rNN_pmc_summary.json), or None"""
-    files = sorted((REPO / "profiles").glob("r*_pmc_summary.json"))
+    profiles/rNN_pmc_summary.json; the ptdl kernel's: rNN_pmc_summary_ptdl.json), or None"""
+    files = sorted((REPO / "profiles").glob("r*_pmc_summary.json" if kernel == "pt" else "r*_pmc_summary_ptdl.json"))
     if not files:
         return None, None
     return json.loads(files[-1].read_text()), files[-1].name
@@ -171,6 +184,56 @@ def spawn_ranks(args, argv):
     return subprocess.run(cmd).returncode
 
 
+def bench_group(args):
+    """--reduce c: the N GPUs of the node from ONE process through the C ABI (mi_group_create / mi_group_render / mi_group_fb_read):
+    the library splits every step's path indices over the devices and adds the framebuffers up on the first one (ncclReduce over
+    xGMI). Same timing window as the torch path: K steps + the reduce and read-back of the finished frame. No torch involved."""
+    import numpy as np
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    cfg = CONFIGS[args.config]
+    scaling = args.scaling or cfg.get("scaling", "weak")
+    scene = pkg.Scene(REPO / "scenes" / cfg["scene"] / "test.nra2", width=cfg["w"], height=cfg["h"], max_verts=cfg["mv"],
+                      sampler=pkg.MI_SAMPLER_PTDL if cfg["sampler"] == "ptdl" else pkg.MI_SAMPLER_PT,
+                      pointsampler=pkg.MI_POINTS_HALTON if args.points == "halton" else pkg.MI_POINTS_RAND)
+    per_frame = cfg["spp"] * scene.width * scene.height
+    job = per_frame if scaling == "strong" else args.gpus * per_frame
+    group = pkg.Group(scene, list(range(args.gpus)), traversal=args.traversal)
+    host = np.zeros((scene.height, scene.width, 3), dtype=np.float32)
+    for k in range(args.warmup):
+        group.render(k * job, job)
+    group.sync()
+    group.fb_clear()
+    group.sync()
+    c0 = group.counters()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        if k == args.steps - 1:
+            group.fb_clear()                           # the finished frame = the last step's samples, like the torch path
+        group.render((args.warmup + k) * job, job)
+    host = group.fb_read()                             # reduce over the GPUs + read-back of the finished frame, inside the window
+    elapsed = time.perf_counter() - t0
+    paths = group.counters()[4] - c0[4]
+    if paths != args.steps * job:
+        raise SystemExit(f"bench.py: the kernels counted {paths} paths, {args.steps * job} were asked for")
+    mean = [float(x) for x in host.astype(np.float64).mean(axis=(0, 1)) * scene.gain(cfg["spp"] * (args.gpus if scaling == "weak" else 1))]
+    ref = REFERENCE_IMAGE_MEAN.get(args.config)
+    if not all(m == m and m > 0.0 for m in mean) or (ref and max(abs(a - b) for a, b in zip(mean, ref)) > IMAGE_MEAN_TOL):
+        raise SystemExit(f"bench.py: image mean {mean} of the finished frame is empty or off the reference's {ref}")
+    out = {"metric": "Msamples/sec (and ms/frame) at 1280x720, 64 spp, regression/0010_pt" if args.config == "cfg2" else "Msamples/sec (and ms/frame), " + args.config,
+           "value": args.steps * job / elapsed / 1e6, "unit": "Msamples/s", "n_gpus": args.gpus, "rccl_ranks": args.gpus if group.uses_rccl() else 0,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling,
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic: regression/0010_pt scene (6 of 7 shapes, scenes/0010_pt), per-path xorshift128+ seeds",
+           "config": {"workload": cfg["name"], "traversal": args.traversal, "paths_per_step": job,
+                      "sharding": f"ONE process, mi_group over {args.gpus} device(s): path-index ranges split in the library ({scaling}), framebuffer "
+                                  f"{'ncclReduce (RCCL)' if group.uses_rccl() else 'peer copies + add kernel'} to device 0 + read-back in the timed region"},
+           "image": {"mean_xyz": mean, "reference_mean_xyz": list(ref) if ref else None, "tolerance": IMAGE_MEAN_TOL if ref else None},
+           "member_kernel_ms": [group.member_kernel_ms(k) for k in range(args.gpus)]}
+    group.close()
+    print(json.dumps(out))
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -187,10 +250,18 @@ def main():
                          "device: no tree handed over, the backend builds its own (csrc/mi_build.h)")
     ap.add_argument("--points", default="rand", choices=["rand", "halton"],
                     help="MOD_pointsampler: rand (regression/0010_pt/config.mk, the default) or halton (SURVEY 8(f) row 2)")
+    ap.add_argument("--traversal", default="fast", choices=["fast", "exact"],
+                    help="fast (the library's default): leaves put aside while a lane descends on, same hits; exact: the reference's order of "
+                         "operations per ray, work counters equal its -DACCEL_DEBUG totals (corona_mi.h, MI_TRAVERSAL_*)")
+    ap.add_argument("--reduce", default="torch", choices=["torch", "c"],
+                    help="torch: one process per GPU, torch.distributed (RCCL) all-reduce of the framebuffer (what the driver launches); c: ONE process, "
+                         "the N GPUs behind the C ABI (mi_group_*: index ranges split in the library, ncclReduce from the library)")
     ap.add_argument("--stub", action="store_true", help="TEST ONLY: no GPU, gloo, a stub instead of the HIP backend (launch / sharding / reduce logic)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.reduce == "c":
+        sys.exit(bench_group(args))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args, sys.argv[1:]))
 
@@ -255,7 +326,7 @@ def main():
             be.set_framebuffer_tensor(fb)
         else:
             # the timed kernels carry no debug counters (only the path count), like the reference without -DACCEL_DEBUG
-            be = pkg.Backend(scene, device=local_rank, device_build=args.tree == "device", counters=False)
+            be = pkg.Backend(scene, device=local_rank, device_build=args.tree == "device", counters=False, traversal=args.traversal)
             be.set_framebuffer(fb.data_ptr())
             # torch's current stream (the default stream, passed as MI_STREAM_DEFAULT): clears and RCCL are ordered with the renders
             be.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -277,6 +348,8 @@ def main():
                     be.set_framebuffer_tensor(buf)
                 else:
                     be.set_framebuffer(buf.data_ptr())
+            else:
+                fb.zero_()                                     # every step renders its own frame (the multi-rank path clears per step too)
             be.render(first, count)
             if use_dist:
                 reducer.end(k)                                 # framebuffer reduce over xGMI (RCCL), asynchronous
@@ -305,6 +378,10 @@ def main():
         if dc[4] != nominal:
             raise SystemExit(f"bench.py: the kernel counted {dc[4]} paths, {nominal} were asked for")
         reduced_sum = float(host_fb.double().sum())
+        # the finished frame itself is checked, not only the path count: mean image (gain-scaled XYZ, like the reference's sidecar) of
+        # the last frame -- with N ranks under weak scaling the reduced frame holds N x spp samples per pixel
+        spp_in_frame = cfg["spp"] * (world if scaling == "weak" else 1)
+        image_mean = [float(x) for x in (host_fb.double().mean(dim=(0, 1)) * scene.gain(spp_in_frame))] if not args.stub else None
 
         # kernel duration with HIP events on the launch stream: re-run launches of this rank's share un-overlapped, outside the timed region
         first, count = pkg.shard_range(0, job, rank, world)
@@ -323,60 +400,83 @@ def main():
         be.sync()
         dc = [b - a for a, b in zip(w0, be.counters())]
         res = dict(cfg=cfg, scene_wh=(scene.width, scene.height), per_frame=per_frame, job=job, elapsed=elapsed, dc=dc, kms=kms,
-                   launch_paths=count, nodes_in_lds=be.nodes_in_lds(), reduced_sum=reduced_sum, steps=steps)
+                   launch_paths=count, nodes_in_lds=be.nodes_in_lds(), reduced_sum=reduced_sum, steps=steps, image_mean=image_mean)
         be.close()
         return res
 
-    def roofline_of(config, r):
-        """algorithmic bytes per launch / launch duration against the HBM peak. The scene is LDS/L2 resident, so this is a
-        work rate and NOT the limiter (see roofline_valu); measured DRAM traffic is reported beside it."""
+    def kernel_name(r):
+        cfg = r["cfg"]
+        inst = ("false", "true" if cfg["sampler"] == "ptdl" else "false", "true" if r["nodes_in_lds"] else "false",
+                "true" if args.points == "halton" else "false",
+                "true" if cfg["scene"] in ("0055_media", "0056_fog", "0058_cam_mb", "0059_mb") else "false", "true" if cfg["scene"] == "0059_mb" else "false", "false",
+                "true" if args.traversal == "fast" and cfg["scene"] != "0059_mb" else "false")
+        return "mi_path_kernel<%s> (RECORD, PTDL, NODES_LDS, HALTON, MEDIA, MB, COUNT, FAST)" % ",".join(inst)
+
+    def work_rate_of(config, r):
+        """SURVEY 8(d)'s figure under its own name: algorithmic bytes per launch / launch duration, beside the HBM peak. The 0.5 MB scene
+        is LDS / L2 resident, so this is a WORK RATE, not traffic -- it may exceed what DRAM could deliver and bounds nothing; what DRAM
+        actually sees is roofline.traffic."""
         dc, paths = r["dc"], max(r["dc"][4], 1)
         live = dict(node_visits=dc[1] / paths, prim_tests=dc[3] / paths, splats=dc[5] / paths)
         work = REFERENCE_WORK.get(config) if args.tree == "reference" and args.points == "rand" else None
         src = "reference -DACCEL_DEBUG counters (tests/golden/counters.json)" if work else "live kernel counters"
         work = work or live
         bytes_per_sample = 128.0 * work["node_visits"] + 104.0 * work["prim_tests"] + 384.0 * work["splats"]
-        achieved = bytes_per_sample * r["launch_paths"] / (r["kms"] * 1e-3) / 1e9
-        prof, prof_name = committed_profile()
-        traffic = None
-        if prof and config == "cfg2" and "FETCH_SIZE" in prof and "WRITE_SIZE" in prof:
-            # FETCH_SIZE counts 128-B requests as 64 B on gfx950 (MI355X_MICROARCH.md, HBM section); counters are in KiB
-            traffic = (2.0 * prof["FETCH_SIZE"] + prof["WRITE_SIZE"]) * 1024.0
-        cfg = r["cfg"]
-        inst = ("false", "true" if cfg["sampler"] == "ptdl" else "false", "true" if r["nodes_in_lds"] else "false",
-                "true" if args.points == "halton" else "false",
-                "true" if cfg["scene"] in ("0055_media", "0056_fog", "0058_cam_mb", "0059_mb") else "false", "true" if cfg["scene"] == "0059_mb" else "false", "false")
-        return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "traffic_source": prof_name if traffic is not None else None,
-                "hbm_measured_gbs": traffic / (r["kms"] * 1e-3) / 1e9 if traffic is not None else None,
-                "limiter": "valu issue, not HBM: the 0.5 MB scene is LDS/L2 resident, so the algorithmic figure is a work rate (it may exceed the "
-                           "HBM peak) and hbm_measured_gbs is what DRAM actually sees; the physical roofline is roofline_valu",
-                "kernel": "mi_path_kernel<%s> (RECORD, PTDL, NODES_LDS, HALTON, MEDIA, MB, COUNT)" % ",".join(inst), "kernel_ms": r["kms"],
-                "algorithmic_bytes_per_sample": bytes_per_sample, "work_counts": src,
-                "work_per_sample": {"node_visits": work["node_visits"], "prim_tests": work["prim_tests"], "splats": work["splats"]},
-                "live_work_per_sample": dict(live, rays=dc[0] / paths)}
+        rate = bytes_per_sample * r["launch_paths"] / (r["kms"] * 1e-3) / 1e9
+        return {"algorithmic_bytes_per_sample": bytes_per_sample, "rate": rate, "unit": "GB/s", "hbm_peak": HBM_PEAK_GBS, "rate_over_hbm_peak": rate / HBM_PEAK_GBS,
+                "work_counts": src, "work_per_sample": {"node_visits": work["node_visits"], "prim_tests": work["prim_tests"], "splats": work["splats"]},
+                "live_work_per_sample": dict(live, rays=dc[0] / paths),
+                "note": "B = 128 N_node + 104 N_prim + 384 N_splat per sample (SURVEY 8(d)) priced with the reference's work counts; served from LDS and L2, not HBM"}
 
-    def roofline_valu_of(r):
-        """What actually bounds the kernel: VALU issue. Wave-instructions per path from the committed PMC passes of this command
-        (SQ_INSTS_VALU / paths per launch) x paths per launch / the live launch duration, against CUs x 4 SIMDs x clock / 2
-        (a wave64 f32 op occupies a SIMD-32 for 2 cycles); lane utilisation and LDS bank-conflict share from the same passes."""
-        prof, prof_name = committed_profile()
+    def roofline_of(config, r):
+        """What bounds the kernel: VALU issue (MFMA is not used, DRAM sees 0.2 % of the algorithmic bytes). achieved = wave64 VALU
+        instructions per second = SQ_INSTS_VALU per path (committed PMC pass of this command, profiles/) x paths per launch / the live
+        launch duration (HIP events on the launch stream); peak = CUs x 4 SIMDs x clock / 2 (a wave64 f32 op occupies a SIMD for two
+        cycles). frac = issue utilisation; useful_lane_frac = frac x lane utilisation is the share of the machine's f32 lanes doing
+        work. traffic = measured HBM bytes per launch (2 FETCH_SIZE + WRITE_SIZE, separate --pmc passes)."""
+        prof, prof_name = committed_profile("ptdl" if r["cfg"]["sampler"] == "ptdl" else "pt")
+        out = {"bound": "valu", "achieved": None, "peak": None, "unit": "G wave64-instr/s", "frac": None, "traffic": None,
+               "kernel": kernel_name(r), "kernel_ms": r["kms"]}
         need = ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "gpu_cycles_per_launch")
-        if not prof or any(k not in prof for k in need):
-            return None
-        prof_paths = float(prof.get("paths_per_launch", 64 * 1280 * 736))
-        prof_ms = float(prof.get("kernel_ms", 0.0)) or None
-        clock_ghz = prof["gpu_cycles_per_launch"] / (prof_ms * 1e6) if prof_ms else 2.4
-        instr_per_path = prof["SQ_INSTS_VALU"] / prof_paths
-        achieved = instr_per_path * r["launch_paths"] / (r["kms"] * 1e-3) / 1e9            # G wave-instructions / s
-        peak = CUS * SIMDS_PER_CU * clock_ghz / 2.0
-        lane = prof["SQ_THREAD_CYCLES_VALU"] / (64.0 * prof["SQ_ACTIVE_INST_VALU"])
-        out = {"bound": "valu", "achieved": achieved, "peak": peak, "unit": "G wave64-instr/s", "frac": achieved / peak,
-               "lane_utilisation": lane, "useful_lane_frac": achieved / peak * lane, "valu_instr_per_path": instr_per_path,
-               "clock_ghz": clock_ghz, "source": prof_name}
-        if "SQ_LDS_BANK_CONFLICT" in prof and prof.get("SQ_LDS_IDX_ACTIVE"):
-            out["lds_bank_conflict_share"] = prof["SQ_LDS_BANK_CONFLICT"] / prof["SQ_LDS_IDX_ACTIVE"]
+        if prof and all(k in prof for k in need) and config in ("cfg2", "cfg3") and args.tree == "reference" and args.points == "rand":
+            prof_paths = float(prof.get("paths_per_launch", 64 * 1280 * 736))
+            prof_ms = float(prof.get("kernel_ms", 0.0)) or None
+            clock_ghz = prof["gpu_cycles_per_launch"] / (prof_ms * 1e6) if prof_ms else 2.4
+            instr_per_path = prof["SQ_INSTS_VALU"] / prof_paths
+            achieved = instr_per_path * r["launch_paths"] / (r["kms"] * 1e-3) / 1e9
+            peak = CUS * SIMDS_PER_CU * clock_ghz / 2.0
+            lane = prof["SQ_THREAD_CYCLES_VALU"] / (64.0 * prof["SQ_ACTIVE_INST_VALU"])
+            build = library_build_id()
+            out.update({"achieved": achieved, "peak": peak, "frac": achieved / peak, "lane_utilisation": lane, "useful_lane_frac": achieved / peak * lane,
+                        "valu_instr_per_path": instr_per_path, "clock_ghz": clock_ghz, "source": prof_name,
+                        # the instruction count belongs to the build the profile was taken from: flagged when that is not the loaded library
+                        "profile_build_id": prof.get("build_id"), "library_build_id": build, "profile_matches_library": prof.get("build_id") == build})
+            if "FETCH_SIZE" in prof and "WRITE_SIZE" in prof:
+                # FETCH_SIZE counts 128-B requests as 64 B on gfx950 (MI355X_MICROARCH.md, HBM section); counters are in KiB
+                out["traffic"] = (2.0 * prof["FETCH_SIZE"] + prof["WRITE_SIZE"]) * 1024.0
+                out["hbm_measured_gbs"] = out["traffic"] / (prof_ms * 1e-3) / 1e9 if prof_ms else None
+            if "SQ_LDS_BANK_CONFLICT" in prof and prof.get("SQ_LDS_IDX_ACTIVE"):
+                out["lds_bank_conflict_share"] = prof["SQ_LDS_BANK_CONFLICT"] / prof["SQ_LDS_IDX_ACTIVE"]
+        # LDS line: the node loop reads 7 x 16 B per node visit (six box planes x 4 children + 4 links) and moves about one 8-B stack
+        # entry in and out per visit; live node visits of the counting launch
+        paths = max(r["dc"][4], 1)
+        lds_bytes = (112.0 + 16.0) * r["dc"][1] if r["nodes_in_lds"] else 16.0 * r["dc"][1]
+        out["lds"] = {"bytes_per_launch": lds_bytes, "achieved": lds_bytes / (r["kms"] * 1e-3) / 1e12, "peak": LDS_PEAK_TBS, "unit": "TB/s",
+                      "frac": lds_bytes / (r["kms"] * 1e-3) / 1e12 / LDS_PEAK_TBS, "per_sample": lds_bytes / paths}
         return out
+
+    def check_image(config, r):
+        """a bench line is only printed for a frame that is the reference's image: exits non-zero on an empty or wrong one"""
+        ref = REFERENCE_IMAGE_MEAN.get(config)
+        if args.stub or r["image_mean"] is None:
+            return None
+        if not all(m == m and m > 0.0 for m in r["image_mean"]):
+            raise SystemExit(f"bench.py: the last frame of {config} is empty or not finite (image mean {r['image_mean']})")
+        if ref and args.tree == "reference":
+            worst = max(abs(a - b) for a, b in zip(r["image_mean"], ref))
+            if worst > IMAGE_MEAN_TOL:
+                raise SystemExit(f"bench.py: image mean of {config} {r['image_mean']} is {worst:.4f} off the reference's {ref} (tolerance {IMAGE_MEAN_TOL})")
+        return {"mean_xyz": r["image_mean"], "reference_mean_xyz": list(ref) if ref else None, "tolerance": IMAGE_MEAN_TOL if ref else None}
 
     scaling = args.scaling or CONFIGS[args.config].get("scaling", "weak")
     main_r = measure(args.config, args.steps, args.warmup, scaling)
@@ -385,7 +485,8 @@ def main():
         # configs[2] (ptdl), the BASELINE configuration furthest from its roofline, timed the same way every run (3 steps)
         sec = measure("cfg3", 3, 1, "weak")
         secondary = {"workload": sec["cfg"]["name"], "value": 3 * sec["job"] / sec["elapsed"] / 1e6, "unit": "Msamples/s", "steps": 3, "warmup": 1,
-                     "ms_per_step": 1e3 * sec["elapsed"] / 3, "scaling": "weak", "roofline": roofline_of("cfg3", sec)}
+                     "ms_per_step": 1e3 * sec["elapsed"] / 3, "scaling": "weak", "roofline": roofline_of("cfg3", sec),
+                     "work_rate_vs_hbm": work_rate_of("cfg3", sec), "image": check_image("cfg3", sec) if rank == 0 else None}
 
     if rank == 0:
         cfg = main_r["cfg"]
@@ -405,19 +506,18 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic: regression/0010_pt scene (6 of 7 shapes, scenes/0010_pt), per-path xorshift128+ seeds",
-            "config": {"workload": cfg["name"], "tree": args.tree, "pointsampler": args.points,
+            "config": {"workload": cfg["name"], "tree": args.tree, "pointsampler": args.points, "traversal": args.traversal,
                        "paths_per_step": main_r["job"], "paths_per_step_per_gpu": main_r["launch_paths"],
                        "sharding": f"path-index ranges x{world} ({scaling}), framebuffer all-reduce + read-back of the last frame in the timed region"},
             # the timed kernel counts paths only; live_work_per_sample comes from one launch of the counting instantiation outside the timed region
             "counters_compiled_in": False,
             "roofline": roofline_of(args.config, main_r),
+            "work_rate_vs_hbm": work_rate_of(args.config, main_r),
         }
         if args.stub:
             out["stub"] = {"reduced_sum_last_frame": main_r["reduced_sum"], "expected": float(main_r["job"])}
         else:
-            rv = roofline_valu_of(main_r) if args.config == "cfg2" else None
-            if rv:
-                out["roofline_valu"] = rv
+            out["image"] = check_image(args.config, main_r)
             if secondary:
                 out["secondary"] = secondary
             if not args.no_cpu_baseline and world == 1 and args.config == "cfg2":

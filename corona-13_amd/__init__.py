@@ -20,7 +20,7 @@ from pathlib import Path
 
 PKG_DIR = Path(__file__).resolve().parent
 REPO_DIR = PKG_DIR.parent
-HOST_LIB = PKG_DIR / "host" / "libcorona_host.so"
+HOST_LIB = Path(os.environ.get("CORONA_HOST_LIB", PKG_DIR / "host" / "libcorona_host.so"))   # override: the sanitizer build (make sanitize)
 MI_LIB = Path(os.environ.get("CORONA_MI_LIB", PKG_DIR / "csrc" / "libcorona_mi.so"))   # override: kernel-variant experiments only
 
 MI_SAMPLER_PT, MI_SAMPLER_PTDL = 0, 1
@@ -296,13 +296,29 @@ def mi_lib():
         m.mi_scene_destroy.restype = None
         m.mi_shutdown.restype = None
         m.mi_last_error.restype = C.c_char_p
+        m.mi_current_device.restype = C.c_int
+        m.mi_group_create.argtypes = [C.POINTER(MiSceneDesc), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
+        m.mi_group_size.argtypes = [C.c_void_p]
+        m.mi_group_scene.argtypes = [C.c_void_p, C.c_int]
+        m.mi_group_scene.restype = C.c_void_p
+        m.mi_group_uses_rccl.argtypes = [C.c_void_p]
+        m.mi_group_render.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+        m.mi_group_fb_reduce.argtypes = [C.c_void_p]
+        m.mi_group_fb_read.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        m.mi_group_fb_clear.argtypes = [C.c_void_p]
+        m.mi_group_sync.argtypes = [C.c_void_p]
+        m.mi_group_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        m.mi_group_destroy.argtypes = [C.c_void_p]
+        m.mi_group_destroy.restype = None
         _mi = m
     return _mi
 
 
 MI_SYMBOLS = ["mi_init", "mi_scene_create", "mi_scene_set_framebuffer", "mi_scene_set_stream", "mi_render",
               "mi_sync", "mi_fb_read", "mi_fb_clear", "mi_fb_device_ptr", "mi_counters", "mi_scene_set_counters", "mi_scene_set_traversal", "mi_trace_paths", "mi_intersect",
-              "mi_last_kernel_ms", "mi_last_kernel_launches", "mi_scene_stats", "mi_scene_destroy", "mi_shutdown", "mi_last_error"]
+              "mi_last_kernel_ms", "mi_last_kernel_launches", "mi_scene_stats", "mi_scene_destroy", "mi_shutdown", "mi_last_error", "mi_current_device",
+              "mi_group_create", "mi_group_size", "mi_group_scene", "mi_group_uses_rccl", "mi_group_render", "mi_group_fb_reduce", "mi_group_fb_read",
+              "mi_group_fb_clear", "mi_group_sync", "mi_group_counters", "mi_group_destroy"]
 
 
 def ray_dtypes():
@@ -426,6 +442,75 @@ class Backend:
     def close(self):
         if self._ptr:
             self.m.mi_scene_destroy(self._ptr)
+            self._ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Group:
+    """Several GPUs of one node behind the C ABI, driven by this one host thread (mi_group_*, corona_mi.h): one copy of the scene per
+    device, path indices split by contiguous ranges, framebuffers added up on member 0 (RCCL ncclReduce over xGMI, or peer copies
+    when a device is named twice). `devices` is a list of device indices."""
+
+    def __init__(self, scene: Scene, devices, traversal: str | None = None, counters: bool = False):
+        self.m = mi_lib()
+        self._ptr = C.c_void_p()
+        arr = (C.c_int * len(devices))(*devices)
+        err = self.m.mi_group_create(scene.desc_ptr, arr, len(devices), C.byref(self._ptr))
+        if err:
+            raise RuntimeError(f"mi_group_create failed ({err}): {self.m.mi_last_error().decode()}")
+        self.scene, self.n = scene, len(devices)
+        for k in range(self.n):
+            member = C.c_void_p(self.m.mi_group_scene(self._ptr, k))
+            if traversal is not None:
+                self._check(self.m.mi_scene_set_traversal(member, {"exact": 0, "fast": 1}[traversal]), "mi_scene_set_traversal")
+            self._check(self.m.mi_scene_set_counters(member, 1 if counters else 0), "mi_scene_set_counters")
+
+    def _check(self, err, what):
+        if err:
+            raise RuntimeError(f"{what} failed ({err}): {self.m.mi_last_error().decode()}")
+
+    def uses_rccl(self):
+        return bool(self.m.mi_group_uses_rccl(self._ptr))
+
+    def render(self, first, count):
+        self._check(self.m.mi_group_render(self._ptr, first, count), "mi_group_render")
+
+    def reduce(self):
+        self._check(self.m.mi_group_fb_reduce(self._ptr), "mi_group_fb_reduce")
+
+    def sync(self):
+        self._check(self.m.mi_group_sync(self._ptr), "mi_group_sync")
+
+    def fb_clear(self):
+        self._check(self.m.mi_group_fb_clear(self._ptr), "mi_group_fb_clear")
+
+    def fb_read(self, accumulate_into=None):
+        import numpy as np
+        if accumulate_into is None:
+            out = np.zeros((self.scene.height, self.scene.width, 3), dtype=np.float32)
+            self._check(self.m.mi_group_fb_read(self._ptr, out.ctypes.data, 0), "mi_group_fb_read")
+            return out
+        self._check(self.m.mi_group_fb_read(self._ptr, accumulate_into.ctypes.data, 1), "mi_group_fb_read")
+        return accumulate_into
+
+    def counters(self):
+        arr = (C.c_uint64 * 8)()
+        self._check(self.m.mi_group_counters(self._ptr, arr), "mi_group_counters")
+        return list(arr)
+
+    def member_kernel_ms(self, k):
+        ms = C.c_float()
+        self._check(self.m.mi_last_kernel_ms(C.c_void_p(self.m.mi_group_scene(self._ptr, k)), C.byref(ms)), "mi_last_kernel_ms")
+        return ms.value
+
+    def close(self):
+        if self._ptr:
+            self.m.mi_group_destroy(self._ptr)
             self._ptr = C.c_void_p()
 
     def __del__(self):

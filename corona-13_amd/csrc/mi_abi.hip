@@ -13,6 +13,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unordered_map>
 #include <vector>
 
 /* ======================================================================================= upload-time kernels */
@@ -90,6 +91,8 @@ struct mi_scene
   void *d_nodes, *d_axes, *d_prims, *d_primgeo, *d_materials, *d_light_prim, *d_light_cdf, *d_light_L;
   void *d_cie, *d_checker, *d_metal, *d_counters, *d_shape_material, *d_shape_L, *d_overflow;
   float *d_fb_own, *d_fb;
+  float *h_stage;                   /* pinned staging buffer of mi_fb_read(accumulate), with the events of its two chunks in flight */
+  hipEvent_t ev_stage[2];
   hipStream_t stream_own, stream;
   hipEvent_t ev0, ev1;
   int have_timing;
@@ -140,15 +143,18 @@ static const void *path_kernel(bool ptdl, bool media, bool mb, bool fast, unsign
 }
 
 extern "C" const char *mi_last_error(void) { return g_err; }
+extern "C" int mi_current_device(void) { return g_device; }
 
 extern "C" int mi_init(int device)
 {
   int n = 0;
   if(hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(MI_ERR_DEVICE, "no HIP device visible");
   if(device < 0)
-  {
+  { /* implicit choice: LOCAL_RANK of a one-process-per-GPU launcher -- unless the launcher already narrowed this process down to one
+       visible GPU (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per rank), where LOCAL_RANK > 0 does not name a device */
     const char *lr = getenv("LOCAL_RANK");
     device = lr ? atoi(lr) : 0;
+    if(device >= n && n == 1) device = 0;
   }
   if(device >= n) return fail(MI_ERR_ARG, "mi_init: no such device (one process per GPU: pass LOCAL_RANK, not a global rank)");
   HIPCHK(hipSetDevice(device));
@@ -321,12 +327,19 @@ static int build_on_device(mi_scene *s, const mi_scene_desc *h, uint32_t *num_no
   return MI_OK;
 }
 
+static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out);
+
 extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
+{ /* on the device mi_init chose for this process (one process per GPU); mi_group_create places scenes on devices by index */
+  if(g_device < 0) { const int e = mi_init(-1); if(e) return e; }
+  return scene_create_on(h, g_device, out);
+}
+
+static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
 {
   if(!h || !out) return fail(MI_ERR_ARG, "mi_scene_create: null argument");
   if(h->struct_size != sizeof(mi_scene_desc) || h->abi_version != MI_ABI_VERSION)
     return fail(MI_ERR_ARG, "mi_scene_create: mi_scene_desc size/version mismatch");
-  if(g_device < 0) { const int e = mi_init(-1); if(e) return e; }
   if(!h->width || !h->height || (h->width & 31) || (h->height & 31)) return fail(MI_ERR_ARG, "film size must be a non-zero multiple of 32");
   if(h->max_verts < 2 || h->max_verts > 32) return fail(MI_ERR_ARG, "max_verts must be in [2,32]");
   if(h->sampler != MI_SAMPLER_PT && h->sampler != MI_SAMPLER_PTDL) return fail(MI_ERR_ARG, "unknown sampler");
@@ -349,7 +362,7 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   mi_scene *s = (mi_scene *)calloc(1, sizeof(mi_scene));
   if(!s) return fail(MI_ERR_NOMEM, "out of host memory");
   s->width = h->width; s->height = h->height;
-  s->device = g_device;
+  s->device = device;
   if(hipSetDevice(s->device) != hipSuccess) { free(s); return fail(MI_ERR_DEVICE, "cannot select the device"); }   /* mi_init may have run on another thread */
   DScene &d = s->d;
   d.width = h->width; d.height = h->height; d.max_verts = h->max_verts; d.sampler = h->sampler; d.frame = h->frame;
@@ -365,6 +378,7 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
   uint32_t N = device_build ? 0 : h->num_nodes;
   std::vector<float> nodes((size_t)MI_NODE_FIELDS*N*4);
   std::vector<uint32_t> axes(N);
+  std::vector<bool> in_leaf(device_build ? 0 : (size_t)h->num_prims, false);
   for(uint32_t n=0;n<N;n++)
   {
     const mi_node &nd = h->nodes[n];
@@ -384,6 +398,11 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
       {
         const uint64_t first = (nd.child[c] ^ MI_NODE_LEAF) >> 5, cntp = nd.child[c] & 31;
         if(first + cntp > h->num_prims) { free(s); return fail(MI_ERR_ARG, "a leaf of the tree points outside the primitive list"); }
+        for(uint64_t q=first;q<first+cntp;q++)
+        { /* leaves are disjoint ranges of the primitive list: the leaf-order pass (mi_mark_ordered_kernel) rewrites records leaf by leaf */
+          if(in_leaf[q]) { free(s); return fail(MI_ERR_ARG, "two leaves of the tree share a primitive"); }
+          in_leaf[q] = true;
+        }
         link = MI_LEAF32 | (uint32_t)(first << 5) | (uint32_t)cntp;
       }
       else link = (uint32_t)nd.child[c];
@@ -546,14 +565,19 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
     const uint32_t sid = MI_PRIMID_SHAPE(h->lights.primid[k]);
     if(sid < h->num_shapes && shape_L[sid] == 0.0f) shape_L[sid] = h->lights.L[k];   /* lights_pdf_next_event: L of the shape */
   }
-  /* emitters: original primid -> builder-order index */
+  /* emitters: original primid -> builder-order index (one hash map over the primitive list: O(P + L), not O(P L)) */
   std::vector<uint32_t> lprim(h->lights.num_prims ? h->lights.num_prims : 1);
-  for(uint32_t k=0;k<h->lights.num_prims;k++)
+  if(h->lights.num_prims)
   {
-    uint32_t found = MI_NOPRIM;
-    for(uint64_t i=0;i<h->num_prims;i++) if(h->primid[i] == h->lights.primid[k]) { found = (uint32_t)i; break; }
-    if(found == MI_NOPRIM) { free(s); return fail(MI_ERR_ARG, "emitter primitive not in the primitive list"); }
-    lprim[k] = found;
+    std::unordered_map<uint64_t, uint32_t> where;
+    where.reserve((size_t)h->num_prims*2);
+    for(uint64_t i=0;i<h->num_prims;i++) where.emplace((uint64_t)h->primid[i], (uint32_t)i);      /* the first occurrence wins, like the scan it replaces */
+    for(uint32_t k=0;k<h->lights.num_prims;k++)
+    {
+      const auto it = where.find((uint64_t)h->lights.primid[k]);
+      if(it == where.end()) { free(s); return fail(MI_ERR_ARG, "emitter primitive not in the primitive list"); }
+      lprim[k] = it->second;
+    }
   }
 
   /* any-hit shadow rays (MI_LIGHT_ANYHIT, mi_device.h): emitter primitives a connection ray cannot cross inside the connection */
@@ -654,8 +678,11 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
       L.prim = cur[k];
       L.type = p.type;
     }
-    if(fast) { if(!e) e = upload(&s->d_lights, lights.data(), lights.size()); }
-    else s->media = true;                               /* the extended kernels keep the generic emitter code */
+    if(h->sampler == MI_SAMPLER_PTDL)
+    { /* only next event estimation reads emitter records: a pt scene stays with the plain kernels whatever its emitters are */
+      if(fast) { if(!e) e = upload(&s->d_lights, lights.data(), lights.size()); }
+      else s->media = true;                             /* the extended kernels keep the generic emitter code */
+    }
   }
   if(!e)
   {
@@ -710,7 +737,7 @@ extern "C" int mi_scene_create(const mi_scene_desc *h, mi_scene **out)
      read from HBM / L2 by the NODES_LDS = false instantiations (CORONA_MI_NODES=global forces that, for tests) */
   const char *nodes_env = getenv("CORONA_MI_NODES");
   const size_t halton_bytes = h->pointsampler == MI_POINTS_HALTON ? (size_t)2*MI_HALTON_LDS : 0;     /* staged head of the permutation tables */
-  const size_t lights_bytes = h->sampler == MI_SAMPLER_PTDL ? (size_t)MI_LIGHTS_LDS*sizeof(DLight) : 0;  /* ptdl: emitter records in LDS */
+  const size_t lights_bytes = (s->d_lights && !s->media) ? (size_t)MI_LIGHTS_LDS*sizeof(DLight) : 0;  /* plain ptdl kernels: emitter records in LDS */
   s->nodes_lds = halton_bytes + lights_bytes + node_bytes + stack_bytes <= 160*1024 && !(nodes_env && !strcmp(nodes_env, "global"));
   s->lds_bytes = halton_bytes + lights_bytes + (s->nodes_lds ? node_bytes : 0) + stack_bytes;
   s->device_built = device_build; s->stack_need = stack_need;
@@ -855,9 +882,31 @@ extern "C" int mi_fb_read(mi_scene *s, float *host_fb, int accumulate)
   const size_t n = 3*(size_t)s->width*s->height;
   HIPCHK(hipStreamSynchronize(s->stream));
   if(!accumulate) { HIPCHK(hipMemcpy(host_fb, s->d_fb, n*sizeof(float), hipMemcpyDeviceToHost)); return MI_OK; }
-  std::vector<float> tmp(n);
-  HIPCHK(hipMemcpy(tmp.data(), s->d_fb, n*sizeof(float), hipMemcpyDeviceToHost));
-  for(size_t i=0;i<n;i++) host_fb[i] += tmp[i];
+  /* accumulate: through a pinned staging buffer of the scene (kept for the next call) in 16 MB chunks -- the add of chunk k (a plain
+     loop over contiguous floats, which the compiler vectorises) runs while chunk k+1 is in flight */
+  if(!s->h_stage)
+  {
+    HIPCHK(hipHostMalloc((void **)&s->h_stage, n*sizeof(float), hipHostMallocDefault));
+    HIPCHK(hipEventCreateWithFlags(&s->ev_stage[0], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&s->ev_stage[1], hipEventDisableTiming));
+  }
+  const size_t chunk = (size_t)1 << 22, nchunks = (n + chunk - 1)/chunk;
+  auto issue = [&](size_t k) -> hipError_t
+  {
+    const size_t off = k*chunk, c = n - off < chunk ? n - off : chunk;
+    hipError_t e = hipMemcpyAsync(s->h_stage + off, s->d_fb + off, c*sizeof(float), hipMemcpyDeviceToHost, s->stream);
+    return e != hipSuccess ? e : hipEventRecord(s->ev_stage[k & 1], s->stream);
+  };
+  HIPCHK(issue(0));
+  for(size_t k=0;k<nchunks;k++)
+  {
+    if(k + 1 < nchunks) HIPCHK(issue(k + 1));
+    HIPCHK(hipEventSynchronize(s->ev_stage[k & 1]));
+    const size_t off = k*chunk, c = n - off < chunk ? n - off : chunk;
+    float *__restrict dst = host_fb + off;
+    const float *__restrict src = s->h_stage + off;
+    for(size_t i=0;i<c;i++) dst[i] += src[i];
+  }
   return MI_OK;
 }
 
@@ -976,11 +1025,228 @@ extern "C" void mi_scene_destroy(mi_scene *s)
                    s->d_cie, s->d_checker, s->d_metal, s->d_counters, s->d_shape_material, s->d_shape_L, s->d_overflow, s->d_fb_own,
                    s->d_halton_dim, s->d_halton_perm, s->d_shape_medium, s->d_prims_t1, s->d_lights };
   delete s->halton_tables;
+  if(s->h_stage) { (void)hipHostFree(s->h_stage); (void)hipEventDestroy(s->ev_stage[0]); (void)hipEventDestroy(s->ev_stage[1]); }
   for(void *b : bufs) if(b) (void)hipFree(b);
   if(s->stream_own) (void)hipStreamDestroy(s->stream_own);
   if(s->ev0) (void)hipEventDestroy(s->ev0);
   if(s->ev1) (void)hipEventDestroy(s->ev1);
   free(s);
+}
+
+
+/* ======================================================================================= several GPUs behind the C ABI
+ * mi_group: one scene per device, driven by ONE host thread -- what the reference's view_render does with its pthread pool
+ * (src/view.c:630-695: hand the progression's path indices to the workers, wait, the framebuffer is shared) for the GPUs of a node.
+ * Paths are independent, so member k renders its contiguous share of [first, first + count) (the same split as
+ * shard_range of the Python view / bench.py) into its own device framebuffer; mi_group_fb_reduce then adds the members'
+ * framebuffers into member 0's: ncclReduce(ncclFloat, ncclSum, root 0) over xGMI when the devices are distinct and RCCL can be
+ * loaded (dlopen: the library does not link against it), else peer copies into a buffer on the root's device and an add kernel
+ * there (also the path of a group with a device named twice: tests on a one-GPU box). */
+#include <dlfcn.h>
+
+__global__ void mi_fb_add_kernel(float *__restrict dst, const float *__restrict src, size_t n)
+{
+  for(size_t i=(size_t)blockIdx.x*blockDim.x + threadIdx.x; i<n; i+=(size_t)gridDim.x*blockDim.x) dst[i] += src[i];
+}
+
+struct mi_rccl
+{ /* the five entry points of librccl used here (rccl.h: ncclCommInitAll :236, ncclCommDestroy :260, ncclReduce :550, ncclGroupStart/End :923) */
+  void *lib;
+  int (*CommInitAll)(void **comm, int ndev, const int *devlist);
+  int (*CommDestroy)(void *comm);
+  int (*Reduce)(const void *send, void *recv, size_t count, int datatype, int op, int root, void *comm, hipStream_t stream);
+  int (*GroupStart)(void);
+  int (*GroupEnd)(void);
+  const char *(*GetErrorString)(int);
+};
+
+struct mi_group
+{
+  int n;
+  mi_scene **member;
+  void **comm;                /* RCCL communicators, one per member, or NULL: peer-copy reduce */
+  mi_rccl rccl;
+  float *d_stage;             /* peer-copy reduce: one framebuffer on the root's device */
+  hipEvent_t *rendered;       /* per member: its last render is complete */
+  size_t fb_floats;
+};
+
+static bool rccl_load(mi_rccl *r)
+{
+  memset(r, 0, sizeof(*r));
+  const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+  for(const char *nm : names) if((r->lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break;
+  if(!r->lib) return false;
+  r->CommInitAll = (int (*)(void **, int, const int *))dlsym(r->lib, "ncclCommInitAll");
+  r->CommDestroy = (int (*)(void *))dlsym(r->lib, "ncclCommDestroy");
+  r->Reduce = (int (*)(const void *, void *, size_t, int, int, int, void *, hipStream_t))dlsym(r->lib, "ncclReduce");
+  r->GroupStart = (int (*)(void))dlsym(r->lib, "ncclGroupStart");
+  r->GroupEnd = (int (*)(void))dlsym(r->lib, "ncclGroupEnd");
+  r->GetErrorString = (const char *(*)(int))dlsym(r->lib, "ncclGetErrorString");
+  if(r->CommInitAll && r->CommDestroy && r->Reduce && r->GroupStart && r->GroupEnd) return true;
+  dlclose(r->lib); r->lib = nullptr;
+  return false;
+}
+
+extern "C" void mi_group_destroy(mi_group *g)
+{
+  if(!g) return;
+  for(int k=0;k<g->n;k++)
+  {
+    if(g->comm && g->comm[k]) { (void)hipSetDevice(g->member[k]->device); (void)g->rccl.CommDestroy(g->comm[k]); }
+    if(g->rendered && g->rendered[k]) { (void)hipSetDevice(g->member[k]->device); (void)hipEventDestroy(g->rendered[k]); }
+  }
+  if(g->d_stage) { (void)hipSetDevice(g->member[0]->device); (void)hipFree(g->d_stage); }
+  for(int k=0;k<g->n;k++) if(g->member && g->member[k]) mi_scene_destroy(g->member[k]);
+  if(g->rccl.lib) dlclose(g->rccl.lib);
+  free(g->member); free(g->comm); free(g->rendered);
+  free(g);
+}
+
+extern "C" int mi_group_create(const mi_scene_desc *desc, const int *devices, int n, mi_group **out)
+{
+  if(!desc || !out || n < 1 || n > 64) return fail(MI_ERR_ARG, "mi_group_create: bad argument");
+  int visible = 0;
+  if(hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) return fail(MI_ERR_DEVICE, "no HIP device visible");
+  mi_group *g = (mi_group *)calloc(1, sizeof(mi_group));
+  if(!g) return fail(MI_ERR_NOMEM, "out of host memory");
+  g->n = n;
+  g->member = (mi_scene **)calloc(n, sizeof(mi_scene *));
+  g->rendered = (hipEvent_t *)calloc(n, sizeof(hipEvent_t));
+  if(!g->member || !g->rendered) { mi_group_destroy(g); return fail(MI_ERR_NOMEM, "out of host memory"); }
+  bool distinct = true;
+  for(int k=0;k<n;k++)
+  {
+    const int dev = devices ? devices[k] : k;                         /* NULL: devices 0 .. n-1 */
+    if(dev < 0 || dev >= visible) { mi_group_destroy(g); return fail(MI_ERR_ARG, "mi_group_create: no such device"); }
+    for(int j=0;j<k;j++) if(g->member[j]->device == dev) distinct = false;
+    const int e = scene_create_on(desc, dev, &g->member[k]);
+    if(e) { mi_group_destroy(g); return e; }
+    if(hipSetDevice(dev) != hipSuccess || hipEventCreateWithFlags(&g->rendered[k], hipEventDisableTiming) != hipSuccess)
+    { mi_group_destroy(g); return fail(MI_ERR_DEVICE, "mi_group_create: cannot create an event"); }
+  }
+  g->fb_floats = 3*(size_t)desc->width*desc->height;
+  /* the reduce: RCCL when the members sit on distinct devices (CORONA_MI_GROUP_REDUCE=peer forces the copies; =rccl insists) */
+  const char *mode = getenv("CORONA_MI_GROUP_REDUCE");
+  const bool want_rccl = mode ? !strcmp(mode, "rccl") : n > 1;
+  if(want_rccl && distinct && rccl_load(&g->rccl))
+  {
+    g->comm = (void **)calloc(n, sizeof(void *));
+    std::vector<int> devs(n);
+    for(int k=0;k<n;k++) devs[k] = g->member[k]->device;
+    const int r = g->comm ? g->rccl.CommInitAll(g->comm, n, devs.data()) : 1;
+    if(r != 0)
+    {
+      fprintf(stderr, "[mi] mi_group_create: ncclCommInitAll failed (%s), using peer copies\n", g->rccl.GetErrorString ? g->rccl.GetErrorString(r) : "?");
+      free(g->comm); g->comm = nullptr;
+    }
+  }
+  else if(mode && !strcmp(mode, "rccl")) { mi_group_destroy(g); return fail(MI_ERR_UNSUPPORTED, "mi_group_create: RCCL reduce asked for, but the devices are not distinct or librccl cannot be loaded"); }
+  if(!g->comm && n > 1)
+  {
+    if(hipSetDevice(g->member[0]->device) != hipSuccess || hipMalloc((void **)&g->d_stage, g->fb_floats*sizeof(float)) != hipSuccess)
+    { mi_group_destroy(g); return fail(MI_ERR_NOMEM, "mi_group_create: cannot allocate the staging framebuffer"); }
+    for(int k=1;k<n;k++) if(g->member[k]->device != g->member[0]->device)
+    { /* peer access where the hardware offers it; hipMemcpyPeerAsync works without it (through the host) */
+      int can = 0;
+      if(hipDeviceCanAccessPeer(&can, g->member[0]->device, g->member[k]->device) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(g->member[k]->device, 0);
+      (void)hipGetLastError();
+    }
+  }
+  *out = g;
+  return MI_OK;
+}
+
+extern "C" int mi_group_size(mi_group *g) { return g ? g->n : 0; }
+extern "C" mi_scene *mi_group_scene(mi_group *g, int k) { return (g && k >= 0 && k < g->n) ? g->member[k] : nullptr; }
+extern "C" int mi_group_uses_rccl(mi_group *g) { return g && g->comm ? 1 : 0; }
+
+extern "C" int mi_group_render(mi_group *g, uint64_t first_index, uint64_t count)
+{ /* member k takes the k-th contiguous share of the range (remainder indices to the lowest members); returns once everything is queued */
+  if(!g) return fail(MI_ERR_ARG, "null group");
+  const uint64_t base = count/(uint64_t)g->n, rem = count%(uint64_t)g->n;
+  for(int k=0;k<g->n;k++)
+  {
+    const uint64_t my = base + ((uint64_t)k < rem ? 1 : 0);
+    const uint64_t start = first_index + (uint64_t)k*base + ((uint64_t)k < rem ? (uint64_t)k : rem);
+    const int e = mi_render(g->member[k], start, my);
+    if(e) return e;
+    HIPCHK(hipEventRecord(g->rendered[k], g->member[k]->stream));
+  }
+  return MI_OK;
+}
+
+extern "C" int mi_group_fb_reduce(mi_group *g)
+{ /* member 0's framebuffer += the others', which are cleared: afterwards the root holds everything rendered so far */
+  if(!g) return fail(MI_ERR_ARG, "null group");
+  if(g->n == 1) return MI_OK;
+  mi_scene *root = g->member[0];
+  if(g->comm)
+  {
+    int r = g->rccl.GroupStart();
+    for(int k=0;k<g->n && r == 0;k++)
+    {
+      HIPCHK(hipSetDevice(g->member[k]->device));
+      r = g->rccl.Reduce(g->member[k]->d_fb, g->member[k]->d_fb, g->fb_floats, 7 /* ncclFloat32 */, 0 /* ncclSum */, 0, g->comm[k], g->member[k]->stream);
+    }
+    const int r2 = g->rccl.GroupEnd();
+    if(r != 0 || r2 != 0) return fail(MI_ERR_DEVICE, "mi_group_fb_reduce: ncclReduce failed");
+  }
+  else
+  {
+    HIPCHK(hipSetDevice(root->device));
+    for(int k=1;k<g->n;k++)
+    {
+      HIPCHK(hipStreamWaitEvent(root->stream, g->rendered[k], 0));
+      HIPCHK(hipMemcpyPeerAsync(g->d_stage, root->device, g->member[k]->d_fb, g->member[k]->device, g->fb_floats*sizeof(float), root->stream));
+      hipLaunchKernelGGL(mi_fb_add_kernel, dim3(2048), dim3(256), 0, root->stream, root->d_fb, (const float *)g->d_stage, g->fb_floats);
+      HIPCHK(hipGetLastError());
+    }
+    /* the members' buffers may be cleared once the root has read them */
+    hipEvent_t done = g->rendered[0];
+    HIPCHK(hipEventRecord(done, root->stream));
+    for(int k=1;k<g->n;k++) { HIPCHK(hipSetDevice(g->member[k]->device)); HIPCHK(hipStreamWaitEvent(g->member[k]->stream, done, 0)); }
+  }
+  for(int k=1;k<g->n;k++) { const int e = mi_fb_clear(g->member[k]); if(e) return e; }
+  return MI_OK;
+}
+
+extern "C" int mi_group_sync(mi_group *g)
+{
+  if(!g) return fail(MI_ERR_ARG, "null group");
+  for(int k=0;k<g->n;k++) { const int e = mi_sync(g->member[k]); if(e) return e; }
+  return MI_OK;
+}
+
+extern "C" int mi_group_fb_clear(mi_group *g)
+{
+  if(!g) return fail(MI_ERR_ARG, "null group");
+  for(int k=0;k<g->n;k++) { const int e = mi_fb_clear(g->member[k]); if(e) return e; }
+  return MI_OK;
+}
+
+extern "C" int mi_group_fb_read(mi_group *g, float *host_fb, int accumulate)
+{ /* reduce, then the root's framebuffer to the host (copy or add, like mi_fb_read) */
+  if(!g) return fail(MI_ERR_ARG, "null group");
+  int e = mi_group_fb_reduce(g);
+  if(!e) e = mi_group_sync(g);
+  if(!e) e = mi_fb_read(g->member[0], host_fb, accumulate);
+  return e;
+}
+
+extern "C" int mi_group_counters(mi_group *g, uint64_t out[8])
+{ /* sums over the members (slot 7, the deepest stack, is their maximum) */
+  if(!g || !out) return fail(MI_ERR_ARG, "null argument");
+  for(int i=0;i<8;i++) out[i] = 0;
+  for(int k=0;k<g->n;k++)
+  {
+    uint64_t c[8];
+    const int e = mi_counters(g->member[k], c);
+    if(e) return e;
+    for(int i=0;i<7;i++) out[i] += c[i];
+    if(c[7] > out[7]) out[7] = c[7];
+  }
+  return MI_OK;
 }
 
 extern "C" void mi_shutdown(void) { g_device = -1; }

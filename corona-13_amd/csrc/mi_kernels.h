@@ -963,24 +963,46 @@ struct RayBox
   uint32_t nearbits, offx, offy, offz;   /* sign bits of the direction; near-plane field of each axis: max planes (fields 3..5) for negative directions */
   float idx, idy, idz;
   bool slow;                             /* a lane of the wave has an infinite 1/dir: literal SSE-semantics slab test for the whole wave */
+  /* FMA slabs (FAST rounds only, MI_SPEC_FMA): -o/d per axis, and the absolute part of the slack of the box test */
+  float nox, noy, noz, slack;
 };
-__device__ __forceinline__ RayBox raybox_setup(const V3 d, const TraceState &ts, uint32_t N)
+#ifndef MI_SPEC_FMA
+#define MI_SPEC_FMA 1
+#endif
+#define MI_FMA_REL 1.0000019073486328125f     /* 1 + 2^-19: relative part of the slack (16 x the 2^-24 unit roundoff both sides can be off by) */
+template<bool FMA = false>
+__device__ __forceinline__ RayBox raybox_setup(const V3 o, const V3 d, const TraceState &ts, uint32_t N)
 {
   RayBox rb;
   const uint32_t near_x = __float_as_uint(d.x) >> 31, near_y = __float_as_uint(d.y) >> 31, near_z = __float_as_uint(d.z) >> 31;
   rb.nearbits = near_x | (near_y << 1) | (near_z << 2);
   rb.idx = ts.idx; rb.idy = ts.idy; rb.idz = ts.idz;
   rb.offx = near_x ? 3u*N : 0u; rb.offy = near_y ? 3u*N : 0u; rb.offz = near_z ? 3u*N : 0u;
-  rb.slow = __any(isinf(rb.idx) || isinf(rb.idy) || isinf(rb.idz));
+  if(FMA)
+  { /* huge 1/dir (a component of the direction below 1e-30) go the literal way too: plane/d - o/d may be inf - inf there */
+    rb.slow = __any(!(fabsf(rb.idx) < 1e30f) || !(fabsf(rb.idy) < 1e30f) || !(fabsf(rb.idz) < 1e30f));
+    const float ox = o.x*rb.idx, oy = o.y*rb.idy, oz = o.z*rb.idz;
+    rb.nox = -ox; rb.noy = -oy; rb.noz = -oz;
+    rb.slack = 4.76837158203125e-07f*fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz));     /* 2^-21 max |o/d| */
+  }
+  else
+  {
+    rb.slow = __any(isinf(rb.idx) || isinf(rb.idy) || isinf(rb.idz));
+    rb.nox = rb.noy = rb.noz = rb.slack = 0.0f;
+  }
   return rb;
 }
 
 /* one inner node of accel_intersect (src/accel.d/qbvhmp.c:1188-1246,1313-1354): the four child boxes against the ray clipped to
  * `dist`, front-to-back order from split axes and ray signs; the nearest hit child becomes `current`, the others are pushed
  * far-first. Returns false if no child is hit (the caller pops). */
-template<int BLOCK, int STACK, class CNT>
+template<int BLOCK, int STACK, bool FMA = false, class CNT>
 __device__ __forceinline__ bool node_visit(const Lds &lds, lds_uint2 *lstack, const RayBox &rb, const V3 o, float dist, uint32_t &current, int &sp, CNT &cnt)
-{
+{ /* FMA (FAST rounds): a plane's distance as fma(plane, 1/d, -o/d) instead of (plane - o)*(1/d) -- one instruction instead of two,
+     24 fewer per visit. The two differ by at most 2^-24 (3 |t| + |o/d|) (one rounding of o/d up front instead of one of the
+     difference), so the box counts as hit when lo <= hi (1 + 2^-19) + 2^-21 max|o/d|: every box the reference's test passes passes
+     here (and a few more: counted work, not results), and the entry distances pushed with the subtrees are compared with the same
+     slack when they are popped (cull_distance). */
   const uint32_t N = lds.num_nodes;
   const uint32_t nearbits = rb.nearbits, offx = rb.offx, offy = rb.offy, offz = rb.offz;
   const float idx = rb.idx, idy = rb.idy, idz = rb.idz;
@@ -990,7 +1012,19 @@ __device__ __forceinline__ bool node_visit(const Lds &lds, lds_uint2 *lstack, co
   const uint4 child = *(const uint4 *)&lds.nodes[6*N + node];
   float tm0, tm1, tm2, tm3;
   mi_u64 M0, M1, M2, M3;    /* child c is hit: lane masks (the compares' own results) in scalar registers, combined by scalar instructions below */
-  if(!slow)
+  if(FMA && !slow)
+  {
+    const float4 nx = lds.nodes[offx + node],       fx = lds.nodes[3*N - offx + node];
+    const float4 ny = lds.nodes[N + offy + node],   fy = lds.nodes[4*N - offy + node];
+    const float4 nz = lds.nodes[2*N + offz + node], fz = lds.nodes[5*N - offz + node];
+#define SLAB(J, C, TM) { \
+    const float lo = fmaxf(fmaxf(fmaxf(__builtin_fmaf(nx.C, idx, rb.nox), __builtin_fmaf(ny.C, idy, rb.noy)), __builtin_fmaf(nz.C, idz, rb.noz)), 0.0f); \
+    const float hi = fminf(fminf(fminf(__builtin_fmaf(fx.C, idx, rb.nox), __builtin_fmaf(fy.C, idy, rb.noy)), __builtin_fmaf(fz.C, idz, rb.noz)), dist); \
+    TM = lo; J = __ballot(lo <= __builtin_fmaf(hi, MI_FMA_REL, rb.slack)); }
+    SLAB(M0, x, tm0) SLAB(M1, y, tm1) SLAB(M2, z, tm2) SLAB(M3, w, tm3)
+#undef SLAB
+  }
+  else if(!slow)
   { /* 4 child slabs, qbvhmp.c:1188-1246. The ray's sign bits pick the entry / exit plane of every slab, which is what
        the reference's min(t0,t1) / max(t0,t1) evaluate to for finite 1/dir and b_min <= b_max (rounding is monotonic;
        empty children are uploaded as [-FLT_MAX, FLT_MAX], see upload_nodes). That leaves v_max3/v_min3 chains
@@ -1085,7 +1119,7 @@ template<int BLOCK, int STACK, bool MB = false, bool ANYHIT = false, bool JOBS =
 __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, const V3 o, const V3 d, uint32_t ignore,
                                             Hit &hit, TraceState &ts, CNT &cnt)
 {
-  const RayBox rb = raybox_setup(d, ts, lds.num_nodes);
+  const RayBox rb = raybox_setup<false>(o, d, ts, lds.num_nodes);
   int sp = ts.sp;
   uint32_t current = ts.done ? MI_LEAF32 : ts.current;
   bool done = ts.done;
@@ -1147,6 +1181,9 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
 #ifndef MI_SPEC_BLOCKED
 #define MI_SPEC_BLOCKED 16    /* the node loop of a round ends once this many lanes hold a leaf they can no longer put aside */
 #endif
+#ifndef MI_SPEC_ANYHIT_WAITS
+#define MI_SPEC_ANYHIT_WAITS 0   /* A/B: a shadow ray that may stop at its first occluder does not run ahead of its leaves */
+#endif
 #define MI_SPEC_JOBS_MAX 512  /* job list entries per wave (one byte each: owner lane | slot << 6) */
 
 template<int BLOCK, int STACK>
@@ -1168,8 +1205,14 @@ __device__ __forceinline__ void trace_round_spec(const Lds &lds, const DPrim *pr
 { /* call from ALL lanes of the wave; busy = this lane has a ray under way */
   constexpr int K = MI_SPEC_K;
   static_assert(K >= 1 && K <= 3, "slots are two bits of a job byte");
+  constexpr bool FMA = MI_SPEC_FMA != 0;
   const unsigned lane = __lane_id();
-  const RayBox rb = raybox_setup(d, ts, lds.num_nodes);
+  const RayBox rb = raybox_setup<FMA>(o, d, ts, lds.num_nodes);
+  /* what a popped subtree's entry distance is compared with: the closest hit so far, with the slack of the FMA box test */
+  /* (a lane whose own ray is degenerate only ever takes part in literal rounds: its entries carry the literal test's distances and
+     are compared as the reference compares them; any other lane's entries may come from FMA rounds and always get the slack) */
+  const bool own_literal = !FMA || !(fabsf(rb.idx) < 1e30f) || !(fabsf(rb.idy) < 1e30f) || !(fabsf(rb.idz) < 1e30f);
+#define MI_CULL_DIST (own_literal ? hit.dist : __builtin_fmaf(hit.dist, MI_FMA_REL, rb.slack))
   lds_uint2 *lstack = (lds_uint2 *)lds.stack;
   int sp = ts.sp;
   bool done = ts.done || !busy;
@@ -1185,7 +1228,7 @@ __device__ __forceinline__ void trace_round_spec(const Lds &lds, const DPrim *pr
     /* room to put it aside (an empty leaf needs none). Not in a wave with a degenerate ray (1/dir infinite): there the box tests
        can yield NaN, the reference's verdict then depends on the distance it happened to know (SSE operand order), and "tested
        against a longer distance = superset" no longer holds -- such waves wait with their leaves like the exact rounds do */
-    const bool advance = leaf && (!(current & 31u) || (!rb.slow && lf[K-1] == 0u));
+    const bool advance = leaf && (!(current & 31u) || (!rb.slow && lf[K-1] == 0u && !(ANYHIT && MI_SPEC_ANYHIT_WAITS && ts.anyhit)));
     const mi_u64 mmove = __ballot(inner || advance);
     if(!mmove) break;
     const mi_u64 mwait = __ballot(leaf && !advance);
@@ -1195,7 +1238,7 @@ __device__ __forceinline__ void trace_round_spec(const Lds &lds, const DPrim *pr
     { const unsigned nround = __popcll(__ballot(!done)); if(lane == 0) cnt.c[8] += MI_PROFILE_LOOPS == 2 ? nround : 1; }
 #endif
     bool pop = false;
-    if(inner) pop = !node_visit<BLOCK, STACK>(lds, lstack, rb, o, hit.dist, current, sp, cnt);
+    if(inner) pop = !node_visit<BLOCK, STACK, FMA>(lds, lstack, rb, o, hit.dist, current, sp, cnt);
     else if(advance)
     {
       if(current & 31u)
@@ -1205,7 +1248,7 @@ __device__ __forceinline__ void trace_round_spec(const Lds &lds, const DPrim *pr
       }
       pop = true;
     }
-    if(pop) stack_pop<BLOCK, STACK>(lds, lstack, hit.dist, sp, current, done);
+    if(pop) stack_pop<BLOCK, STACK>(lds, lstack, MI_CULL_DIST, sp, current, done);
   }
   MI_TT(cnt, 0)
   /* -------- leaf phase: the (lane, slot, primitive) tests of all put-aside leaves dealt out over the 64 lanes */
@@ -1323,7 +1366,8 @@ __device__ __forceinline__ void trace_round_spec(const Lds &lds, const DPrim *pr
       }
     }
     if(ANYHIT && ts.anyhit && hit.prim != MI_NOPRIM && !done) { sp = 0; current = MI_LEAF32; done = true; }   /* an occluder is all such a shadow ray needs */
-    else if(holds) stack_pop<BLOCK, STACK>(lds, lstack, hit.dist, sp, current, done);
+    else if(holds) stack_pop<BLOCK, STACK>(lds, lstack, MI_CULL_DIST, sp, current, done);
+#undef MI_CULL_DIST
     MI_TT(cnt, 3)
   }
   if(busy) { ts.sp = sp; ts.current = current; ts.done = done; }

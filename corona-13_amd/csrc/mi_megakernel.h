@@ -40,6 +40,12 @@
 #ifndef MI_PARK_TRACE
 #define MI_PARK_TRACE 1   /* the tail lanes' traversal state waits in LDS while the others shade (kernels with a distributed leaf phase) */
 #endif
+#ifndef MI_PARK_PATH
+#define MI_PARK_PATH 2    /* FAST kernels (1: ptdl only): part of the path state waits in LDS for the length of a traversal slice (PARK_PS) */
+#endif
+#ifndef MI_PARK_ENTRIES
+#define MI_PARK_ENTRIES 4
+#endif
 #ifndef MI_STACK
 #if MI_LEAF_JOBS
 #define MI_STACK (MI_STACK_LDS - 3)   /* the top three entries of a lane's column hold the results of the distributed leaf phase (leaf_jobs) */
@@ -69,7 +75,12 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
   /* pt: the primitive tests of a traversal round are dealt out over all lanes of the wave (leaf_jobs); the ptdl kernels keep the
      per-lane leaf loop -- there the extra live registers of the job loop spill (A/B in DESIGN.md) */
   constexpr bool JOBS = !FAST && MI_LEAF_JOBS && (!PTDL || MI_LEAF_JOBS_PTDL) && (!MEDIA || MI_LEAF_JOBS_MEDIA) && (!MB || MI_LEAF_JOBS_MB);
-  constexpr int STACK = (JOBS || FAST) ? MI_STACK_LDS - 3 : MI_STACK_LDS;     /* FAST: the rounds of trace_round_spec (mi_kernels.h), same result slots */
+  /* PARK_PS: the part of the path state no traversal round looks at (generator, pdf product, pixel: 8 dwords) waits in the lane's LDS
+     column for the length of a slice, so that the rounds' registers (a job pass holds a whole primitive record and a second ray) do
+     not push path state into scratch, from where the shading blocks would fetch it back word by word. Costs four stack entries. */
+  constexpr bool PARK_PS = MI_PARK_PATH && FAST && (PTDL || MI_PARK_PATH == 2);
+  constexpr int PARK_N = PARK_PS ? MI_PARK_ENTRIES : 0;        /* 8-byte entries of the column that hold parked path state */
+  constexpr int STACK = ((JOBS || FAST) ? MI_STACK_LDS - 3 : MI_STACK_LDS) - PARK_N;     /* FAST: the rounds of trace_round_spec (mi_kernels.h), same result slots */
   Counters<COUNT || RECORD> cnt;        /* COUNT = false: only the path count (see Counters, mi_kernels.h) */
   PathState ps;
   ps.active = 0;
@@ -130,6 +141,19 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
       const V3 o = ray_origin<PTDL>(ps, tr_shadow), d = tr_shadow ? ps.sh_dir : ps.dir;
       const uint32_t ignore = ps.ignore;     /* the shadow ray of a vertex starts on the same primitive as its extension ray */
       const unsigned tail = exhausted_wave ? 1u : (unsigned)(PTDL ? MI_TAIL_LANES_PTDL : MI_TAIL_LANES);
+      lds_uint2 *parked = (lds_uint2 *)lds.stack + (STACK + 3)*MI_BLOCK;
+      if(PARK_PS)
+      {
+        parked[0] = mi_u32x2{(uint32_t)ps.rng.s0, (uint32_t)(ps.rng.s0 >> 32)};
+        parked[MI_BLOCK] = mi_u32x2{(uint32_t)ps.rng.s1, (uint32_t)(ps.rng.s1 >> 32)};
+        const unsigned long long pp = (unsigned long long)__double_as_longlong(ps.pdfprod);
+        parked[2*MI_BLOCK] = mi_u32x2{(uint32_t)pp, (uint32_t)(pp >> 32)};
+        parked[3*MI_BLOCK] = mi_u32x2{__float_as_uint(ps.pixel_i), __float_as_uint(ps.pixel_j)};
+        if(PARK_N >= 5) parked[4*MI_BLOCK] = mi_u32x2{__float_as_uint(ps.lambda), __float_as_uint(ps.scramble)};
+        if(PARK_N >= 6) parked[5*MI_BLOCK] = mi_u32x2{__float_as_uint(ps.throughput), __float_as_uint(ps.pdf)};
+        if(PARK_N >= 7) parked[6*MI_BLOCK] = mi_u32x2{__float_as_uint(ps.prev_cos), __float_as_uint(ps.cur_ior)};
+        if(PARK_N >= 8) parked[7*MI_BLOCK] = mi_u32x2{(uint32_t)ps.media.ids, (uint32_t)(ps.media.ids >> 32)};
+      }
       while(true)
       {
         const bool busy = tracing && !ts.done;
@@ -139,6 +163,18 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
         if(FAST) { trace_round_spec<MI_BLOCK, STACK, MB, PTDL && MI_ANYHIT>(lds, sc.prims, o, d, ignore, hit, ts, busy, cnt); continue; }
         if(busy) trace_round<MI_BLOCK, STACK, MB, PTDL && MI_ANYHIT, JOBS>(lds, sc.prims, o, d, ignore, hit, ts, cnt);
         if(JOBS) leaf_jobs<MI_BLOCK, STACK, MB, PTDL && MI_ANYHIT>(lds, sc.prims, o, d, ignore, hit, ts, busy, cnt);   /* every lane of the wave takes part */
+      }
+      if(PARK_PS)
+      {
+        const mi_u32x2 a = parked[0], b = parked[MI_BLOCK], c = parked[2*MI_BLOCK], e = parked[3*MI_BLOCK];
+        ps.rng.s0 = (unsigned long long)a.x | ((unsigned long long)a.y << 32);
+        ps.rng.s1 = (unsigned long long)b.x | ((unsigned long long)b.y << 32);
+        ps.pdfprod = __longlong_as_double((long long)((unsigned long long)c.x | ((unsigned long long)c.y << 32)));
+        ps.pixel_i = __uint_as_float(e.x); ps.pixel_j = __uint_as_float(e.y);
+        if(PARK_N >= 5) { const mi_u32x2 f = parked[4*MI_BLOCK]; ps.lambda = __uint_as_float(f.x); ps.scramble = __uint_as_float(f.y); }
+        if(PARK_N >= 6) { const mi_u32x2 f = parked[5*MI_BLOCK]; ps.throughput = __uint_as_float(f.x); ps.pdf = __uint_as_float(f.y); }
+        if(PARK_N >= 7) { const mi_u32x2 f = parked[6*MI_BLOCK]; ps.prev_cos = __uint_as_float(f.x); ps.cur_ior = __uint_as_float(f.y); }
+        if(PARK_N >= 8) { const mi_u32x2 f = parked[7*MI_BLOCK]; ps.media.ids = (unsigned long long)f.x | ((unsigned long long)f.y << 32); }
       }
     }
     MI_PHASE(cnt, 1)

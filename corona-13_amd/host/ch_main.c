@@ -3,12 +3,17 @@
  *
  *   corona-mi <scene.nra2> [-s spp] [-w width] [-h height] [-x postfix] [--frame n] [--batch n]
  *             [--sampler pt|ptdl] [--pointsampler rand|halton] [--max-verts n] [--rgb2spec lut]  [--iso v] [-c cam] [--info] [--device-build]
+ *             [--gpus n | --devices i,j,...] [--traversal exact|fast]
+ *
+ * --gpus n renders on the first n GPUs of the node, --devices on the listed ones (a device may be named twice): every batch's path
+ * indices are split over them (mi_group_render) and the framebuffers are added up on the first one (mi_group_fb_reduce: RCCL over
+ * xGMI) before the image is read back -- the single host thread stands where the reference's worker pool stood.
  *
  * --info validates the scene files (.nra2, .geo, .cam) on the host and prints what the backend would get, without
  * touching a GPU (validators for the on-disk formats).
  *
  * Progression loop of view_render() (src/view.c:630-695) with the pthread pool dispatch (643-645)
- * replaced by one mi_render() per batch; writes <basename><postfix>_fb00.pfm like view_write_images
+ * replaced by one mi_group_render() per batch; writes <basename><postfix>_fb00.pfm like view_write_images
  * (src/view.c:543-552) and a sidecar with the mean image and timings.
  * -t (threads) is accepted and ignored: the workers are the GPU's wavefronts.
  */
@@ -36,9 +41,25 @@ int main(int argc, char *argv[])
   opt.verbose = 1;
   uint64_t spp = 10, batch = 1;              /* display_open default: 10 progressions */
   const char *postfix = "render";
-  int info_only = 0, device_build = 0;
+  int info_only = 0, device_build = 0, traversal = -1;
+  int devices[64], num_devices = 0;
   for(int i=2;i<argc;i++)
   {
+    if(!strcmp(argv[i], "--gpus") && i+1 < argc)
+    {
+      num_devices = atoi(argv[++i]);
+      if(num_devices < 1 || num_devices > 64) { fprintf(stderr, "[main] --gpus takes 1..64\n"); return 1; }
+      for(int k=0;k<num_devices;k++) devices[k] = k;
+      continue;
+    }
+    if(!strcmp(argv[i], "--devices") && i+1 < argc)
+    {
+      num_devices = 0;
+      for(char *tok = strtok(argv[++i], ","); tok && num_devices < 64; tok = strtok(0, ",")) devices[num_devices++] = atoi(tok);
+      if(!num_devices) { fprintf(stderr, "[main] --devices takes a list like 0,1,2\n"); return 1; }
+      continue;
+    }
+    if(!strcmp(argv[i], "--traversal") && i+1 < argc) { traversal = !strcmp(argv[++i], "exact") ? MI_TRAVERSAL_EXACT : MI_TRAVERSAL_FAST; continue; }
     if(!strcmp(argv[i], "-s") && i+1 < argc) spp = strtoull(argv[++i], 0, 10);
     else if(!strcmp(argv[i], "-w") && i+1 < argc) opt.width = atoi(argv[++i]);
     else if(!strcmp(argv[i], "-h") && i+1 < argc) opt.height = atoi(argv[++i]);
@@ -84,10 +105,18 @@ int main(int argc, char *argv[])
     ch_scene_free(scene);
     return 0;
   }
-  mi_scene *dev = 0;
+  mi_group *group = 0;
   mi_scene_desc without_tree = *d;
   if(device_build) { without_tree.nodes = 0; without_tree.num_nodes = 0; d = &without_tree; }
-  if(mi_init(-1) || mi_scene_create(d, &dev)) { fprintf(stderr, "[main] %s\n", mi_last_error()); return 2; }
+  if(!num_devices)
+  { /* one GPU: the one mi_init picks (LOCAL_RANK under a one-process-per-GPU launcher, else device 0) */
+    if(mi_init(-1)) { fprintf(stderr, "[main] %s\n", mi_last_error()); return 2; }
+    devices[0] = mi_current_device();
+    num_devices = 1;
+  }
+  if(mi_group_create(d, devices, num_devices, &group)) { fprintf(stderr, "[main] %s\n", mi_last_error()); return 2; }
+  if(traversal >= 0) for(int k=0;k<num_devices;k++) mi_scene_set_traversal(mi_group_scene(group, k), traversal);
+  if(num_devices > 1) printf("[main] %d GPUs, framebuffer reduce: %s\n", num_devices, mi_group_uses_rccl(group) ? "RCCL (ncclReduce)" : "peer copies + add kernel");
 
   const uint64_t per = (uint64_t)d->width*d->height;
   uint64_t counter = 0, overlays = 0;
@@ -96,7 +125,7 @@ int main(int argc, char *argv[])
   { /* view_render: step the sample counter in batch_frames * W*H intervals (src/view.c:636-638) */
     const uint64_t b = overlays + batch > spp ? spp - overlays : batch;
     const double t0 = now();
-    if(mi_render(dev, counter, b*per) || mi_sync(dev)) { fprintf(stderr, "[main] %s\n", mi_last_error()); return 3; }
+    if(mi_group_render(group, counter, b*per) || mi_group_sync(group)) { fprintf(stderr, "[main] %s\n", mi_last_error()); return 3; }
     t_prog += now() - t0;
     counter += b*per; overlays += b;
     printf("  %.3f s/frame, %lu spp      \r", (now() - t0)/b, (unsigned long)overlays);
@@ -104,7 +133,7 @@ int main(int argc, char *argv[])
   }
   float *fb = (float *)calloc(3*per, sizeof(float));
   const double t0 = now();
-  if(mi_fb_read(dev, fb, 0)) return 3;
+  if(mi_group_fb_read(group, fb, 0)) return 3;            /* the framebuffer reduce over the GPUs and the read-back are part of the progression's time */
   t_prog += now() - t0;
 
   char base[1024], fn[1200];
@@ -117,7 +146,7 @@ int main(int argc, char *argv[])
   double mean[3] = {0, 0, 0};
   for(uint64_t i=0;i<per;i++) for(int k=0;k<3;k++) mean[k] += fb[3*i+k];
   uint64_t cnt[8];
-  mi_counters(dev, cnt);
+  mi_group_counters(group, cnt);
   strncat(fn, ".txt", sizeof(fn) - strlen(fn) - 1);
   FILE *f = fopen(fn, "wb");
   if(f)
@@ -138,7 +167,7 @@ int main(int argc, char *argv[])
   printf("\n[main] rendered %lu spp in %.3f s (%.2f Msamples/s), saved %s%s_fb00.pfm\n", (unsigned long)overlays, t_prog,
       overlays*per/t_prog*1e-6, base, postfix);
   free(fb);
-  mi_scene_destroy(dev);
+  mi_group_destroy(group);
   mi_shutdown();
   ch_scene_free(scene);
   return 0;

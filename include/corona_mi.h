@@ -208,6 +208,8 @@ typedef struct mi_scene mi_scene;   /* opaque, device resident */
 /* Select and initialise the HIP device this process renders on (one process per GPU).
  * device < 0: use LOCAL_RANK from the environment, else 0.   replaces: threads_init (include/threads.h:68-130) */
 int  mi_init(int device);
+/* the device mi_init selected for this process, or -1 before it ran */
+int  mi_current_device(void);
 
 /* Upload the scene, build the device layout, allocate + clear the device framebuffer.
  * replaces: the per-module *_init state reachable from work_sample (accel/prims/shader/lights/view). */
@@ -315,6 +317,29 @@ int  mi_scene_stats(mi_scene *s, uint32_t out[4]);
 
 void mi_scene_destroy(mi_scene *s);
 void mi_shutdown(void);
+
+/* ---------------------------------------------------------------------------------------- several GPUs of one node, one host thread
+ * replaces: the worker pool behind view_render (src/view.c:630-695: the progression's path indices are handed out to all workers,
+ * which splat into one shared framebuffer) for the GPUs of a node. A group holds one copy of the scene per device; path indices
+ * are independent, so mi_group_render gives member k the k-th contiguous share of [first, first + count) with no exchange during
+ * rendering; the only exchange is the framebuffer: mi_group_fb_reduce adds the members' framebuffers into member 0's (and clears
+ * the others) -- ncclReduce(ncclFloat, ncclSum, 3*W*H, root 0) over xGMI when the devices are distinct (librccl is loaded with
+ * dlopen, the library does not link against it), else peer copies to the root's device and an add kernel there.
+ * devices == NULL means devices 0 .. n-1; a device may be named twice (two members on one GPU: tests, or two streams of one device).
+ * mi_group_scene(g, k) is member k's scene for the per-scene calls (mi_scene_set_traversal, mi_scene_set_counters, mi_last_kernel_ms ...).
+ * One process per GPU with an external reduce (bench.py: torch.distributed all_reduce) remains the other way to use several GPUs. */
+typedef struct mi_group mi_group;
+int  mi_group_create(const mi_scene_desc *desc, const int *devices, int n, mi_group **out);
+int  mi_group_size(mi_group *g);
+mi_scene *mi_group_scene(mi_group *g, int k);
+int  mi_group_uses_rccl(mi_group *g);                                    /* 1: ncclReduce, 0: peer copies + add kernel */
+int  mi_group_render(mi_group *g, uint64_t first_index, uint64_t count); /* queues the shares on the members' streams, returns */
+int  mi_group_fb_reduce(mi_group *g);                                    /* member 0 += members 1..n-1, which are cleared; stream ordered */
+int  mi_group_fb_read(mi_group *g, float *host_fb, int accumulate);      /* reduce, wait, mi_fb_read of member 0 */
+int  mi_group_fb_clear(mi_group *g);
+int  mi_group_sync(mi_group *g);
+int  mi_group_counters(mi_group *g, uint64_t out[8]);
+void mi_group_destroy(mi_group *g);
 
 /* human readable description of the last error on this thread ("" if none) */
 const char *mi_last_error(void);

@@ -45,7 +45,7 @@ _oracle = None
 def oracle_lib():
     global _oracle
     if _oracle is None:
-        so = REPO / "oracle" / "liboracle.so"
+        so = Path(os.environ.get("CORONA_ORACLE_LIB", REPO / "oracle" / "liboracle.so"))     # override: the sanitizer build (make sanitize)
         if not so.exists():
             subprocess.check_call(["make", "-C", str(REPO / "oracle"), "liboracle.so"])
         pkg = load_pkg()

@@ -941,3 +941,47 @@ def test_leaf_phase_corner_cases(tmp_path, traversal):
             be.close()
     finally:
         desc.nodes, desc.num_nodes = keep_nodes, keep_n
+
+
+@pytest.mark.parametrize("reduce", ["peer", "rccl"])
+def test_group_behind_the_c_abi(monkeypatch, reduce):
+    """several GPUs from ONE host thread through the C ABI (mi_group_*, corona_mi.h; the reference's dispatcher src/view.c:630-695):
+    a group of one is the single render; a group of two members on device 0 (two copies of the scene, the frame's path indices
+    split in two contiguous ranges, framebuffers added up on member 0 by peer copy + add kernel) equals the single render up to the
+    order of the float atomics; with one member the RCCL code path (dlopen'ed librccl, ncclCommInitAll + ncclReduce) runs too.
+    Accumulating read-back (mi_fb_read(accumulate = 1), the reference host's per-batch path) adds frame after frame."""
+    monkeypatch.setenv("CORONA_MI_GROUP_REDUCE", reduce)
+    scene = make_scene(SCENE_0010, width=512, height=288, max_verts=8)
+    per = 4 * scene.width * scene.height
+    single = pkg.Backend(scene, counters=False)
+    single.render(0, per)
+    ref = single.fb_read()
+    one = pkg.Group(scene, [0])
+    assert one.uses_rccl() == (reduce == "rccl")
+    one.render(0, per)
+    img = one.fb_read()
+    assert np.abs(img - ref).max() <= 1e-4 * ref.max() and one.counters()[4] == per
+    # progressive: two more frames accumulated on the host equal a render of the three frames' indices
+    acc = img.copy()
+    for k in (1, 2):
+        one.fb_clear()
+        one.render(k * per, per)
+        one.fb_read(accumulate_into=acc)
+    single.fb_clear()
+    single.render(0, 3 * per)
+    ref3 = single.fb_read()
+    assert np.abs(acc - ref3).max() <= 2e-4 * ref3.max()
+    one.close()
+    if reduce == "peer":
+        two = pkg.Group(scene, [0, 0])
+        assert not two.uses_rccl()
+        two.render(0, 3 * per)
+        got = two.fb_read()
+        assert np.abs(got - ref3).max() <= 2e-4 * ref3.max() and two.counters()[4] == 3 * per
+        again = two.fb_read()                          # the reduce cleared member 1: reading twice adds nothing
+        assert np.array_equal(again, got)
+        two.close()
+    else:
+        with pytest.raises(RuntimeError, match="not distinct"):
+            pkg.Group(scene, [0, 0])                   # RCCL needs distinct devices: asked for explicitly, that is an error, not a silent fallback
+    single.close()
