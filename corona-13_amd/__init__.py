@@ -106,6 +106,11 @@ class MiPathRecord(C.Structure):
                 ("splat", MiPathSplat * MI_REC_MAX_SPLATS), ("v", MiPathVertex * MI_REC_MAX_VERTS)]
 
 
+class MiBsdfTest(C.Structure):
+    _fields_ = [("bsdf", C.c_uint32), ("param", C.c_float * 2), ("roughness", C.c_float), ("reflect", C.c_uint32), ("count", C.c_uint32),
+                ("lambda_", C.c_float), ("size", C.c_uint32), ("spp", C.c_uint32)]
+
+
 class ChOptions(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("max_verts", C.c_uint32), ("sampler", C.c_uint32),
                 ("frame", C.c_uint64), ("cam_file", C.c_char_p), ("rgb2spec_lut", C.c_char_p),
@@ -287,6 +292,7 @@ def mi_lib():
         m.mi_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         m.mi_scene_set_counters.argtypes = [C.c_void_p, C.c_int]
         m.mi_scene_set_traversal.argtypes = [C.c_void_p, C.c_int]
+        m.mi_scene_set_metal_reference.argtypes = [C.c_void_p, C.c_int]
         m.mi_trace_paths.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
         m.mi_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         m.mi_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
@@ -296,6 +302,7 @@ def mi_lib():
         m.mi_scene_destroy.restype = None
         m.mi_shutdown.restype = None
         m.mi_last_error.restype = C.c_char_p
+        m.mi_bsdf_test_run.argtypes = [C.c_void_p, C.POINTER(MiBsdfTest), C.POINTER(C.c_double)]
         m.mi_current_device.restype = C.c_int
         m.mi_group_create.argtypes = [C.POINTER(MiSceneDesc), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
         m.mi_group_size.argtypes = [C.c_void_p]
@@ -315,8 +322,8 @@ def mi_lib():
 
 
 MI_SYMBOLS = ["mi_init", "mi_scene_create", "mi_scene_set_framebuffer", "mi_scene_set_stream", "mi_render",
-              "mi_sync", "mi_fb_read", "mi_fb_clear", "mi_fb_device_ptr", "mi_counters", "mi_scene_set_counters", "mi_scene_set_traversal", "mi_trace_paths", "mi_intersect",
-              "mi_last_kernel_ms", "mi_last_kernel_launches", "mi_scene_stats", "mi_scene_destroy", "mi_shutdown", "mi_last_error", "mi_current_device",
+              "mi_sync", "mi_fb_read", "mi_fb_clear", "mi_fb_device_ptr", "mi_counters", "mi_scene_set_counters", "mi_scene_set_traversal", "mi_scene_set_metal_reference", "mi_trace_paths", "mi_intersect",
+              "mi_last_kernel_ms", "mi_last_kernel_launches", "mi_scene_stats", "mi_scene_destroy", "mi_shutdown", "mi_last_error", "mi_current_device", "mi_bsdf_test_run",
               "mi_group_create", "mi_group_size", "mi_group_scene", "mi_group_uses_rccl", "mi_group_render", "mi_group_fb_reduce", "mi_group_fb_read",
               "mi_group_fb_clear", "mi_group_sync", "mi_group_counters", "mi_group_destroy"]
 
@@ -360,6 +367,10 @@ class Backend:
         """'exact': the reference's order of operations per ray (counters equal its -DACCEL_DEBUG totals); 'fast' (the library's
         default): leaves put aside while the lane descends on -- same hits, other work counters (corona_mi.h)"""
         self._check(self.m.mi_scene_set_traversal(self._ptr, {"exact": 0, "fast": 1}[mode]), "mi_scene_set_traversal")
+
+    def set_metal_reference(self, enable):
+        """end the metal samples the reference BUILD's NaN ends (corona_mi.h: mi_scene_set_metal_reference)"""
+        self._check(self.m.mi_scene_set_metal_reference(self._ptr, 1 if enable else 0), "mi_scene_set_metal_reference")
 
     def _check(self, err, what):
         if err:
@@ -418,6 +429,15 @@ class Backend:
         rays["max_dist"] = np.float32(3.4028234663852886e38) if max_dist is None else max_dist
         out = np.zeros(n, dtype=HIT_DTYPE)
         self._check(self.m.mi_intersect(self._ptr, rays.ctypes.data, n, out.ctypes.data), "mi_intersect")
+        return out
+
+    def bsdf_test(self, bsdf, param, roughness, reflect, count=4, lambda_=525.0, size=512, spp=8):
+        """the reference's BSDF battle test on the device (mi_bsdf_test_run): rows of (ebsdf, bsdf, epdf, pdf), one per incidence angle"""
+        import numpy as np
+        kind = {"diffuse": 0, "dielectric": 1, "metal": 2}[bsdf]
+        t = MiBsdfTest(bsdf=kind, param=(C.c_float * 2)(*param), roughness=roughness, reflect=reflect, count=count, lambda_=lambda_, size=size, spp=spp)
+        out = np.zeros((count, 4), dtype=np.float64)
+        self._check(self.m.mi_bsdf_test_run(self._ptr, C.byref(t), out.ctypes.data_as(C.POINTER(C.c_double))), "mi_bsdf_test_run")
         return out
 
     def last_kernel_ms(self):

@@ -743,6 +743,7 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
   s->device_built = device_build; s->stack_need = stack_need;
   { const char *ce = getenv("CORONA_MI_COUNTERS"); s->counting = ce && atoi(ce) ? 1 : 0; }
   { const char *te = getenv("CORONA_MI_TRAVERSAL"); s->fast = !(te && !strcmp(te, "exact")); }
+  { const char *me = getenv("CORONA_MI_METAL"); d.metal_reference = (me && !strcmp(me, "reference")) ? 1u : 0u; }
   { /* the kernels this scene can launch (record / counting / traversal variants of its configuration) may use the whole LDS */
     std::vector<const void *> kernels = { (const void *)mi_intersect_kernel<true, false>, (const void *)mi_intersect_kernel<false, false>,
                                           (const void *)mi_intersect_kernel<true, true>, (const void *)mi_intersect_kernel<false, true> };
@@ -800,6 +801,13 @@ extern "C" int mi_scene_set_counters(mi_scene *s, int enable)
 {
   MI_ENTER(s, "null scene");
   s->counting = enable ? 1 : 0;
+  return MI_OK;
+}
+
+extern "C" int mi_scene_set_metal_reference(mi_scene *s, int enable)
+{
+  MI_ENTER(s, "null scene");
+  s->d.metal_reference = enable ? 1u : 0u;
   return MI_OK;
 }
 
@@ -1033,6 +1041,107 @@ extern "C" void mi_scene_destroy(mi_scene *s)
   free(s);
 }
 
+
+/* ======================================================================================= test hook: the BSDF battle test on the device
+ * The reference's tools/battle-test.c:57-266 (what regression/0052_dielectric and 0053_dielectric run) on the kernels' own
+ * sample_* / brdf_* / pdf_* functions: a synthetic vertex with n = gn = (0, 0, +-1), shading rs .06 rd .8 rg 1 em 0 and the given
+ * roughness, in vacuum; per incidence angle k (omega_in = (0, sqrt(u), -+sqrt(1 - u)), u = k / (count - 0.5))
+ *   ebsdf, epdf   spp * size^2 calls of sample(): sum of the returned weights / number of samples that land in the tested hemisphere
+ *   bsdf, pdf     brdf() and pdf() summed over a size^2 grid on the projected hemisphere (times 4 / size^2)
+ * which regression/makebattletest.sh:13-14 compares ((bsdf - ebsdf)^2 < 1e-5, (pdf - epdf)^2 < 1e-5). */
+struct BsdfTestSetup { Surf sf; Shading sh; V3 wi; float eta_ratio; uint32_t bsdf; int metal; float lambda; };
+__device__ __forceinline__ BsdfTestSetup bsdf_test_setup(const mi_bsdf_test &t, uint32_t k)
+{
+  BsdfTestSetup b;
+  const float nz = t.reflect ? 1.0f : -1.0f;
+  b.sf.x = mk3(0, 0, 0); b.sf.n = b.sf.gn = mk3(0.0f, 0.0f, nz);
+  get_onb(b.sf.n, b.sf.a, b.sf.b);                          /* battle-test.c:99: the plain frame, not the scrambled one */
+  b.sf.u = b.sf.v = b.sf.s = b.sf.t = 0.0f; b.sf.flags = 0;
+  b.sh.rs = 0.06f; b.sh.rd = 0.8f; b.sh.em = 0.0f; b.sh.rg = 1.0f; b.sh.roughness = t.roughness;
+  const float u = k/((float)(t.count - 1) + .5f), v = 0.0f;
+  b.wi = mk3(sqrtf(u)*sinf(2.0f*MI_PI_F*v), sqrtf(u)*cosf(2.0f*MI_PI_F*v), t.reflect ? -sqrtf(1 - u) : sqrtf(1 - u));
+  b.bsdf = t.bsdf; b.metal = (int)t.param[0]; b.lambda = t.lambda;
+  b.eta_ratio = 1.0f;
+  if(t.bsdf == MI_BSDF_DIELECTRIC)
+  { /* prepare, dielectric.c:64-81: e[1] is vacuum, the interior the glass: path_eta_ratio = 1 / eta(lambda) */
+    b.eta_ratio = 1.0f/eta_from_abbe(t.param[0], t.param[1], t.lambda);
+    if(fabsf(1.0f - b.eta_ratio/1.0f) < 1e-3f) b.sh.roughness = 0.0f;
+  }
+  return b;
+}
+
+__global__ void mi_bsdf_test_sample_kernel(DScene sc, mi_bsdf_test t, uint32_t k, unsigned long long samples, double *out)
+{ /* out[0] += sum of weights, out[1] += samples in the tested hemisphere */
+  const BsdfTestSetup b = bsdf_test_setup(t, k);
+  double sw = 0.0, sn = 0.0;
+  for(unsigned long long i=(unsigned long long)blockIdx.x*blockDim.x + threadIdx.x; i<samples; i+=(unsigned long long)gridDim.x*blockDim.x)
+  {
+    Rng rng;
+    rng_seed(rng, i, 666ull + k);
+    PointSampler<false> pts(sc, rng, i, 0);
+    BsdfSample bs;
+    if(b.bsdf == MI_BSDF_DIFFUSE) sample_diffuse(pts, b.sf, b.sh, s_absorb, bs);
+    else if(b.bsdf == MI_BSDF_DIELECTRIC) sample_dielectric(pts, b.sf, b.sh, b.wi, b.eta_ratio, s_absorb, bs);
+    else sample_metal(sc, pts, b.sf, b.sh, b.wi, 1.0f, b.metal, b.lambda, s_absorb, bs);
+    float w = bs.weight;
+    if(!(bs.omega.x == bs.omega.x)) w = 1e20f;             /* battle-test.c:138-145: a NaN direction shows up as a huge weight */
+    if(bs.omega.z <= 0.0f || !(bs.omega.z == bs.omega.z)) continue;
+    if(w <= 0.0f) continue;
+    sw += (double)w; sn += 1.0;
+  }
+  for(int off=32;off>0;off>>=1) { sw += __shfl_down(sw, off); sn += __shfl_down(sn, off); }
+  if(__lane_id() == 0) { atomicAdd(out + 0, sw); atomicAdd(out + 1, sn); }
+}
+
+__global__ void mi_bsdf_test_eval_kernel(DScene sc, mi_bsdf_test t, uint32_t k, double *out)
+{ /* out[2] += brdf over the grid, out[3] += pdf over the grid (battle-test.c:177-213; the spp repetitions of a cell are identical) */
+  const BsdfTestSetup b = bsdf_test_setup(t, k);
+  double sb = 0.0, sp = 0.0;
+  const unsigned long long cells = (unsigned long long)t.size*t.size;
+  for(unsigned long long c=(unsigned long long)blockIdx.x*blockDim.x + threadIdx.x; c<cells; c+=(unsigned long long)gridDim.x*blockDim.x)
+  {
+    const int i = (int)(c % t.size), j = (int)(c / t.size);
+    const float ox = (float)(2.0*i/(float)t.size - 1.), oy = (float)(2.0*j/(float)t.size - 1.);
+    const float len2 = ox*ox + oy*oy;
+    if(!(len2 < 1.)) continue;
+    const V3 wo = mk3(ox, oy, sqrtf(1 - len2));
+    BsdfEval be;
+    float pdf;
+    if(b.bsdf == MI_BSDF_DIFFUSE) { be = brdf_diffuse(b.sf, b.sh, wo); pdf = (float)(1.0f/MI_PI_D); }
+    else if(b.bsdf == MI_BSDF_DIELECTRIC) { be = brdf_dielectric(b.sf, b.sh, b.wi, wo, b.eta_ratio); pdf = pdf_dielectric(b.sf, b.sh, b.wi, wo, b.eta_ratio, be.mode); }
+    else { be = brdf_metal(sc, b.sf, b.sh, b.wi, wo, 1.0f, b.metal, b.lambda); pdf = pdf_metal(b.sf, b.sh, b.wi, wo, be.mode); }
+    const float scale = 4.0f/(float)(t.size*t.size);
+    sb += (double)(be.value*scale); sp += (double)(pdf*scale);
+  }
+  for(int off=32;off>0;off>>=1) { sb += __shfl_down(sb, off); sp += __shfl_down(sp, off); }
+  if(__lane_id() == 0) { atomicAdd(out + 2, sb); atomicAdd(out + 3, sp); }
+}
+
+extern "C" int mi_bsdf_test_run(mi_scene *s, const mi_bsdf_test *t, double *out)
+{
+  if(!s || !t || !out) return fail(MI_ERR_ARG, "null argument");
+  MI_ENTER(s, "null scene");
+  if(t->bsdf > MI_BSDF_METAL || !t->count || t->count > 64 || !t->size || !t->spp) return fail(MI_ERR_ARG, "mi_bsdf_test_run: bad description");
+  if(t->bsdf == MI_BSDF_METAL && (!s->d_metal || t->param[0] < 0.0f || t->param[0] > 4.0f)) return fail(MI_ERR_ARG, "mi_bsdf_test_run: no such metal");
+  double *d_out = nullptr;
+  HIPCHK(hipMalloc((void **)&d_out, sizeof(double)*4*t->count));
+  hipError_t e = hipMemsetAsync(d_out, 0, sizeof(double)*4*t->count, s->stream);
+  const unsigned long long samples = (unsigned long long)t->spp*t->size*t->size;
+  for(uint32_t k=0;k<t->count && e == hipSuccess;k++)
+  {
+    hipLaunchKernelGGL(mi_bsdf_test_sample_kernel, dim3(1024), dim3(256), 0, s->stream, s->d, *t, k, samples, d_out + 4*k);
+    hipLaunchKernelGGL(mi_bsdf_test_eval_kernel, dim3(256), dim3(256), 0, s->stream, s->d, *t, k, d_out + 4*k);
+    e = hipGetLastError();
+  }
+  if(e == hipSuccess) e = hipStreamSynchronize(s->stream);
+  if(e == hipSuccess) e = hipMemcpy(out, d_out, sizeof(double)*4*t->count, hipMemcpyDeviceToHost);
+  (void)hipFree(d_out);
+  if(e != hipSuccess) { snprintf(g_err, sizeof(g_err), "mi_bsdf_test_run: %s", hipGetErrorString(e)); fprintf(stderr, "[mi] %s\n", g_err); return MI_ERR_DEVICE; }
+  for(uint32_t k=0;k<t->count;k++) { out[4*k+1] /= (double)samples; const double w = out[4*k+0]/(double)samples; out[4*k+0] = w; }
+  /* order like the reference prints them: ebsdf bsdf epdf pdf */
+  for(uint32_t k=0;k<t->count;k++) { const double ebsdf = out[4*k+0], epdf = out[4*k+1], bsdf = out[4*k+2], pdf = out[4*k+3]; out[4*k+0] = ebsdf; out[4*k+1] = bsdf; out[4*k+2] = epdf; out[4*k+3] = pdf; }
+  return MI_OK;
+}
 
 /* ======================================================================================= several GPUs behind the C ABI
  * mi_group: one scene per device, driven by ONE host thread -- what the reference's view_render does with its pthread pool

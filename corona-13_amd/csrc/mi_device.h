@@ -115,6 +115,7 @@ struct DScene
   uint32_t num_nodes, num_prims;
   const float4  *nodes;            /* [MI_NODE_FIELDS][num_nodes] */
   uint32_t root_link;              /* link of node 0: its split axes << MI_AXES_SHIFT */
+  uint32_t metal_reference;        /* metal sample() ends the paths the reference BUILD's NaN ends (mi_scene_set_metal_reference) */
   const DPrim  *prims;
   const DPrimGeo *primgeo;
   float aabb[6];

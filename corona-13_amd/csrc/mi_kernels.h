@@ -344,17 +344,21 @@ struct Hit
 
 /* ------------------------------------------------------------------------------------------ primitives */
 __device__ __forceinline__ float sphere_t(const V3 c, float radius, const V3 ro, const V3 rd)
-{ /* _geo_sphere_intersect, include/geo/sphere.h:112-144 */
-  const float a = dot3(rd, rd);
+{ /* _geo_sphere_intersect, include/geo/sphere.h:112-144, with the roundings of the reference BUILD (its FMA contraction, from the
+     disassembly of prims_intersect; the oracle restates the same sequence): dot products y*y, then fused x, then fused z; the
+     discriminant fma(b, b, -(4 a) c). The quadratic cancels badly for rays from afar; the fused forms put the hit point 1.4e-5
+     (rms) off the sphere instead of 1.8e-5, and fewer grazing rays start inside it. */
   const V3 o = sub3(ro, c);
-  const float b = 2.0f*dot3(o, rd);
-  const float cc = dot3(o, o) - radius*radius;
+  const float a = __builtin_fmaf(rd.z, rd.z, __builtin_fmaf(rd.x, rd.x, rd.y*rd.y));
+  const float od = __builtin_fmaf(rd.z, o.z, __builtin_fmaf(rd.x, o.x, rd.y*o.y));
+  const float b = od + od;
+  const float cc = __builtin_fmaf(o.z, o.z, __builtin_fmaf(o.x, o.x, o.y*o.y)) - radius*radius;
   if(a == 0)
   {
     if(b != 0) return -cc/b;
     return -FLT_MAX;
   }
-  const float discrim = b*b - 4.0f*a*cc;
+  const float discrim = __builtin_fmaf(b, b, -((a*4.0f)*cc));
   if(discrim < 0) return -FLT_MAX;
   const float sq = mi_sqrt(discrim);
   const float temp = b < 0 ? -0.5f*(b - sq) : -0.5f*(b + sq);
@@ -1829,6 +1833,26 @@ __device__ __forceinline__ float fresnel_metal(float n1, float n2, float k2, flo
   return DCLAMP((Rs2 + Rp2)*.5f, 0.0f, 1.0f);
 }
 
+/* MI_METAL_REFERENCE (mi_scene_set_metal_reference): what the reference BUILD's metal sample() does on top of fresnel_metal. Its
+ * plugin (gcc 11 -O3 -ffast-math -march=x86-64-v3; disassembly of libmetal.so, sample+0x1bb..0x259) forms costi as
+ * sqrt(0.5 fma(eta2r, sinr, len - 1)) with cost2r = fma(-eta2r, sinr, 1), len = sqrt(fma(cost2r, cost2r, cost2i^2)): near normal
+ * incidence on the microfacet len == cost2r and what is left under the root is the rounding error of cost2r, negative for every
+ * other sample -- NaN, clamped to R = 0, the path ends. Half of the samples with sin^2 < 2.4e-4 cost2r / |eta2i| (3e-3 for gold at
+ * 525 nm, 5e-2 at 720 nm), 2-4 % of all samples of a rough gold surface; its brdf() / pdf() are compiled differently and lose
+ * nothing. Restated operation by operation (fused where the plugin fuses), same predicate in the CPU restatement used by the tests. */
+__device__ __forceinline__ bool metal_reference_kills(float n1, float n2, float k2, float cosr)
+{
+  const float sinr = __builtin_fmaf(-cosr, cosr, 1.0f);
+  const float den = __builtin_fmaf(n2, n2, k2*k2);
+  const float etar = (n1*n2)/den;
+  const float etai = -((k2*n1)/den);
+  const float cost2i = (__builtin_fmaf(cosr, cosr, -1.0f)*-2.0f)*(etar*etai);
+  const float eta2r = __builtin_fmaf(etar, etar, -(etai*etai));
+  const float cost2r = __builtin_fmaf(-eta2r, sinr, 1.0f);
+  const float len = sqrtf(__builtin_fmaf(cost2r, cost2r, cost2i*cost2i));
+  return 0.5f*__builtin_fmaf(eta2r, sinr, len - 1.0f) < 0.0f;
+}
+
 /* ------------------------------------------------------------------------------------------ bsdf sampling */
 struct BsdfSample
 {
@@ -1958,7 +1982,7 @@ __device__ __forceinline__ void sample_metal(const DScene &sc, PS &pts, const Su
   if(!(cosr > 0.0f)) return;
   const int i = (int)DCLAMP((lambda - 360.0f)/5.0f, 0, 94);              /* fresnel.h:519-531 */
   const float n2 = sc.metal_ior[(mat*95 + i)*2 + 0], k2 = -sc.metal_ior[(mat*95 + i)*2 + 1];
-  const float R = fresnel_metal(n1, n2, k2, cosr);
+  const float R = (sc.metal_reference && metal_reference_kills(n1, n2, k2, cosr)) ? 0.0f : fresnel_metal(n1, n2, k2, cosr);
   bs.mode = s_reflect;
   bs.omega = mk3(wi.x + 2.0f*cosr*h.x, wi.y + 2.0f*cosr*h.y, wi.z + 2.0f*cosr*h.z);
   if(dot3(bs.omega, n) <= 0.0f) return;

@@ -252,6 +252,15 @@ float *mi_fb_device_ptr(mi_scene *s);
 int  mi_counters(mi_scene *s, uint64_t out[8]);
 int  mi_scene_set_counters(mi_scene *s, int enable);
 
+/* The reference BUILD's metal sampler ends 2-4 % of the paths at a rough conductor that its formula does not: in its compiled
+ * sample() (gcc -O3 -ffast-math, FMA) the imaginary part of the transmitted cosine comes out as the square root of a rounding
+ * error near normal incidence on the microfacet, negative every other time; the NaN is clamped to R = 0 (src/shaders/metal.c:79-157,
+ * 219-265; csrc/mi_kernels.h: metal_reference_kills). Off (default): the formula as written, sampling and evaluation consistent
+ * (the BSDF battle test passes). On (or CORONA_MI_METAL=reference when the scene is created): the same samples are ended as the
+ * reference build ends them -- images of metal scenes then carry the reference's energy, the battle test fails where the
+ * reference's own does. */
+int  mi_scene_set_metal_reference(mi_scene *s, int enable);
+
 /* How a ray walks the tree. Both modes return the same closest hit, bit for bit (distance, primitive, u, v), hence the same paths
  * and images; they differ in the WORK they do for it:
  *   MI_TRAVERSAL_EXACT  the reference's order of operations ray by ray (accel_intersect, src/accel.d/qbvhmp.c:1262-1390): a leaf is
@@ -302,6 +311,24 @@ int  mi_trace_paths(mi_scene *s, uint64_t first_index, uint64_t count, mi_path_r
 typedef struct mi_ray { float pos[3], dir[3]; uint32_t ignore; float max_dist; } mi_ray;
 typedef struct mi_hit { mi_primid primid; uint32_t prim; float dist, u, v; uint32_t pad[2]; } mi_hit;   /* 32 B */
 int  mi_intersect(mi_scene *s, const mi_ray *rays, uint64_t n, mi_hit *host_out);
+
+/* Test hook: the reference's BSDF battle test (tools/battle-test.c:57-266; regression/0052_dielectric, 0053_dielectric) on the
+ * kernels' own sample / eval / pdf functions. A synthetic vertex in vacuum with normal (0, 0, +1) (reflect = 1: the reflected
+ * hemisphere is tested) or (0, 0, -1) (reflect = 0: the transmitted one), shading rs .06, rd .8, rg 1 and the given roughness; for
+ * each of `count` incidence angles out[4k..4k+3] = ebsdf, bsdf, epdf, pdf like the reference prints them: the integral of bsdf cos
+ * estimated from spp * size^2 calls of sample() and summed from the evaluation over a size^2 grid, and the same for the pdf.
+ * regression/makebattletest.sh:13-14 passes iff (bsdf - ebsdf)^2 < 1e-5 and (pdf - epdf)^2 < 1e-5. The scene only lends its tables. */
+typedef struct mi_bsdf_test
+{
+  uint32_t bsdf;          /* MI_BSDF_DIFFUSE / MI_BSDF_DIELECTRIC / MI_BSDF_METAL */
+  float    param[2];      /* dielectric: n_d, Abbe number; metal: table (0 Ti, 1 Cu, 2 Fe, 3 Au, 4 Ag; src/shaders/fresnel.h:21-27) */
+  float    roughness;
+  uint32_t reflect;
+  uint32_t count;         /* incidence angles (the regression tests: 4) */
+  float    lambda;        /* nm (the tool: 525) */
+  uint32_t size, spp;     /* grid (512) and samples per cell (8) */
+} mi_bsdf_test;
+int  mi_bsdf_test_run(mi_scene *s, const mi_bsdf_test *t, double *out);
 
 /* Time of the last mi_render launch on the device in milliseconds (HIP events on the scene's
  * stream), and kernel launches since creation. For bench.py's roofline figure. */

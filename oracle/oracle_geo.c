@@ -106,17 +106,24 @@ static int o_tri_intersect(const float *v0, const float *v1, const float *v2, mi
 }
 
 static float o_sphere_t(const float *center, float radius, const o_ray *ray)
-{ /* _geo_sphere_intersect, include/geo/sphere.h:112-144 */
-  const float a = dot3(ray->dir, ray->dir);
-  const float o[3] = {ray->pos[0]-center[0], ray->pos[1]-center[1], ray->pos[2]-center[2]};
-  const float b = 2.0f*dot3(o, ray->dir);
-  const float c = dot3(o, o) - radius*radius;
+{ /* _geo_sphere_intersect, include/geo/sphere.h:112-144 -- with the roundings of the reference BUILD (gcc -O3 -ffast-math with FMA;
+     disassembly of prims_intersect in oracle/_ref, +0xb4c..0xd8e): the three dot products are y*y first, then fused x, then
+     fused z, and the discriminant is fma(b, b, -(4 a) c). The quadratic cancels badly for a ray from afar (b^2 and 4ac agree in
+     their leading digits), the fused forms carry one rounding less where it matters: hit points of the plain-C evaluation lie
+     1.8e-5 off the sphere (rms, rays from the camera), the reference's 1.4e-5 -- and a hit point inside the sphere sends its
+     grazing rays back into it. With these roundings the distance is the reference's bit for bit on the same ray. */
+  const float dx = ray->dir[0], dy = ray->dir[1], dz = ray->dir[2];
+  const float ox = ray->pos[0]-center[0], oy = ray->pos[1]-center[1], oz = ray->pos[2]-center[2];
+  const float a = fmaf(dz, dz, fmaf(dx, dx, dy*dy));
+  const float od = fmaf(dz, oz, fmaf(dx, ox, dy*oy));
+  const float b = od + od;
+  const float c = fmaf(oz, oz, fmaf(ox, ox, oy*oy)) - radius*radius;
   if(a == 0)
   {
     if(b != 0) return -c/b;
     return -FLT_MAX;
   }
-  const float discrim = b*b - 4.0f*a*c;
+  const float discrim = fmaf(b, b, -((a*4.0f)*c));
   if(discrim < 0) return -FLT_MAX;
   const float sq = sqrtf(discrim);
   const float temp = b < 0 ? -0.5f*(b - sq) : -0.5f*(b + sq);

@@ -9,7 +9,7 @@ pkg = load_pkg()
 name = sys.argv[1] if len(sys.argv) > 1 else "pt_mv8"
 g = np.load(GOLDEN / f"tilemeans_{name}.npz")
 sampler = pkg.MI_SAMPLER_PTDL if "ptdl" in name else pkg.MI_SAMPLER_PT
-scene = make_scene(SCENE_ROUGH if "rough" in name else SCENE_0010, width=int(g["width"]), height=720 if int(g["height"]) == 736 else int(g["height"]), max_verts=int(g["max_verts"]), sampler=sampler)
+scene = make_scene(SCENE_METAL if "metal" in name else SCENE_ROUGH if "rough" in name else SCENE_0010, width=int(g["width"]), height=720 if int(g["height"]) == 736 else int(g["height"]), max_verts=int(g["max_verts"]), sampler=sampler)
 be = pkg.Backend(scene, counters=False)
 per = scene.width * scene.height
 spp = int(g["spp"])
@@ -29,4 +29,10 @@ print("tiles", ref.shape, "spp", spp, "mean gpu", gpu.mean(axis=(0, 1)), "ref", 
 print("mean d^2 %.3e  mean 2 var %.3e  ratio %.2f" % ((d ** 2).mean(), (2 * var).mean(), (d ** 2).mean() / (2 * var).mean()))
 print("mean z^2 %.2f  robust sigma(z) %.2f  median z %.3f" % ((z ** 2).mean(), 1.4826 * np.median(np.abs(z - np.median(z))), np.median(z)))
 print("fraction |z| > 3: %.4f  > 4: %.4f; corr of the lit rows (8..): %.5f" % ((np.abs(z) > 3).mean(), (np.abs(z) > 4).mean(), np.corrcoef(gpu[8:, :, 1].ravel(), ref[8:, :, 1].ravel())[0, 1]))
+order = np.argsort(-np.abs(z[..., 1]).ravel())[:24]
+print("most significant luminance tiles (row, col): z, gpu / ref")
+print("  ".join("(%d,%d) %+.1f %.4f" % (i // z.shape[1], i % z.shape[1], z[..., 1].ravel()[i], (gpu[..., 1] / ref[..., 1]).ravel()[i]) for i in order))
+sig = np.abs(z[..., 1]) > 3
+if sig.any():
+    print("tiles with |z| > 3: %d, their summed luminance gpu / ref = %.4f; all other tiles: %.4f" % (sig.sum(), gpu[..., 1][sig].sum() / ref[..., 1][sig].sum(), gpu[..., 1][~sig].sum() / ref[..., 1][~sig].sum()))
 be.close()
