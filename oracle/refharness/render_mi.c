@@ -74,7 +74,7 @@ typedef struct { int surface; int interior; } ref_interior_t;                   
 typedef struct render_t
 {
   pthread_mutex_t mutex;
-  mi_scene *scene;
+  mi_group *scene;              /* one member per GPU (CORONA_MI_GPUS=n or CORONA_MI_DEVICES=i,j,..; default: the one mi_init picks) */
   /* storage behind the descriptor */
   mi_node *nodes;
   mi_shape *shapes;
@@ -104,7 +104,7 @@ void render_cleanup(render_t *r)
   {
     fprintf(stderr, "[render_mi] %lu paths on the device in %.3f s (%.1f Msamples/s including read-back)\n", (unsigned long)r->paths, r->t_device,
         r->t_device > 0 ? r->paths/r->t_device/1e6 : 0.0);
-    mi_scene_destroy(r->scene);
+    mi_group_destroy(r->scene);
     mi_shutdown();
   }
   free(r->nodes); free(r->shapes); free(r->vtxidx); free(r->vtx); free(r->materials); free(r->cdf); free(r->cie); free(r->checker); free(r->metal);
@@ -113,7 +113,7 @@ void render_cleanup(render_t *r)
 
 render_tls_t *render_tls_init() { return (render_tls_t *)common_alloc(256, sizeof(render_tls_t)); }
 void render_tls_cleanup(render_tls_t *r) { free(r); }
-void render_clear() { if(rt.render->scene) mi_fb_clear(rt.render->scene); }
+void render_clear() { if(rt.render->scene) mi_group_fb_clear(rt.render->scene); }
 void render_print_info(FILE *fd) { fprintf(fd, "render   : global illumination on the MI355X backend (libcorona_mi.so through the C ABI)\n"); }
 void render_splat(const path_t *p, const mf_t value) { view_splat(p, value); }
 
@@ -341,8 +341,15 @@ static int setup(render_t *r)
       if((f = fopen(fn, "wb"))) { fwrite(d.nodes, sizeof(mi_node), d.num_nodes, f); fclose(f); }
     }
   }
-  if(mi_init(-1)) return 1;
-  if(mi_scene_create(&d, &r->scene)) return 1;
+  /* the GPUs of the node stand where the pool's workers stood (src/view.c:630-695): every progression's indices are split over
+     them, the framebuffers are added up on the first one (mi_group_*, corona_mi.h) */
+  int devices[64], ndev = 0;
+  const char *list = getenv("CORONA_MI_DEVICES"), *count = getenv("CORONA_MI_GPUS");
+  if(list) { char buf[256]; snprintf(buf, sizeof(buf), "%s", list); for(char *tok = strtok(buf, ","); tok && ndev < 64; tok = strtok(0, ",")) devices[ndev++] = atoi(tok); }
+  else if(count) { ndev = atoi(count); if(ndev < 1) ndev = 1; if(ndev > 64) ndev = 64; for(int k=0;k<ndev;k++) devices[k] = k; }
+  if(!ndev) { if(mi_init(-1)) return 1; devices[0] = mi_current_device(); ndev = 1; }
+  if(mi_group_create(&d, devices, ndev, &r->scene)) return 1;
+  if(ndev > 1) fprintf(stderr, "[render_mi] %d GPUs, framebuffer reduce: %s\n", ndev, mi_group_uses_rccl(r->scene) ? "RCCL (ncclReduce)" : "peer copies + add kernel");
   fprintf(stderr, "[render_mi] scene handed to the device: %u nodes, %lu primitives, %u shapes, %u shaders, %u emitter primitives, film %ux%u\n",
       d.num_nodes, (unsigned long)d.num_prims, d.num_shapes, d.num_materials, d.lights.num_prims, d.width, d.height);
   return 0;
@@ -362,16 +369,16 @@ void render_sample_path(uint64_t index)
     const uint64_t end = t->end;
     const ref_view_t *view = (const ref_view_t *)rt.view;
     const double t0 = common_time_wallclock();
-    mi_fb_clear(r->scene);
+    mi_group_fb_clear(r->scene);
     uint64_t n = 1;
-    if(next == index + 1 && next < end) { mi_render(r->scene, index, end - index); n = end - index; }
+    if(next == index + 1 && next < end) { mi_group_render(r->scene, index, end - index); n = end - index; }
     else
     { /* another worker had drawn an index in between: this path, then the unclaimed rest */
-      mi_render(r->scene, index, 1);
-      if(next < end) { mi_render(r->scene, next, end - next); n += end - next; }
+      mi_group_render(r->scene, index, 1);
+      if(next < end) { mi_group_render(r->scene, next, end - next); n += end - next; }
     }
     /* the progression's contract: after the pool's barrier fb[] has received all splats of [counter, end) */
-    mi_fb_read(r->scene, view->fb[0].fb, 1);
+    mi_group_fb_read(r->scene, view->fb[0].fb, 1);
     r->t_device += common_time_wallclock() - t0;
     r->paths += n;
   }

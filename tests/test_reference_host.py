@@ -105,8 +105,10 @@ def compare_descriptors(dump, sampler):
     assert {"film", "aabb", "cam", "lights", "material", "shape", "tree"} <= seen
 
 
-def run_reference_host(binary, scene, threads, postfix, spp=16, batch=16, dump=None):
+def run_reference_host(binary, scene, threads, postfix, spp=16, batch=16, dump=None, devices=None):
     env = dict(os.environ, LD_LIBRARY_PATH=str(REF / "shaders_mv8"), CORONA_MI_DATA=str(REPO / "corona-13_amd" / "data"))
+    if devices:
+        env["CORONA_MI_DEVICES"] = devices
     if dump:
         env["CORONA_MI_DESC_DUMP"] = str(dump)
     out = subprocess.run([str(REF / binary), str(scene), "-s", str(spp), "--batch", str(batch), "-w", "256", "-h", "256", "-t", str(threads), "-x", postfix],
@@ -176,3 +178,9 @@ def test_reference_host_image_equals_our_host(sampler, tmp_path):
     assert "1048579 paths on the device" in out.stderr, out.stderr
     ip = read_pfm(tmp_path / "scenes" / "0010_pt" / "test_refhost_p4_fb00.pfm")
     assert np.allclose(ip.sum(axis=(0, 1)), ia.sum(axis=(0, 1)), rtol=2e-3)
+    # the reference host on "two GPUs" (two members of an mi_group on device 0, CORONA_MI_DEVICES=0,0): the progression's indices
+    # are split in the library and the two framebuffers are added up on the first member before the reference reads its image back
+    out = run_reference_host(binary, scene, 1, "_refhost_g2", devices="0,0")
+    assert "2 GPUs, framebuffer reduce: peer copies + add kernel" in out.stderr and "1048576 paths on the device" in out.stderr, out.stderr
+    ig = read_pfm(tmp_path / "scenes" / "0010_pt" / "test_refhost_g2_fb00.pfm")
+    assert np.abs(ig - ia).max() <= 1e-4 * float(np.abs(ia).max())
