@@ -49,6 +49,10 @@ class MiNode(C.Structure):
                 ("axis0", C.c_int32), ("axis00", C.c_int32), ("axis01", C.c_int32), ("parent", C.c_int32)]
 
 
+class MiNodeAabb(C.Structure):
+    _fields_ = [("aabb", (C.c_float * 4) * 6)]
+
+
 class MiShadeOp(C.Structure):
     _fields_ = [("kind", C.c_uint32), ("slot", C.c_uint32), ("coeff", C.c_float * 3),
                 ("mul", C.c_float), ("roughness", C.c_float), ("pad", C.c_uint32)]
@@ -84,7 +88,7 @@ class MiSceneDesc(C.Structure):
                 ("num_materials", C.c_uint32), ("materials", C.POINTER(MiMaterial)),
                 ("lights", MiLights), ("cam", MiCamera),
                 ("cie_xyz", C.POINTER(C.c_float)), ("checker", C.POINTER(C.c_float)), ("metal_ior", C.POINTER(C.c_float)),
-                ("pointsampler", C.c_uint32), ("exterior", C.c_uint32)]
+                ("pointsampler", C.c_uint32), ("exterior", C.c_uint32), ("nodes_t1", C.POINTER(MiNodeAabb))]
 
 
 class MiPathVertex(C.Structure):

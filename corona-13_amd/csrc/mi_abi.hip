@@ -106,7 +106,7 @@ struct mi_scene
   int counting;                     /* launch the COUNT instantiations (mi_scene_set_counters / CORONA_MI_COUNTERS) */
   int fast;                         /* launch the FAST instantiations (mi_scene_set_traversal / CORONA_MI_TRAVERSAL): same hits, other work counters */
   bool media;                       /* some shape is filled with a homogeneous medium: MEDIA instantiations */
-  void *d_shape_medium, *d_prims_t1, *d_lights;
+  void *d_shape_medium, *d_prims_t1, *d_lights, *d_nodes_t1;
   /* Halton point sampler */
   bool halton;
   HaltonTables *halton_tables;
@@ -410,6 +410,18 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
     }
     axes[n] = (uint32_t)(nd.axis0 & 3) | ((uint32_t)(nd.axis00 & 3) << 2) | ((uint32_t)(nd.axis01 & 3) << 4);
   }
+  /* the shutter-close boxes, if the caller's tree carries them: same SoA, same treatment of empty children */
+  std::vector<float> nodes_t1;
+  if(!device_build && h->nodes_t1)
+  {
+    nodes_t1.resize((size_t)6*N*4);
+    for(uint32_t n=0;n<N;n++) for(int k=0;k<3;k++) for(int c=0;c<4;c++)
+    {
+      const float b0 = h->nodes_t1[n].aabb[k][c], b1 = h->nodes_t1[n].aabb[k+3][c];
+      nodes_t1[((size_t)k*N + n)*4 + c]     = b0 > b1 ? b1 : b0;
+      nodes_t1[((size_t)(k+3)*N + n)*4 + c] = b0 > b1 ? b0 : b1;
+    }
+  }
   /* primitives: resolve primid -> vtxidx -> vtx once */
   std::vector<DPrim> prims(h->num_prims ? h->num_prims : 1);
   std::vector<DPrimGeo> pgeo(h->num_prims ? h->num_prims : 1);
@@ -604,6 +616,7 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
   {
     UP(d_nodes, nodes.data(), nodes.size());
     UP(d_axes, axes.data(), axes.size());
+    if(!nodes_t1.empty()) { UP(d_nodes_t1, nodes_t1.data(), nodes_t1.size()); }
   }
   UP(d_prims, prims.data(), prims.size());
   UP(d_primgeo, pgeo.data(), pgeo.size());
@@ -698,7 +711,7 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
   { mi_scene_destroy(s); return fail(MI_ERR_DEVICE, "cannot create stream/events"); }
   s->stream = s->stream_own;
 
-  d.nodes = (const float4 *)s->d_nodes;
+  d.nodes = (const float4 *)s->d_nodes; d.nodes_t1 = (const float4 *)s->d_nodes_t1;
   d.prims = (const DPrim *)s->d_prims; d.primgeo = (const DPrimGeo *)s->d_primgeo;
   d.materials = (const DMaterial *)s->d_materials;
   d.shape_medium = (const DShapeMedium *)s->d_shape_medium;
@@ -731,8 +744,10 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
   d.fb = s->d_fb;
   d.counters = (unsigned long long *)s->d_counters;
 
-  const size_t node_bytes = (size_t)MI_NODE_FIELDS*N*16;
-  const size_t stack_bytes = (size_t)MI_STACK_LDS*MI_BLOCK*sizeof(uint2) + (size_t)(MI_BLOCK/64)*MI_JOBS_LDS;   /* + the waves' job lists */
+  /* a scene with moving primitives runs the motion-blur kernels: shallower stack columns, and both box sets of the nodes in LDS */
+  const bool mb_kernels = s->d_prims_t1 != nullptr;
+  const size_t node_bytes = (size_t)(MI_NODE_FIELDS + (mb_kernels && s->d_nodes_t1 ? 6 : 0))*N*16;
+  const size_t stack_bytes = (size_t)(mb_kernels ? MI_STACK_LDS_MB : MI_STACK_LDS)*MI_BLOCK*sizeof(uint2) + (size_t)(MI_BLOCK/64)*MI_JOBS_LDS;   /* + the waves' job lists */
   /* the tree lives in LDS next to the traversal stacks when it fits (0010_pt: 50 KB + 96 KB of 160 KB); larger trees are
      read from HBM / L2 by the NODES_LDS = false instantiations (CORONA_MI_NODES=global forces that, for tests) */
   const char *nodes_env = getenv("CORONA_MI_NODES");
@@ -779,7 +794,7 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
   if(per_cu*MI_BLOCK > 2048) per_cu = 2048/MI_BLOCK;
   s->grid = prop.multiProcessorCount*per_cu;
   {
-    const size_t extra = stack_need > MI_STACK ? (size_t)(stack_need - MI_STACK) : 1;
+    const size_t extra = stack_need > MI_STACK_MIN ? (size_t)(stack_need - MI_STACK_MIN) : 1;
     if(hipMalloc(&s->d_overflow, extra*(size_t)s->grid*MI_BLOCK*sizeof(uint2)) != hipSuccess)
     { mi_scene_destroy(s); return fail(MI_ERR_NOMEM, "cannot allocate the traversal stack overflow area"); }
   }
@@ -1031,7 +1046,7 @@ extern "C" void mi_scene_destroy(mi_scene *s)
   (void)hipSetDevice(s->device);
   void *bufs[] = { s->d_nodes, s->d_axes, s->d_prims, s->d_primgeo, s->d_materials, s->d_light_prim, s->d_light_cdf, s->d_light_L,
                    s->d_cie, s->d_checker, s->d_metal, s->d_counters, s->d_shape_material, s->d_shape_L, s->d_overflow, s->d_fb_own,
-                   s->d_halton_dim, s->d_halton_perm, s->d_shape_medium, s->d_prims_t1, s->d_lights };
+                   s->d_halton_dim, s->d_halton_perm, s->d_shape_medium, s->d_prims_t1, s->d_lights, s->d_nodes_t1 };
   delete s->halton_tables;
   if(s->h_stage) { (void)hipHostFree(s->h_stage); (void)hipEventDestroy(s->ev_stage[0]); (void)hipEventDestroy(s->ev_stage[1]); }
   for(void *b : bufs) if(b) (void)hipFree(b);

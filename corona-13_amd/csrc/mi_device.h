@@ -114,6 +114,7 @@ struct DScene
   /* accel */
   uint32_t num_nodes, num_prims;
   const float4  *nodes;            /* [MI_NODE_FIELDS][num_nodes] */
+  const float4  *nodes_t1;         /* [6][num_nodes] or NULL: the child boxes at shutter close, same field order (mi_scene_desc.nodes_t1) */
   uint32_t root_link;              /* link of node 0: its split axes << MI_AXES_SHIFT */
   uint32_t metal_reference;        /* metal sample() ends the paths the reference BUILD's NaN ends (mi_scene_set_metal_reference) */
   const DPrim  *prims;

@@ -649,6 +649,7 @@ struct Lds
 {
   const float4 *nodes;      /* [MI_NODE_FIELDS][num_nodes] in LDS (or in HBM when the tree does not fit, see lds_setup) */
   uint32_t root;            /* link of node 0 (its split axes << MI_AXES_SHIFT) */
+  const float4 *nodes_t1;   /* [6][num_nodes] in HBM / L2 or NULL: the child boxes at shutter close (motion-blur kernels, DScene.nodes_t1) */
   uint2 *stack;             /* [STACK][BLOCK] in LDS, this thread's column */
   uint2 *overflow;          /* [extra][total threads] in HBM: entries beyond STACK (rare). The workgroup's row; the thread's column is
                                added where it is used, so that no per-thread 64-bit pointer lives in registers through the kernel */
@@ -689,7 +690,10 @@ __device__ __forceinline__ const float4 *lights_lds()
   return (const float4 *)(mi_dynamic_lds + (HALTON ? 2*MI_HALTON_LDS : 0));
 }
 
-template<int BLOCK, bool NODES_LDS, bool HALTON = false, bool LIGHTS = false>
+#ifndef MI_STACK_LDS_MB
+#define MI_STACK_LDS_MB 7   /* entries per lane of the motion-blur kernels' stack columns: the five entries less make room for the nodes' second box set */
+#endif
+template<int BLOCK, bool NODES_LDS, bool HALTON = false, bool LIGHTS = false, int COLUMN = MI_STACK_LDS, bool T1 = false>
 __device__ __forceinline__ Lds lds_setup(const DScene &sc, unsigned char *smem, uint2 *stack_overflow)
 {
   const uint32_t N = sc.num_nodes;
@@ -713,19 +717,24 @@ __device__ __forceinline__ Lds lds_setup(const DScene &sc, unsigned char *smem, 
   if(NODES_LDS)
   {
     float4 *lds_nodes = (float4 *)smem;
-    const size_t stack_off = (size_t)MI_NODE_FIELDS*N*16;
+    /* motion-blur kernels: the shutter-close boxes of the nodes (six more fields) behind the shutter-open ones, if the tree has them */
+    const bool t1 = T1 && sc.nodes_t1 != nullptr;
+    const size_t stack_off = (size_t)(MI_NODE_FIELDS + (t1 ? 6 : 0))*N*16;
     lds_stack = (uint2 *)(smem + stack_off);
     for(uint32_t i=threadIdx.x;i<MI_NODE_FIELDS*N;i+=BLOCK) lds_nodes[i] = sc.nodes[i];
+    if(t1) for(uint32_t i=threadIdx.x;i<6*N;i+=BLOCK) lds_nodes[MI_NODE_FIELDS*N + i] = sc.nodes_t1[i];
     __syncthreads();
     lds.nodes = lds_nodes;
+    lds.nodes_t1 = t1 ? lds_nodes + (size_t)MI_NODE_FIELDS*N : nullptr;
   }
   else
   {
     lds_stack = (uint2 *)smem;
     lds.nodes = sc.nodes;
+    lds.nodes_t1 = sc.nodes_t1;
   }
   lds.stack = lds_stack + threadIdx.x; lds.num_nodes = N; lds.root = sc.root_link;
-  lds.jobs = (unsigned char *)(lds_stack + (size_t)MI_STACK_LDS*BLOCK) + (threadIdx.x >> 6)*MI_JOBS_LDS;
+  lds.jobs = (unsigned char *)(lds_stack + (size_t)COLUMN*BLOCK) + (threadIdx.x >> 6)*MI_JOBS_LDS;
   lds.overflow_stride = gridDim.x*BLOCK;
   lds.overflow = stack_overflow + (size_t)blockIdx.x*BLOCK;
   return lds;
@@ -969,6 +978,7 @@ struct RayBox
   bool slow;                             /* a lane of the wave has an infinite 1/dir: literal SSE-semantics slab test for the whole wave */
   /* FMA slabs (FAST rounds only, MI_SPEC_FMA): -o/d per axis, and the absolute part of the slack of the box test */
   float nox, noy, noz, slack;
+  float w0, w1;                          /* motion-blur kernels: 1 - time, time of the ray (weights of the shutter-open / -close boxes) */
 };
 #ifndef MI_SPEC_FMA
 #define MI_SPEC_FMA 1
@@ -981,6 +991,7 @@ __device__ __forceinline__ RayBox raybox_setup(const V3 o, const V3 d, const Tra
   const uint32_t near_x = __float_as_uint(d.x) >> 31, near_y = __float_as_uint(d.y) >> 31, near_z = __float_as_uint(d.z) >> 31;
   rb.nearbits = near_x | (near_y << 1) | (near_z << 2);
   rb.idx = ts.idx; rb.idy = ts.idy; rb.idz = ts.idz;
+  rb.w0 = 1.0f - ts.time; rb.w1 = ts.time;
   rb.offx = near_x ? 3u*N : 0u; rb.offy = near_y ? 3u*N : 0u; rb.offz = near_z ? 3u*N : 0u;
   if(FMA)
   { /* huge 1/dir (a component of the direction below 1e-30) go the literal way too: plane/d - o/d may be inf - inf there */
@@ -1000,7 +1011,7 @@ __device__ __forceinline__ RayBox raybox_setup(const V3 o, const V3 d, const Tra
 /* one inner node of accel_intersect (src/accel.d/qbvhmp.c:1188-1246,1313-1354): the four child boxes against the ray clipped to
  * `dist`, front-to-back order from split axes and ray signs; the nearest hit child becomes `current`, the others are pushed
  * far-first. Returns false if no child is hit (the caller pops). */
-template<int BLOCK, int STACK, bool FMA = false, class CNT>
+template<int BLOCK, int STACK, bool FMA = false, bool MB = false, class CNT>
 __device__ __forceinline__ bool node_visit(const Lds &lds, lds_uint2 *lstack, const RayBox &rb, const V3 o, float dist, uint32_t &current, int &sp, CNT &cnt)
 { /* FMA (FAST rounds): a plane's distance as fma(plane, 1/d, -o/d) instead of (plane - o)*(1/d) -- one instruction instead of two,
      24 fewer per visit. The two differ by at most 2^-24 (3 |t| + |o/d|) (one rounding of o/d up front instead of one of the
@@ -1016,6 +1027,19 @@ __device__ __forceinline__ bool node_visit(const Lds &lds, lds_uint2 *lstack, co
   const uint4 child = *(const uint4 *)&lds.nodes[6*N + node];
   float tm0, tm1, tm2, tm3;
   mi_u64 M0, M1, M2, M3;    /* child c is hit: lane masks (the compares' own results) in scalar registers, combined by scalar instructions below */
+  /* one field of the node: the planes of the four children -- in a motion-blur kernel whose tree carries the shutter-close boxes too
+     (lds.nodes_t1), the planes at the ray's time, aabb0 (1 - t) + aabb1 t (qbvhmp.c:1208-1224: two products and a sum as there).
+     Rounding is monotonic, so the interpolated lower plane of a box never lies above its upper one and the sign-selected slabs
+     below stay what the reference's min / max of the two plane distances evaluate to. */
+  const float4 *t1p = MB ? lds.nodes_t1 : nullptr;
+  const float w0 = rb.w0, w1 = rb.w1;
+  auto field = [&](uint32_t i) -> float4
+  {
+    const float4 a_ = lds.nodes[i];
+    if(!MB || !t1p) return a_;
+    const float4 b_ = t1p[i];
+    return make_float4(a_.x*w0 + b_.x*w1, a_.y*w0 + b_.y*w1, a_.z*w0 + b_.z*w1, a_.w*w0 + b_.w*w1);
+  };
   if(FMA && !slow)
   {
     const float4 nx = lds.nodes[offx + node],       fx = lds.nodes[3*N - offx + node];
@@ -1033,9 +1057,9 @@ __device__ __forceinline__ bool node_visit(const Lds &lds, lds_uint2 *lstack, co
        the reference's min(t0,t1) / max(t0,t1) evaluate to for finite 1/dir and b_min <= b_max (rounding is monotonic;
        empty children are uploaded as [-FLT_MAX, FLT_MAX], see upload_nodes). That leaves v_max3/v_min3 chains
        instead of 48 compare+select pairs (each pair costs a VCC hazard nop on gfx950). */
-    const float4 nx = lds.nodes[offx + node],       fx = lds.nodes[3*N - offx + node];
-    const float4 ny = lds.nodes[N + offy + node],   fy = lds.nodes[4*N - offy + node];
-    const float4 nz = lds.nodes[2*N + offz + node], fz = lds.nodes[5*N - offz + node];
+    const float4 nx = field(offx + node),       fx = field(3*N - offx + node);
+    const float4 ny = field(N + offy + node),   fy = field(4*N - offy + node);
+    const float4 nz = field(2*N + offz + node), fz = field(5*N - offz + node);
 #define SLAB(J, C, TM) { \
     const float lo = fmaxf(fmaxf(fmaxf((nx.C - o.x)*idx, (ny.C - o.y)*idy), (nz.C - o.z)*idz), 0.0f); \
     const float hi = fminf(fminf(fminf((fx.C - o.x)*idx, (fy.C - o.y)*idy), (fz.C - o.z)*idz), dist); \
@@ -1046,8 +1070,8 @@ __device__ __forceinline__ bool node_visit(const Lds &lds, lds_uint2 *lstack, co
   else
   { /* a lane of this wave has a zero direction component (1/dir infinite): 0*inf NaNs are possible and the reference's
        SSE min/max semantics (second operand on NaN) decide; evaluate them literally with ordered compares */
-    const float4 mnx = lds.nodes[0*N + node], mny = lds.nodes[1*N + node], mnz = lds.nodes[2*N + node];
-    const float4 mxx = lds.nodes[3*N + node], mxy = lds.nodes[4*N + node], mxz = lds.nodes[5*N + node];
+    const float4 mnx = field(0*N + node), mny = field(1*N + node), mnz = field(2*N + node);
+    const float4 mxx = field(3*N + node), mxy = field(4*N + node), mxz = field(5*N + node);
 #define SLAB(J, X0, X1, Y0, Y1, Z0, Z1, TM) { \
     float lo = 0.0f, hi = dist; \
     float t0 = ((X0) - o.x)*idx, t1 = ((X1) - o.x)*idx; \
@@ -1144,7 +1168,7 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
 #ifdef MI_PROFILE_LOOPS
       if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) cnt.c[8] += MI_PROFILE_LOOPS == 2 ? nround : 1;   /* wave-level inner iterations (2: lanes still under way) */
 #endif
-      if(node_visit<BLOCK, STACK>(lds, lstack, rb, o, hit.dist, current, sp, cnt)) {}
+      if(node_visit<BLOCK, STACK, false, MB>(lds, lstack, rb, o, hit.dist, current, sp, cnt)) {}
       else
       { /* pop, skipping entries that start behind the current hit (qbvhmp.c:1357-1364) */
         current = MI_LEAF32;          /* empty leaf: falls out of this loop; `done` if the stack runs dry */

@@ -46,6 +46,9 @@
 #ifndef MI_PARK_ENTRIES
 #define MI_PARK_ENTRIES 4
 #endif
+/* the shallowest LDS stack among the instantiations (FAST kernels with parked path state; motion-blur kernels): the overflow area
+   in HBM is sized for it */
+#define MI_STACK_MIN ((MI_STACK_LDS - 3 - MI_PARK_ENTRIES) < MI_STACK_LDS_MB ? (MI_STACK_LDS - 3 - MI_PARK_ENTRIES) : MI_STACK_LDS_MB)
 #ifndef MI_STACK
 #if MI_LEAF_JOBS
 #define MI_STACK (MI_STACK_LDS - 3)   /* the top three entries of a lane's column hold the results of the distributed leaf phase (leaf_jobs) */
@@ -61,7 +64,8 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
                                                            uint2 *stack_overflow)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const Lds lds = lds_setup<MI_BLOCK, NODES_LDS, HALTON, PTDL && !MEDIA>(sc, smem, stack_overflow);
+  constexpr int COLUMN = MB ? MI_STACK_LDS_MB : MI_STACK_LDS;      /* stack entries per lane in LDS */
+  const Lds lds = lds_setup<MI_BLOCK, NODES_LDS, HALTON, PTDL && !MEDIA, COLUMN, MB>(sc, smem, stack_overflow);
 
   /* every workgroup owns a contiguous part of the path index range and hands it out through an LDS counter: the
      wave-level refill below then needs no global atomic at all (one shared counter costs ~11 ns per wave refill) */
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
      not push path state into scratch, from where the shading blocks would fetch it back word by word. Costs four stack entries. */
   constexpr bool PARK_PS = MI_PARK_PATH && FAST && (PTDL || MI_PARK_PATH == 2);
   constexpr int PARK_N = PARK_PS ? MI_PARK_ENTRIES : 0;        /* 8-byte entries of the column that hold parked path state */
-  constexpr int STACK = ((JOBS || FAST) ? MI_STACK_LDS - 3 : MI_STACK_LDS) - PARK_N;     /* FAST: the rounds of trace_round_spec (mi_kernels.h), same result slots */
+  constexpr int STACK = ((JOBS || FAST) ? COLUMN - 3 : COLUMN) - PARK_N;     /* FAST: the rounds of trace_round_spec (mi_kernels.h), same result slots */
   Counters<COUNT || RECORD> cnt;        /* COUNT = false: only the path count (see Counters, mi_kernels.h) */
   PathState ps;
   ps.active = 0;

@@ -15,9 +15,10 @@ typedef struct ch_geo
   mi_vtx    *vtx;
 } ch_geo;
 
-void ch_prim_bounds(const ch_geo *g, mi_primid pi, float *box6);
+void ch_prim_bounds(const ch_geo *g, mi_primid pi, float *box6);                        /* enclosing the whole motion */
+void ch_prim_bounds_at(const ch_geo *g, mi_primid pi, float *box6, int state);          /* 0 shutter open, 1 shutter close, 2 both */
 int  ch_qbvh_build(const ch_geo *g, mi_primid *primid, uint64_t num_prims,
-                   mi_node **nodes_out, uint32_t *num_nodes_out, float *aabb6);
+                   mi_node **nodes_out, uint32_t *num_nodes_out, float *aabb6, mi_node_aabb **nodes_t1_out);
 float ch_prim_area(const ch_geo *g, mi_primid pi);
 
 /* sigmoid-polynomial spectrum at wavelength lambda [nm] (include/rgb2spec.h:139-149, exact rsqrt) */

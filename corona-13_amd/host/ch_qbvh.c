@@ -49,16 +49,26 @@ static void qb_onb(const float *n, float *u, float *v)
   v[2] = n[0]*u[1] - u[0]*n[1];
 }
 
-/* shutter-open bounds of one primitive */
-void ch_prim_bounds(const ch_geo *g, mi_primid pi, float *box)
+/* bounds of one primitive: `state` 0 = at shutter open (what the reference builds its tree on, prims_get_bounds_shutter_open),
+ * 1 = at shutter close (what it refits the second box set to, prims_get_bounds_shutter_close, src/prims.c:41-60),
+ * 2 = the box enclosing both (the whole linear motion). A static primitive has one box. */
+void ch_prim_bounds_at(const ch_geo *g, mi_primid pi, float *box, int state)
 {
   const mi_shape *sh = g->shapes + MI_PRIMID_SHAPE(pi);
   const mi_vtxidx *vi = g->vtxidx + sh->vtxidx_base + MI_PRIMID_VI(pi);
   const mi_vtx *vtx = g->vtx + sh->vtx_base;
   const uint32_t vcnt = MI_PRIMID_VCNT(pi);
+  if(MI_PRIMID_MB(pi) && state == 2)
+  {
+    float b1[6];
+    ch_prim_bounds_at(g, pi, box, 0);
+    ch_prim_bounds_at(g, pi, b1, 1);
+    for(int d=0;d<3;d++) { box[d] = fminf(box[d], b1[d]); box[3+d] = fmaxf(box[3+d], b1[3+d]); }
+    return;
+  }
   if(vcnt < MI_PRIM_TRI && MI_PRIMID_MB(pi))
-  { /* moving sphere / line: the box of each state (radii are those of the shutter-open vertices, sphere.h:7-11, line.h:10-16),
-       then the box enclosing both */
+  { /* moving sphere / line (vertices interleaved shutter open / close): the static primitive of that state; radii are those of
+       the shutter-open vertices (sphere.h:7-11, line.h:10-16) */
     ch_geo one = *g;
     mi_vtxidx idx[2];
     mi_vtx v[2];
@@ -69,22 +79,13 @@ void ch_prim_bounds(const ch_geo *g, mi_primid pi, float *box)
     shapes[MI_PRIMID_SHAPE(pi)] = sh1;
     one.shapes = shapes; one.vtxidx = idx; one.vtx = v;
     const mi_primid still = (pi & ~(1ull << 60)) & ~(0x0fffffffull << 32);     /* same primitive, not moving, vertex index 0 */
-    for(uint32_t t=0;t<2;t++)
+    for(uint32_t k=0;k<vcnt;k++)
     {
-      for(uint32_t k=0;k<vcnt;k++)
-      {
-        idx[k].v = k; idx[k].uv = vi[k].uv;
-        v[k] = vtx[2*vi[k].v + t];
-        v[k].n = vtx[2*vi[k].v].n;
-      }
-      float b[6];
-      ch_prim_bounds(&one, still, b);
-      for(int d=0;d<3;d++)
-      {
-        box[d] = t ? fminf(box[d], b[d]) : b[d];
-        box[3+d] = t ? fmaxf(box[3+d], b[3+d]) : b[3+d];
-      }
+      idx[k].v = k; idx[k].uv = vi[k].uv;
+      v[k] = vtx[2*vi[k].v + (state ? 1 : 0)];
+      v[k].n = vtx[2*vi[k].v].n;
     }
+    ch_prim_bounds_at(&one, still, box, 0);
     return;
   }
   if(vcnt == MI_PRIM_SPHERE)
@@ -111,15 +112,13 @@ void ch_prim_bounds(const ch_geo *g, mi_primid pi, float *box)
     }
   }
   else
-  { /* include/geo/triangle.h:7-19 */
-    /* motion-blurred triangles / quads (vertices interleaved shutter open / close, include/geo.h:108-138): the box encloses both
-       states, i.e. the whole linear motion. The reference keeps one box per state and interpolates them per ray
-       (src/accel.d/qbvhmp.c:1208-1224); a static enclosing box gives the same closest hits with more node visits */
-    const uint32_t mb = MI_PRIMID_MB(pi);
+  { /* include/geo/triangle.h:7-33; motion-blurred triangles / quads keep their vertices interleaved shutter open / close
+       (include/geo.h:108-138) */
+    const uint32_t mb = MI_PRIMID_MB(pi), t = (mb && state) ? 1u : 0u;
     for(int d=0;d<3;d++)
     {
-      float m = vtx[(mb+1)*vi[0].v].v[d], M = m;
-      for(uint32_t k=0;k<vcnt;k++) for(uint32_t t=0;t<=mb;t++)
+      float m = vtx[(mb+1)*vi[0].v + t].v[d], M = m;
+      for(uint32_t k=1;k<vcnt;k++)
       {
         const float x = vtx[(mb+1)*vi[k].v + t].v[d];
         m = fminf(x, m); M = fmaxf(x, M);
@@ -128,6 +127,9 @@ void ch_prim_bounds(const ch_geo *g, mi_primid pi, float *box)
     }
   }
 }
+
+/* the box enclosing the whole motion of one primitive (scene box, device build) */
+void ch_prim_bounds(const ch_geo *g, mi_primid pi, float *box) { ch_prim_bounds_at(g, pi, box, 2); }
 
 /* best of 7 equidistant planes along dimension d of box `aabb` for prims [left,right) */
 static float qb_split(const qb_t *q, int64_t left, int64_t right, const float *aabb, int d, float *split)
@@ -285,7 +287,39 @@ static void qb_node(qb_t *q, uint32_t ni, int64_t left, int64_t right, const flo
   }
 }
 
-int ch_qbvh_build(const ch_geo *g, mi_primid *primid, uint64_t num_prims, mi_node **nodes_out, uint32_t *num_nodes_out, float *aabb)
+/* the second box set of the reference's nodes (qbvh_node_t.aabb1): a leaf's box bounds the shutter-close state of its primitives
+ * (bound_leaf_t1, qbvhmp.c:854-873), an inner child's the four boxes of that child, bottom-up (accel_refit, qbvhmp.c:259-283) */
+static void qb_refit_t1(const qb_t *q, mi_node_aabb *t1, uint32_t ni)
+{
+  const mi_node *node = q->nodes + ni;
+  for(int c=0;c<4;c++)
+  {
+    float *lo[3], *hi[3];
+    for(int d=0;d<3;d++) { lo[d] = &t1[ni].aabb[d][c]; hi[d] = &t1[ni].aabb[3+d][c]; *lo[d] = FLT_MAX; *hi[d] = -FLT_MAX; }
+    if(node->child[c] & MI_NODE_LEAF)
+    {
+      const uint64_t first = (node->child[c] ^ MI_NODE_LEAF) >> 5, cnt = node->child[c] & 31u;
+      for(uint64_t k=first;k<first+cnt;k++)
+      {
+        float b[6];
+        ch_prim_bounds_at(q->geo, q->primid[k], b, 1);
+        for(int d=0;d<3;d++) { *lo[d] = QMIN(*lo[d], b[d]); *hi[d] = QMAX(*hi[d], b[3+d]); }
+      }
+    }
+    else
+    {
+      const uint32_t ch = (uint32_t)node->child[c];
+      qb_refit_t1(q, t1, ch);
+      for(int d=0;d<3;d++) { *lo[d] = t1[ch].aabb[d][0]; *hi[d] = t1[ch].aabb[3+d][0]; }
+      for(int k=1;k<4;k++) for(int d=0;d<3;d++) { *lo[d] = QMIN(*lo[d], t1[ch].aabb[d][k]); *hi[d] = QMAX(*hi[d], t1[ch].aabb[3+d][k]); }
+    }
+  }
+}
+
+/* builds the tree on the shutter-open boxes like the reference (compute_aabb, qbvhmp.c:1034-1065). aabb = the scene box over the
+ * whole motion. nodes_t1_out (may be NULL): the shutter-close boxes, allocated only if a primitive moves (else *nodes_t1_out = NULL) */
+int ch_qbvh_build(const ch_geo *g, mi_primid *primid, uint64_t num_prims, mi_node **nodes_out, uint32_t *num_nodes_out, float *aabb,
+                  mi_node_aabb **nodes_t1_out)
 {
   qb_t q;
   memset(&q, 0, sizeof(q));
@@ -294,14 +328,21 @@ int ch_qbvh_build(const ch_geo *g, mi_primid *primid, uint64_t num_prims, mi_nod
   q.nodes = (mi_node *)calloc(q.cap_nodes, sizeof(mi_node));
   q.box = (float *)malloc(sizeof(float)*6*(num_prims ? num_prims : 1));
   if(!q.nodes || !q.box) { free(q.nodes); free(q.box); return MI_ERR_NOMEM; }
-  for(int k=0;k<3;k++) { aabb[k] = FLT_MAX; aabb[3+k] = -FLT_MAX; }
+  float open[6];
+  int moving = 0;
+  for(int k=0;k<3;k++) { aabb[k] = open[k] = FLT_MAX; aabb[3+k] = open[3+k] = -FLT_MAX; }
   for(uint64_t i=0;i<num_prims;i++)
   {
-    ch_prim_bounds(g, primid[i], q.box + 6*i);
+    float whole[6];
+    ch_prim_bounds_at(g, primid[i], q.box + 6*i, 0);
+    ch_prim_bounds_at(g, primid[i], whole, 2);
+    if(MI_PRIMID_MB(primid[i])) moving = 1;
     for(int k=0;k<3;k++)
     {
-      if(aabb[k]   > q.box[6*i+k])   aabb[k]   = q.box[6*i+k];
-      if(aabb[3+k] < q.box[6*i+3+k]) aabb[3+k] = q.box[6*i+3+k];
+      if(open[k]   > q.box[6*i+k])   open[k]   = q.box[6*i+k];
+      if(open[3+k] < q.box[6*i+3+k]) open[3+k] = q.box[6*i+3+k];
+      if(aabb[k]   > whole[k])   aabb[k]   = whole[k];
+      if(aabb[3+k] < whole[3+k]) aabb[3+k] = whole[3+k];
     }
   }
   q.num_nodes = 1;
@@ -315,7 +356,18 @@ int ch_qbvh_build(const ch_geo *g, mi_primid *primid, uint64_t num_prims, mi_nod
     }
     n->axis0 = 0; n->axis00 = 1; n->axis01 = 1; n->parent = -1;
   }
-  else qb_node(&q, 0, 0, (int64_t)num_prims, aabb, 0, -1, 0);
+  else qb_node(&q, 0, 0, (int64_t)num_prims, open, 0, -1, 0);
+  if(nodes_t1_out)
+  {
+    *nodes_t1_out = NULL;
+    if(moving && num_prims)
+    {
+      mi_node_aabb *t1 = (mi_node_aabb *)calloc(q.num_nodes, sizeof(mi_node_aabb));
+      if(!t1) { free(q.nodes); free(q.box); return MI_ERR_NOMEM; }
+      qb_refit_t1(&q, t1, 0);
+      *nodes_t1_out = t1;
+    }
+  }
   free(q.box);
   *nodes_out = q.nodes;
   *num_nodes_out = q.num_nodes;

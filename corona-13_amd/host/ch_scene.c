@@ -45,6 +45,7 @@ struct ch_scene
   ch_geo geo;
   mi_primid *primid;
   mi_node *nodes;
+  mi_node_aabb *nodes_t1;        /* shutter-close boxes of the nodes, or NULL (no moving primitive) */
   mi_material *materials;
   mi_primid *light_primid;
   float *light_cdf, *light_L;
@@ -647,9 +648,9 @@ int ch_scene_load(const char *nra2_path, const ch_options *opt_in, ch_scene **ou
   if((err = compile_all_materials(s))) goto fail;
   if((err = init_lights(s))) goto fail;
   if((err = load_camera(s))) goto fail;
-  if((err = ch_qbvh_build(&s->geo, s->primid, d->num_prims, &s->nodes, &d->num_nodes, d->aabb))) goto fail;
+  if((err = ch_qbvh_build(&s->geo, s->primid, d->num_prims, &s->nodes, &d->num_nodes, d->aabb, &s->nodes_t1))) goto fail;
 
-  d->nodes = s->nodes; d->primid = s->primid;
+  d->nodes = s->nodes; d->nodes_t1 = s->nodes_t1; d->primid = s->primid;
   d->num_shapes = s->geo.num_shapes; d->shapes = s->geo.shapes;
   d->num_vtxidx = s->geo.num_vtxidx; d->vtxidx = s->geo.vtxidx;
   d->num_vtx = s->geo.num_vtx; d->vtx = s->geo.vtx;
@@ -713,7 +714,7 @@ void ch_scene_free(ch_scene *s)
   if(!s) return;
   if(g_cie_table == s->cie) g_cie_table = 0;
   free(s->shader); free(s->geo.shapes); free(s->geo.vtxidx); free(s->geo.vtx);
-  free(s->primid); free(s->nodes); free(s->materials);
+  free(s->primid); free(s->nodes); free(s->nodes_t1); free(s->materials);
   free(s->light_primid); free(s->light_cdf); free(s->light_L);
   free(s->cie); free(s->checker); free(s->metal);
   free(s);

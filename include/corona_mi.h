@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 2
+#define MI_ABI_VERSION 3
 
 /* ---- error codes (negative ints, reference style: non-zero == failure) ---------- */
 #define MI_OK              0
@@ -79,6 +79,7 @@ typedef struct mi_node
   int32_t  axis0, axis00, axis01;
   int32_t  parent;
 } mi_node;
+typedef struct mi_node_aabb { float aabb[6][4]; } mi_node_aabb;   /* one more set of child boxes, same layout as mi_node.aabb */
 
 /* ---- materials: the dlopen'ed shader chain of one .nra2 material, compiled to a closed set
  *      (src/shader.c:693-757, src/shaders/{mult,color,colorcheckersg,dielectric,metal}.c) ---------- */
@@ -201,6 +202,11 @@ typedef struct mi_scene_desc
   uint32_t pointsampler;      /* MI_POINTS_*: which MOD_pointsampler maps (path, dimension) to a number in [0,1) */
   uint32_t exterior;          /* 0: the scene sits in vacuum; k+1: material k (MI_BSDF_MEDIUM) is the global exterior medium,
                                  `exterior <k> 0` in the .nra2 (src/shader.c:544-565,699-716; volume lights are out of scope) */
+  const mi_node_aabb *nodes_t1; /* [num_nodes] or NULL. The child boxes at shutter CLOSE (qbvh_node_t.aabb1, src/accel.d/qbvhmp.c:62-81,
+                                 259-283,854-873: leaves refitted to the shutter-close state of their primitives, inner nodes bottom-up).
+                                 With it mi_node.aabb holds the shutter-OPEN boxes and every ray tests the boxes interpolated at its
+                                 path's time, aabb (1 - t) + aabb1 t (qbvhmp.c:1188-1224) -- the reference's traversal work for scenes
+                                 with motion-blurred primitives. NULL: mi_node.aabb must enclose the whole motion (static test) */
 } mi_scene_desc;
 
 typedef struct mi_scene mi_scene;   /* opaque, device resident */

@@ -309,17 +309,23 @@ void o_accel_intersect(o_ctx *c, const o_ray *ray, o_hit *hit)
   int sp = 0;
   uint64_t current;
   const mi_node *node = s->nodes;
+  /* scenes with motion-blurred primitives carry a second set of boxes (shutter close): every ray tests the boxes interpolated at
+     its time, aabb0 (1 - t) + aabb1 t (qbvhmp.c:1208-1224); static scenes test aabb0 as it is (there the lerp is the identity) */
+  const float w0 = 1.0f - ray->time, w1 = ray->time;
   while(1)
   {
     float tmin[4];
     int hitm[4], any = 0;
+    const mi_node_aabb *nt1 = s->nodes_t1 ? s->nodes_t1 + (node - s->nodes) : 0;
     for(int j=0;j<4;j++)
     { /* aabb_intersect, qbvhmp.c:1188-1246, with SSE min/max semantics (second operand on NaN) */
       float lo = 0.0f, hi = hit->dist;
       for(int k=0;k<3;k++)
       {
-        const float t0 = (node->aabb[k][j]   - ray->pos[k])*invdir[k];
-        const float t1 = (node->aabb[k+3][j] - ray->pos[k])*invdir[k];
+        const float b0 = nt1 ? node->aabb[k][j]*w0   + nt1->aabb[k][j]*w1   : node->aabb[k][j];
+        const float b1 = nt1 ? node->aabb[k+3][j]*w0 + nt1->aabb[k+3][j]*w1 : node->aabb[k+3][j];
+        const float t0 = (b0 - ray->pos[k])*invdir[k];
+        const float t1 = (b1 - ray->pos[k])*invdir[k];
         const float mn = t0 < t1 ? t0 : t1;
         const float mx = t0 > t1 ? t0 : t1;
         lo = lo > mn ? lo : mn;

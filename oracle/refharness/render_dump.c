@@ -50,6 +50,13 @@ static void dump_tree(const char *fn)
     fwrite(ax, sizeof(ax), 1, f);
   }
   fwrite(rt.prims->primid, sizeof(primid_t), rt.prims->num_prims, f);
+  /* appended (readers of the older layout stop above): the shutter-close boxes of every node, qbvh_node_t.aabb1 */
+  for(uint64_t n=0;n<a->num_nodes;n++)
+  {
+    float box[6][4];
+    for(int k=0;k<6;k++) for(int c=0;c<4;c++) box[k][c] = a->tree[n].aabb1[k].f[c];
+    fwrite(box, sizeof(box), 1, f);
+  }
   fclose(f);
 }
 

@@ -77,6 +77,7 @@ typedef struct render_t
   mi_group *scene;              /* one member per GPU (CORONA_MI_GPUS=n or CORONA_MI_DEVICES=i,j,..; default: the one mi_init picks) */
   /* storage behind the descriptor */
   mi_node *nodes;
+  mi_node_aabb *nodes_t1;
   mi_shape *shapes;
   mi_vtxidx *vtxidx;
   mi_vtx *vtx;
@@ -107,7 +108,7 @@ void render_cleanup(render_t *r)
     mi_group_destroy(r->scene);
     mi_shutdown();
   }
-  free(r->nodes); free(r->shapes); free(r->vtxidx); free(r->vtx); free(r->materials); free(r->cdf); free(r->cie); free(r->checker); free(r->metal);
+  free(r->nodes); free(r->nodes_t1); free(r->shapes); free(r->vtxidx); free(r->vtx); free(r->materials); free(r->cdf); free(r->cie); free(r->checker); free(r->metal);
   free(r);
 }
 
@@ -240,6 +241,17 @@ static int setup(render_t *r)
   }
   d.nodes = r->nodes;
   memcpy(d.aabb, a->aabb, sizeof(d.aabb));
+  { /* a scene with motion-blurred primitives: the shutter-close boxes of the nodes go over too (qbvh_node_t.aabb1), the backend
+       then interpolates the boxes per ray like accel_intersect does (qbvhmp.c:1208-1224) */
+    int moving = 0;
+    for(uint64_t k=0;k<rt.prims->num_prims && !moving;k++) moving = rt.prims->primid[k].mb;
+    if(moving)
+    {
+      r->nodes_t1 = (mi_node_aabb *)calloc(a->num_nodes, sizeof(mi_node_aabb));
+      for(uint64_t n=0;n<a->num_nodes;n++) for(int k=0;k<6;k++) for(int c=0;c<4;c++) r->nodes_t1[n].aabb[k][c] = a->tree[n].aabb1[k].f[c];
+      d.nodes_t1 = r->nodes_t1;
+    }
+  }
 
   /* primitives: the reference's primid array as the builder left it; vertex arrays of all shapes behind one another */
   const prims_t *p = rt.prims;

@@ -10,7 +10,7 @@ sources under /root/reference) and writes small data files that are committed:
   counters.json              -DACCEL_DEBUG work counters (rays, node visits, box hits, prim tests) for 1 spp
   tilemeans_<cfg>.npz        32x32 tile means + image means of high-spp reference renders (statistical oracle)
 
-Usage: python3 tests/golden/make_golden.py [quick|paths|images|all]
+Usage: python3 tests/golden/make_golden.py [quick|paths|mb|images|all]
 """
 import json
 import os
@@ -70,22 +70,34 @@ def dump_paths(name, binary, mv, scene, w, h, n):
     return work
 
 
-def dump_tree(work):
+def dump_tree(work, name="tree_0010"):
     d = (work / "tree.bin").read_bytes()
     magic, nn, npr = struct.unpack("<QQQ", d[:24])
     off = 24
     aabb = np.frombuffer(d, dtype="<f4", count=6, offset=off); off += 24
     node_dt = np.dtype([("box", "<f4", (6, 4)), ("child", "<u8", 4), ("ax", "<i4", 4)])
     nodes = np.frombuffer(d, dtype=node_dt, count=nn, offset=off); off += nn * node_dt.itemsize
-    prim = np.frombuffer(d, dtype="<u8", count=npr, offset=off)
-    np.savez_compressed(GOLD / "tree_0010.npz", aabb=aabb, box=nodes["box"], child=nodes["child"], ax=nodes["ax"], primid=prim)
-    print("wrote tree", nn, "nodes")
+    prim = np.frombuffer(d, dtype="<u8", count=npr, offset=off); off += 8 * npr
+    box1 = np.frombuffer(d, dtype="<f4", count=nn * 24, offset=off).reshape(nn, 6, 4)      # shutter-close boxes (qbvh_node_t.aabb1)
+    np.savez_compressed(GOLD / f"{name}.npz", aabb=aabb, box=nodes["box"], child=nodes["child"], ax=nodes["ax"], primid=prim, box1=box1)
+    print("wrote", name, nn, "nodes")
+
+
+def dump_mb_tree():
+    """the reference's tree of scenes/0059_mb (moving backdrop and cylinder cap): built on the shutter-open boxes, second box set
+    refitted to the shutter-close state (src/accel.d/qbvhmp.c:259-283,854-873)"""
+    work = Path(tempfile.mkdtemp(prefix="corona_ref_"))
+    run_ref("dump_pt_xs_mv8", 8, "0059_mb", ["-s", "1", "-w", "256", "-h", "256", "-t", "1", "-x", "_dump"],
+            env={"CORONA_DUMP_N": "16", "CORONA_DUMP_FILE": str(work / "paths.bin"), "CORONA_DUMP_TREE": str(work / "tree.bin")}, work=work)
+    dump_tree(work, "tree_0059_mb")
 
 
 def counters():
     out = {}
-    for name, binary in [("pt_mv8", "corona_pt_xs_mv8_dbg"), ("ptdl_mv8", "corona_ptdl_xs_mv8_dbg")]:
-        _, log = run_ref(binary, 8, "0010_pt", ["-s", "1", "-w", "1280", "-h", "720", "-t", "1", "-x", "_dbg"])
+    for name, binary, scene in [("pt_mv8", "corona_pt_xs_mv8_dbg", "0010_pt"), ("ptdl_mv8", "corona_ptdl_xs_mv8_dbg", "0010_pt"),
+                                # moving geometry: the reference interpolates the node boxes per ray (qbvhmp.c:1208-1224)
+                                ("mb_pt_mv8", "corona_pt_xs_mv8_dbg", "0059_mb"), ("mb_round_pt_mv8", "corona_pt_xs_mv8_dbg", "0062_mb_round")]:
+        _, log = run_ref(binary, 8, scene, ["-s", "1", "-w", "1280", "-h", "720", "-t", "1", "-x", "_dbg"])
         m = re.search(r"accel_intersect: (\d+) aabb_intersect (\d+) / (\d+) prims_intersect (\d+)", log)
         out[name] = {"paths": 1280 * 736, "rays": int(m.group(1)), "box_hits": int(m.group(2)),
                      "node_visits": int(m.group(3)), "prim_tests": int(m.group(4))}
@@ -175,12 +187,17 @@ def main():
         dump_paths("halton_fog_ptdl_mv8", "dump_ptdl_halton_mv8", 8, "0056_fog", 1280, 720, 6000)   # free-flight dimension from the Halton sampler
         dump_paths("halton_ptdl_rough_mv32", "dump_ptdl_halton_mv32", 32, "0052_rough", 1280, 720, 2000)
         counters()
+    if what in ("mb", "quick", "paths", "all"):
+        dump_mb_tree()
+        if what == "mb":
+            counters()
     if what in ("images", "all"):
         tilemeans("pt_mv8", "corona_pt_sfmt_mv8", 8, "0010_pt", 1280, 720, 2048)
         tilemeans("ptdl_mv8", "corona_ptdl_sfmt_mv8", 8, "0010_pt", 1280, 720, 512)
         tilemeans("rough_mv32", "corona_pt_sfmt_mv32", 32, "0052_rough", 1280, 720, 512)
         tilemeans("pt_mv4_256", "corona_pt_sfmt_mv4", 4, "0010_pt", 256, 256, 4096)
         image_pair("pt_mv8_64", "corona_pt_sfmt_mv8", 8, "0010_pt", 64, 64, 65536)
+        tilemeans("metal_ptdl_mv8", "corona_ptdl_sfmt_mv8", 8, "0053_metal", 1280, 720, 1024)
 
 
 if __name__ == "__main__":

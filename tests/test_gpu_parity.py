@@ -1059,3 +1059,25 @@ def test_metal_image_against_the_reference_render(reference_build):
     # the sphere fills the tiles around row 9..11, column 17..22 (first-hit statistics of the oracle): no cluster of dark tiles there
     zs = z[9:12, 17:23, 1]
     assert np.abs(np.median(zs)) < 1.0 and (zs < -4).sum() <= 1, zs
+
+
+@pytest.mark.parametrize("scene_path,key", [(SCENE_MB, "mb_pt_mv8"), (SCENE_MB_ROUND, "mb_round_pt_mv8")])
+def test_motion_blur_traversal_work_equals_the_reference(scene_path, key):
+    """moving geometry with the reference's time-interpolated node boxes (mi_scene_desc.nodes_t1: the shutter-close boxes next to the
+    shutter-open ones, interpolated per ray in the motion-blur kernels; src/accel.d/qbvhmp.c:1208-1224): one sample per pixel of
+    the 1280x720 film does the reference's traversal work -- rays, node visits, box hits, primitive tests within 3e-3 of its own
+    -DACCEL_DEBUG totals (tests/golden/counters.json) and equal to the oracle's; and the same image as the oracle."""
+    gold = json.loads((GOLDEN / "counters.json").read_text())[key]
+    scene = make_scene(scene_path, width=1280, height=720, max_verts=8)
+    assert bool(scene.desc.nodes_t1)
+    n = scene.width * scene.height
+    be = pkg.Backend(scene, traversal="exact")
+    be.render(0, n)
+    fb, cnt = be.fb_read(), be.counters()
+    be.close()
+    for k, name in ((0, "rays"), (1, "node_visits"), (2, "box_hits"), (3, "prim_tests")):
+        assert abs(cnt[k] - gold[name]) <= 3e-3 * gold[name], (name, cnt[k], gold[name])
+    ofb, ocnt, _ = oracle_render(scene, 0, n, threads=8)
+    for k in range(4):
+        assert abs(cnt[k] - ocnt[k]) <= 1e-3 * ocnt[k], (k, cnt[k], ocnt[k])
+    assert np.sqrt((((fb - ofb) * scene.gain(1)) ** 2).sum() / n) < 0.05

@@ -60,6 +60,39 @@ def test_qbvh_equals_reference_tree():
     assert seen == 428
 
 
+def test_qbvh_of_a_motion_blurred_scene_equals_the_reference_tree():
+    """scenes/0059_mb (the backdrop's 4096 quads and the cylinder cap move): the reference builds on the shutter-OPEN boxes and refits
+    a second box set to the shutter-close state (src/accel.d/qbvhmp.c:259-283,854-873, 1034-1065); tests/golden/tree_0059_mb.npz is
+    that tree dumped from the real reference. Same topology, primitive order and shutter-open boxes to the bit, and the same
+    shutter-close boxes (mi_scene_desc.nodes_t1) to the bit."""
+    from helpers import SCENE_MB
+    g = np.load(GOLDEN / "tree_0059_mb.npz")
+    s = make_scene(SCENE_MB, inject=False, width=256, height=256, max_verts=8)
+    d = s.desc
+    assert d.num_nodes == len(g["box"]) and bool(d.nodes_t1)
+    assert np.array_equal(np.ctypeslib.as_array(d.primid, (d.num_prims,)), g["primid"])
+    stack, seen = [(0, 0)], 0
+    while stack:
+        rn, mn = stack.pop()
+        seen += 1
+        node, t1 = d.nodes[mn], d.nodes_t1[mn]
+        box = np.array([[node.aabb[k][c] for c in range(4)] for k in range(6)], dtype=np.float32)
+        box1 = np.array([[t1.aabb[k][c] for c in range(4)] for k in range(6)], dtype=np.float32)
+        assert np.array_equal(box, g["box"][rn]) and np.array_equal(box1, g["box1"][rn]), (rn, box1, g["box1"][rn])
+        assert (node.axis0, node.axis00, node.axis01) == tuple(int(x) for x in g["ax"][rn][:3])
+        for c in range(4):
+            rc, mc = int(g["child"][rn][c]), int(node.child[c])
+            assert (rc >> 63) == (mc >> 63)
+            if rc >> 63:
+                assert rc == mc
+            else:
+                stack.append((rc, mc))
+    assert seen == d.num_nodes
+    assert (g["box1"] != g["box"]).any()                      # the two box sets do differ
+    # a static scene carries no second set
+    assert not make_scene(SCENE_0010, inject=False, width=256, height=256, max_verts=8).desc.nodes_t1
+
+
 def test_leaves_cover_all_prims_once():
     s = make_scene(SCENE_0010, inject=False, width=256, height=256, max_verts=4)
     d = s.desc

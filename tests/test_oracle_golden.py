@@ -274,3 +274,19 @@ def test_halton_tables_match_libc_drand48():
         assert list(table[off[dim]:off[dim] + size]) == want, b
     # base 3 keeps the identity permutation: five digits reversed
     assert table[off[1] + 1] == 81 and table[off[1] + 3] == 27
+
+
+def test_motion_blur_work_counters_equal_the_reference():
+    """scenes/0059_mb with the node boxes interpolated at every ray's time (mi_scene_desc.nodes_t1; src/accel.d/qbvhmp.c:1208-1224):
+    the oracle's rays, node visits, box hits and primitive tests on a quarter of the reference's 1-spp frame scale to the
+    reference's own -DACCEL_DEBUG totals (tests/golden/counters.json, corona_pt_xs_mv8_dbg) within 1 % -- with one static box
+    around each primitive's whole motion the same frame costs 7 % more node visits, 14 % more box hits, 33 % more primitive tests."""
+    import json
+    from helpers import SCENE_MB, oracle_render
+    gold = json.loads((GOLDEN / "counters.json").read_text())["mb_pt_mv8"]
+    scene = make_scene(SCENE_MB, width=1280, height=720, max_verts=8)
+    n = scene.width * scene.height // 4
+    _, cnt, _ = oracle_render(scene, 0, n, threads=8)
+    assert cnt[4] == n
+    for k, key in ((0, "rays"), (1, "node_visits"), (2, "box_hits"), (3, "prim_tests")):
+        assert abs(4 * cnt[k] / gold[key] - 1) < 1e-2, (key, 4 * cnt[k], gold[key])
