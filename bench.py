@@ -198,7 +198,7 @@ def bench_group(args):
                       pointsampler=pkg.MI_POINTS_HALTON if args.points == "halton" else pkg.MI_POINTS_RAND)
     per_frame = cfg["spp"] * scene.width * scene.height
     job = per_frame if scaling == "strong" else args.gpus * per_frame
-    group = pkg.Group(scene, list(range(args.gpus)), traversal=args.traversal)
+    group = pkg.Group(scene, list(range(args.gpus)), traversal=None if args.traversal == "auto" else args.traversal)
     host = np.zeros((scene.height, scene.width, 3), dtype=np.float32)
     for k in range(args.warmup):
         group.render(k * job, job)
@@ -250,9 +250,10 @@ def main():
                          "device: no tree handed over, the backend builds its own (csrc/mi_build.h)")
     ap.add_argument("--points", default="rand", choices=["rand", "halton"],
                     help="MOD_pointsampler: rand (regression/0010_pt/config.mk, the default) or halton (SURVEY 8(f) row 2)")
-    ap.add_argument("--traversal", default="fast", choices=["fast", "exact"],
-                    help="fast (the library's default): leaves put aside while a lane descends on, same hits; exact: the reference's order of "
-                         "operations per ray, work counters equal its -DACCEL_DEBUG totals (corona_mi.h, MI_TRAVERSAL_*)")
+    ap.add_argument("--traversal", default="auto", choices=["auto", "fast", "exact"],
+                    help="auto (the library's choice per scene: fast for the plain pt kernels, exact otherwise); fast: leaves put aside while a lane "
+                         "descends on, same hits; exact: the reference's order of operations per ray, work counters equal its -DACCEL_DEBUG totals "
+                         "(corona_mi.h, MI_TRAVERSAL_*)")
     ap.add_argument("--reduce", default="torch", choices=["torch", "c"],
                     help="torch: one process per GPU, torch.distributed (RCCL) all-reduce of the framebuffer (what the driver launches); c: ONE process, "
                          "the N GPUs behind the C ABI (mi_group_*: index ranges split in the library, ncclReduce from the library)")
@@ -326,7 +327,8 @@ def main():
             be.set_framebuffer_tensor(fb)
         else:
             # the timed kernels carry no debug counters (only the path count), like the reference without -DACCEL_DEBUG
-            be = pkg.Backend(scene, device=local_rank, device_build=args.tree == "device", counters=False, traversal=args.traversal)
+            be = pkg.Backend(scene, device=local_rank, device_build=args.tree == "device", counters=False,
+                             traversal=None if args.traversal == "auto" else args.traversal)
             be.set_framebuffer(fb.data_ptr())
             # torch's current stream (the default stream, passed as MI_STREAM_DEFAULT): clears and RCCL are ordered with the renders
             be.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -400,7 +402,8 @@ def main():
         be.sync()
         dc = [b - a for a, b in zip(w0, be.counters())]
         res = dict(cfg=cfg, scene_wh=(scene.width, scene.height), per_frame=per_frame, job=job, elapsed=elapsed, dc=dc, kms=kms,
-                   launch_paths=count, nodes_in_lds=be.nodes_in_lds(), reduced_sum=reduced_sum, steps=steps, image_mean=image_mean)
+                   launch_paths=count, nodes_in_lds=be.nodes_in_lds(), reduced_sum=reduced_sum, steps=steps, image_mean=image_mean,
+                   traversal="stub" if args.stub else be.traversal())
         be.close()
         return res
 
@@ -409,7 +412,7 @@ def main():
         inst = ("false", "true" if cfg["sampler"] == "ptdl" else "false", "true" if r["nodes_in_lds"] else "false",
                 "true" if args.points == "halton" else "false",
                 "true" if cfg["scene"] in ("0055_media", "0056_fog", "0058_cam_mb", "0059_mb") else "false", "true" if cfg["scene"] == "0059_mb" else "false", "false",
-                "true" if args.traversal == "fast" and cfg["scene"] != "0059_mb" else "false")
+                "true" if r["traversal"] == "fast" else "false")
         return "mi_path_kernel<%s> (RECORD, PTDL, NODES_LDS, HALTON, MEDIA, MB, COUNT, FAST)" % ",".join(inst)
 
     def work_rate_of(config, r):
@@ -506,7 +509,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic: regression/0010_pt scene (6 of 7 shapes, scenes/0010_pt), per-path xorshift128+ seeds",
-            "config": {"workload": cfg["name"], "tree": args.tree, "pointsampler": args.points, "traversal": args.traversal,
+            "config": {"workload": cfg["name"], "tree": args.tree, "pointsampler": args.points, "traversal": main_r["traversal"],
                        "paths_per_step": main_r["job"], "paths_per_step_per_gpu": main_r["launch_paths"],
                        "sharding": f"path-index ranges x{world} ({scaling}), framebuffer all-reduce + read-back of the last frame in the timed region"},
             # the timed kernel counts paths only; live_work_per_sample comes from one launch of the counting instantiation outside the timed region

@@ -296,6 +296,7 @@ def mi_lib():
         m.mi_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         m.mi_scene_set_counters.argtypes = [C.c_void_p, C.c_int]
         m.mi_scene_set_traversal.argtypes = [C.c_void_p, C.c_int]
+        m.mi_scene_get_traversal.argtypes = [C.c_void_p]
         m.mi_scene_set_metal_reference.argtypes = [C.c_void_p, C.c_int]
         m.mi_trace_paths.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
         m.mi_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
@@ -326,7 +327,7 @@ def mi_lib():
 
 
 MI_SYMBOLS = ["mi_init", "mi_scene_create", "mi_scene_set_framebuffer", "mi_scene_set_stream", "mi_render",
-              "mi_sync", "mi_fb_read", "mi_fb_clear", "mi_fb_device_ptr", "mi_counters", "mi_scene_set_counters", "mi_scene_set_traversal", "mi_scene_set_metal_reference", "mi_trace_paths", "mi_intersect",
+              "mi_sync", "mi_fb_read", "mi_fb_clear", "mi_fb_device_ptr", "mi_counters", "mi_scene_set_counters", "mi_scene_set_traversal", "mi_scene_get_traversal", "mi_scene_set_metal_reference", "mi_trace_paths", "mi_intersect",
               "mi_last_kernel_ms", "mi_last_kernel_launches", "mi_scene_stats", "mi_scene_destroy", "mi_shutdown", "mi_last_error", "mi_current_device", "mi_bsdf_test_run",
               "mi_group_create", "mi_group_size", "mi_group_scene", "mi_group_uses_rccl", "mi_group_render", "mi_group_fb_reduce", "mi_group_fb_read",
               "mi_group_fb_clear", "mi_group_sync", "mi_group_counters", "mi_group_destroy"]
@@ -371,6 +372,10 @@ class Backend:
         """'exact': the reference's order of operations per ray (counters equal its -DACCEL_DEBUG totals); 'fast' (the library's
         default): leaves put aside while the lane descends on -- same hits, other work counters (corona_mi.h)"""
         self._check(self.m.mi_scene_set_traversal(self._ptr, {"exact": 0, "fast": 1}[mode]), "mi_scene_set_traversal")
+
+    def traversal(self):
+        """the traversal mode the next render uses ('exact' / 'fast')"""
+        return "fast" if self.m.mi_scene_get_traversal(self._ptr) == 1 else "exact"
 
     def set_metal_reference(self, enable):
         """end the metal samples the reference BUILD's NaN ends (corona_mi.h: mi_scene_set_metal_reference)"""

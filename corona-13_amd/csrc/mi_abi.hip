@@ -757,7 +757,11 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
   s->lds_bytes = halton_bytes + lights_bytes + (s->nodes_lds ? node_bytes : 0) + stack_bytes;
   s->device_built = device_build; s->stack_need = stack_need;
   { const char *ce = getenv("CORONA_MI_COUNTERS"); s->counting = ce && atoi(ce) ? 1 : 0; }
-  { const char *te = getenv("CORONA_MI_TRAVERSAL"); s->fast = !(te && !strcmp(te, "exact")); }
+  { /* default: the FAST rounds where they win -- the plain pt kernels (+2 %); the ptdl kernels break even and the extended ones
+       (media, moving camera) lose 3-8 % to the extra registers of the rounds, so those keep the exact rounds */
+    const char *te = getenv("CORONA_MI_TRAVERSAL");
+    s->fast = te ? strcmp(te, "exact") != 0 : (h->sampler == MI_SAMPLER_PT && !s->media);
+  }
   { const char *me = getenv("CORONA_MI_METAL"); d.metal_reference = (me && !strcmp(me, "reference")) ? 1u : 0u; }
   { /* the kernels this scene can launch (record / counting / traversal variants of its configuration) may use the whole LDS */
     std::vector<const void *> kernels = { (const void *)mi_intersect_kernel<true, false>, (const void *)mi_intersect_kernel<false, false>,
@@ -832,6 +836,12 @@ extern "C" int mi_scene_set_traversal(mi_scene *s, int mode)
   if(mode != MI_TRAVERSAL_EXACT && mode != MI_TRAVERSAL_FAST) return fail(MI_ERR_ARG, "mi_scene_set_traversal: unknown mode");
   s->fast = mode == MI_TRAVERSAL_FAST;
   return MI_OK;
+}
+
+extern "C" int mi_scene_get_traversal(mi_scene *s)
+{ /* the mode the next mi_render uses: scenes with moving primitives always run the exact rounds */
+  if(!s) return -1;
+  return (s->fast && !s->d_prims_t1) ? MI_TRAVERSAL_FAST : MI_TRAVERSAL_EXACT;
 }
 
 extern "C" int mi_scene_set_stream(mi_scene *s, void *hip_stream)

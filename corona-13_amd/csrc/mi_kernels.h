@@ -981,7 +981,8 @@ struct RayBox
   float w0, w1;                          /* motion-blur kernels: 1 - time, time of the ray (weights of the shutter-open / -close boxes) */
 };
 #ifndef MI_SPEC_FMA
-#define MI_SPEC_FMA 1
+#define MI_SPEC_FMA 1      /* 1: in the ptdl kernels (-1 %) and the ray-level test kernel; the pt kernel gains 0.6 % and pays with its only three spilled
+                              registers (four more live values per round), so it keeps the two-instruction form and needs no scratch. 2: everywhere */
 #endif
 #define MI_FMA_REL 1.0000019073486328125f     /* 1 + 2^-19: relative part of the slack (16 x the 2^-24 unit roundoff both sides can be off by) */
 template<bool FMA = false>
@@ -1090,7 +1091,8 @@ __device__ __forceinline__ bool node_visit(const Lds &lds, lds_uint2 *lstack, co
     SLAB(M3, mnx.w, mxx.w, mny.w, mxy.w, mnz.w, mxz.w, tm3)
 #undef SLAB
   }
-  if(!__builtin_amdgcn_inverse_ballot_w64(M0 | M1 | M2 | M3)) return false;
+  const bool any_child = __builtin_amdgcn_inverse_ballot_w64(M0 | M1 | M2 | M3);
+  if(any_child)
   {
     MI_COUNT(cnt, 1, 1);
     MI_COUNT(cnt, 2, (uint32_t)__builtin_amdgcn_inverse_ballot_w64(M0) + (uint32_t)__builtin_amdgcn_inverse_ballot_w64(M1) + (uint32_t)__builtin_amdgcn_inverse_ballot_w64(M2) + (uint32_t)__builtin_amdgcn_inverse_ballot_w64(M3));
@@ -1138,7 +1140,7 @@ __device__ __forceinline__ bool node_visit(const Lds &lds, lds_uint2 *lstack, co
     current = h00 ? c00 : h01 ? c01 : h10 ? c10 : c11;
     MI_COUNT_MAX(cnt, 7, (uint32_t)sp);
   }
-  return true;
+  return any_child;
 }
 
 /* one "while-while" round of accel_intersect (src/accel.d/qbvhmp.c:1262-1390, static boxes): descend inner nodes until this
@@ -1227,13 +1229,12 @@ __device__ __forceinline__ void stack_pop(const Lds &lds, lds_uint2 *lstack, flo
   }
 }
 
-template<int BLOCK, int STACK, bool MB, bool ANYHIT, class CNT>
+template<int BLOCK, int STACK, bool MB, bool ANYHIT, bool FMA, class CNT>
 __device__ __forceinline__ void trace_round_spec(const Lds &lds, const DPrim *prims, const V3 o, const V3 d, uint32_t ignore,
                                                  Hit &hit, TraceState &ts, bool busy, CNT &cnt)
 { /* call from ALL lanes of the wave; busy = this lane has a ray under way */
   constexpr int K = MI_SPEC_K;
   static_assert(K >= 1 && K <= 3, "slots are two bits of a job byte");
-  constexpr bool FMA = MI_SPEC_FMA != 0;
   const unsigned lane = __lane_id();
   const RayBox rb = raybox_setup<FMA>(o, d, ts, lds.num_nodes);
   /* what a popped subtree's entry distance is compared with: the closest hit so far, with the slack of the FMA box test */
@@ -1411,7 +1412,7 @@ __device__ __forceinline__ void accel_intersect(const Lds &lds, const DPrim *pri
   if(!live) { ts.done = true; MI_COUNT(cnt, 0, (uint32_t)-1); }
   if(FAST)
   {
-    while(__any(!ts.done)) trace_round_spec<BLOCK, STACK, false, false>(lds, prims, o, d, ignore, hit, ts, !ts.done, cnt);
+    while(__any(!ts.done)) trace_round_spec<BLOCK, STACK, false, false, MI_SPEC_FMA != 0>(lds, prims, o, d, ignore, hit, ts, !ts.done, cnt);
     return;
   }
 #if MI_LEAF_JOBS

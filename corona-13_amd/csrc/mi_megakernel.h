@@ -44,11 +44,15 @@
 #define MI_PARK_PATH 2    /* FAST kernels (1: ptdl only): part of the path state waits in LDS for the length of a traversal slice (PARK_PS) */
 #endif
 #ifndef MI_PARK_ENTRIES
-#define MI_PARK_ENTRIES 4
+#define MI_PARK_ENTRIES 4      /* ptdl: 8 dwords parked (generator, pdf product, pixel); A/B 4 / 5 / 6 / 7 entries: 38.79 / 40.35 / 38.62 / 39.73 ms */
+#endif
+#ifndef MI_PARK_ENTRIES_PT
+#define MI_PARK_ENTRIES_PT 5   /* pt: + wavelength and frame scramble -- the kernel then needs no scratch at all */
 #endif
 /* the shallowest LDS stack among the instantiations (FAST kernels with parked path state; motion-blur kernels): the overflow area
    in HBM is sized for it */
-#define MI_STACK_MIN ((MI_STACK_LDS - 3 - MI_PARK_ENTRIES) < MI_STACK_LDS_MB ? (MI_STACK_LDS - 3 - MI_PARK_ENTRIES) : MI_STACK_LDS_MB)
+#define MI_PARK_ENTRIES_MAX (MI_PARK_ENTRIES > MI_PARK_ENTRIES_PT ? MI_PARK_ENTRIES : MI_PARK_ENTRIES_PT)
+#define MI_STACK_MIN ((MI_STACK_LDS - 3 - MI_PARK_ENTRIES_MAX) < MI_STACK_LDS_MB ? (MI_STACK_LDS - 3 - MI_PARK_ENTRIES_MAX) : MI_STACK_LDS_MB)
 #ifndef MI_STACK
 #if MI_LEAF_JOBS
 #define MI_STACK (MI_STACK_LDS - 3)   /* the top three entries of a lane's column hold the results of the distributed leaf phase (leaf_jobs) */
@@ -83,7 +87,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
      column for the length of a slice, so that the rounds' registers (a job pass holds a whole primitive record and a second ray) do
      not push path state into scratch, from where the shading blocks would fetch it back word by word. Costs four stack entries. */
   constexpr bool PARK_PS = MI_PARK_PATH && FAST && (PTDL || MI_PARK_PATH == 2);
-  constexpr int PARK_N = PARK_PS ? MI_PARK_ENTRIES : 0;        /* 8-byte entries of the column that hold parked path state */
+  constexpr int PARK_N = PARK_PS ? (PTDL ? MI_PARK_ENTRIES : MI_PARK_ENTRIES_PT) : 0;        /* 8-byte entries of the column that hold parked path state */
   constexpr int STACK = ((JOBS || FAST) ? COLUMN - 3 : COLUMN) - PARK_N;     /* FAST: the rounds of trace_round_spec (mi_kernels.h), same result slots */
   Counters<COUNT || RECORD> cnt;        /* COUNT = false: only the path count (see Counters, mi_kernels.h) */
   PathState ps;
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
         const unsigned nbusy = __popcll(__ballot(busy));
         if(!nbusy) break;
         if(nbusy < tail && __any(tracing && ts.done)) break;
-        if(FAST) { trace_round_spec<MI_BLOCK, STACK, MB, PTDL && MI_ANYHIT>(lds, sc.prims, o, d, ignore, hit, ts, busy, cnt); continue; }
+        if(FAST) { trace_round_spec<MI_BLOCK, STACK, MB, PTDL && MI_ANYHIT, MI_SPEC_FMA == 2 || (MI_SPEC_FMA == 1 && PTDL)>(lds, sc.prims, o, d, ignore, hit, ts, busy, cnt); continue; }
         if(busy) trace_round<MI_BLOCK, STACK, MB, PTDL && MI_ANYHIT, JOBS>(lds, sc.prims, o, d, ignore, hit, ts, cnt);
         if(JOBS) leaf_jobs<MI_BLOCK, STACK, MB, PTDL && MI_ANYHIT>(lds, sc.prims, o, d, ignore, hit, ts, busy, cnt);   /* every lane of the wave takes part */
       }

@@ -272,14 +272,17 @@ int  mi_scene_set_metal_reference(mi_scene *s, int enable);
  *   MI_TRAVERSAL_EXACT  the reference's order of operations ray by ray (accel_intersect, src/accel.d/qbvhmp.c:1262-1390): a leaf is
  *                       tested before the next subtree is chosen, so node visits / box hits / primitive tests equal the
  *                       reference's -DACCEL_DEBUG totals. For counter parity and as the yardstick of the fast mode.
- *   MI_TRAVERSAL_FAST   (default) a lane that reaches a leaf puts it aside and goes on descending against the distance known so
- *                       far; the put-aside leaves of the whole wave are tested together. A few per cent more node visits and
- *                       primitive tests (they are counted), far fewer idle lane-slots (csrc/mi_kernels.h, trace_round_spec).
- * CORONA_MI_TRAVERSAL=exact|fast in the environment sets the mode a scene is created with. Scenes with motion-blurred
- * primitives always run the exact rounds. No reference counterpart. */
+ *   MI_TRAVERSAL_FAST   a lane that reaches a leaf puts it aside and goes on descending against the distance known so far; the
+ *                       put-aside leaves of the whole wave are tested together. A few per cent more node visits and primitive
+ *                       tests (they are counted), fewer idle lane-slots (csrc/mi_kernels.h, trace_round_spec).
+ * A scene is created in the mode that is faster for its kernels: FAST for the plain pt kernels (+2 %), EXACT for ptdl (break even)
+ * and for scenes with media or a moving camera (the FAST rounds' registers cost them 3-8 %); CORONA_MI_TRAVERSAL=exact|fast in the
+ * environment overrides that, mi_scene_set_traversal changes it later. Scenes with motion-blurred primitives always run the exact
+ * rounds. mi_scene_get_traversal returns the mode the next mi_render uses. No reference counterpart. */
 #define MI_TRAVERSAL_EXACT 0
 #define MI_TRAVERSAL_FAST  1
 int  mi_scene_set_traversal(mi_scene *s, int mode);
+int  mi_scene_get_traversal(mi_scene *s);
 
 /* Debug/test entry: trace `count` paths starting at `first` and write one mi_path_record per
  * path (no splatting into the framebuffer). Used by the parity tests to compare path by path. */
