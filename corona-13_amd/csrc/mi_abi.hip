@@ -18,7 +18,7 @@
 
 /* ======================================================================================= upload-time kernels */
 /* Upload-time pass over the child links (one thread per link): an inner link takes the split axes of the node it points to into
- * bits 25..30, so that a node visit needs no separate look-up of its axes (one LDS read less per visit, and no second round trip in
+ * bits 24..29, so that a node visit needs no separate look-up of its axes (one LDS read less per visit, and no second round trip in
  * front of the box reads). `axes` = axis0 | axis00 << 2 | axis01 << 4 per node, as the host builder / the device build leave them. */
 __global__ void mi_fold_axes_kernel(float4 *nodes, const uint32_t *axes, uint32_t N)
 {
@@ -643,7 +643,7 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
     e = build_on_device(s, h, &N, &stack_need);
     d.num_nodes = N;
   }
-  if(!e && N >= (1u << MI_AXES_SHIFT)) e = fail(MI_ERR_UNSUPPORTED, "more than 2^25 nodes");
+  if(!e && N >= (1u << MI_AXES_SHIFT)) e = fail(MI_ERR_UNSUPPORTED, "more than 2^24 nodes");
   if(!e && N)
   { /* the split axes of every node move into the links that point to it (mi_fold_axes_kernel); the root's go into the scene */
     uint32_t root_axes = 0;

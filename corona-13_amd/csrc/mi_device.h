@@ -3,7 +3,7 @@
  *  nodes      SoA of 16-byte lanes, node-major inside each field (stage to LDS; a wave whose lanes sit in
  *             different nodes then spreads over all sixteen 16-B LDS slots instead of two):
  *               field 0..2  min x,y,z of the 4 children       field 3..5  max x,y,z
- *               field 6     4 child links: bit31 leaf | first_prim<<5 | count, else node index | the CHILD's split axes << 25
+ *               field 6     4 child links: bit31 leaf | first_prim<<5 | count, else node index | the CHILD's split axes << 24
  *                           (axis0 | axis00<<2 | axis01<<4, MI_AXES_SHIFT: a visit knows its node's axes from the link it arrived
  *                           by -- no second LDS read per visit, folded in at upload by mi_fold_axes_kernel)
  *             = 112 B per node (reference qbvh_node_t: 256 B, src/accel.d/qbvhmp.c:62-81)
@@ -18,8 +18,8 @@
 #include "corona_mi.h"
 
 #define MI_LEAF32 0x80000000u
-#define MI_AXES_SHIFT 25           /* inner link: node index in bits 0..24, the node's split axes in bits 25..30 */
-#define MI_NODE_MASK 0x01ffffffu
+#define MI_AXES_SHIFT 24           /* inner link: node index in bits 0..23, the node's split axes in bits 24..29 */
+#define MI_NODE_MASK 0x00ffffffu
 #define MI_NODE_FIELDS 7
 #define MI_COUNTER_SHARDS 256
 /* light_prim[] bit 31: a shadow ray towards this emitter primitive may stop at the FIRST occluder it finds (any-hit) instead of

@@ -648,6 +648,7 @@ __device__ __forceinline__ void analytic_intersect(const DPrim *prims, uint32_t 
 struct Lds
 {
   const float4 *nodes;      /* [MI_NODE_FIELDS][num_nodes] in LDS (or in HBM when the tree does not fit, see lds_setup) */
+  bool nodes_in_lds;        /* compile-time constant after inlining (lds_setup<NODES_LDS>) */
   uint32_t root;            /* link of node 0 (its split axes << MI_AXES_SHIFT) */
   const float4 *nodes_t1;   /* [6][num_nodes] in HBM / L2 or NULL: the child boxes at shutter close (motion-blur kernels, DScene.nodes_t1) */
   uint2 *stack;             /* [STACK][BLOCK] in LDS, this thread's column */
@@ -669,6 +670,8 @@ __device__ __forceinline__ void stack_push(const Lds &lds, int sp, uint2 e)
 }
 typedef unsigned int mi_u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) mi_u32x2 lds_uint2;   /* typed LDS pointer: ds_read/ds_write instead of flat */
+typedef float mi_f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const mi_f32x4 lds_f32x4;
 template<int BLOCK, int STACK>
 __device__ __forceinline__ uint2 stack_top(const Lds &lds, const lds_uint2 *lstack, int sp)
 {
@@ -724,13 +727,13 @@ __device__ __forceinline__ Lds lds_setup(const DScene &sc, unsigned char *smem, 
     for(uint32_t i=threadIdx.x;i<MI_NODE_FIELDS*N;i+=BLOCK) lds_nodes[i] = sc.nodes[i];
     if(t1) for(uint32_t i=threadIdx.x;i<6*N;i+=BLOCK) lds_nodes[MI_NODE_FIELDS*N + i] = sc.nodes_t1[i];
     __syncthreads();
-    lds.nodes = lds_nodes;
+    lds.nodes = lds_nodes; lds.nodes_in_lds = true;
     lds.nodes_t1 = t1 ? lds_nodes + (size_t)MI_NODE_FIELDS*N : nullptr;
   }
   else
   {
     lds_stack = (uint2 *)smem;
-    lds.nodes = sc.nodes;
+    lds.nodes = sc.nodes; lds.nodes_in_lds = false;
     lds.nodes_t1 = sc.nodes_t1;
   }
   lds.stack = lds_stack + threadIdx.x; lds.num_nodes = N; lds.root = sc.root_link;
@@ -1012,9 +1015,10 @@ __device__ __forceinline__ RayBox raybox_setup(const V3 o, const V3 d, const Tra
 /* one inner node of accel_intersect (src/accel.d/qbvhmp.c:1188-1246,1313-1354): the four child boxes against the ray clipped to
  * `dist`, front-to-back order from split axes and ray signs; the nearest hit child becomes `current`, the others are pushed
  * far-first. Returns false if no child is hit (the caller pops). */
-template<int BLOCK, int STACK, bool FMA = false, bool MB = false, class CNT>
-__device__ __forceinline__ bool node_visit(const Lds &lds, lds_uint2 *lstack, const RayBox &rb, const V3 o, float dist, uint32_t &current, int &sp, CNT &cnt)
-{ /* FMA (FAST rounds): a plane's distance as fma(plane, 1/d, -o/d) instead of (plane - o)*(1/d) -- one instruction instead of two,
+template<int BLOCK, int STACK, bool FMA = false, bool MB = false, class CNT, class MISS>
+__device__ __forceinline__ bool node_visit(const Lds &lds, lds_uint2 *lstack, const RayBox &rb, const V3 o, float dist, uint32_t &current, int &sp, CNT &cnt, MISS &&miss)
+{ /* miss(): what the caller does when no child is hit, as the else branch of the test (the exact rounds pop right there -- as a second
+     conditional after the call the same code compiled to a node loop with four more divergent regions, +6 % branches) */ /* FMA (FAST rounds): a plane's distance as fma(plane, 1/d, -o/d) instead of (plane - o)*(1/d) -- one instruction instead of two,
      24 fewer per visit. The two differ by at most 2^-24 (3 |t| + |o/d|) (one rounding of o/d up front instead of one of the
      difference), so the box counts as hit when lo <= hi (1 + 2^-19) + 2^-21 max|o/d|: every box the reference's test passes passes
      here (and a few more: counted work, not results), and the entry distances pushed with the subtrees are compared with the same
@@ -1023,9 +1027,35 @@ __device__ __forceinline__ bool node_visit(const Lds &lds, lds_uint2 *lstack, co
   const uint32_t nearbits = rb.nearbits, offx = rb.offx, offy = rb.offy, offz = rb.offz;
   const float idx = rb.idx, idy = rb.idy, idz = rb.idz;
   const bool slow = rb.slow;
-  const uint32_t node = current & MI_NODE_MASK;
-  const uint32_t ax = current >> MI_AXES_SHIFT;        /* the node's split axes travel in the link (mi_fold_axes_kernel) */
-  const uint4 child = *(const uint4 *)&lds.nodes[6*N + node];
+  /* byte offset of the node inside a field: a 24-bit multiply reads only the link's index bits, so the axes in front of them need no
+     mask in the chain pop -> address -> LDS read (v_mad_u32_u24 with the field's base as addend) */
+  const uint32_t ax = (current >> MI_AXES_SHIFT) & 63u;        /* the node's split axes travel in the link (mi_fold_axes_kernel) */
+  auto at = [&](const float4 *base, uint32_t f) -> float4
+  {
+    if(lds.nodes_in_lds)
+    { /* (written as the instruction: the compiler turns a 24-bit multiply by 16 back into shift + mask) */
+      const uint32_t b = (uint32_t)(uintptr_t)(lds_f32x4 *)(base + f);
+      uint32_t a;
+      asm("v_mad_u32_u24 %0, %1, 16, %2" : "=v"(a) : "v"(current), "v"(b));
+      const mi_f32x4 q = *(lds_f32x4 *)(uintptr_t)a;
+      return make_float4(q.x, q.y, q.z, q.w);
+    }
+    return base[f + (current & MI_NODE_MASK)];
+  };
+  auto at_uniform = [&](const float4 *base, uint32_t f) -> float4
+  { /* the same with a wave-uniform field offset: the base stays in a scalar register */
+    if(lds.nodes_in_lds)
+    {
+      const uint32_t b = (uint32_t)(uintptr_t)(lds_f32x4 *)(base + f);
+      uint32_t a;
+      asm("v_mad_u32_u24 %0, %1, 16, %2" : "=v"(a) : "v"(current), "s"(b));
+      const mi_f32x4 q = *(lds_f32x4 *)(uintptr_t)a;
+      return make_float4(q.x, q.y, q.z, q.w);
+    }
+    return base[f + (current & MI_NODE_MASK)];
+  };
+  const float4 child4 = at_uniform(lds.nodes, 6*N);
+  const uint4 child = make_uint4(__float_as_uint(child4.x), __float_as_uint(child4.y), __float_as_uint(child4.z), __float_as_uint(child4.w));
   float tm0, tm1, tm2, tm3;
   mi_u64 M0, M1, M2, M3;    /* child c is hit: lane masks (the compares' own results) in scalar registers, combined by scalar instructions below */
   /* one field of the node: the planes of the four children -- in a motion-blur kernel whose tree carries the shutter-close boxes too
@@ -1034,18 +1064,18 @@ __device__ __forceinline__ bool node_visit(const Lds &lds, lds_uint2 *lstack, co
      below stay what the reference's min / max of the two plane distances evaluate to. */
   const float4 *t1p = MB ? lds.nodes_t1 : nullptr;
   const float w0 = rb.w0, w1 = rb.w1;
-  auto field = [&](uint32_t i) -> float4
+  auto field = [&](uint32_t f, bool uniform = false) -> float4
   {
-    const float4 a_ = lds.nodes[i];
+    const float4 a_ = uniform ? at_uniform(lds.nodes, f) : at(lds.nodes, f);
     if(!MB || !t1p) return a_;
-    const float4 b_ = t1p[i];
+    const float4 b_ = uniform ? at_uniform(t1p, f) : at(t1p, f);
     return make_float4(a_.x*w0 + b_.x*w1, a_.y*w0 + b_.y*w1, a_.z*w0 + b_.z*w1, a_.w*w0 + b_.w*w1);
   };
   if(FMA && !slow)
   {
-    const float4 nx = lds.nodes[offx + node],       fx = lds.nodes[3*N - offx + node];
-    const float4 ny = lds.nodes[N + offy + node],   fy = lds.nodes[4*N - offy + node];
-    const float4 nz = lds.nodes[2*N + offz + node], fz = lds.nodes[5*N - offz + node];
+    const float4 nx = at(lds.nodes, offx),       fx = at(lds.nodes, 3*N - offx);
+    const float4 ny = at(lds.nodes, N + offy),   fy = at(lds.nodes, 4*N - offy);
+    const float4 nz = at(lds.nodes, 2*N + offz), fz = at(lds.nodes, 5*N - offz);
 #define SLAB(J, C, TM) { \
     const float lo = fmaxf(fmaxf(fmaxf(__builtin_fmaf(nx.C, idx, rb.nox), __builtin_fmaf(ny.C, idy, rb.noy)), __builtin_fmaf(nz.C, idz, rb.noz)), 0.0f); \
     const float hi = fminf(fminf(fminf(__builtin_fmaf(fx.C, idx, rb.nox), __builtin_fmaf(fy.C, idy, rb.noy)), __builtin_fmaf(fz.C, idz, rb.noz)), dist); \
@@ -1058,9 +1088,9 @@ __device__ __forceinline__ bool node_visit(const Lds &lds, lds_uint2 *lstack, co
        the reference's min(t0,t1) / max(t0,t1) evaluate to for finite 1/dir and b_min <= b_max (rounding is monotonic;
        empty children are uploaded as [-FLT_MAX, FLT_MAX], see upload_nodes). That leaves v_max3/v_min3 chains
        instead of 48 compare+select pairs (each pair costs a VCC hazard nop on gfx950). */
-    const float4 nx = field(offx + node),       fx = field(3*N - offx + node);
-    const float4 ny = field(N + offy + node),   fy = field(4*N - offy + node);
-    const float4 nz = field(2*N + offz + node), fz = field(5*N - offz + node);
+    const float4 nx = field(offx),       fx = field(3*N - offx);
+    const float4 ny = field(N + offy),   fy = field(4*N - offy);
+    const float4 nz = field(2*N + offz), fz = field(5*N - offz);
 #define SLAB(J, C, TM) { \
     const float lo = fmaxf(fmaxf(fmaxf((nx.C - o.x)*idx, (ny.C - o.y)*idy), (nz.C - o.z)*idz), 0.0f); \
     const float hi = fminf(fminf(fminf((fx.C - o.x)*idx, (fy.C - o.y)*idy), (fz.C - o.z)*idz), dist); \
@@ -1071,8 +1101,8 @@ __device__ __forceinline__ bool node_visit(const Lds &lds, lds_uint2 *lstack, co
   else
   { /* a lane of this wave has a zero direction component (1/dir infinite): 0*inf NaNs are possible and the reference's
        SSE min/max semantics (second operand on NaN) decide; evaluate them literally with ordered compares */
-    const float4 mnx = field(0*N + node), mny = field(1*N + node), mnz = field(2*N + node);
-    const float4 mxx = field(3*N + node), mxy = field(4*N + node), mxz = field(5*N + node);
+    const float4 mnx = field(0*N, true), mny = field(1*N, true), mnz = field(2*N, true);
+    const float4 mxx = field(3*N, true), mxy = field(4*N, true), mxz = field(5*N, true);
 #define SLAB(J, X0, X1, Y0, Y1, Z0, Z1, TM) { \
     float lo = 0.0f, hi = dist; \
     float t0 = ((X0) - o.x)*idx, t1 = ((X1) - o.x)*idx; \
@@ -1140,6 +1170,7 @@ __device__ __forceinline__ bool node_visit(const Lds &lds, lds_uint2 *lstack, co
     current = h00 ? c00 : h01 ? c01 : h10 ? c10 : c11;
     MI_COUNT_MAX(cnt, 7, (uint32_t)sp);
   }
+  else miss();
   return any_child;
 }
 
@@ -1170,8 +1201,7 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
 #ifdef MI_PROFILE_LOOPS
       if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) cnt.c[8] += MI_PROFILE_LOOPS == 2 ? nround : 1;   /* wave-level inner iterations (2: lanes still under way) */
 #endif
-      if(node_visit<BLOCK, STACK, false, MB>(lds, lstack, rb, o, hit.dist, current, sp, cnt)) {}
-      else
+      node_visit<BLOCK, STACK, false, MB>(lds, lstack, rb, o, hit.dist, current, sp, cnt, [&]()
       { /* pop, skipping entries that start behind the current hit (qbvhmp.c:1357-1364) */
         current = MI_LEAF32;          /* empty leaf: falls out of this loop; `done` if the stack runs dry */
         done = true;
@@ -1181,7 +1211,7 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
           const uint2 e = stack_top<BLOCK, STACK>(lds, lstack, sp);
           if(!(__uint_as_float(e.y) > hit.dist)) { current = e.x; done = false; break; }
         }
-      }
+      });
     }
   }
   ts.sp = sp; ts.current = current; ts.done = done;
@@ -1267,7 +1297,7 @@ __device__ __forceinline__ void trace_round_spec(const Lds &lds, const DPrim *pr
     { const unsigned nround = __popcll(__ballot(!done)); if(lane == 0) cnt.c[8] += MI_PROFILE_LOOPS == 2 ? nround : 1; }
 #endif
     bool pop = false;
-    if(inner) pop = !node_visit<BLOCK, STACK, FMA>(lds, lstack, rb, o, hit.dist, current, sp, cnt);
+    if(inner) pop = !node_visit<BLOCK, STACK, FMA>(lds, lstack, rb, o, hit.dist, current, sp, cnt, [](){});
     else if(advance)
     {
       if(current & 31u)

@@ -38,7 +38,14 @@
 #define MI_LEAF_JOBS_MB 0     /* ... in the motion-blur pt kernels: parity green, but 1748 against 1923 Msamples/s on 0059_mb (every moving primitive is a put-off test) */
 #endif
 #ifndef MI_PARK_TRACE
-#define MI_PARK_TRACE 1   /* the tail lanes' traversal state waits in LDS while the others shade (kernels with a distributed leaf phase) */
+#define MI_PARK_TRACE 1   /* the tail lanes' traversal state waits in LDS while the others shade: 1 = in the ptdl FAST kernel (38.6 against 40.4 ms),
+                             2 = in every kernel with a distributed leaf phase (costs the pt kernels 0.1-0.2 ms of 19: same-box A/B) */
+#endif
+#ifndef MI_PRIO
+#define MI_PRIO 1         /* issue priority of a wave (s_setprio) by part of its iteration: the pt kernels put the traversal slice first (its chains
+                             of dependent LDS reads are what a wave waits for), the ptdl kernels the shading (next event estimation, where their
+                             spilled registers come back). Same-box A/B, cfg 2 / cfg 3: slice first 18.73 / 38.57 ms, shading first 19.09 / 38.02,
+                             no priorities 18.89 / 38.32 */
 #endif
 #ifndef MI_PARK_PATH
 #define MI_PARK_PATH 2    /* FAST kernels (1: ptdl only): part of the path state waits in LDS for the length of a traversal slice (PARK_PS) */
@@ -150,6 +157,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
       const uint32_t ignore = ps.ignore;     /* the shadow ray of a vertex starts on the same primitive as its extension ray */
       const unsigned tail = exhausted_wave ? 1u : (unsigned)(PTDL ? MI_TAIL_LANES_PTDL : MI_TAIL_LANES);
       lds_uint2 *parked = (lds_uint2 *)lds.stack + (STACK + 3)*MI_BLOCK;
+      if(MI_PRIO) __builtin_amdgcn_s_setprio(PTDL ? 0 : 3);
       if(PARK_PS)
       {
         parked[0] = mi_u32x2{(uint32_t)ps.rng.s0, (uint32_t)(ps.rng.s0 >> 32)};
@@ -185,12 +193,13 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
         if(PARK_N >= 8) { const mi_u32x2 f = parked[7*MI_BLOCK]; ps.media.ids = (unsigned long long)f.x | ((unsigned long long)f.y << 32); }
       }
     }
+    if(MI_PRIO) __builtin_amdgcn_s_setprio(PTDL ? 3 : 0);
     MI_PHASE(cnt, 1)
     MI_TT(cnt, 4)
     /* The lanes of the tail keep their ray. Its traversal state (closest hit so far, node, stack pointer: 6 dwords; the three 1/dir
        are formed again) would sit in eleven registers through the shading of the other lanes, where the kernel's register pressure
        peaks -- between two rounds the three result slots of the lane's LDS column (leaf phase) are free and take it instead. */
-    constexpr bool PARK = MI_PARK_TRACE && (FAST || JOBS) && !MB;
+    constexpr bool PARK = MI_PARK_TRACE && (MI_PARK_TRACE == 2 ? (FAST || JOBS) : (FAST && PTDL)) && !MB;
     const bool keep = tracing && !ts.done;
     if(PARK && keep)
     {

@@ -8,7 +8,8 @@ sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parent.par
 from helpers import *
 
 pkg = load_pkg()
-old = "r02" in os.environ.get("CORONA_MI_LIB", "")
+lib = os.environ.get("CORONA_MI_LIB", "")
+old = "r02" in lib or os.environ.get("AB_ABI2") == "1"          # a library of ABI 2 (round 2, or this round before nodes_t1)
 if old:
     class Dummy:                                   # entry points the round-2 library does not have yet
         argtypes = restype = None
@@ -24,15 +25,18 @@ if old:
     _cdll, C.CDLL = C.CDLL, Lenient
     pkg.mi_lib()
     C.CDLL = _cdll
-out = [("r02 library" if old else "this library") + ":"]
+out = [(os.path.basename(lib) if lib else "this library") + (" exact" if "--exact" in sys.argv else "") + ":"]
+only = os.environ.get("AB_ONLY")
 for name, path, sampler in (("pt", SCENE_0010, 0), ("ptdl", SCENE_0010, 1), ("media pt", SCENE_MEDIA, 0), ("media ptdl", SCENE_MEDIA, 1), ("fog pt", SCENE_FOG, 0), ("cam_mb pt", SCENE_CAM_MB, 0)):
+    if only and name != only:
+        continue
     scene = make_scene(path, width=1280, height=720, max_verts=8, sampler=sampler)
     if old:
         d = scene.desc_ptr.contents
         d.struct_size = C.sizeof(pkg.MiSceneDesc) - 8
         d.abi_version = 2
     be = pkg.Backend(scene, counters=False)
-    if not old and "--exact" in sys.argv:
+    if "r02" not in lib and "--exact" in sys.argv:
         be.set_traversal("exact")
     per = 64 * scene.width * scene.height
     be.render(0, per // 8); be.sync()
