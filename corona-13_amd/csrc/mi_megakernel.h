@@ -28,8 +28,12 @@
 #ifndef MI_LEAF_JOBS
 #define MI_LEAF_JOBS 1
 #endif
+#ifndef MI_LEAF_JOBS_MEDIA_PTDL
+#define MI_LEAF_JOBS_MEDIA_PTDL 0   /* ... but not in the extended ptdl kernels: 38 against 28 spilled registers, scenes/0055_media 51.1 against 48.9 ms */
+#endif
 #ifndef MI_LEAF_JOBS_PTDL
-#define MI_LEAF_JOBS_PTDL 0   /* A/B switch: the distributed leaf phase in the ptdl kernels too */
+#define MI_LEAF_JOBS_PTDL 1   /* the distributed leaf phase in the ptdl kernels too: a loss as long as the kernel spilled 30-47 registers (rounds 1-2:
+                                 +3 %), a gain since the path state's dead values are retired early (MI_EARLY_KILL, mi_path.h): cfg 3 36.9 -> 35.9 ms */
 #endif
 #ifndef MI_LEAF_JOBS_MEDIA
 #define MI_LEAF_JOBS_MEDIA 1  /* ... in the extended (media / moving camera) pt kernels: +7 % (0055_media, 0056_fog, 0058_cam_mb) */
@@ -40,6 +44,11 @@
 #ifndef MI_PARK_TRACE
 #define MI_PARK_TRACE 1   /* the tail lanes' traversal state waits in LDS while the others shade: 1 = in the ptdl FAST kernel (38.6 against 40.4 ms),
                              2 = in every kernel with a distributed leaf phase (costs the pt kernels 0.1-0.2 ms of 19: same-box A/B) */
+#endif
+#ifndef MI_CHAIN
+#define MI_CHAIN 0        /* 1: ptdl kernels (exact rounds): a lane traces the shadow ray and the extension ray of a vertex back to back in one slice.
+                             Same results; cfg 3 40.0 ms against 38.2 at the slice tail of 12 lanes, 37.96 against 38.0 at 24 (same-box A/B): the
+                             lanes without a connection wait for the chained ones as long as those used to wait for the slice to end. Off. */
 #endif
 #ifndef MI_PRIO
 #define MI_PRIO 1         /* issue priority of a wave (s_setprio) by part of its iteration: the pt kernels put the traversal slice first (its chains
@@ -52,6 +61,10 @@
 #endif
 #ifndef MI_PARK_ENTRIES
 #define MI_PARK_ENTRIES 4      /* ptdl: 8 dwords parked (generator, pdf product, pixel); A/B 4 / 5 / 6 / 7 entries: 38.79 / 40.35 / 38.62 / 39.73 ms */
+#endif
+#ifndef MI_PARK_ENTRIES_EXACT
+#define MI_PARK_ENTRIES_EXACT 3   /* ptdl kernels with the exact rounds and the distributed leaf phase: generator and pdf product (6 dwords) wait in the lane's
+                                     stack column during a slice: 16 against 21 spilled registers, cfg 3 35.9 against 36.3 ms (2 / 4 / 5 entries: 18 / 18 / 18) */
 #endif
 #ifndef MI_PARK_ENTRIES_PT
 #define MI_PARK_ENTRIES_PT 5   /* pt: + wavelength and frame scramble -- the kernel then needs no scratch at all */
@@ -87,15 +100,20 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
   const unsigned long long blk_lo = count/nb*blockIdx.x + (blockIdx.x < count%nb ? blockIdx.x : count%nb);
   const unsigned long long blk_hi = blk_lo + count/nb + (blockIdx.x < count%nb ? 1 : 0);
 
-  /* pt: the primitive tests of a traversal round are dealt out over all lanes of the wave (leaf_jobs); the ptdl kernels keep the
-     per-lane leaf loop -- there the extra live registers of the job loop spill (A/B in DESIGN.md) */
-  constexpr bool JOBS = !FAST && MI_LEAF_JOBS && (!PTDL || MI_LEAF_JOBS_PTDL) && (!MEDIA || MI_LEAF_JOBS_MEDIA) && (!MB || MI_LEAF_JOBS_MB);
+  /* the primitive tests of a traversal round are dealt out over all lanes of the wave (leaf_jobs) -- in the pt kernels and, since the
+     path state's dead values are retired early (MI_EARLY_KILL), in the plain ptdl kernels; the extended ptdl kernels and the motion-blur
+     kernels keep the per-lane leaf loop: there the extra live registers of the job loop still spill (A/B in DESIGN.md) */
+  constexpr bool JOBS = !FAST && MI_LEAF_JOBS && (!PTDL || MI_LEAF_JOBS_PTDL) && (!MEDIA || MI_LEAF_JOBS_MEDIA) && (!(PTDL && MEDIA) || MI_LEAF_JOBS_MEDIA_PTDL) && (!MB || MI_LEAF_JOBS_MB);
   /* PARK_PS: the part of the path state no traversal round looks at (generator, pdf product, pixel: 8 dwords) waits in the lane's LDS
      column for the length of a slice, so that the rounds' registers (a job pass holds a whole primitive record and a second ray) do
      not push path state into scratch, from where the shading blocks would fetch it back word by word. Costs four stack entries. */
-  constexpr bool PARK_PS = MI_PARK_PATH && FAST && (PTDL || MI_PARK_PATH == 2);
-  constexpr int PARK_N = PARK_PS ? (PTDL ? MI_PARK_ENTRIES : MI_PARK_ENTRIES_PT) : 0;        /* 8-byte entries of the column that hold parked path state */
-  constexpr int STACK = ((JOBS || FAST) ? COLUMN - 3 : COLUMN) - PARK_N;     /* FAST: the rounds of trace_round_spec (mi_kernels.h), same result slots */
+  constexpr bool CHAIN = MI_CHAIN && PTDL && !FAST;    /* shadow ray and extension ray of a vertex in one slice (below) */
+  constexpr bool PARK_PS = MI_PARK_PATH && !MB && (FAST ? (PTDL || MI_PARK_PATH == 2) : (JOBS && PTDL && MI_PARK_ENTRIES_EXACT > 0));
+  constexpr int PARK_N = !PARK_PS ? 0 : !FAST ? MI_PARK_ENTRIES_EXACT : PTDL ? MI_PARK_ENTRIES : MI_PARK_ENTRIES_PT;   /* 8-byte entries of the column that hold parked path state */
+  constexpr int RESULT_SLOTS = (JOBS || FAST) ? 3 : 0;                       /* FAST: the rounds of trace_round_spec (mi_kernels.h), same result slots */
+  constexpr int STACK = COLUMN - RESULT_SLOTS - PARK_N;
+  static_assert(STACK >= MI_STACK_MIN, "the overflow area is sized for MI_STACK_MIN entries in LDS (mi_abi.hip)");
+  static_assert(!(CHAIN && PARK_PS), "a chained lane draws the free-flight distance of its extension ray inside the slice: the generator must not be parked");
   Counters<COUNT || RECORD> cnt;        /* COUNT = false: only the path count (see Counters, mi_kernels.h) */
   PathState ps;
   ps.active = 0;
@@ -153,18 +171,18 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
        MI_TAIL_LANES rays is still under way. Those lanes keep their traversal state (registers + LDS stack) and go on in the
        next iteration next to the fresh rays of the lanes that shade now, so one long ray does not hold 63 lanes idle. */
     {
-      const V3 o = ray_origin<PTDL>(ps, tr_shadow), d = tr_shadow ? ps.sh_dir : ps.dir;
+      V3 o = ray_origin<PTDL>(ps, tr_shadow), d = tr_shadow ? ps.sh_dir : ps.dir;
       const uint32_t ignore = ps.ignore;     /* the shadow ray of a vertex starts on the same primitive as its extension ray */
       const unsigned tail = exhausted_wave ? 1u : (unsigned)(PTDL ? MI_TAIL_LANES_PTDL : MI_TAIL_LANES);
-      lds_uint2 *parked = (lds_uint2 *)lds.stack + (STACK + 3)*MI_BLOCK;
+      lds_uint2 *parked = (lds_uint2 *)lds.stack + (STACK + RESULT_SLOTS)*MI_BLOCK;
       if(MI_PRIO) __builtin_amdgcn_s_setprio(PTDL ? 0 : 3);
       if(PARK_PS)
       {
         parked[0] = mi_u32x2{(uint32_t)ps.rng.s0, (uint32_t)(ps.rng.s0 >> 32)};
         parked[MI_BLOCK] = mi_u32x2{(uint32_t)ps.rng.s1, (uint32_t)(ps.rng.s1 >> 32)};
         const unsigned long long pp = (unsigned long long)__double_as_longlong(ps.pdfprod);
-        parked[2*MI_BLOCK] = mi_u32x2{(uint32_t)pp, (uint32_t)(pp >> 32)};
-        parked[3*MI_BLOCK] = mi_u32x2{__float_as_uint(ps.pixel_i), __float_as_uint(ps.pixel_j)};
+        if(PARK_N >= 3) parked[2*MI_BLOCK] = mi_u32x2{(uint32_t)pp, (uint32_t)(pp >> 32)};
+        if(PARK_N >= 4) parked[3*MI_BLOCK] = mi_u32x2{__float_as_uint(ps.pixel_i), __float_as_uint(ps.pixel_j)};
         if(PARK_N >= 5) parked[4*MI_BLOCK] = mi_u32x2{__float_as_uint(ps.lambda), __float_as_uint(ps.scramble)};
         if(PARK_N >= 6) parked[5*MI_BLOCK] = mi_u32x2{__float_as_uint(ps.throughput), __float_as_uint(ps.pdf)};
         if(PARK_N >= 7) parked[6*MI_BLOCK] = mi_u32x2{__float_as_uint(ps.prev_cos), __float_as_uint(ps.cur_ior)};
@@ -172,6 +190,26 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
       }
       while(true)
       {
+        if(CHAIN)
+        { /* a lane whose shadow ray is through goes straight on with the extension ray of the same vertex (both are known since the
+             vertex was shaded, the path state holds both): path_visible's verdict (src/pathspace.c:311-344) is taken now, the splat
+             it may lead to is made in front of the next vertex's shading (shadow_splat) -- the order the reference has them in. The
+             lane neither idles to the end of the slice nor sits through a shading phase in which it has nothing but that verdict to do. */
+          const bool sw = tracing && ts.done && tr_shadow && ps.active;
+          if(__any(sw))
+          {
+            if(sw)
+            {
+              const bool visible = (hit.dist >= ps.sh_dist) || (hit.prim == MI_NOPRIM) || (hit.prim == (ps.sh_light & ~MI_LIGHT_ANYHIT));
+              ps.sh_pending = visible ? 2 : 0;
+              tr_shadow = false;
+              hit.prim = MI_NOPRIM; hit.dist = MEDIA ? media_free_flight<PTDL, HALTON>(sc, ps) : FLT_MAX; hit.u = hit.v = 0.0f;
+              trace_begin(lds, ts, ps.dir, cnt);
+              if(MB) { ts.time = ps.time; ts.prims_t1 = sc.prims_t1; }
+              d = ps.dir; o = ray_origin<PTDL>(ps, false);
+            }
+          }
+        }
         const bool busy = tracing && !ts.done;
         const unsigned nbusy = __popcll(__ballot(busy));
         if(!nbusy) break;
@@ -182,11 +220,11 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
       }
       if(PARK_PS)
       {
-        const mi_u32x2 a = parked[0], b = parked[MI_BLOCK], c = parked[2*MI_BLOCK], e = parked[3*MI_BLOCK];
+        const mi_u32x2 a = parked[0], b = parked[MI_BLOCK];
         ps.rng.s0 = (unsigned long long)a.x | ((unsigned long long)a.y << 32);
         ps.rng.s1 = (unsigned long long)b.x | ((unsigned long long)b.y << 32);
-        ps.pdfprod = __longlong_as_double((long long)((unsigned long long)c.x | ((unsigned long long)c.y << 32)));
-        ps.pixel_i = __uint_as_float(e.x); ps.pixel_j = __uint_as_float(e.y);
+        if(PARK_N >= 3) { const mi_u32x2 c = parked[2*MI_BLOCK]; ps.pdfprod = __longlong_as_double((long long)((unsigned long long)c.x | ((unsigned long long)c.y << 32))); }
+        if(PARK_N >= 4) { const mi_u32x2 e = parked[3*MI_BLOCK]; ps.pixel_i = __uint_as_float(e.x); ps.pixel_j = __uint_as_float(e.y); }
         if(PARK_N >= 5) { const mi_u32x2 f = parked[4*MI_BLOCK]; ps.lambda = __uint_as_float(f.x); ps.scramble = __uint_as_float(f.y); }
         if(PARK_N >= 6) { const mi_u32x2 f = parked[5*MI_BLOCK]; ps.throughput = __uint_as_float(f.x); ps.pdf = __uint_as_float(f.y); }
         if(PARK_N >= 7) { const mi_u32x2 f = parked[6*MI_BLOCK]; ps.prev_cos = __uint_as_float(f.x); ps.cur_ior = __uint_as_float(f.y); }
@@ -215,7 +253,11 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
       tracing = false;
       mi_path_record *rec = RECORD ? records + (ps.index - first) : nullptr;
       if(tr_shadow) shadow_resolve<RECORD>(sc, ps, hit, rec, cnt, splat);
-      else path_shade<RECORD, PTDL, HALTON, MEDIA, MB>(sc, ps, hit, shape_material, shape_L, rec, cnt, splat);
+      else
+      {
+        if(CHAIN && ps.sh_pending == 2) shadow_splat<RECORD>(sc, ps, rec, cnt, splat);      /* the connection made at the vertex this ray left */
+        path_shade<RECORD, PTDL, HALTON, MEDIA, MB>(sc, ps, hit, shape_material, shape_L, rec, cnt, splat);
+      }
     }
 
     if(PARK)

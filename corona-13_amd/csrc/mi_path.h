@@ -61,6 +61,9 @@ __device__ __forceinline__ V3 ray_origin(const PathState &ps, bool shadow)
   return mk3(ps.prev_x.x + ps.org_eps*d.x, ps.prev_x.y + ps.org_eps*d.y, ps.prev_x.z + ps.org_eps*d.z);
 }
 
+#ifndef MI_EARLY_KILL
+#define MI_EARLY_KILL 1
+#endif
 /* a splat to be carried out by the wave (splat_wave) after the divergent part of the iteration */
 struct SplatReq { bool pending; float c0, c1, c2; };
 
@@ -196,13 +199,11 @@ __device__ __forceinline__ void path_generate(const DScene &sc, PathState &ps, u
 }
 
 /* the shadow ray of the pending next-event connection has been traced into `hit` */
+/* the splat of a next-event connection that path_visible has passed (ps.sh_value, ps.sh_length) */
 template<bool RECORD, class CNT>
-__device__ __forceinline__ void shadow_resolve(const DScene &sc, PathState &ps, const Hit &hit, mi_path_record *rec, CNT &cnt, SplatReq &splat)
+__device__ __forceinline__ void shadow_splat(const DScene &sc, PathState &ps, mi_path_record *rec, CNT &cnt, SplatReq &splat)
 {
-   /* path_visible, src/pathspace.c:311-344: closest hit up to the emitter's primitive (all surfaces in scope are opaque) */
   ps.sh_pending = 0;
-  const bool visible = (hit.dist >= ps.sh_dist) || (hit.prim == MI_NOPRIM) || (hit.prim == (ps.sh_light & ~MI_LIGHT_ANYHIT));
-  if(visible)
   {
     const float value = ps.sh_value;
     const bool ok = splat_value_ok(value);
@@ -223,6 +224,15 @@ __device__ __forceinline__ void shadow_resolve(const DScene &sc, PathState &ps, 
       if(!RECORD) { splat.pending = true; splat.c0 = col[0]; splat.c1 = col[1]; splat.c2 = col[2]; }
     }
   }
+}
+
+template<bool RECORD, class CNT>
+__device__ __forceinline__ void shadow_resolve(const DScene &sc, PathState &ps, const Hit &hit, mi_path_record *rec, CNT &cnt, SplatReq &splat)
+{
+   /* path_visible, src/pathspace.c:311-344: closest hit up to the emitter's primitive (all surfaces in scope are opaque) */
+  ps.sh_pending = 0;
+  const bool visible = (hit.dist >= ps.sh_dist) || (hit.prim == MI_NOPRIM) || (hit.prim == (ps.sh_light & ~MI_LIGHT_ANYHIT));
+  if(visible) shadow_splat<RECORD>(sc, ps, rec, cnt, splat);
 }
 
 /* ------------------------------------------------------------------------------------------ homogeneous media
@@ -283,6 +293,15 @@ __device__ __forceinline__ void path_shade_volume(const DScene &sc, PathState &p
     rec_vertex<RECORD>(rec, v, MI_PRIMID_INVALID, dist, sf.x, sf.n, sf.gn, omega, s_absorb, 0, vthr, vpdf, 0.0f, 0.0f, z, 0.0f, med.med);
     rec->length = ps.length; rec->throughput = (ps.throughput*0.0f)/epdf;
   }
+#if MI_EARLY_KILL
+  { /* as in path_shade: what the state held about the previous vertex and the arrived ray is read, what replaces it is known */
+    ps.prev_x = sf.x; ps.org_eps = 0.0f; ps.ignore = MI_NOPRIM;
+    if(!PTDL) ps.org = sf.x;
+    ps.prev_cos = 0.0f; ps.throughput = 0.0f; ps.pdf = 0.0f;
+    ps.prev_material_modes = material_modes;
+    if(PTDL) { ps.sh_dir = mk3(0.0f, 0.0f, 0.0f); ps.sh_dist = 0.0f; ps.sh_value = 0.0f; ps.sh_light = 0u; ps.sh_length = 0; }
+  }
+#endif
   if(PTDL && ps.length >= (int)sc.max_verts) alive = false;
   if(PTDL && alive)
   { /* next event estimation from the volume vertex, ptdl.c:136-148 */
@@ -426,6 +445,13 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
   const int v = ps.length;                         /* index of the vertex being created */
   bool alive = true;
   const V3 omega = ps.dir;
+#if MI_EARLY_KILL
+  if(PTDL)
+  { /* the connection of the previous vertex is resolved before its extension ray is shaded: what it left in the path state is dead,
+       but only overwritten if this vertex makes a connection of its own -- seven registers through the whole function otherwise */
+    ps.sh_dir = mk3(0.0f, 0.0f, 0.0f); ps.sh_dist = 0.0f; ps.sh_value = 0.0f; ps.sh_light = 0u; ps.sh_length = 0;
+  }
+#endif
   if(hit.prim == MI_NOPRIM)
   { /* left the scene: environment vertex, src/pathspace.c:856-873; black sky => nothing to add, path ends */
     const float G = ps.prev_cos;                   /* path_G with an environment end point */
@@ -574,7 +600,7 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
         if(ok)
         {
           MI_COUNT(cnt, 5, 1);
-          if(!RECORD) { splat.pending = true; splat.c0 = col[0]; splat.c1 = col[1]; splat.c2 = col[2]; }
+          if(!RECORD) { splat.pending = true; splat.c0 += col[0]; splat.c1 += col[1]; splat.c2 += col[2]; }   /* += : a chained ptdl lane may have splatted its connection this iteration (same pixel) */
         }
         if(!PTDL && ps.length > 3)
         { /* path_russian_roulette, src/pathspace.c:273-292 */
@@ -590,6 +616,19 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
           }
         }
       }
+#if MI_EARLY_KILL
+      /* Everything the path state holds about vertex v-1 and the ray that arrived has been read by now, and what replaces it is known
+         -- the compiler cannot see that, because the assignments at the end of the function are conditional (the path may end; nobody
+         reads its state then). Made here, the old values do not occupy registers through next event estimation and the bsdf sample,
+         where the kernel's register pressure peaks: the vertex itself (sf.x) is what the next rays leave from. */
+      {
+        const float eps0 = DMAX(DMAX(.5f, fabsf(sf.x.x)), DMAX(fabsf(sf.x.y), fabsf(sf.x.z)))*1e-4f;
+        ps.prev_x = sf.x; ps.org_eps = eps0; ps.ignore = hit.prim;
+        if(!PTDL) ps.org = sf.x;
+        ps.prev_cos = 0.0f; ps.throughput = 0.0f; ps.pdf = 0.0f;
+        ps.prev_material_modes = material_modes;
+      }
+#endif
       if(PTDL && ps.length >= (int)sc.max_verts) alive = false;           /* ptdl.c:122 */
       if(PTDL && alive)
       { /* next event estimation at vertex v: ptdl.c:136-148, nee_sample include/pathspace/nee.h:87-243 */
