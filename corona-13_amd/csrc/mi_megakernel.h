@@ -237,7 +237,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
     /* The lanes of the tail keep their ray. Its traversal state (closest hit so far, node, stack pointer: 6 dwords; the three 1/dir
        are formed again) would sit in eleven registers through the shading of the other lanes, where the kernel's register pressure
        peaks -- between two rounds the three result slots of the lane's LDS column (leaf phase) are free and take it instead. */
-    constexpr bool PARK = MI_PARK_TRACE && (MI_PARK_TRACE == 2 ? (FAST || JOBS) : (FAST && PTDL)) && !MB;
+    constexpr bool PARK = MI_PARK_TRACE && (MI_PARK_TRACE == 2 ? (FAST || JOBS) : MI_PARK_TRACE == 3 ? ((FAST || JOBS) && PTDL) : (FAST && PTDL)) && !MB;
     const bool keep = tracing && !ts.done;
     if(PARK && keep)
     {
