@@ -1239,10 +1239,19 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
 #define MI_SPEC_K 1           /* leaves a lane may put aside per round; one more can wait in `current`. A/B on cfg 2, 1 / 2 / 3: 18.68 / 18.92 / 20.25 ms */
 #endif
 #ifndef MI_SPEC_BLOCKED
-#define MI_SPEC_BLOCKED 16    /* the node loop of a round ends once this many lanes hold a leaf they can no longer put aside */
+#define MI_SPEC_BLOCKED 64    /* the node loop of a round ends once this many lanes hold a leaf they can no longer put aside; 64 = never. Re-swept
+                                 after the exact node loop was repaired (cfg 2, same box): 16 / 24 / 32 / 40 / 48 / 64 = 18.87 / 18.50 / 18.31 / 18.18 /
+                                 18.20 / 18.19 ms -- a blocked lane loses less by waiting than the wave loses by turning to its leaves early */
+#endif
+#ifndef MI_SPEC_TAIL_INNER
+#define MI_SPEC_TAIL_INNER 6  /* ... and once fewer than this many lanes still move while others wait (the exact rounds' MI_TAIL_INNER is 4):
+                                 2 / 4 / 6 / 8 / 12 = 19.24 / 18.19 / 18.13 / 18.13-18.16 / 18.31 ms */
 #endif
 #ifndef MI_SPEC_ANYHIT_WAITS
 #define MI_SPEC_ANYHIT_WAITS 0   /* A/B: a shadow ray that may stop at its first occluder does not run ahead of its leaves */
+#endif
+#ifndef MI_SPEC_SPLIT_POP
+#define MI_SPEC_SPLIT_POP 0
 #endif
 #define MI_SPEC_JOBS_MAX 512  /* job list entries per wave (one byte each: owner lane | slot << 6) */
 
@@ -1291,11 +1300,23 @@ __device__ __forceinline__ void trace_round_spec(const Lds &lds, const DPrim *pr
     const mi_u64 mmove = __ballot(inner || advance);
     if(!mmove) break;
     const mi_u64 mwait = __ballot(leaf && !advance);
-    if(__popcll(mmove) < MI_TAIL_INNER && (mwait || __any(lf[0] != 0u))) break;
+    if(__popcll(mmove) < MI_SPEC_TAIL_INNER && (mwait || __any(lf[0] != 0u))) break;
     if(__popcll(mwait) >= MI_SPEC_BLOCKED) break;
 #ifdef MI_PROFILE_LOOPS
     { const unsigned nround = __popcll(__ballot(!done)); if(lane == 0) cnt.c[8] += MI_PROFILE_LOOPS == 2 ? nround : 1; }
 #endif
+#if MI_SPEC_SPLIT_POP
+    if(inner) node_visit<BLOCK, STACK, FMA>(lds, lstack, rb, o, hit.dist, current, sp, cnt, [&]() { stack_pop<BLOCK, STACK>(lds, lstack, MI_CULL_DIST, sp, current, done); });
+    else if(advance)
+    {
+      if(current & 31u)
+      {
+#pragma unroll
+        for(int k=0;k<K;k++) if(lf[k] == 0u) { lf[k] = current; break; }
+      }
+      stack_pop<BLOCK, STACK>(lds, lstack, MI_CULL_DIST, sp, current, done);
+    }
+#else
     bool pop = false;
     if(inner) pop = !node_visit<BLOCK, STACK, FMA>(lds, lstack, rb, o, hit.dist, current, sp, cnt, [](){});
     else if(advance)
@@ -1308,6 +1329,7 @@ __device__ __forceinline__ void trace_round_spec(const Lds &lds, const DPrim *pr
       pop = true;
     }
     if(pop) stack_pop<BLOCK, STACK>(lds, lstack, MI_CULL_DIST, sp, current, done);
+#endif
   }
   MI_TT(cnt, 0)
   /* -------- leaf phase: the (lane, slot, primitive) tests of all put-aside leaves dealt out over the 64 lanes */
