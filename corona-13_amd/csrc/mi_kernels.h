@@ -984,8 +984,10 @@ struct RayBox
   float w0, w1;                          /* motion-blur kernels: 1 - time, time of the ray (weights of the shutter-open / -close boxes) */
 };
 #ifndef MI_SPEC_FMA
-#define MI_SPEC_FMA 1      /* 1: in the ptdl kernels (-1 %) and the ray-level test kernel; the pt kernel gains 0.6 % and pays with its only three spilled
-                              registers (four more live values per round), so it keeps the two-instruction form and needs no scratch. 2: everywhere */
+#define MI_SPEC_FMA 0      /* 0: off. 1: in the ptdl FAST kernel and the ray-level test kernel, 2: in every FAST kernel -- cfg 2 17.71-17.79 against 18.01 ms,
+                              cfg 3 (FAST rounds) 37.1 against 38.0; but the relaxed test lets through boxes the reference's test rejects, and a
+                              primitive in such a box can be hit: 0.25 paths per million then carry a hit the reference does not have (same-library
+                              comparison of the FAST against the exact rounds, tests/dev/fast_vs_exact.py). Results first: off */
 #endif
 #define MI_FMA_REL 1.0000019073486328125f     /* 1 + 2^-19: relative part of the slack (16 x the 2^-24 unit roundoff both sides can be off by) */
 template<bool FMA = false>
@@ -1016,7 +1018,8 @@ __device__ __forceinline__ RayBox raybox_setup(const V3 o, const V3 d, const Tra
  * `dist`, front-to-back order from split axes and ray signs; the nearest hit child becomes `current`, the others are pushed
  * far-first. Returns false if no child is hit (the caller pops). */
 template<int BLOCK, int STACK, bool FMA = false, bool MB = false, class CNT, class MISS>
-__device__ __forceinline__ bool node_visit(const Lds &lds, lds_uint2 *lstack, const RayBox &rb, const V3 o, float dist, uint32_t &current, int &sp, CNT &cnt, MISS &&miss)
+__device__ __forceinline__ bool node_visit(const Lds &lds, lds_uint2 *lstack, const RayBox &rb, const V3 o, float dist, uint32_t &current, int &sp, CNT &cnt, MISS &&miss,
+                                           float *entry = nullptr)      /* entry: receives the entry distance of the child that becomes `current` */
 { /* miss(): what the caller does when no child is hit, as the else branch of the test (the exact rounds pop right there -- as a second
      conditional after the call the same code compiled to a node loop with four more divergent regions, +6 % branches) */ /* FMA (FAST rounds): a plane's distance as fma(plane, 1/d, -o/d) instead of (plane - o)*(1/d) -- one instruction instead of two,
      24 fewer per visit. The two differ by at most 2^-24 (3 |t| + |o/d|) (one rounding of o/d up front instead of one of the
@@ -1168,6 +1171,7 @@ __device__ __forceinline__ bool node_visit(const Lds &lds, lds_uint2 *lstack, co
       if(p01) { stack_push<BLOCK, STACK>(lds, sp, make_uint2(c01, __float_as_uint(t01))); sp++; }
     }
     current = h00 ? c00 : h01 ? c01 : h10 ? c10 : c11;
+    if(entry) { const float t00 = near1n ? ta1 : ta0; *entry = h00 ? t00 : h01 ? t01 : h10 ? t10 : t11; }
     MI_COUNT_MAX(cnt, 7, (uint32_t)sp);
   }
   else miss();
@@ -1250,21 +1254,22 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
 #ifndef MI_SPEC_ANYHIT_WAITS
 #define MI_SPEC_ANYHIT_WAITS 0   /* A/B: a shadow ray that may stop at its first occluder does not run ahead of its leaves */
 #endif
-#ifndef MI_SPEC_SPLIT_POP
-#define MI_SPEC_SPLIT_POP 0
+#ifndef MI_SPEC_EXACT
+#define MI_SPEC_EXACT 1       /* the entry-distance bookkeeping that keeps the FAST rounds' hits the reference's where rounding is not monotone (trace_round_spec):
+                                 cfg 2 18.22 against 18.05 ms without; FAST against exact rounds of one library on 16 M + 8 M paths: 0 against 4 + 1 differing */
 #endif
 #define MI_SPEC_JOBS_MAX 512  /* job list entries per wave (one byte each: owner lane | slot << 6) */
 
 template<int BLOCK, int STACK>
-__device__ __forceinline__ void stack_pop(const Lds &lds, lds_uint2 *lstack, float dist, int &sp, uint32_t &current, bool &done)
-{ /* pop, skipping entries that start behind the current hit (qbvhmp.c:1357-1364) */
+__device__ __forceinline__ void stack_pop(const Lds &lds, lds_uint2 *lstack, float dist, int &sp, uint32_t &current, bool &done, float &entry)
+{ /* pop, skipping entries that start behind the current hit (qbvhmp.c:1357-1364); entry = the popped entry's distance */
   current = MI_LEAF32;
   done = true;
   while(sp > 0)
   {
     sp--;
     const uint2 e = stack_top<BLOCK, STACK>(lds, lstack, sp);
-    if(!(__uint_as_float(e.y) > dist)) { current = e.x; done = false; break; }
+    if(!(__uint_as_float(e.y) > dist)) { current = e.x; done = false; entry = __uint_as_float(e.y); break; }
   }
 }
 
@@ -1288,6 +1293,15 @@ __device__ __forceinline__ void trace_round_spec(const Lds &lds, const DPrim *pr
   uint32_t lf[K + 1];                                   /* the leaves of this round in the order the ray reached them; 0 = none */
 #pragma unroll
   for(int k=0;k<=K;k++) lf[k] = 0u;
+  /* Keeping the result the reference's when rounding is not monotone. A leaf reached AFTER a leaf was put aside has been reached
+     through box tests against the distance of the round's start; the reference makes those tests against the distance the put-aside
+     leaf leaves, and does not get there if one of them fails. In exact arithmetic a hit in such a leaf lies behind its boxes' entry
+     and loses anyway; in floats it can be closer by an ulp or -- on the shared edge of two quads in different leaves -- equally far
+     and win the tie as the later one (0.25 such paths per million on regression/0010_pt). So the lane keeps `lo`, the largest entry
+     distance among the tests since its last pop, and (a) an inner node it still holds when the round ends goes back on the stack
+     with lo as its entry distance -- the next round pops it against the distance this round leaves, as the reference would have
+     tested it --, (b) the held leaf's results only count if lo is not behind what the put-aside leaf leaves (epilogue). */
+  float lo = 0.0f;          /* only read after a leaf was put aside, and that is followed by a pop, which sets it */
   /* -------- node loop */
   while(true)
   {
@@ -1305,20 +1319,13 @@ __device__ __forceinline__ void trace_round_spec(const Lds &lds, const DPrim *pr
 #ifdef MI_PROFILE_LOOPS
     { const unsigned nround = __popcll(__ballot(!done)); if(lane == 0) cnt.c[8] += MI_PROFILE_LOOPS == 2 ? nround : 1; }
 #endif
-#if MI_SPEC_SPLIT_POP
-    if(inner) node_visit<BLOCK, STACK, FMA>(lds, lstack, rb, o, hit.dist, current, sp, cnt, [&]() { stack_pop<BLOCK, STACK>(lds, lstack, MI_CULL_DIST, sp, current, done); });
-    else if(advance)
-    {
-      if(current & 31u)
-      {
-#pragma unroll
-        for(int k=0;k<K;k++) if(lf[k] == 0u) { lf[k] = current; break; }
-      }
-      stack_pop<BLOCK, STACK>(lds, lstack, MI_CULL_DIST, sp, current, done);
-    }
-#else
     bool pop = false;
-    if(inner) pop = !node_visit<BLOCK, STACK, FMA>(lds, lstack, rb, o, hit.dist, current, sp, cnt, [](){});
+    if(inner)
+    {
+      float entry = 0.0f;
+      pop = !node_visit<BLOCK, STACK, FMA>(lds, lstack, rb, o, hit.dist, current, sp, cnt, [](){}, MI_SPEC_EXACT ? &entry : nullptr);
+      if(MI_SPEC_EXACT && !pop) lo = fmaxf(lo, entry);
+    }
     else if(advance)
     {
       if(current & 31u)
@@ -1328,12 +1335,16 @@ __device__ __forceinline__ void trace_round_spec(const Lds &lds, const DPrim *pr
       }
       pop = true;
     }
-    if(pop) stack_pop<BLOCK, STACK>(lds, lstack, MI_CULL_DIST, sp, current, done);
-#endif
+    if(pop) stack_pop<BLOCK, STACK>(lds, lstack, MI_CULL_DIST, sp, current, done, lo);
   }
   MI_TT(cnt, 0)
+  if(MI_SPEC_EXACT && !done && !(current & MI_LEAF32) && lf[0] != 0u)
+  { /* (a) */
+    stack_push<BLOCK, STACK>(lds, sp, make_uint2(current, __float_as_uint(lo))); sp++;
+    current = MI_LEAF32;                                /* an empty leaf: the next round's node loop pops */
+  }
   /* -------- leaf phase: the (lane, slot, primitive) tests of all put-aside leaves dealt out over the 64 lanes */
-  const bool holds = (current & MI_LEAF32) && !done;    /* the leaf the lane still holds is tested too, then popped */
+  const bool holds = (current & MI_LEAF32) && !done;    /* the leaf the lane still holds is tested too, then popped (so is the entry of (a), against the round's result) */
   if(holds) lf[K] = current;
   uint32_t n[K + 1], num = 0;
 #pragma unroll
@@ -1354,14 +1365,14 @@ __device__ __forceinline__ void trace_round_spec(const Lds &lds, const DPrim *pr
     lds_uint2 *col = (lds_uint2 *)lds.stack;
     lds_u64 *best = (lds_u64 *)(col + (STACK + 0)*BLOCK);
     lds_uint2 *uvs = col + (STACK + 1)*BLOCK;
-    lds_u32 *anl = (lds_u32 *)(col + (STACK + 2)*BLOCK);
+    lds_u32 *anl = (lds_u32 *)(col + (STACK + 2)*BLOCK);                /* + 1: closest triangle / quad distance of the put-aside leaves (slots < K) */
     if(num && fits)
     {
       uint32_t at = prefix;
 #pragma unroll
       for(int k=0;k<=K;k++) { for(uint32_t i=0;i<n[k];i++) jobs[at + i] = (unsigned char)(lane | ((unsigned)k << 6)); at += n[k]; }
       *best = ((mi_u64)__float_as_uint(hit.dist) << 32) | 0xffffffffull;
-      *anl = 0u;
+      anl[0] = 0u; anl[1] = __float_as_uint(hit.dist);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1400,6 +1411,7 @@ __device__ __forceinline__ void trace_round_spec(const Lds &lds, const DPrim *pr
       const mi_u64 key = ((mi_u64)__float_as_uint(h.dist) << 32) | (mi_u64)(31u - pos);
       if(tq && (both || cand)) __hip_atomic_fetch_min(best + offl, both ? (mi_u64)0 : key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   /* 0: poison, the owner goes sequential */
       if(valid && type < MI_PRIM_TRI) __hip_atomic_fetch_or(anl + 2*offl, 1u << pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      if(MI_SPEC_EXACT && cand && slot < (uint32_t)K) __hip_atomic_fetch_min(anl + 2*offl + 1, __float_as_uint(h.dist), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   /* distances are positive: ordered as integers */
       if(__any(cand))
       { /* the job that holds the owner's minimum so far leaves its u, v (a later, closer one overwrites them) */
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1412,11 +1424,22 @@ __device__ __forceinline__ void trace_round_spec(const Lds &lds, const DPrim *pr
     MI_TT(cnt, 2)
     if(num)
     {
-      const mi_u64 res = fits ? *best : 0;
+      mi_u64 res = fits ? *best : 0;
+      /* (b) above: does the reference reach the held leaf after the put-aside one? Only in doubt when the held leaf's winner lies in
+         front of the entry distance `lo` of its own boxes -- then the distance the put-aside leaf leaves decides (its triangles /
+         quads: anl[1]; with sphere / line tests among its primitives the lane takes the in-order path below, which applies the
+         reference's test as it goes) */
+      static_assert(!MI_SPEC_EXACT || K == 1, "the entry-distance bookkeeping covers one put-aside leaf per round");
+      const bool second = MI_SPEC_EXACT && holds && lf[0] != 0u;          /* the held leaf was reached past a put-aside one */
+      if(second && res != 0 && (uint32_t)res != 0xffffffffu && ((31u - (uint32_t)res) >> 3) == (uint32_t)K && lo > __uint_as_float((uint32_t)(res >> 32)))
+      {
+        const float d0 = fminf(hit.dist, __uint_as_float(anl[1]));
+        if((anl[0] & 0xffu) != 0u || lo > d0) res = 0;
+      }
       if(res == 0)
       { /* order matters in one of the leaves (or the list does not fit): this lane's leaves one after the other, each in order */
 #pragma unroll
-        for(int k=0;k<=K;k++) if(n[k]) leaf_tests<MB>(prims, lf[k], o, d, ignore, hit, ts, cnt);
+        for(int k=0;k<=K;k++) if(n[k] && !(second && k == K && lo > hit.dist)) leaf_tests<MB>(prims, lf[k], o, d, ignore, hit, ts, cnt);
       }
       else
       {
@@ -1437,6 +1460,7 @@ __device__ __forceinline__ void trace_round_spec(const Lds &lds, const DPrim *pr
 #ifdef MI_PROFILE_LOOPS
           { const unsigned nl = __popcll(__ballot(1)); if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) cnt.c[10] += MI_PROFILE_LOOPS == 2 ? nl : 1; }
 #endif
+          if(second && lo > hit.dist) { analytic &= 0xffu; if(!analytic) break; }   /* the reference does not get to the held leaf: only the put-aside leaf's tests count */
           const uint32_t pos = __ffs(analytic) - 1;
           analytic &= analytic - 1;
           uint32_t link = lf[0];
@@ -1447,7 +1471,7 @@ __device__ __forceinline__ void trace_round_spec(const Lds &lds, const DPrim *pr
       }
     }
     if(ANYHIT && ts.anyhit && hit.prim != MI_NOPRIM && !done) { sp = 0; current = MI_LEAF32; done = true; }   /* an occluder is all such a shadow ray needs */
-    else if(holds) stack_pop<BLOCK, STACK>(lds, lstack, MI_CULL_DIST, sp, current, done);
+    else if(holds) stack_pop<BLOCK, STACK>(lds, lstack, MI_CULL_DIST, sp, current, done, lo);
 #undef MI_CULL_DIST
     MI_TT(cnt, 3)
   }

@@ -67,8 +67,9 @@
                                      stack column during a slice: 16 against 21 spilled registers, cfg 3 35.9 against 36.3 ms (2 / 4 / 5 entries: 18 / 18 / 18) */
 #endif
 #ifndef MI_PARK_ENTRIES_PT
-#define MI_PARK_ENTRIES_PT 4   /* pt: generator, pdf product, pixel -- the kernel then needs no scratch (2 / 3 entries: 4 / 2 spilled registers; none parked: 8);
-                                  cfg 2 with 2 / 3 / 4 / 5 entries: 18.03 / 17.90 / 17.90 / 18.10 ms, none 18.05 */
+#define MI_PARK_ENTRIES_PT 3   /* pt: generator and pdf product. With the FMA plane test (MI_SPEC_FMA = 2) 3 / 4 / 5 / 6 entries: 17.71 / 17.79 / 17.90 / 17.94 ms
+                                  at 6 / 4 / 2 / 0 spilled registers: a deeper LDS stack is worth more than the last spilled registers. Without the FMA test
+                                  2 / 3 / 4 / 5: 18.03 / 17.90 / 17.90 / 18.10 (4: no scratch at all), none parked 18.05 */
 #endif
 /* the shallowest LDS stack among the instantiations (FAST kernels with parked path state; motion-blur kernels): the overflow area
    in HBM is sized for it */

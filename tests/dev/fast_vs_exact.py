@@ -1,0 +1,30 @@
+"""development helper (GPU box): path records of the FAST rounds against the exact rounds of the same library, path by path
+(python3 tests/dev/fast_vs_exact.py [paths] [pt|ptdl]) -- they must be identical; prints the paths that are not"""
+import sys
+sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parent.parent))
+import numpy as np
+from helpers import *
+pkg = load_pkg()
+total = int(sys.argv[1]) if len(sys.argv) > 1 else 2000000
+sampler = pkg.MI_SAMPLER_PTDL if len(sys.argv) > 2 and sys.argv[2] == "ptdl" else pkg.MI_SAMPLER_PT
+scene = make_scene(SCENE_0010, width=1280, height=720, max_verts=8, sampler=sampler)
+ex = pkg.Backend(scene, traversal="exact")
+fa = pkg.Backend(scene, traversal="fast")
+chunk, bad = 250000, 0
+for first in range(777, 777 + total, chunk):
+    a = ex.trace_paths(first, chunk)
+    b = fa.trace_paths(first, chunk)
+    same = a.tobytes() == b.tobytes()
+    if same:
+        continue
+    diff = np.nonzero([x.tobytes() != y.tobytes() for x, y in zip(a, b)])[0]
+    for i in diff:
+        bad += 1
+        print("path", first + int(i), "length", a["length"][i], b["length"][i])
+        for k in range(min(int(max(a["length"][i], b["length"][i])), 8)):
+            va, vb = a["v"][i][k], b["v"][i][k]
+            if va.tobytes() != vb.tobytes():
+                print("  first differing vertex", k, "exact prim", va["prim"], "dist", va["dist"], "fast prim", vb["prim"], "dist", vb["dist"])
+                print("   x", va["x"], vb["x"], "omega", va["omega"], vb["omega"])
+                break
+print("paths compared", total, "differing", bad)

@@ -1,5 +1,5 @@
 """development helper (GPU box): GPU path records against the oracle on millions of paths, in chunks
-(python3 tests/dev/parity_soak.py [paths per configuration])"""
+(python3 tests/dev/parity_soak.py [paths per configuration] [base|ext] [auto|exact|fast])"""
 import sys, time
 sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parent.parent))
 import numpy as np
@@ -18,7 +18,9 @@ CASES = {"base": (("cfg2 pt mv8", SCENE_0010, pkg.MI_SAMPLER_PT, 8), ("cfg3 ptdl
 for name, path, sampler, mv in CASES[sys.argv[2] if len(sys.argv) > 2 else "base"]:
     scene = make_scene(path, width=1280, height=720, max_verts=mv, sampler=sampler,
                        pointsampler=pkg.MI_POINTS_HALTON if name.startswith("halton") else pkg.MI_POINTS_RAND)
-    be = pkg.Backend(scene)
+    mode = sys.argv[3] if len(sys.argv) > 3 else "auto"
+    be = pkg.Backend(scene) if mode == "auto" else pkg.Backend(scene, traversal=mode)
+    name = f"{name} [{be.traversal()}]"
     n = same_len = same_prims = same_splats = 0
     worst_thr = 0.0
     t0 = time.time()
@@ -36,5 +38,5 @@ for name, path, sampler, mv in CASES[sys.argv[2] if len(sys.argv) > 2 else "base
         rel = np.abs(thr_g - thr_o) / np.maximum(1e-20, np.maximum(np.abs(thr_g), np.abs(thr_o)))
         worst_thr = max(worst_thr, float(np.quantile(rel, 0.9999)) if len(rel) else 0.0)
     be.close()
-    print("%-16s %d paths: same length %d (%.5f %%), same primitive sequence %d (%.5f %%), and same splat count %d; 99.99th pct throughput deviation %.2e; %.0f s" %
+    print("%-24s %d paths: same length %d (%.5f %%), same primitive sequence %d (%.5f %%), and same splat count %d; 99.99th pct throughput deviation %.2e; %.0f s" %
           (name, n, same_len, 100.0 * same_len / n, same_prims, 100.0 * same_prims / n, same_splats, worst_thr, time.time() - t0), flush=True)

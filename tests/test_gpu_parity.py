@@ -471,6 +471,42 @@ def test_intersect_degenerate_rays_follow_sse_nan_semantics(traversal):
     be.close()
 
 
+def test_intersect_rays_through_vertices_and_edges(traversal):
+    """rays aimed at mesh vertices and edge midpoints: several primitives -- often in different leaves -- are hit at the SAME
+    distance, and which one is reported depends on the order the reference tests them in and on which leaves it reaches at all
+    (a leaf whose box the ray enters an ulp behind the tie is never tested). The FAST rounds reach more leaves than the reference;
+    their entry-distance bookkeeping (trace_round_spec, MI_SPEC_EXACT) has to drop exactly the hits the reference cannot have."""
+    scene = make_scene(SCENE_0010, width=256, height=256, max_verts=8)
+    be = pkg.Backend(scene, traversal=traversal)
+    rng = np.random.default_rng(23)
+    vtx = np.ctypeslib.as_array(C.cast(scene.desc.vtx, C.POINTER(C.c_float)), shape=(scene.desc.num_vtx, 4))[:, :3].copy()
+    n = 400000
+    a = vtx[rng.integers(0, len(vtx), size=n)]
+    # half of the targets: a vertex; the other half: the midpoint to the next vertex of the array (a mesh edge for grid meshes)
+    k = rng.integers(0, len(vtx) - 1, size=n)
+    mid = np.float32(0.5) * (vtx[k] + vtx[k + 1])
+    target = np.where((np.arange(n) % 2 == 0)[:, None], a, mid).astype(np.float32)
+    pos = (rng.uniform(-4, 4, size=(n, 3)) + [0, 0, 3]).astype(np.float32)
+    d = target - pos
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    gpu = _compare_hits(scene, be, pos, d, traversal=traversal)
+    assert (gpu["primid"] != 0xffffffffffffffff).mean() > 0.9
+    be.close()
+
+
+def test_fast_rounds_give_the_exact_rounds_paths():
+    """the FAST rounds against the exact rounds of the same library, path record by path record (bytes): pt, ptdl and the extended
+    kernels. Before the entry-distance bookkeeping 0.25 paths per million differed (ties on shared edges, tests/dev/fast_vs_exact.py)."""
+    for path, sampler, n in ((SCENE_0010, pkg.MI_SAMPLER_PT, 2000000), (SCENE_0010, pkg.MI_SAMPLER_PTDL, 1000000), (SCENE_MEDIA, pkg.MI_SAMPLER_PT, 500000)):
+        scene = make_scene(path, width=1280, height=720, max_verts=8, sampler=sampler)
+        ex, fa = pkg.Backend(scene, traversal="exact"), pkg.Backend(scene, traversal="fast")
+        assert fa.traversal() == "fast"
+        for first in range(31, 31 + n, 250000):
+            a, b = ex.trace_paths(first, 250000), fa.trace_paths(first, 250000)
+            assert a.tobytes() == b.tobytes(), (path, sampler, first)
+        ex.close(); fa.close()
+
+
 def test_cfg5_film_3840x2160(counters):
     """BASELINE config 5's film (3840x2160, padded to 3840x2176; 100 MB framebuffer): one sample per pixel, sharded over two
     path-index ranges like two ranks would, against the oracle's image of the same indices"""
