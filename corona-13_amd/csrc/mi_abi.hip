@@ -757,11 +757,11 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
   s->lds_bytes = halton_bytes + lights_bytes + (s->nodes_lds ? node_bytes : 0) + stack_bytes;
   s->device_built = device_build; s->stack_need = stack_need;
   { const char *ce = getenv("CORONA_MI_COUNTERS"); s->counting = ce && atoi(ce) ? 1 : 0; }
-  { /* default: the FAST rounds where they win (same-box A/B) -- the pt kernels without a global medium: cfg 2
-       18.0 against 18.7 ms, scenes/0055_media 20.8 / 21.3, moving camera 19.8 / 20.4; in a global fog (39.8 / 41.3: most vertices are
-       volume vertices) and in the ptdl kernels (35.8 / 36.8; media 48.8 / 56.6) the exact rounds are the quicker ones */
+  { /* default: the FAST rounds where they win (same-box A/B) -- the plain pt kernels: cfg 2 18.2 against 18.7 ms.
+       The extended pt kernels break even (scenes/0055_media 21.6 / 21.4, moving camera 20.3 / 20.4), a global fog (41.3 / 39.8) and the
+       ptdl kernels (36.8 / 35.8; media 56.6 / 48.8) are quicker with the exact rounds */
     const char *te = getenv("CORONA_MI_TRAVERSAL");
-    s->fast = te ? strcmp(te, "exact") != 0 : (h->sampler == MI_SAMPLER_PT && !h->exterior);
+    s->fast = te ? strcmp(te, "exact") != 0 : (h->sampler == MI_SAMPLER_PT && !s->media);
   }
   { const char *me = getenv("CORONA_MI_METAL"); d.metal_reference = (me && !strcmp(me, "reference")) ? 1u : 0u; }
   { /* the kernels this scene can launch (record / counting / traversal variants of its configuration) may use the whole LDS */

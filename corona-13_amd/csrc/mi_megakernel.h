@@ -67,9 +67,8 @@
                                      stack column during a slice: 16 against 21 spilled registers, cfg 3 35.9 against 36.3 ms (2 / 4 / 5 entries: 18 / 18 / 18) */
 #endif
 #ifndef MI_PARK_ENTRIES_PT
-#define MI_PARK_ENTRIES_PT 3   /* pt: generator and pdf product. With the FMA plane test (MI_SPEC_FMA = 2) 3 / 4 / 5 / 6 entries: 17.71 / 17.79 / 17.90 / 17.94 ms
-                                  at 6 / 4 / 2 / 0 spilled registers: a deeper LDS stack is worth more than the last spilled registers. Without the FMA test
-                                  2 / 3 / 4 / 5: 18.03 / 17.90 / 17.90 / 18.10 (4: no scratch at all), none parked 18.05 */
+#define MI_PARK_ENTRIES_PT 4   /* pt: generator, pdf product, pixel (one spilled register left; 2 / 3 / 4 entries: 18.24 / 18.23 / 18.22 ms at 6 / 3 / 1 spilled
+                                  registers, 5 entries: none, but the shallower LDS stack costs 1 %) */
 #endif
 /* the shallowest LDS stack among the instantiations (FAST kernels with parked path state; motion-blur kernels): the overflow area
    in HBM is sized for it */

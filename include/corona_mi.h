@@ -273,11 +273,12 @@ int  mi_scene_set_metal_reference(mi_scene *s, int enable);
  *                       tested before the next subtree is chosen, so node visits / box hits / primitive tests equal the
  *                       reference's -DACCEL_DEBUG totals. For counter parity and as the yardstick of the fast mode.
  *   MI_TRAVERSAL_FAST   a lane that reaches a leaf puts it aside and goes on descending against the distance known so far; the
- *                       put-aside leaves of the whole wave are tested together. A few per cent more node visits and primitive
- *                       tests (they are counted), fewer idle lane-slots (csrc/mi_kernels.h, trace_round_spec).
- * A scene is created in the mode that is faster for its kernels: FAST for pt scenes without a global medium (4 % on
- * regression/0010_pt, 3 % with interior media or a moving camera), EXACT for ptdl and for pt in a global fog; CORONA_MI_TRAVERSAL=exact|fast
- * in the environment overrides that, mi_scene_set_traversal changes it later. Scenes with motion-blurred primitives always run the exact
+ *                       put-aside leaves of the whole wave are tested together. Same hits, path records and images (the rounds keep
+ *                       track of what the reference would not have reached, csrc/mi_kernels.h: trace_round_spec); a few per cent
+ *                       more node visits and primitive tests (they are counted), fewer idle lane-slots.
+ * A scene is created in the mode that is faster for its kernels: FAST for plain pt scenes (2.5 % on regression/0010_pt), EXACT for
+ * ptdl and for scenes with media or a moving camera (break even or slower there); CORONA_MI_TRAVERSAL=exact|fast in the environment
+ * overrides that, mi_scene_set_traversal changes it later. Scenes with motion-blurred primitives always run the exact
  * rounds. mi_scene_get_traversal returns the mode the next mi_render uses. No reference counterpart. */
 #define MI_TRAVERSAL_EXACT 0
 #define MI_TRAVERSAL_FAST  1
