@@ -744,10 +744,11 @@ __device__ __forceinline__ Lds lds_setup(const DScene &sc, unsigned char *smem, 
 }
 
 #ifndef MI_TAIL_INNER
-#define MI_TAIL_INNER 4
+#define MI_TAIL_INNER 6      /* end of round 3, with MI_LEAF_EXIT 64: 3 / 4 / 6 / 8 = 35.85 / 35.55 / 35.39 / 35.45 ms on cfg 3, 18.80 / 18.64 / 18.55 / 18.55 on cfg 2 (exact rounds) */
 #endif
 #ifndef MI_LEAF_EXIT
-#define MI_LEAF_EXIT 48   /* leaf_jobs kernels: the node loop of a round ends once this many lanes wait with a leaf (a full pass of jobs); 64 = never. A/B 24..56 */
+#define MI_LEAF_EXIT 64   /* leaf_jobs kernels: the node loop of a round ends once this many lanes wait with a leaf; 64 = never. Round 2: 48 (a full pass of jobs;
+                             A/B 24..56); re-swept at the end of round 3 (32 / 40 / 48 / 56 / 64: 36.10 / 36.09 / 35.77 / 35.74 / 35.30-35.55 ms on cfg 3): the rule is off */
 #endif
 #ifndef MI_LEAF_JOBS
 #define MI_LEAF_JOBS 1   /* 1: the primitive tests of a round are dealt out over all 64 lanes of the wave (leaf_jobs) */
