@@ -301,7 +301,7 @@ struct PointSampler
  * 10 % through register pressure, the pt kernel 1 %); mi_scene_set_counters() selects the counting kernels.
  * Development builds append more: -DMI_PROFILE_LOOPS wave-level loop iterations (c[8..10]), -DMI_PROFILE_PHASES lane-0 clock
  * ticks per phase (c[8+k]), their occurrences (c[16+k]), the last marker (c[30]) and time stamp (c[31]). */
-#if defined(MI_PROFILE_PHASES) || defined(MI_PROFILE_LOOPS) || defined(MI_PROFILE_TRAV)
+#if defined(MI_PROFILE_PHASES) || defined(MI_PROFILE_LOOPS) || defined(MI_PROFILE_TRAV) || defined(MI_PROFILE_BLOCKS)
 #define MI_CNT 32
 #else
 #define MI_CNT 8
@@ -324,6 +324,13 @@ template<bool ON> struct Counters
 #else
 #define MI_PHASE_INIT(cnt)
 #define MI_PHASE(cnt, k)
+#endif
+/* -DMI_PROFILE_BLOCKS (development build, tools/block_probe.py): how full the wave is where it executes a block of the shading code:
+ * every lane that runs block k counts itself, the first active lane counts the execution; counter k leaves the kernel as lanes | executions << 36 */
+#ifdef MI_PROFILE_BLOCKS
+#define MI_BLK(cnt, k) { (cnt).c[8 + (k)]++; if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) (cnt).c[16 + (k)]++; }
+#else
+#define MI_BLK(cnt, k)
 #endif
 /* -DMI_PROFILE_TRAV (development build, tools/trav_probe.py): lane 0's clock ticks per part of a wave iteration, summed over the
  * launch into counters 0..6: 0 node loop, 1 job list set-up, 2 job passes, 3 owners' epilogue (results, sphere / line tests, pop),

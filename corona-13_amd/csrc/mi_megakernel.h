@@ -299,28 +299,35 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
 #ifdef MI_PROFILE_TRAV     /* development build: counters 0..6 become lane 0's ticks per part of the wave iteration (tools/trav_probe.py); 7 stays */
   for(int k=0;k<8;k++) cnt.c[k] = lane ? 0u : cnt.c[8 + k];
 #endif
+#ifdef MI_PROFILE_BLOCKS
+  unsigned long long block_out[8];
+  for(int k=0;k<8;k++) block_out[k] = (unsigned long long)cnt.c[8 + k] | ((unsigned long long)cnt.c[16 + k] << 36);
+#endif
 #ifdef MI_PROFILE_PHASES   /* development build: the 8 counters become lane 0's phase ticks | occurrences << 36 (tools/phase_probe.py) */
   unsigned long long phase_out[8];
   for(int k=0;k<8;k++) phase_out[k] = lane ? 0ull : ((unsigned long long)cnt.c[8 + k] | ((unsigned long long)cnt.c[16 + k] << 36));
 #endif
   unsigned long long *shard = sc.counters + (size_t)(blockIdx.x % MI_COUNTER_SHARDS)*8;
-#if !defined(MI_PROFILE_PHASES) && !defined(MI_PROFILE_TRAV)
+#if !defined(MI_PROFILE_PHASES) && !defined(MI_PROFILE_TRAV) && !defined(MI_PROFILE_BLOCKS)
   if(cnt.on) atomicMax(shard + 7, (unsigned long long)cnt.c[7]);     /* deepest traversal stack use */
 #endif
   /* ------------------------------------------------------------ flush work counters: wave reduction, one atomic per wave */
 #pragma unroll
   for(int k=0;k<8;k++)
   {
-#ifndef MI_PROFILE_TRAV
+#if !defined(MI_PROFILE_TRAV) && !defined(MI_PROFILE_BLOCKS)
     if(!cnt.on && k != 4) continue;         /* the plain kernels only count paths */
 #endif
     unsigned long long c = cnt.c[k];
+#ifdef MI_PROFILE_BLOCKS
+    c = block_out[k];
+#endif
 #ifdef MI_PROFILE_PHASES
     c = phase_out[k];
     if(k == 7) { if(lane == 0 && c) atomicAdd(shard + 7, c); continue; }
 #endif
     for(int off=32;off>0;off>>=1) c += __shfl_down(c, off);
-#ifndef MI_PROFILE_TRAV
+#if !defined(MI_PROFILE_TRAV) && !defined(MI_PROFILE_BLOCKS)
     if(k == 7) continue;                    /* slot 7 is a maximum, flushed above */
 #endif
     if(lane == 0 && c) atomicAdd(shard + k, c);

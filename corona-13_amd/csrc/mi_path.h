@@ -131,6 +131,7 @@ template<bool RECORD, bool HALTON, bool MEDIA = false, class CNT>
 __device__ __forceinline__ void path_generate(const DScene &sc, PathState &ps, unsigned long long index, mi_path_record *rec, CNT &cnt)
 {
   /* path_init + first half of path_extend (length == 0), src/pathspace.c:13-28,210-249 */
+  MI_BLK(cnt, 0)
   ps.index = index;
   rng_seed(ps.rng, ps.index, sc.frame);
   PointSampler<HALTON> pts(sc, ps.rng, index, 0);
@@ -442,6 +443,7 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
     return;
   }
 
+  MI_BLK(cnt, 1)
   const int v = ps.length;                         /* index of the vertex being created */
   bool alive = true;
   const V3 omega = ps.dir;
@@ -474,6 +476,7 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
   else
   {
     /* shader_prepare, src/shader.c:462-542 */
+    MI_BLK(cnt, 2)
     Surf sf;
     const V3 rorg = ray_origin<PTDL>(ps, false);
     sf.x = mk3(rorg.x + hit.dist*ps.dir.x, rorg.y + hit.dist*ps.dir.y, rorg.z + hit.dist*ps.dir.z);
@@ -573,6 +576,7 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
       }
       if(mode & s_emit)
       { /* sampler_create_path: src/sampler.d/pt.c:45-52 / src/sampler.d/ptdl.c:116-121 */
+        MI_BLK(cnt, 3)
         float w;
         if(PTDL)
         { /* balance heuristic against next event estimation, ptdl.c:78-88 + nee_pdf, include/pathspace/nee.h:21-47 */
@@ -639,6 +643,7 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
           const float rnd = pts(MI_DIM_NEE_LIGHT1);
           if(!(rnd < sc.p_sky) && rnd < sc.p_sky + sc.p_geo)
           { /* lights_sample_next_event, src/lights.d/list.c:130-174 (arguments drawn right to left) */
+            MI_BLK(cnt, 4)
             const float r3 = pts(MI_DIM_NEE_Y);
             const float r2 = pts(MI_DIM_NEE_X);
             const float r1 = pts(MI_DIM_NEE_LIGHT2);
@@ -785,9 +790,9 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
         BsdfSample bs;
         get_scrambled_onb(ps.scramble, sf.n, sf.a, sf.b);              /* the vertex's tangent frame, see surface_setup */
         PointSampler<HALTON> pts(sc, ps.rng, ps.index, rand_beg_extend<PTDL>(v + 1));   /* the vertex the sample leads to */
-        if(mat_bsdf == MI_BSDF_DIFFUSE) sample_diffuse(pts, sf, sh, mode, bs);
-        else if(mat_bsdf == MI_BSDF_DIELECTRIC) sample_dielectric(pts, sf, sh, omega, eta_ratio, mode, bs);
-        else sample_metal(sc, pts, sf, sh, omega, ps.cur_ior, (int)mat_p0, ps.lambda, mode, bs);
+        if(mat_bsdf == MI_BSDF_DIFFUSE) { MI_BLK(cnt, 5) sample_diffuse(pts, sf, sh, mode, bs); }
+        else if(mat_bsdf == MI_BSDF_DIELECTRIC) { MI_BLK(cnt, 6) sample_dielectric(pts, sf, sh, omega, eta_ratio, mode, bs); }
+        else { MI_BLK(cnt, 7) sample_metal(sc, pts, sf, sh, omega, ps.cur_ior, (int)mat_p0, ps.lambda, mode, bs); }
         MI_PHASE(cnt, 7)
         /* shader_sample tail, src/shader.c:582-589 */
         bs.omega = normalise3(bs.omega);
