@@ -56,6 +56,10 @@
                              spilled registers come back). Same-box A/B, cfg 2 / cfg 3: slice first 18.73 / 38.57 ms, shading first 19.09 / 38.02,
                              no priorities 18.89 / 38.32 */
 #endif
+#ifndef MI_PRIO_PT_TRACE
+#define MI_PRIO_PT_TRACE 3
+#define MI_PRIO_PT_SHADE 0
+#endif
 #ifndef MI_PRIO_PTDL_TRACE
 #define MI_PRIO_PTDL_TRACE 0
 #define MI_PRIO_PTDL_SHADE 3
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
       const uint32_t ignore = ps.ignore;     /* the shadow ray of a vertex starts on the same primitive as its extension ray */
       const unsigned tail = exhausted_wave ? 1u : (unsigned)(PTDL ? MI_TAIL_LANES_PTDL : MI_TAIL_LANES);
       lds_uint2 *parked = (lds_uint2 *)lds.stack + (STACK + RESULT_SLOTS)*MI_BLOCK;
-      if(MI_PRIO) __builtin_amdgcn_s_setprio(PTDL ? MI_PRIO_PTDL_TRACE : 3);
+      if(MI_PRIO) __builtin_amdgcn_s_setprio(PTDL ? MI_PRIO_PTDL_TRACE : MI_PRIO_PT_TRACE);
       if(PARK_PS)
       {
         parked[0] = mi_u32x2{(uint32_t)ps.rng.s0, (uint32_t)(ps.rng.s0 >> 32)};
@@ -236,7 +240,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
         if(PARK_N >= 8) { const mi_u32x2 f = parked[7*MI_BLOCK]; ps.media.ids = (unsigned long long)f.x | ((unsigned long long)f.y << 32); }
       }
     }
-    if(MI_PRIO) __builtin_amdgcn_s_setprio(PTDL ? MI_PRIO_PTDL_SHADE : 0);
+    if(MI_PRIO) __builtin_amdgcn_s_setprio(PTDL ? MI_PRIO_PTDL_SHADE : MI_PRIO_PT_SHADE);
     MI_PHASE(cnt, 1)
     MI_TT(cnt, 4)
     /* The lanes of the tail keep their ray. Its traversal state (closest hit so far, node, stack pointer: 6 dwords; the three 1/dir
