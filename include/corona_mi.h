@@ -343,8 +343,8 @@ int  mi_bsdf_test_run(mi_scene *s, const mi_bsdf_test *t, double *out);
 /* Time of the last mi_render launch on the device in milliseconds (HIP events on the scene's
  * stream), and kernel launches since creation. For bench.py's roofline figure. */
 int  mi_last_kernel_ms(mi_scene *s, float *ms);
-/* number of traversal-kernel launches the last mi_render needed: 1 for the megakernel; one per bounce batch for the
- * wavefront pipeline, whose mi_last_kernel_ms spans the whole launch sequence */
+/* number of kernel launches the last mi_render needed: 1 unless the index range exceeds what one launch takes (2^31 paths per
+ * workgroup); mi_last_kernel_ms then spans the whole sequence */
 int  mi_last_kernel_launches(mi_scene *s, uint64_t *launches);
 
 /* what the backend made of the scene: out[0] 4-wide nodes, out[1] 1 if the tree is staged in LDS (0: traversed from HBM),
