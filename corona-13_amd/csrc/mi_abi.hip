@@ -759,7 +759,7 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
   { const char *ce = getenv("CORONA_MI_COUNTERS"); s->counting = ce && atoi(ce) ? 1 : 0; }
   { /* default: the FAST rounds where they win (same-box A/B) -- the plain pt kernels: cfg 2 18.2 against 18.7 ms.
        The extended pt kernels break even (scenes/0055_media 21.6 / 21.4, moving camera 20.3 / 20.4), a global fog (41.3 / 39.8) and the
-       ptdl kernels (36.8 / 35.8; media 56.6 / 48.8) are quicker with the exact rounds */
+       ptdl kernels (40.7 / 35.2; media 56.6 / 48.8) are quicker with the exact rounds */
     const char *te = getenv("CORONA_MI_TRAVERSAL");
     s->fast = te ? strcmp(te, "exact") != 0 : (h->sampler == MI_SAMPLER_PT && !s->media);
   }
