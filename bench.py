@@ -202,6 +202,8 @@ def bench_group(args):
     host = np.zeros((scene.height, scene.width, 3), dtype=np.float32)
     for k in range(args.warmup):
         group.render(k * job, job)
+    if args.warmup:
+        group.fb_read()                                # the first reduce sets up the communicators / peer mappings: part of the warm-up
     group.sync()
     group.fb_clear()
     group.sync()
