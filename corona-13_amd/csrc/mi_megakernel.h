@@ -29,7 +29,8 @@
 #define MI_LEAF_JOBS 1
 #endif
 #ifndef MI_LEAF_JOBS_MEDIA_PTDL
-#define MI_LEAF_JOBS_MEDIA_PTDL 0   /* ... but not in the extended ptdl kernels: 38 against 28 spilled registers, scenes/0055_media 51.1 against 48.9 ms */
+#define MI_LEAF_JOBS_MEDIA_PTDL 1   /* ... and in the extended ptdl kernels: a loss before path_shade_volume retired its dead values early too (scenes/0055_media 51.1
+                                       against 48.9 ms), a gain since: 48.1 against 48.9, global fog 119.1 / 120.7, moving camera 39.8 / 41.2 */
 #endif
 #ifndef MI_LEAF_JOBS_PTDL
 #define MI_LEAF_JOBS_PTDL 1   /* the distributed leaf phase in the ptdl kernels too: a loss as long as the kernel spilled 30-47 registers (rounds 1-2:
@@ -110,8 +111,8 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
   const unsigned long long blk_hi = blk_lo + count/nb + (blockIdx.x < count%nb ? 1 : 0);
 
   /* the primitive tests of a traversal round are dealt out over all lanes of the wave (leaf_jobs) -- in the pt kernels and, since the
-     path state's dead values are retired early (MI_EARLY_KILL), in the plain ptdl kernels; the extended ptdl kernels and the motion-blur
-     kernels keep the per-lane leaf loop: there the extra live registers of the job loop still spill (A/B in DESIGN.md) */
+     path state's dead values are retired early (MI_EARLY_KILL), in the ptdl kernels; the motion-blur kernels keep the per-lane leaf
+     loop: every moving primitive is a put-off test there (A/B in DESIGN.md) */
   constexpr bool JOBS = !FAST && MI_LEAF_JOBS && (!PTDL || MI_LEAF_JOBS_PTDL) && (!MEDIA || MI_LEAF_JOBS_MEDIA) && (!(PTDL && MEDIA) || MI_LEAF_JOBS_MEDIA_PTDL) && (!MB || MI_LEAF_JOBS_MB);
   /* PARK_PS: the part of the path state no traversal round looks at (generator, pdf product, pixel: 8 dwords) waits in the lane's LDS
      column for the length of a slice, so that the rounds' registers (a job pass holds a whole primitive record and a second ray) do

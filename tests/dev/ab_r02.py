@@ -27,7 +27,7 @@ if old:
     C.CDLL = _cdll
 out = [(os.path.basename(lib) if lib else "this library") + (" exact" if "--exact" in sys.argv else "") + ":"]
 only = os.environ.get("AB_ONLY")
-for name, path, sampler in (("pt", SCENE_0010, 0), ("ptdl", SCENE_0010, 1), ("media pt", SCENE_MEDIA, 0), ("media ptdl", SCENE_MEDIA, 1), ("fog pt", SCENE_FOG, 0), ("cam_mb pt", SCENE_CAM_MB, 0)):
+for name, path, sampler in (("pt", SCENE_0010, 0), ("ptdl", SCENE_0010, 1), ("media pt", SCENE_MEDIA, 0), ("media ptdl", SCENE_MEDIA, 1), ("fog pt", SCENE_FOG, 0), ("cam_mb pt", SCENE_CAM_MB, 0), ("fog ptdl", SCENE_FOG, 1), ("cam_mb ptdl", SCENE_CAM_MB, 1)):
     if only and name != only:
         continue
     scene = make_scene(path, width=1280, height=720, max_verts=8, sampler=sampler)
