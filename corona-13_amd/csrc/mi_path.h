@@ -261,6 +261,45 @@ __device__ __forceinline__ float media_free_flight(const DScene &sc, PathState &
 __device__ __forceinline__ float media_transmittance(const Medium &m, float dist) { return m.med >= 0 ? expf(-dist*m.mu_t) : 1.0f; }
 __device__ __forceinline__ float media_pdf_to_surface(const Medium &m, float dist) { return (m.med >= 0 && m.mu_s > 0.0f) ? expf(-dist*m.mu_t) : 1.0f; }
 
+/* next event estimation from a one-burst emitter record (DLight, mi_device.h: static triangle / quad emitters with colour-only
+ * materials) in the EXTENDED kernels, when the scene's emitters allow it (sc.lights): lights_sample_next_event + prims_sample +
+ * prims_retime + the emitter's shader_prepare (src/lights.d/list.c:130-174, src/prims.c:178-252) from ten 16-B loads instead of the
+ * chain emitter list -> primitive -> shading record -> material -> ops. The arithmetic of the plain kernels' branch in path_shade
+ * (kept inline there: as a function it cost that kernel 3.6 %). */
+__device__ __forceinline__ void light_record_sample(const DScene &sc, float r1, float r2, float r3, float lambda, const V3 from,
+                                                    uint32_t &lpe, Surf &ls, Shading &lsh, float &lpdf, float &ldist, V3 &ol)
+{
+  const uint32_t t = sample_cdf(sc.light_cdf, (int)sc.num_lights, r1);
+  const float4 *lq = (const float4 *)(sc.lights + t);
+  const float4 q0 = lq[0], q1 = lq[1], q2 = lq[2], q3 = lq[3], q4 = lq[4], q5 = lq[5], q6 = lq[6], q7 = lq[7], q8 = lq[8], q9 = lq[9];
+  lpe = __float_as_uint(q9.x);
+  const bool quad = __float_as_uint(q9.y) == MI_PRIM_QUAD;
+  const V3 v0 = mk3(q0.x, q0.y, q0.z), v1 = mk3(q0.w, q1.x, q1.y), v2 = mk3(q1.z, q1.w, q2.x), v3 = mk3(q2.y, q2.z, q2.w);
+  float hu, hv;
+  if(quad) { hu = r2; hv = r3; }
+  else { const float a = mi_sqrt(r2); hu = r3*a; hv = (1.0f-r3)*a; }
+  const bool second = quad && !(hv >= hu);
+  const float u = second ? hu - hv : hu;
+  const float vv = !quad ? hv : second ? hv : hv - hu;
+  ls.x = second ? tri_retime(v0, v2, v3, u, vv) : tri_retime(v0, v1, v2, u, vv);
+  ls.u = hu; ls.v = hv;
+  ol = sub3(ls.x, from);
+  ldist = mi_sqrt(dot3(ol, ol));
+  const double il = 1./(double)ldist;
+  ol = mk3((float)((double)ol.x*il), (float)((double)ol.y*il), (float)((double)ol.z*il));
+  const V3 n0 = mk3(q3.x, q3.y, q3.z);
+  const V3 na = second ? mk3(q4.z, q4.w, q5.x) : mk3(q3.w, q4.x, q4.y);      /* n2 : n1 */
+  const V3 nb = second ? mk3(q5.y, q5.z, q5.w) : mk3(q4.z, q4.w, q5.x);      /* n3 : n2 */
+  ls.gn = second ? mk3(q6.w, q7.x, q7.y) : mk3(q6.x, q6.y, q6.z);
+  const float w = 1.0f - u - vv;
+  ls.n = normalise3(mk3(u*nb.x + vv*na.x + w*n0.x, u*nb.y + vv*na.y + w*n0.y, u*nb.z + vv*na.z + w*n0.z));
+  ls.flags = 0;
+  const float ec[3] = { q7.z, q7.w, q8.x };
+  lsh.em = q8.y*spectrum_eval(ec, lambda);
+  lsh.roughness = q8.z;
+  lpdf = q8.w;
+}
+
 /* the extension ray ended at the sampled free-flight distance ps.clip before any geometry: a volume vertex
  * (path_propagate src/pathspace.c:745-751,771-776; shader_prepare src/shader.c:476-501; manifold_init manifold.h:236-246;
  * phase function src/shaders/medium_rgb.c:61-102; next event estimation as for surfaces) */
@@ -314,19 +353,27 @@ __device__ __forceinline__ void path_shade_volume(const DScene &sc, PathState &p
       const float r3 = pts(MI_DIM_NEE_Y);
       const float r2 = pts(MI_DIM_NEE_X);
       const float r1 = pts(MI_DIM_NEE_LIGHT2);
-      const uint32_t t = sample_cdf(sc.light_cdf, (int)sc.num_lights, r1);
-      const uint32_t lpe = sc.light_prim[t], lp = lpe & ~MI_LIGHT_ANYHIT;   /* bit 31: any-hit shadow ray allowed (mi_device.h) */
+      uint32_t lpe;
       Surf ls;
-      ls.x = prim_sample<MB>(sc.prims[lp], sc.primgeo[lp], r2, r3, ls.u, ls.v, MB ? sc.prims_t1 + lp : nullptr, ps.time);
-      V3 ol = sub3(ls.x, sf.x);
-      const float ldist = mi_sqrt(dot3(ol, ol));
-      const double il = 1./(double)ldist;
-      ol = mk3((float)((double)ol.x*il), (float)((double)ol.y*il), (float)((double)ol.z*il));
-      const uint4 lhead = *(const uint4 *)&sc.primgeo[lp];
-      surface_setup<MB>(sc, lp, lhead, ol, ps.scramble, ls, ps.time);
       Shading lsh;
-      run_prepare_ops(sc, sc.materials[lhead.y], sc.materials[lhead.y].num_ops, ls, ps.lambda, lsh);
-      float lpdf = sc.light_L[t];
+      V3 ol;
+      float ldist, lpdf;
+      if(!MB && sc.lights != nullptr) light_record_sample(sc, r1, r2, r3, ps.lambda, sf.x, lpe, ls, lsh, lpdf, ldist, ol);
+      else
+      {
+        const uint32_t t = sample_cdf(sc.light_cdf, (int)sc.num_lights, r1);
+        lpe = sc.light_prim[t];                                 /* bit 31: any-hit shadow ray allowed (mi_device.h) */
+        const uint32_t lp = lpe & ~MI_LIGHT_ANYHIT;
+        ls.x = prim_sample<MB>(sc.prims[lp], sc.primgeo[lp], r2, r3, ls.u, ls.v, MB ? sc.prims_t1 + lp : nullptr, ps.time);
+        ol = sub3(ls.x, sf.x);
+        ldist = mi_sqrt(dot3(ol, ol));
+        const double il = 1./(double)ldist;
+        ol = mk3((float)((double)ol.x*il), (float)((double)ol.y*il), (float)((double)ol.z*il));
+        const uint4 lhead = *(const uint4 *)&sc.primgeo[lp];
+        surface_setup<MB>(sc, lp, lhead, ol, ps.scramble, ls, ps.time);
+        run_prepare_ops(sc, sc.materials[lhead.y], sc.materials[lhead.y].num_ops, ls, ps.lambda, lsh);
+        lpdf = sc.light_L[t];
+      }
       float edf = lsh.em/lpdf;
       if(lsh.roughness > 1.0f-1e-4f) edf = (float)((double)edf*((double)1.0f/MI_PI_D));
       else
@@ -697,6 +744,11 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
               lsh.em = q8.y*spectrum_eval(ec, ps.lambda);
               lsh.roughness = q8.z;
               lpdf = q8.w;
+            }
+            else if(MEDIA && !MB && sc.lights != nullptr)
+            { /* extended kernels, emitters with records */
+              light_record_sample(sc, r1, r2, r3, ps.lambda, sf.x, lpe, ls, lsh, lpdf, ldist, ol);
+              lp = lpe & ~MI_LIGHT_ANYHIT;
             }
             else
             {
