@@ -428,6 +428,14 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
   std::vector<DPrimT1> prims_t1;                            /* allocated when the first motion-blurred primitive shows up */
   memset(pgeo.data(), 0, pgeo.size()*sizeof(DPrimGeo));
   memset(prims.data(), 0, prims.size()*sizeof(DPrim));
+  /* material queues (mi_regroup.h): the class of a primitive is the compact index of its material's bsdf among the surface bsdfs the scene uses */
+  uint32_t bsdf_class[MI_BSDF_METAL + 1] = { 0u, 0u, 0u }, num_classes = 0;
+  {
+    bool used[MI_BSDF_METAL + 1] = { false, false, false };
+    for(uint32_t i=0;i<h->num_shapes;i++)
+      if((uint32_t)h->shapes[i].material < h->num_materials && h->materials[h->shapes[i].material].bsdf <= MI_BSDF_METAL) used[h->materials[h->shapes[i].material].bsdf] = true;
+    for(uint32_t b=0;b<=MI_BSDF_METAL;b++) if(used[b]) bsdf_class[b] = num_classes++;
+  }
   for(uint64_t i=0;i<h->num_prims;i++)
   {
     const mi_primid pi = h->primid[i];
@@ -447,6 +455,7 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
     q.primid_lo = (uint32_t)pi; q.primid_hi = (uint32_t)(pi >> 32);
     if((uint32_t)sh.material >= h->num_materials || h->materials[sh.material].bsdf > MI_BSDF_METAL)
     { free(s); return fail(MI_ERR_UNSUPPORTED, "shape uses a material outside the scope"); }
+    q.cls = bsdf_class[h->materials[sh.material].bsdf];
     if(vc == MI_PRIM_LINE) { pgeo[i].f[18] = (vi[0].uv >> 21)/2048.0f; pgeo[i].f[19] = ((vi[0].uv & 0x1ffc00u) >> 10)/2048.0f; }
     else for(uint32_t k=0;k<vc;k++) { pgeo[i].f[18+2*k] = half2float(vi[k].uv & 0xffffu); pgeo[i].f[19+2*k] = half2float(vi[k].uv >> 16); }
     if(mb && vc < MI_PRIM_TRI)
@@ -755,6 +764,19 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
   const size_t lights_bytes = (s->d_lights && !s->media) ? (size_t)MI_LIGHTS_LDS*sizeof(DLight) : 0;  /* plain ptdl kernels: emitter records in LDS */
   s->nodes_lds = halton_bytes + lights_bytes + node_bytes + stack_bytes <= 160*1024 && !(nodes_env && !strcmp(nodes_env, "global"));
   s->lds_bytes = halton_bytes + lights_bytes + (s->nodes_lds ? node_bytes : 0) + stack_bytes;
+  { /* material queues (mi_regroup.h): the pools take what is left of the CU's LDS behind the job lists (plain kernels only: the extended
+       ones carry more path state than an entry holds). CORONA_MI_REGROUP=0 switches the exchange off, =<bytes> limits the pools. */
+    const char *re = getenv("CORONA_MI_REGROUP");
+    const size_t static_bytes = 256;                        /* blk_next, the pools' control words, alignment */
+    size_t room = s->lds_bytes + static_bytes < 160*1024 ? 160*1024 - s->lds_bytes - static_bytes : 0;
+    if(re && atol(re) >= 0 && (size_t)atol(re) < room) room = (size_t)atol(re);
+    if(room > MI_POOL_BYTES_MAX) room = MI_POOL_BYTES_MAX;
+    room &= ~(size_t)15;
+    const bool on = MI_REGROUP && num_classes > 1 && !s->media && !mb_kernels && room >= 2048;
+    d.pool_classes = on ? num_classes : 0u;
+    d.pool_bytes = on ? (uint32_t)room : 0u;
+    s->lds_bytes += d.pool_bytes;
+  }
   s->device_built = device_build; s->stack_need = stack_need;
   { const char *ce = getenv("CORONA_MI_COUNTERS"); s->counting = ce && atoi(ce) ? 1 : 0; }
   { /* default: the FAST rounds where they win (same-box A/B) -- the plain pt kernels: cfg 2 18.2 against 18.7 ms.

@@ -57,7 +57,9 @@ struct DPrimGeo                    /* 176 B: everything the shading side needs a
   uint32_t material;
   uint32_t uv0;                    /* raw uv word of vertex 0: 0 = the primitive has no texture coordinates (src/prims.c:300) */
   uint32_t primid_lo;              /* the reference's packed primid (records, medium stack shape id) */
-  uint32_t primid_hi, pad[3];
+  uint32_t primid_hi;
+  uint32_t cls;                    /* class of the material for the exchange between waves (mi_regroup.h): compact index of its bsdf among those the scene uses */
+  uint32_t pad[2];
   float f[35];                     /* tri/quad: decoded vertex normals n0..n3 [0..11], geometric normal of (v0 v1 v2) [12..14] and of
                                       (v0 v2 v3) [15..17]. line: unit axis d [0..2], 1/|v1-v0| [3], onb a [4..6], b [7..9] of d;
                                       cone: onb of the intersection-side axis [10..12], [13..15].
@@ -144,6 +146,8 @@ struct DScene
   uint32_t exterior_index;          /* = number of shapes */
   const uint4 *halton_dim;
   const unsigned short *halton_perm;
+  /* material queues (mi_regroup.h): bytes of LDS behind the job lists that the pools may use, classes in use (< 2: no exchange) */
+  uint32_t pool_bytes, pool_classes;
 };
 
 #endif

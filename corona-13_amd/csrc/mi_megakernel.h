@@ -10,6 +10,7 @@
 #define MI_MEGAKERNEL_H
 
 #include "mi_path.h"
+#include "mi_regroup.h"
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -104,8 +105,13 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
   /* every workgroup owns a contiguous part of the path index range and hands it out through an LDS counter: the
      wave-level refill below then needs no global atomic at all (one shared counter costs ~11 ns per wave refill) */
   __shared__ unsigned int blk_next;
-  if(threadIdx.x == 0) blk_next = 0;
+  /* material queues (mi_regroup.h): the plain kernels trade surface vertices between the waves of the workgroup, by class of the material */
+  constexpr bool REGROUP = MI_REGROUP && !MEDIA && !MB;
+  __shared__ PoolCtl pool_ctl;
+  if(threadIdx.x == 0) { blk_next = 0; pool_ctl.lock = 0u; for(int c=0;c<MI_POOL_CLASSES;c++) pool_ctl.cnt[c] = 0u; }
   __syncthreads();
+  Pool pool;
+  if(REGROUP) pool = pool_setup<RECORD, HALTON>(sc, lds.jobs - (threadIdx.x >> 6)*MI_JOBS_LDS + (MI_BLOCK/64)*MI_JOBS_LDS, &pool_ctl);
   const unsigned long long nb = gridDim.x;
   const unsigned long long blk_lo = count/nb*blockIdx.x + (blockIdx.x < count%nb ? blockIdx.x : count%nb);
   const unsigned long long blk_hi = blk_lo + count/nb + (blockIdx.x < count%nb ? 1 : 0);
@@ -162,8 +168,11 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
         }
       }
     }
-    if(!__any(ps.active || ps.sh_pending)) break;
     const bool exhausted_wave = __any(exhausted);   /* this block's index range has run dry */
+    if(!__any(ps.active || ps.sh_pending))
+    { /* nothing left in this wave -- but vertices other waves posted may still wait in the pools: a wave only leaves when they are empty */
+      if(!REGROUP || !pool.cap || pool_total(pool) == 0u) break;
+    }
     MI_PHASE(cnt, 0)
 
     /* ------------------------------------------------------------ one ray per busy lane: a pending shadow ray first, else the extension ray */
@@ -242,6 +251,9 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
       }
     }
     if(MI_PRIO) __builtin_amdgcn_s_setprio(PTDL ? MI_PRIO_PTDL_SHADE : MI_PRIO_PT_SHADE);
+#ifdef MI_EXP_BARRIER      /* experiment 0 of the regrouping work: what lock step of the sixteen waves costs by itself (cfg 2 +30 %, cfg 3 +21 %) */
+    __builtin_amdgcn_s_barrier();
+#endif
     MI_PHASE(cnt, 1)
     MI_TT(cnt, 4)
     /* The lanes of the tail keep their ray. Its traversal state (closest hit so far, node, stack pointer: 6 dwords; the three 1/dir
@@ -258,7 +270,33 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
     }
     SplatReq splat;
     splat.pending = false; splat.c0 = splat.c1 = splat.c2 = 0.0f;
-    if(tracing && ts.done)
+    if(REGROUP)
+    { /* material queues (mi_regroup.h). What needs no material is done where the ray ended: the verdict of a shadow ray, the end of a
+         path that left the scene. Then the wave trades surface vertices with the pools, and shades what it holds afterwards. */
+      static_assert(!REGROUP || !CHAIN, "a chained lane's connection is splatted in front of the next vertex's shading");
+      const bool fin = tracing && ts.done;
+      uint32_t cls = 0u;
+      const bool surf0 = fin && !tr_shadow && hit.prim != MI_NOPRIM;
+      if(surf0 && pool.cap) cls = sc.primgeo[hit.prim].cls;       /* under way while the lanes below finish their paths */
+      if(fin && (tr_shadow || hit.prim == MI_NOPRIM))
+      {
+        tracing = false;
+        mi_path_record *rec = RECORD ? records + (ps.index - first) : nullptr;
+        if(tr_shadow) shadow_resolve<RECORD>(sc, ps, hit, rec, cnt, splat);
+        else path_escape<RECORD, MEDIA>(sc, ps, rec, cnt);
+      }
+      /* a lane that still owes this iteration a splat keeps its pixel: it is free from the next iteration on */
+      const bool freelane = !tracing && !ps.active && !ps.sh_pending && !splat.pending;
+      regroup_exchange<RECORD, PTDL, HALTON>(pool, ps, hit, ts, tracing, tr_shadow, surf0, cls, freelane, exhausted_wave);
+      if(tracing && ts.done)
+      {
+        tracing = false;
+        mi_path_record *rec = RECORD ? records + (ps.index - first) : nullptr;
+        __builtin_assume(hit.prim != MI_NOPRIM);     /* paths that left the scene have ended above */
+        path_shade<RECORD, PTDL, HALTON, MEDIA, MB>(sc, ps, hit, shape_material, shape_L, rec, cnt, splat);
+      }
+    }
+    else if(tracing && ts.done)
     {
       tracing = false;
       mi_path_record *rec = RECORD ? records + (ps.index - first) : nullptr;

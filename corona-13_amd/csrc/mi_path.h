@@ -30,7 +30,7 @@ struct PathState
   float cur_ior;            /* e[v].vol.ior */
   Media media;
   /* per path */
-  float lambda, pixel_i, pixel_j, scramble;
+  float lambda, scramble, pixel_i, pixel_j;   /* (pairs that travel together through LDS lie next to each other: mi_regroup.h) */
   Rng rng;
   unsigned long long index;
   int length;               /* number of complete vertices */
@@ -476,6 +476,33 @@ __device__ __forceinline__ void path_shade_volume(const DScene &sc, PathState &p
     }
   }
   if(!alive) { ps.active = 0; cnt.c[4]++; }
+}
+
+/* the extension ray left the scene: environment vertex, src/pathspace.c:856-873; black sky => nothing to add, the path ends.
+ * (A function of its own since round 4: the kernels that trade vertices between waves, mi_regroup.h, end such paths before the exchange.) */
+template<bool RECORD, bool MEDIA, class CNT>
+__device__ __forceinline__ void path_escape(const DScene &sc, PathState &ps, mi_path_record *rec, CNT &cnt)
+{
+  const int v = ps.length;
+  const V3 omega = ps.dir;
+  {
+    const float G = ps.prev_cos;                   /* path_G with an environment end point */
+    /* a purely absorbing medium reaches here with clip == FLT_MAX: transmittance exp(-FLT_MAX mu_t), pdf 1 (src/shader.c:99-100) */
+    const float env_T = MEDIA ? media_transmittance(ps.cur, FLT_MAX) : 1.0f;
+    const float vpdf = MEDIA ? (ps.pdf*1.0f)*G : ps.pdf*G;
+    ps.pdfprod *= (double)vpdf;
+    ps.length++;
+    MI_COUNT(cnt, 6, 1);
+    if(RECORD)
+    {
+      const V3 x = mk3(ps.prev_x.x + sc.far_dist*omega.x, ps.prev_x.y + sc.far_dist*omega.y, ps.prev_x.z + sc.far_dist*omega.z);
+      Shading z; z.roughness = 1.0f; z.rs = z.rd = z.rg = z.em = 0.0f;
+      rec_vertex<RECORD>(rec, v, MI_PRIMID_INVALID, FLT_MAX, x, mk3(0, 0, 0), mk3(0, 0, 0), omega, s_absorb, s_environment,
+                         MEDIA ? ps.throughput*(env_T/1.0f) : ps.throughput, vpdf, 0.0f, 0.0f, z, 0.0f, -1);
+      rec->length = ps.length; rec->throughput = 0.0f;
+    }
+  }
+  ps.active = 0; cnt.c[4]++;
 }
 
 /* the extension ray ps.org/ps.dir has been traced into `hit`: create vertex v = ps.length, then either end the path
