@@ -301,7 +301,7 @@ struct PointSampler
  * 10 % through register pressure, the pt kernel 1 %); mi_scene_set_counters() selects the counting kernels.
  * Development builds append more: -DMI_PROFILE_LOOPS wave-level loop iterations (c[8..10]), -DMI_PROFILE_PHASES lane-0 clock
  * ticks per phase (c[8+k]), their occurrences (c[16+k]), the last marker (c[30]) and time stamp (c[31]). */
-#if defined(MI_PROFILE_PHASES) || defined(MI_PROFILE_LOOPS) || defined(MI_PROFILE_TRAV) || defined(MI_PROFILE_BLOCKS)
+#if defined(MI_PROFILE_PHASES) || defined(MI_PROFILE_LOOPS) || defined(MI_PROFILE_TRAV) || defined(MI_PROFILE_BLOCKS) || defined(MI_PROFILE_POOL)
 #define MI_CNT 32
 #else
 #define MI_CNT 8
@@ -327,6 +327,14 @@ template<bool ON> struct Counters
 #endif
 /* -DMI_PROFILE_BLOCKS (development build, tools/block_probe.py): how full the wave is where it executes a block of the shading code:
  * every lane that runs block k counts itself, the first active lane counts the execution; counter k leaves the kernel as lanes | executions << 36 */
+/* -DMI_PROFILE_POOL (development build, tools/pool_probe.py): the exchange between waves (mi_regroup.h) in the same format: per wave
+ * iteration 0 = exchanges made | lanes posted, 1 = lanes pulled, 2 = turns to a class the wave's own lanes are not mostly in | lanes
+ * shaded in such a turn, 3 = spins on the lock, 4 = vertices that could not be posted (pool full) */
+#ifdef MI_PROFILE_POOL
+#define MI_POOLSTAT(cnt, k, lanes, execs) { if(__lane_id() == 0) { (cnt).c[8 + (k)] += (lanes); (cnt).c[16 + (k)] += (execs); } }
+#else
+#define MI_POOLSTAT(cnt, k, lanes, execs)
+#endif
 #ifdef MI_PROFILE_BLOCKS
 #define MI_BLK(cnt, k) { (cnt).c[8 + (k)]++; if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) (cnt).c[16 + (k)]++; }
 #else

@@ -66,6 +66,9 @@
 #define MI_PRIO_PTDL_TRACE 0
 #define MI_PRIO_PTDL_SHADE 3
 #endif
+#ifndef MI_REGROUP_EARLY_SHADOW
+#define MI_REGROUP_EARLY_SHADOW 0
+#endif
 #ifndef MI_PARK_PATH
 #define MI_PARK_PATH 2    /* FAST kernels (1: ptdl only): part of the path state waits in LDS for the length of a traversal slice (PARK_PS) */
 #endif
@@ -108,10 +111,14 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
   /* material queues (mi_regroup.h): the plain kernels trade surface vertices between the waves of the workgroup, by class of the material */
   constexpr bool REGROUP = MI_REGROUP && !MEDIA && !MB;
   __shared__ PoolCtl pool_ctl;
-  if(threadIdx.x == 0) { blk_next = 0; pool_ctl.lock = 0u; for(int c=0;c<MI_POOL_CLASSES;c++) pool_ctl.cnt[c] = 0u; }
-  __syncthreads();
+  if(threadIdx.x == 0) blk_next = 0;
   Pool pool;
-  if(REGROUP) pool = pool_setup<RECORD, HALTON>(sc, lds.jobs - (threadIdx.x >> 6)*MI_JOBS_LDS + (MI_BLOCK/64)*MI_JOBS_LDS, &pool_ctl);
+  if(REGROUP)
+  {
+    pool = pool_setup<RECORD, HALTON>(sc, lds.jobs - (threadIdx.x >> 6)*MI_JOBS_LDS + (MI_BLOCK/64)*MI_JOBS_LDS, &pool_ctl);
+    pool_init(pool, &pool_ctl);
+  }
+  __syncthreads();
   const unsigned long long nb = gridDim.x;
   const unsigned long long blk_lo = count/nb*blockIdx.x + (blockIdx.x < count%nb ? blockIdx.x : count%nb);
   const unsigned long long blk_hi = blk_lo + count/nb + (blockIdx.x < count%nb ? 1 : 0);
@@ -171,7 +178,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
     const bool exhausted_wave = __any(exhausted);   /* this block's index range has run dry */
     if(!__any(ps.active || ps.sh_pending))
     { /* nothing left in this wave -- but vertices other waves posted may still wait in the pools: a wave only leaves when they are empty */
-      if(!REGROUP || !pool.cap || pool_total(pool) == 0u) break;
+      if(!REGROUP || !pool.E || pool_empty(pool)) break;
     }
     MI_PHASE(cnt, 0)
 
@@ -277,7 +284,8 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
       const bool fin = tracing && ts.done;
       uint32_t cls = 0u;
       const bool surf0 = fin && !tr_shadow && hit.prim != MI_NOPRIM;
-      if(surf0 && pool.cap) cls = sc.primgeo[hit.prim].cls;       /* under way while the lanes below finish their paths */
+      if(surf0 && pool.E) cls = sc.primgeo[hit.prim].cls;       /* under way while the lanes below finish their paths */
+#if MI_REGROUP_EARLY_SHADOW
       if(fin && (tr_shadow || hit.prim == MI_NOPRIM))
       {
         tracing = false;
@@ -285,15 +293,28 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
         if(tr_shadow) shadow_resolve<RECORD>(sc, ps, hit, rec, cnt, splat);
         else path_escape<RECORD, MEDIA>(sc, ps, rec, cnt);
       }
+#else
+      /* (the verdict of a finished shadow ray stays where it was, next to path_shade: resolving it first made lanes free that
+         almost always owe a splat, at the price of a third divergent region -- cfg 3 +4 % without the exchange) */
+      if(fin && !tr_shadow && hit.prim == MI_NOPRIM)
+      {
+        tracing = false;
+        path_escape<RECORD, MEDIA>(sc, ps, RECORD ? records + (ps.index - first) : nullptr, cnt);
+      }
+#endif
       /* a lane that still owes this iteration a splat keeps its pixel: it is free from the next iteration on */
       const bool freelane = !tracing && !ps.active && !ps.sh_pending && !splat.pending;
-      regroup_exchange<RECORD, PTDL, HALTON>(pool, ps, hit, ts, tracing, tr_shadow, surf0, cls, freelane, exhausted_wave);
+      regroup_exchange<RECORD, PTDL, HALTON, MI_PRIO ? (PTDL ? MI_PRIO_PTDL_SHADE : MI_PRIO_PT_SHADE) : 0>(pool, ps, hit, ts, tracing, tr_shadow, surf0, cls, freelane, exhausted_wave, cnt);
       if(tracing && ts.done)
       {
         tracing = false;
         mi_path_record *rec = RECORD ? records + (ps.index - first) : nullptr;
-        __builtin_assume(hit.prim != MI_NOPRIM);     /* paths that left the scene have ended above */
-        path_shade<RECORD, PTDL, HALTON, MEDIA, MB>(sc, ps, hit, shape_material, shape_L, rec, cnt, splat);
+        if(PTDL && !MI_REGROUP_EARLY_SHADOW && tr_shadow) shadow_resolve<RECORD>(sc, ps, hit, rec, cnt, splat);
+        else
+        {
+          __builtin_assume(hit.prim != MI_NOPRIM);     /* paths that left the scene have ended above */
+          path_shade<RECORD, PTDL, HALTON, MEDIA, MB>(sc, ps, hit, shape_material, shape_L, rec, cnt, splat);
+        }
       }
     }
     else if(tracing && ts.done)
@@ -334,6 +355,9 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
 #ifdef MI_PROFILE_TRAV
     cnt.c[15]++;            /* wave iterations */
 #endif
+#ifdef MI_PROFILE_POOL
+    { const unsigned long long t_now = clock64(); MI_POOLSTAT(cnt, 7, 0, 1) cnt.c[30] = (uint32_t)(t_now >> 4); }   /* wave iterations (a maximum over the workgroups) */
+#endif
   }
 
 #ifdef MI_PROFILE_LOOPS    /* development build: box hits / splats / vertices become wave-level inner iterations / leaf slots / analytic passes */
@@ -342,7 +366,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
 #ifdef MI_PROFILE_TRAV     /* development build: counters 0..6 become lane 0's ticks per part of the wave iteration (tools/trav_probe.py); 7 stays */
   for(int k=0;k<8;k++) cnt.c[k] = lane ? 0u : cnt.c[8 + k];
 #endif
-#ifdef MI_PROFILE_BLOCKS
+#if defined(MI_PROFILE_BLOCKS) || defined(MI_PROFILE_POOL)
   unsigned long long block_out[8];
   for(int k=0;k<8;k++) block_out[k] = (unsigned long long)cnt.c[8 + k] | ((unsigned long long)cnt.c[16 + k] << 36);
 #endif
@@ -351,18 +375,18 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
   for(int k=0;k<8;k++) phase_out[k] = lane ? 0ull : ((unsigned long long)cnt.c[8 + k] | ((unsigned long long)cnt.c[16 + k] << 36));
 #endif
   unsigned long long *shard = sc.counters + (size_t)(blockIdx.x % MI_COUNTER_SHARDS)*8;
-#if !defined(MI_PROFILE_PHASES) && !defined(MI_PROFILE_TRAV) && !defined(MI_PROFILE_BLOCKS)
+#if !defined(MI_PROFILE_PHASES) && !defined(MI_PROFILE_TRAV) && !defined(MI_PROFILE_BLOCKS) && !defined(MI_PROFILE_POOL)
   if(cnt.on) atomicMax(shard + 7, (unsigned long long)cnt.c[7]);     /* deepest traversal stack use */
 #endif
   /* ------------------------------------------------------------ flush work counters: wave reduction, one atomic per wave */
 #pragma unroll
   for(int k=0;k<8;k++)
   {
-#if !defined(MI_PROFILE_TRAV) && !defined(MI_PROFILE_BLOCKS)
+#if !defined(MI_PROFILE_TRAV) && !defined(MI_PROFILE_BLOCKS) && !defined(MI_PROFILE_POOL)
     if(!cnt.on && k != 4) continue;         /* the plain kernels only count paths */
 #endif
     unsigned long long c = cnt.c[k];
-#ifdef MI_PROFILE_BLOCKS
+#if defined(MI_PROFILE_BLOCKS) || defined(MI_PROFILE_POOL)
     c = block_out[k];
 #endif
 #ifdef MI_PROFILE_PHASES
@@ -370,7 +394,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
     if(k == 7) { if(lane == 0 && c) atomicAdd(shard + 7, c); continue; }
 #endif
     for(int off=32;off>0;off>>=1) c += __shfl_down(c, off);
-#if !defined(MI_PROFILE_TRAV) && !defined(MI_PROFILE_BLOCKS)
+#if !defined(MI_PROFILE_TRAV) && !defined(MI_PROFILE_BLOCKS) && !defined(MI_PROFILE_POOL)
     if(k == 7) continue;                    /* slot 7 is a maximum, flushed above */
 #endif
     if(lane == 0 && c) atomicAdd(shard + k, c);
