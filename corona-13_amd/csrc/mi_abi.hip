@@ -756,13 +756,16 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
   /* a scene with moving primitives runs the motion-blur kernels: shallower stack columns, and both box sets of the nodes in LDS */
   const bool mb_kernels = s->d_prims_t1 != nullptr;
   const size_t node_bytes = (size_t)(MI_NODE_FIELDS + (mb_kernels && s->d_nodes_t1 ? 6 : 0))*N*16;
-  const size_t stack_bytes = (size_t)(mb_kernels ? MI_STACK_LDS_MB : MI_STACK_LDS)*MI_BLOCK*sizeof(uint2) + (size_t)(MI_BLOCK/64)*MI_JOBS_LDS;   /* + the waves' job lists */
+  /* (the column of the plain kernels is shorter since round 4: they use the LDS for the pools of mi_regroup.h; s->media is final here) */
+  const int column = mb_kernels ? MI_STACK_LDS_MB : s->media ? MI_STACK_LDS : MI_STACK_LDS_PLAIN;
+  const size_t stack_bytes = (size_t)column*MI_BLOCK*sizeof(uint2) + (size_t)(MI_BLOCK/64)*MI_JOBS_LDS;   /* + the waves' job lists */
+  const size_t isect_stack_bytes = (size_t)MI_STACK_LDS*MI_BLOCK*sizeof(uint2) + (size_t)(MI_BLOCK/64)*MI_JOBS_LDS;   /* mi_intersect_kernel: full columns, no pools */
   /* the tree lives in LDS next to the traversal stacks when it fits (0010_pt: 50 KB + 96 KB of 160 KB); larger trees are
      read from HBM / L2 by the NODES_LDS = false instantiations (CORONA_MI_NODES=global forces that, for tests) */
   const char *nodes_env = getenv("CORONA_MI_NODES");
   const size_t halton_bytes = h->pointsampler == MI_POINTS_HALTON ? (size_t)2*MI_HALTON_LDS : 0;     /* staged head of the permutation tables */
   const size_t lights_bytes = (s->d_lights && !s->media) ? (size_t)MI_LIGHTS_LDS*sizeof(DLight) : 0;  /* plain ptdl kernels: emitter records in LDS */
-  s->nodes_lds = halton_bytes + lights_bytes + node_bytes + stack_bytes <= 160*1024 && !(nodes_env && !strcmp(nodes_env, "global"));
+  s->nodes_lds = halton_bytes + lights_bytes + node_bytes + (stack_bytes > isect_stack_bytes ? stack_bytes : isect_stack_bytes) <= 160*1024 && !(nodes_env && !strcmp(nodes_env, "global"));
   s->lds_bytes = halton_bytes + lights_bytes + (s->nodes_lds ? node_bytes : 0) + stack_bytes;
   { /* material queues (mi_regroup.h): the pools take what is left of the CU's LDS behind the job lists (plain kernels only: the extended
        ones carry more path state than an entry holds). CORONA_MI_REGROUP=0 switches the exchange off, =<bytes> limits the pools. */
@@ -776,14 +779,22 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
     d.pool_classes = on ? num_classes : 0u;
     d.pool_bytes = on ? (uint32_t)room : 0u;
     s->lds_bytes += d.pool_bytes;
+    /* one launch size for every kernel of the scene: mi_intersect_kernel keeps full stack columns */
+    const size_t isect_bytes = halton_bytes + lights_bytes + (s->nodes_lds ? node_bytes : 0) + isect_stack_bytes;
+    if(s->lds_bytes < isect_bytes) s->lds_bytes = isect_bytes;
   }
   s->device_built = device_build; s->stack_need = stack_need;
   { const char *ce = getenv("CORONA_MI_COUNTERS"); s->counting = ce && atoi(ce) ? 1 : 0; }
   { /* default: the FAST rounds where they win (same-box A/B) -- the plain pt kernels: cfg 2 18.2 against 18.7 ms.
        The extended pt kernels break even (scenes/0055_media 21.6 / 21.4, moving camera 20.3 / 20.4), a global fog (41.3 / 39.8) and the
        ptdl kernels (40.7 / 35.2; media 56.6 / 48.8) are quicker with the exact rounds */
+    /* Round 4: with the exchange between waves (mi_regroup.h) the pools want the LDS the FAST rounds park path state in, and the exact
+       rounds are the quicker ones (cfg 2 15.7 against 16.7 ms): 'auto' = FAST only for plain pt scenes that run without the exchange */
     const char *te = getenv("CORONA_MI_TRAVERSAL");
-    s->fast = te ? strcmp(te, "exact") != 0 : (h->sampler == MI_SAMPLER_PT && !s->media);
+    const bool fast_default = h->sampler == MI_SAMPLER_PT && !s->media && d.pool_bytes == 0u;
+    if(te && strcmp(te, "exact") && strcmp(te, "fast") && strcmp(te, "auto") && te[0])
+      fprintf(stderr, "[mi] CORONA_MI_TRAVERSAL=%s is not one of exact / fast / auto: using auto\n", te);
+    s->fast = (te && !strcmp(te, "exact")) ? 0 : (te && !strcmp(te, "fast")) ? 1 : fast_default;
   }
   { const char *me = getenv("CORONA_MI_METAL"); d.metal_reference = (me && !strcmp(me, "reference")) ? 1u : 0u; }
   { /* the kernels this scene can launch (record / counting / traversal variants of its configuration) may use the whole LDS */

@@ -66,6 +66,11 @@
 #define MI_PRIO_PTDL_TRACE 0
 #define MI_PRIO_PTDL_SHADE 3
 #endif
+#ifndef MI_REFILL_MIN
+#define MI_REFILL_MIN (MI_REGROUP ? 12 : 1)   /* with the exchange between waves (mi_regroup.h) the lanes of a wave become free in bursts (a wave that posts all its vertices) and in
+                                  dribbles (one that pulled what the pool had): the dribbles wait. cfg 2 / cfg 3 with 1 / 8 / 16 / 24: 15.94 / 15.74 / 15.77 / 15.89 ms and
+                                  30.3 / 29.4 / 29.3 / 29.3; without the exchange a loss (18.7 against 18.4 ms) */
+#endif
 #ifndef MI_REGROUP_EARLY_SHADOW
 #define MI_REGROUP_EARLY_SHADOW 0
 #endif
@@ -86,7 +91,13 @@
 /* the shallowest LDS stack among the instantiations (FAST kernels with parked path state; motion-blur kernels): the overflow area
    in HBM is sized for it */
 #define MI_PARK_ENTRIES_MAX (MI_PARK_ENTRIES > MI_PARK_ENTRIES_PT ? MI_PARK_ENTRIES : MI_PARK_ENTRIES_PT)
-#define MI_STACK_MIN ((MI_STACK_LDS - 3 - MI_PARK_ENTRIES_MAX) < MI_STACK_LDS_MB ? (MI_STACK_LDS - 3 - MI_PARK_ENTRIES_MAX) : MI_STACK_LDS_MB)
+#ifndef MI_STACK_LDS_RG
+#define MI_STACK_LDS_RG 10     /* entries per lane of the plain kernels' stack columns since they trade vertices through pools in LDS (mi_regroup.h): 16 KB more
+                                  for the pools are worth more than two stack entries -- cfg 2 / cfg 3, columns of 12 / 11 / 10 / 9 / 8 entries:
+                                  (17.3) / 16.28 / 16.01 / 15.93 / 16.09 ms and (31.9) / 30.8 / 30.4 / 30.4 / 30.6 ms; the same columns without the exchange: 18.5 / 18.4 */
+#endif
+#define MI_STACK_LDS_PLAIN (MI_REGROUP ? MI_STACK_LDS_RG : MI_STACK_LDS)
+#define MI_STACK_MIN ((MI_STACK_LDS_PLAIN - 3 - MI_PARK_ENTRIES_MAX) < MI_STACK_LDS_MB ? (MI_STACK_LDS_PLAIN - 3 - MI_PARK_ENTRIES_MAX) : MI_STACK_LDS_MB)
 #ifndef MI_STACK
 #if MI_LEAF_JOBS
 #define MI_STACK (MI_STACK_LDS - 3)   /* the top three entries of a lane's column hold the results of the distributed leaf phase (leaf_jobs) */
@@ -102,7 +113,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
                                                            uint2 *stack_overflow)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int COLUMN = MB ? MI_STACK_LDS_MB : MI_STACK_LDS;      /* stack entries per lane in LDS */
+  constexpr int COLUMN = MB ? MI_STACK_LDS_MB : MEDIA ? MI_STACK_LDS : MI_STACK_LDS_PLAIN;      /* stack entries per lane in LDS */
   const Lds lds = lds_setup<MI_BLOCK, NODES_LDS, HALTON, PTDL && !MEDIA, COLUMN, MB>(sc, smem, stack_overflow);
 
   /* every workgroup owns a contiguous part of the path index range and hands it out through an LDS counter: the
@@ -160,7 +171,9 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
     {
       const bool want = !ps.active && !ps.sh_pending;
       const unsigned long long m = __ballot(want);
-      if(m)
+      /* MI_REFILL_MIN: a few idle lanes wait for company -- path_generate costs the wave the same for 3 lanes as for 60 -- unless the wave
+         has little else under way */
+      if(m && (MI_REFILL_MIN <= 1 || __popcll(m) >= MI_REFILL_MIN || __popcll(__ballot(tracing || ps.active || ps.sh_pending)) < 64 - 2*MI_REFILL_MIN))
       {
         const unsigned n = __popcll(m);
         unsigned int base = 0;

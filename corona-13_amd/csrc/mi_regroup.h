@@ -35,7 +35,7 @@
 #define MI_POOL_HIGH 48            /* own lanes + pool of a class from which on a wave turns to that class */
 #endif
 #ifndef MI_POOL_POLICY
-#define MI_POOL_POLICY 1
+#define MI_POOL_POLICY 2
 #endif
 #ifndef MI_POOL_AGE
 #define MI_POOL_AGE 24             /* ... or when fewer than this many entries are still free */
@@ -46,12 +46,19 @@
 
 typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
 typedef __attribute__((address_space(3))) unsigned char lds_u8_t;
+typedef __attribute__((address_space(3))) unsigned short lds_u16_t;
 typedef unsigned int mi_u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) mi_u32x4 lds_uint4;
 #define MI_SEL3(A, I) ((I) == 0 ? (A)[0] : (I) == 1 ? (A)[1] : (A)[2])
 
-/* control words: one 16-byte line {entries listed per class, free entries} that a wave reads and writes whole, then the lock */
-struct __attribute__((aligned(16))) PoolCtl { uint32_t cnt[MI_POOL_CLASSES], nfree; uint32_t lock, pad[3]; };
+/* control words. `state` IS the lock: four 16-bit counts {entries listed per class 0..2, free entries} packed into 64 bits while nobody
+ * is inside a critical section, all ones while somebody is. A wave enters with ONE atomic exchange (all ones in, the counts out -- or
+ * all ones out: spin) and leaves by storing the new counts: lock, look and unlock cost one LDS round trip together (as three
+ * separate operations each was a round trip through an LDS that fifteen other waves traverse a tree in: 6 000 ticks held per
+ * section). `hint` is a copy of the counts for looks from outside (written when leaving; may lag). */
+typedef __attribute__((address_space(3))) unsigned long long lds_u64_t;
+#define MI_POOL_LOCKED (~0ull)
+struct __attribute__((aligned(16))) PoolCtl { unsigned long long state, hint; };
 
 /* 8-byte words of a path vertex on its way through a pool */
 template<bool RECORD, bool HALTON> struct PoolLayout { static constexpr int SLOTS = RECORD ? 16 : HALTON ? 15 : 14; };
@@ -66,7 +73,7 @@ template<bool RECORD, bool HALTON> struct PoolLayout { static constexpr int SLOT
 struct Pool
 {
   lds_uint2 *data;          /* [slot][E] */
-  lds_u8_t *list;           /* [MI_POOL_CLASSES + 1][E]: entry numbers per class, then the free entries */
+  lds_u16_t *list;          /* [MI_POOL_CLASSES + 1][E]: entry numbers per class, then the free entries */
   lds_u32_t *ctl;           /* PoolCtl */
   uint32_t E;               /* entries; 0 = no exchange */
 };
@@ -77,42 +84,54 @@ __device__ __forceinline__ Pool pool_setup(const DScene &sc, unsigned char *base
   constexpr uint32_t NS = PoolLayout<RECORD, HALTON>::SLOTS;
   Pool p;
   p.ctl = (lds_u32_t *)ctl;
-  uint32_t E = sc.pool_classes > 1u ? sc.pool_bytes/(NS*8u + MI_POOL_CLASSES + 1u) : 0u;
-  if(E > 248u) E = 248u;
+  uint32_t E = sc.pool_classes > 1u ? sc.pool_bytes/(NS*8u + 2u*(MI_POOL_CLASSES + 1u)) : 0u;
+  if(E > 1024u) E = 1024u;
   E &= ~7u;
   if(E < 32u) E = 0u;
   p.E = E;
   p.data = (lds_uint2 *)base;
-  p.list = (lds_u8_t *)(base + (size_t)NS*8u*E);
+  p.list = (lds_u16_t *)(base + (size_t)NS*8u*E);
   return p;
 }
 /* call from all threads of the workgroup before the barrier that starts the kernel */
 __device__ __forceinline__ void pool_init(const Pool &p, PoolCtl *ctl)
 {
-  if(threadIdx.x == 0) { for(int c=0;c<MI_POOL_CLASSES;c++) ctl->cnt[c] = 0u; ctl->nfree = p.E; ctl->lock = 0u; }
-  if(threadIdx.x < p.E) p.list[MI_POOL_CLASSES*p.E + threadIdx.x] = (unsigned char)threadIdx.x;
+  if(threadIdx.x == 0) { ctl->state = (unsigned long long)p.E << 48; ctl->hint = ctl->state; }
+  if(threadIdx.x < p.E) p.list[MI_POOL_CLASSES*p.E + threadIdx.x] = (unsigned short)threadIdx.x;
 }
 
 __device__ __forceinline__ bool pool_empty(const Pool &p)
 { /* no complete vertex waits in any class (entries a wave is still writing are that wave's business: it is alive and looks again) */
-  uint32_t t = 0;
-  for(int c=0;c<MI_POOL_CLASSES;c++) t += __hip_atomic_load(p.ctl + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  return t == 0u;
+  const unsigned long long h = __hip_atomic_load((lds_u64_t *)p.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  return (h & 0xffffffffffffull) == 0ull;
 }
 
-__device__ __forceinline__ void pool_lock(const Pool &pool)
-{ /* one lane spins; LDS operations of a wave are carried out in order, and the fences wait for them: what is written under the lock is
-     in place before the store that releases it */
+/* enter a critical section: the counts, the same in every lane */
+__device__ __forceinline__ unsigned long long pool_enter(const Pool &pool)
+{
+  unsigned long long st = MI_POOL_LOCKED;
   if(__lane_id() == 0)
-    while(__hip_atomic_exchange(pool.ctl + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) __builtin_amdgcn_s_sleep(1);
+    while((st = __hip_atomic_exchange((lds_u64_t *)pool.ctl, MI_POOL_LOCKED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == MI_POOL_LOCKED) __builtin_amdgcn_s_sleep(1);
+  st = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)st) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(st >> 32)) << 32);
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
   __builtin_amdgcn_wave_barrier();
+  return st;
 }
-__device__ __forceinline__ void pool_unlock(const Pool &pool)
+/* leave it with new counts. LDS operations of a wave are carried out in order: the list entries written in the section are in place
+   before the store that opens it; the fence waits for the section's READS (another wave may overwrite those list entries afterwards) */
+template<bool READS>
+__device__ __forceinline__ void pool_leave(const Pool &pool, unsigned long long st)
 {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-  if(__lane_id() == 0) __hip_atomic_store(pool.ctl + 4, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if(READS) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");       /* order for the compiler only */
+  if(__lane_id() == 0)
+  {
+    __hip_atomic_store((lds_u64_t *)pool.ctl, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store((lds_u64_t *)pool.ctl + 1, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
 }
+#define MI_POOL_UNPACK(ST, P, NFREE) { (P)[0] = (uint32_t)(ST) & 0xffffu; (P)[1] = (uint32_t)((ST) >> 16) & 0xffffu; (P)[2] = (uint32_t)((ST) >> 32) & 0xffffu; (NFREE) = (uint32_t)((ST) >> 48); }
+#define MI_POOL_PACK(P, NFREE) ((unsigned long long)(P)[0] | ((unsigned long long)(P)[1] << 16) | ((unsigned long long)(P)[2] << 32) | ((unsigned long long)(NFREE) << 48))
 
 /* The exchange of one wave iteration. Call from ALL lanes of the wave.
  *   surf      this lane's extension ray has ended on a primitive and the vertex is not shaded yet (hit, ps are that vertex's)
@@ -142,10 +161,10 @@ __device__ __forceinline__ void regroup_exchange(const Pool &pool, PathState &ps
   int chosen = -1;
   uint32_t k[MI_POOL_CLASSES], m = 0;
   auto look = [&]()
-  {
-    const mi_u32x4 v = *(lds_uint4 *)pool.ctl;
-    p[0] = (uint32_t)__builtin_amdgcn_readfirstlane((int)v.x); p[1] = (uint32_t)__builtin_amdgcn_readfirstlane((int)v.y);
-    p[2] = (uint32_t)__builtin_amdgcn_readfirstlane((int)v.z); nfree = (uint32_t)__builtin_amdgcn_readfirstlane((int)v.w);
+  { /* from outside: the hint */
+    unsigned long long h = __hip_atomic_load((lds_u64_t *)pool.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    h = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)h) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(h >> 32)) << 32);
+    MI_POOL_UNPACK(h, p, nfree)
   };
   auto decide = [&]()
   {
@@ -213,18 +232,35 @@ __device__ __forceinline__ void regroup_exchange(const Pool &pool, PathState &ps
   look();
   decide();
   if(m + k[0] + k[1] + k[2] == 0u) return;
+  /* (what does not depend on the counts is formed before the lock is taken) */
+  uint32_t crank = 0;         /* rank of the lane's vertex among the wave's vertices of its class */
+#pragma unroll
+  for(int c=0;c<MI_POOL_CLASSES;c++)
+  {
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mc[c] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mc[c], 0u));
+    if(cls == (uint32_t)c) crank = rank;
+  }
   /* ---- first critical section: entries off the free list for the vertices to post, entries off the chosen class's list to pull */
 #ifdef MI_PROFILE_POOL
   const unsigned long long t_wait = clock64();
 #endif
   __builtin_amdgcn_s_setprio(3);
-  pool_lock(pool);
+  {
+    const unsigned long long st = pool_enter(pool);
+    MI_POOL_UNPACK(st, p, nfree)
+  }
 #ifdef MI_PROFILE_POOL
   const unsigned long long t_got = clock64();
   MI_POOLSTAT(cnt, 3, (uint32_t)((t_got - t_wait) >> 4), 1)      /* ticks / 16 waiting for the lock */
 #endif
-  look();
-  decide();
+  /* the plan was made on the hint; inside, the true counts only cut it down */
+  if(chosen >= 0 || k[0] + k[1] + k[2] != 0u)
+  {
+    uint32_t room = nfree, freed = F;
+#pragma unroll
+    for(int c=0;c<MI_POOL_CLASSES;c++) { if(k[c] > room) k[c] = room; room -= k[c]; freed += k[c]; }
+    if(chosen >= 0) { const uint32_t pc = MI_SEL3(p, chosen); if(m > pc) m = pc; if(m > freed) m = freed; }
+  }
 #ifdef MI_PROFILE_POOL
   {
     uint32_t posted = 0, left = 0, nmax = 0;
@@ -236,15 +272,7 @@ __device__ __forceinline__ void regroup_exchange(const Pool &pool, PathState &ps
     if(chosen >= 0) MI_POOLSTAT(cnt, 5, MI_SEL3(n, chosen) + m, 1)       /* lanes of the chosen class shaded in an iteration with an exchange */
   }
 #endif
-  bool post = false;
-  uint32_t crank = 0;         /* rank among the posted vertices of the lane's class */
-#pragma unroll
-  for(int c=0;c<MI_POOL_CLASSES;c++)
-  {
-    if(k[c] == 0u) continue;
-    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mc[c] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mc[c], 0u));
-    if(surf && cls == (uint32_t)c && rank < k[c]) { post = true; crank = rank; }
-  }
+  const bool post = surf && (int)cls != chosen && crank < MI_SEL3(k, cls);
   const mi_u64 mpost = __ballot(post);
   const uint32_t K = k[0] + k[1] + k[2];
   const uint32_t prank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mpost >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mpost, 0u));
@@ -254,13 +282,12 @@ __device__ __forceinline__ void regroup_exchange(const Pool &pool, PathState &ps
   uint32_t id_post = 0, id_pull = 0;
   if(post) id_post = pool.list[MI_POOL_CLASSES*E + (nfree - 1u - prank)];
   if(pull) id_pull = pool.list[(uint32_t)chosen*E + (MI_SEL3(p, chosen) - 1u - trank)];
-  if(__lane_id() == 0)
   {
-    mi_u32x4 v = { p[0], p[1], p[2], nfree - K };
-    if(chosen == 0) v.x -= m; else if(chosen == 1) v.y -= m; else if(chosen == 2) v.z -= m;
-    *(lds_uint4 *)pool.ctl = v;
+    uint32_t q[MI_POOL_CLASSES] = { p[0], p[1], p[2] };
+#pragma unroll
+    for(int c=0;c<MI_POOL_CLASSES;c++) if(c == chosen) q[c] -= m;
+    pool_leave<true>(pool, MI_POOL_PACK(q, nfree - K));
   }
-  pool_unlock(pool);
 #ifdef MI_PROFILE_POOL
   MI_POOLSTAT(cnt, 6, (uint32_t)((clock64() - t_got) >> 4), 1)   /* ticks / 16 holding it */
 #endif
@@ -327,16 +354,16 @@ __device__ __forceinline__ void regroup_exchange(const Pool &pool, PathState &ps
   }
   /* ---- second critical section: the written entries onto their classes' lists, the read ones back onto the free list */
   __builtin_amdgcn_s_setprio(3);
-  pool_lock(pool);             /* (the fences wait for the LDS reads and writes above) */
-  look();
-  if(post) pool.list[cls*E + MI_SEL3(p, cls) + crank] = (unsigned char)id_post;
-  if(pull) pool.list[MI_POOL_CLASSES*E + nfree + trank] = (unsigned char)id_pull;
-  if(__lane_id() == 0)
   {
-    const mi_u32x4 v = { p[0] + k[0], p[1] + k[1], p[2] + k[2], nfree + m };
-    *(lds_uint4 *)pool.ctl = v;
+    const unsigned long long st = pool_enter(pool);
+    MI_POOL_UNPACK(st, p, nfree)
   }
-  pool_unlock(pool);
+  if(post) pool.list[cls*E + MI_SEL3(p, cls) + crank] = (unsigned short)id_post;
+  if(pull) pool.list[MI_POOL_CLASSES*E + nfree + trank] = (unsigned short)id_pull;
+  {
+    const uint32_t q[MI_POOL_CLASSES] = { p[0] + k[0], p[1] + k[1], p[2] + k[2] };
+    pool_leave<false>(pool, MI_POOL_PACK(q, nfree + m));
+  }
   __builtin_amdgcn_s_setprio(PRIO);
 }
 

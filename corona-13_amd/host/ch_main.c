@@ -59,7 +59,15 @@ int main(int argc, char *argv[])
       if(!num_devices) { fprintf(stderr, "[main] --devices takes a list like 0,1,2\n"); return 1; }
       continue;
     }
-    if(!strcmp(argv[i], "--traversal") && i+1 < argc) { traversal = !strcmp(argv[++i], "exact") ? MI_TRAVERSAL_EXACT : MI_TRAVERSAL_FAST; continue; }
+    if(!strcmp(argv[i], "--traversal") && i+1 < argc)
+    { /* exact | fast | auto (= the scene's default); anything else is an error, not silently FAST */
+      const char *t = argv[++i];
+      if(!strcmp(t, "exact")) traversal = MI_TRAVERSAL_EXACT;
+      else if(!strcmp(t, "fast")) traversal = MI_TRAVERSAL_FAST;
+      else if(!strcmp(t, "auto")) traversal = -1;
+      else { fprintf(stderr, "[corona-mi] --traversal %s: expected exact, fast or auto\n", t); return 1; }
+      continue;
+    }
     if(!strcmp(argv[i], "-s") && i+1 < argc) spp = strtoull(argv[++i], 0, 10);
     else if(!strcmp(argv[i], "-w") && i+1 < argc) opt.width = atoi(argv[++i]);
     else if(!strcmp(argv[i], "-h") && i+1 < argc) opt.height = atoi(argv[++i]);
