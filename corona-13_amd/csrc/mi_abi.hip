@@ -764,7 +764,9 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
      read from HBM / L2 by the NODES_LDS = false instantiations (CORONA_MI_NODES=global forces that, for tests) */
   const char *nodes_env = getenv("CORONA_MI_NODES");
   const size_t halton_bytes = h->pointsampler == MI_POINTS_HALTON ? (size_t)2*MI_HALTON_LDS : 0;     /* staged head of the permutation tables */
-  const size_t lights_bytes = (s->d_lights && !s->media) ? (size_t)MI_LIGHTS_LDS*sizeof(DLight) : 0;  /* plain ptdl kernels: emitter records in LDS */
+  /* plain ptdl kernels: emitter records in LDS. The same predicate as the kernel's (lds_setup<..., LIGHTS = PTDL && !MEDIA> advances by these
+     bytes whether or not the scene has emitter records: a ptdl scene without emitters still needs them allocated) */
+  const size_t lights_bytes = (h->sampler == MI_SAMPLER_PTDL && !s->media) ? (size_t)MI_LIGHTS_LDS*sizeof(DLight) : 0;
   s->nodes_lds = halton_bytes + lights_bytes + node_bytes + (stack_bytes > isect_stack_bytes ? stack_bytes : isect_stack_bytes) <= 160*1024 && !(nodes_env && !strcmp(nodes_env, "global"));
   s->lds_bytes = halton_bytes + lights_bytes + (s->nodes_lds ? node_bytes : 0) + stack_bytes;
   { /* material queues (mi_regroup.h): the pools take what is left of the CU's LDS behind the job lists (plain kernels only: the extended
@@ -1235,8 +1237,18 @@ struct mi_group
   void **comm;                /* RCCL communicators, one per member, or NULL: peer-copy reduce */
   mi_rccl rccl;
   float *d_stage;             /* peer-copy reduce: one framebuffer on the root's device */
-  hipEvent_t *rendered;       /* per member: its last render is complete */
+  hipEvent_t *rendered;       /* per member: everything queued on its stream for its framebuffer (render, clear) is complete */
+  hipEvent_t reduced;         /* peer-copy reduce: the root has read the members' framebuffers */
   size_t fb_floats;
+  bool broken;                /* a member's launch failed in mi_group_render: the framebuffers hold a partial frame until mi_group_fb_clear */
+};
+
+/* the group entry points select their members' devices; the calling thread gets its own device back (callers mix in torch / HIP code) */
+struct DeviceRestore
+{
+  int dev; bool ok;
+  DeviceRestore() : dev(0), ok(hipGetDevice(&dev) == hipSuccess) {}
+  ~DeviceRestore() { if(ok) (void)hipSetDevice(dev); }
 };
 
 static bool rccl_load(mi_rccl *r)
@@ -1259,12 +1271,14 @@ static bool rccl_load(mi_rccl *r)
 extern "C" void mi_group_destroy(mi_group *g)
 {
   if(!g) return;
+  DeviceRestore restore;
   for(int k=0;k<g->n;k++)
   {
     if(g->comm && g->comm[k]) { (void)hipSetDevice(g->member[k]->device); (void)g->rccl.CommDestroy(g->comm[k]); }
     if(g->rendered && g->rendered[k]) { (void)hipSetDevice(g->member[k]->device); (void)hipEventDestroy(g->rendered[k]); }
   }
   if(g->d_stage) { (void)hipSetDevice(g->member[0]->device); (void)hipFree(g->d_stage); }
+  if(g->reduced) { (void)hipSetDevice(g->member[0]->device); (void)hipEventDestroy(g->reduced); }
   for(int k=0;k<g->n;k++) if(g->member && g->member[k]) mi_scene_destroy(g->member[k]);
   if(g->rccl.lib) dlclose(g->rccl.lib);
   free(g->member); free(g->comm); free(g->rendered);
@@ -1274,6 +1288,7 @@ extern "C" void mi_group_destroy(mi_group *g)
 extern "C" int mi_group_create(const mi_scene_desc *desc, const int *devices, int n, mi_group **out)
 {
   if(!desc || !out || n < 1 || n > 64) return fail(MI_ERR_ARG, "mi_group_create: bad argument");
+  DeviceRestore restore;
   int visible = 0;
   if(hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) return fail(MI_ERR_DEVICE, "no HIP device visible");
   mi_group *g = (mi_group *)calloc(1, sizeof(mi_group));
@@ -1312,7 +1327,8 @@ extern "C" int mi_group_create(const mi_scene_desc *desc, const int *devices, in
   else if(mode && !strcmp(mode, "rccl")) { mi_group_destroy(g); return fail(MI_ERR_UNSUPPORTED, "mi_group_create: RCCL reduce asked for, but the devices are not distinct or librccl cannot be loaded"); }
   if(!g->comm && n > 1)
   {
-    if(hipSetDevice(g->member[0]->device) != hipSuccess || hipMalloc((void **)&g->d_stage, g->fb_floats*sizeof(float)) != hipSuccess)
+    if(hipSetDevice(g->member[0]->device) != hipSuccess || hipMalloc((void **)&g->d_stage, g->fb_floats*sizeof(float)) != hipSuccess ||
+       hipEventCreateWithFlags(&g->reduced, hipEventDisableTiming) != hipSuccess)
     { mi_group_destroy(g); return fail(MI_ERR_NOMEM, "mi_group_create: cannot allocate the staging framebuffer"); }
     for(int k=1;k<n;k++) if(g->member[k]->device != g->member[0]->device)
     { /* peer access where the hardware offers it; hipMemcpyPeerAsync works without it (through the host) */
@@ -1332,14 +1348,21 @@ extern "C" int mi_group_uses_rccl(mi_group *g) { return g && g->comm ? 1 : 0; }
 extern "C" int mi_group_render(mi_group *g, uint64_t first_index, uint64_t count)
 { /* member k takes the k-th contiguous share of the range (remainder indices to the lowest members); returns once everything is queued */
   if(!g) return fail(MI_ERR_ARG, "null group");
+  DeviceRestore restore;
   const uint64_t base = count/(uint64_t)g->n, rem = count%(uint64_t)g->n;
   for(int k=0;k<g->n;k++)
   {
     const uint64_t my = base + ((uint64_t)k < rem ? 1 : 0);
     const uint64_t start = first_index + (uint64_t)k*base + ((uint64_t)k < rem ? (uint64_t)k : rem);
-    const int e = mi_render(g->member[k], start, my);
-    if(e) return e;
-    HIPCHK(hipEventRecord(g->rendered[k], g->member[k]->stream));
+    int e = mi_render(g->member[k], start, my);
+    if(!e && hipEventRecord(g->rendered[k], g->member[k]->stream) != hipSuccess) e = fail(MI_ERR_DEVICE, "mi_group_render: cannot record an event");
+    if(e)
+    { /* the members before k have their shares queued: let them finish, and refuse to reduce or read the partial frame (mi_group_fb_clear
+         makes the group usable again) */
+      for(int j=0;j<k;j++) (void)mi_sync(g->member[j]);
+      g->broken = true;
+      return e;
+    }
   }
   return MI_OK;
 }
@@ -1347,7 +1370,9 @@ extern "C" int mi_group_render(mi_group *g, uint64_t first_index, uint64_t count
 extern "C" int mi_group_fb_reduce(mi_group *g)
 { /* member 0's framebuffer += the others', which are cleared: afterwards the root holds everything rendered so far */
   if(!g) return fail(MI_ERR_ARG, "null group");
+  if(g->broken) return fail(MI_ERR_DEVICE, "mi_group_fb_reduce: a launch of the last mi_group_render failed, the framebuffers hold a partial frame (mi_group_fb_clear first)");
   if(g->n == 1) return MI_OK;
+  DeviceRestore restore;
   mi_scene *root = g->member[0];
   if(g->comm)
   {
@@ -1371,17 +1396,22 @@ extern "C" int mi_group_fb_reduce(mi_group *g)
       HIPCHK(hipGetLastError());
     }
     /* the members' buffers may be cleared once the root has read them */
-    hipEvent_t done = g->rendered[0];
-    HIPCHK(hipEventRecord(done, root->stream));
-    for(int k=1;k<g->n;k++) { HIPCHK(hipSetDevice(g->member[k]->device)); HIPCHK(hipStreamWaitEvent(g->member[k]->stream, done, 0)); }
+    HIPCHK(hipEventRecord(g->reduced, root->stream));
+    for(int k=1;k<g->n;k++) { HIPCHK(hipSetDevice(g->member[k]->device)); HIPCHK(hipStreamWaitEvent(g->member[k]->stream, g->reduced, 0)); }
   }
-  for(int k=1;k<g->n;k++) { const int e = mi_fb_clear(g->member[k]); if(e) return e; }
+  for(int k=1;k<g->n;k++)
+  { /* ... and the root's NEXT copy of a member's buffer has to wait for this clear: `rendered` covers it (two reduces in a row, or a
+       reduce and a read, used to copy buffers whose clear was still in flight) */
+    const int e = mi_fb_clear(g->member[k]); if(e) return e;
+    HIPCHK(hipEventRecord(g->rendered[k], g->member[k]->stream));
+  }
   return MI_OK;
 }
 
 extern "C" int mi_group_sync(mi_group *g)
 {
   if(!g) return fail(MI_ERR_ARG, "null group");
+  DeviceRestore restore;
   for(int k=0;k<g->n;k++) { const int e = mi_sync(g->member[k]); if(e) return e; }
   return MI_OK;
 }
@@ -1389,13 +1419,20 @@ extern "C" int mi_group_sync(mi_group *g)
 extern "C" int mi_group_fb_clear(mi_group *g)
 {
   if(!g) return fail(MI_ERR_ARG, "null group");
-  for(int k=0;k<g->n;k++) { const int e = mi_fb_clear(g->member[k]); if(e) return e; }
+  DeviceRestore restore;
+  for(int k=0;k<g->n;k++)
+  {
+    const int e = mi_fb_clear(g->member[k]); if(e) return e;
+    HIPCHK(hipEventRecord(g->rendered[k], g->member[k]->stream));
+  }
+  g->broken = false;
   return MI_OK;
 }
 
 extern "C" int mi_group_fb_read(mi_group *g, float *host_fb, int accumulate)
 { /* reduce, then the root's framebuffer to the host (copy or add, like mi_fb_read) */
   if(!g) return fail(MI_ERR_ARG, "null group");
+  DeviceRestore restore;
   int e = mi_group_fb_reduce(g);
   if(!e) e = mi_group_sync(g);
   if(!e) e = mi_fb_read(g->member[0], host_fb, accumulate);
@@ -1405,6 +1442,7 @@ extern "C" int mi_group_fb_read(mi_group *g, float *host_fb, int accumulate)
 extern "C" int mi_group_counters(mi_group *g, uint64_t out[8])
 { /* sums over the members (slot 7, the deepest stack, is their maximum) */
   if(!g || !out) return fail(MI_ERR_ARG, "null argument");
+  DeviceRestore restore;
   for(int i=0;i<8;i++) out[i] = 0;
   for(int k=0;k<g->n;k++)
   {

@@ -253,6 +253,9 @@ __device__ __forceinline__ void regroup_exchange(const Pool &pool, PathState &ps
   const unsigned long long t_got = clock64();
   MI_POOLSTAT(cnt, 3, (uint32_t)((t_got - t_wait) >> 4), 1)      /* ticks / 16 waiting for the lock */
 #endif
+#ifdef MI_POOL_CS_SLEEP      /* experiment: how much the kernel time depends on the length of the critical section */
+  __builtin_amdgcn_s_sleep(MI_POOL_CS_SLEEP);
+#endif
   /* the plan was made on the hint; inside, the true counts only cut it down */
   if(chosen >= 0 || k[0] + k[1] + k[2] != 0u)
   {

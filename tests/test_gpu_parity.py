@@ -1019,6 +1019,15 @@ def test_group_behind_the_c_abi(monkeypatch, reduce):
         assert np.abs(got - ref3).max() <= 2e-4 * ref3.max() and two.counters()[4] == 3 * per
         again = two.fb_read()                          # the reduce cleared member 1: reading twice adds nothing
         assert np.array_equal(again, got)
+        # reduce, reduce, read without a render or a sync in between: the root's second copy of member 1's framebuffer has to wait for
+        # the clear the first reduce queued behind it (round 3 ordered it only against the stale `rendered` event: values counted twice)
+        for rep in range(3):
+            two.fb_clear()
+            two.render(0, 3 * per)
+            two.reduce()
+            two.reduce()
+            twice = two.fb_read()
+            assert np.abs(twice - ref3).max() <= 2e-4 * ref3.max(), rep
         two.close()
     else:
         with pytest.raises(RuntimeError, match="not distinct"):
@@ -1117,3 +1126,32 @@ def test_motion_blur_traversal_work_equals_the_reference(scene_path, key):
     for k in range(4):
         assert abs(cnt[k] - ocnt[k]) <= 1e-3 * ocnt[k], (k, cnt[k], ocnt[k])
     assert np.sqrt((((fb - ofb) * scene.gain(1)) ** 2).sum() / n) < 0.05
+
+
+@pytest.mark.gpu
+def test_ptdl_scene_without_emitters(tmp_path):
+    """a ptdl scene whose shapes emit nothing (lights.num_prims == 0: no emitter records on the device) -- the plain ptdl kernels lay their
+    LDS out with room for the records whether or not there are any, so the host has to allocate it by the same rule (round 3 took the
+    bytes off when d_lights was NULL: the job lists of the last waves lay outside the allocation). Paths against the oracle, black image."""
+    import shutil
+    src = SCENE_0010.parent
+    dst = tmp_path / "0010_dark"
+    shutil.copytree(src, dst)
+    nra = (dst / "test.nra2").read_text().replace("color e 3200 3200 3200 1.", "color d 0.5 0.5 0.5").replace("color e 10 10 10 1.", "color d 0.5 0.5 0.5")
+    (dst / "test.nra2").write_text(nra)
+    scene = make_scene(dst / "test.nra2", width=256, height=144, max_verts=8, sampler=pkg.MI_SAMPLER_PTDL)
+    assert scene.desc.lights.num_prims == 0
+    n = 20000
+    ora = oracle_records(scene, 0, n)
+    for mode in ("exact", "fast"):
+        be = pkg.Backend(scene, traversal=mode)
+        gpu = be.trace_paths(0, n)
+        same = (gpu["length"] == ora["length"]) & (gpu["num_splats"] == ora["num_splats"])
+        for k in range(1, 8):
+            m = ora["length"] > k
+            same &= ~m | (gpu["v"]["prim"][:, k] == ora["v"]["prim"][:, k])
+        assert (~same).sum() <= 1, (mode, int((~same).sum()))
+        be2 = pkg.Backend(scene, traversal=mode, counters=False)
+        be2.render(0, 4 * scene.width * scene.height)
+        assert float(np.abs(be2.fb_read()).max()) == 0.0 and be2.counters()[4] == 4 * scene.width * scene.height
+        be.close(); be2.close()
