@@ -106,6 +106,7 @@ struct mi_scene
   int counting;                     /* launch the COUNT instantiations (mi_scene_set_counters / CORONA_MI_COUNTERS) */
   int fast;                         /* launch the FAST instantiations (mi_scene_set_traversal / CORONA_MI_TRAVERSAL): same hits, other work counters */
   bool media;                       /* some shape is filled with a homogeneous medium: MEDIA instantiations */
+  bool norg;                        /* ... of those, the ones without the exchange between waves (scattering exterior medium) */
   void *d_shape_medium, *d_prims_t1, *d_lights, *d_nodes_t1;
   /* Halton point sampler */
   bool halton;
@@ -126,8 +127,12 @@ extern template const void *mi_path_part<false, false, false, true>(unsigned, co
 extern template const void *mi_path_part<true,  false, false, true>(unsigned, const PathLaunch *);
 extern template const void *mi_path_part<false, true,  false, true>(unsigned, const PathLaunch *);
 extern template const void *mi_path_part<true,  true,  false, true>(unsigned, const PathLaunch *);
+extern template const void *mi_path_part<false, true,  false, false, true>(unsigned, const PathLaunch *);
+extern template const void *mi_path_part<true,  true,  false, false, true>(unsigned, const PathLaunch *);
+extern template const void *mi_path_part<false, true,  false, true,  true>(unsigned, const PathLaunch *);
+extern template const void *mi_path_part<true,  true,  false, true,  true>(unsigned, const PathLaunch *);
 
-static const void *path_kernel(bool ptdl, bool media, bool mb, bool fast, unsigned which, const PathLaunch *L)
+static const void *path_kernel(bool ptdl, bool media, bool mb, bool fast, bool norg, unsigned which, const PathLaunch *L)
 {
 #ifdef MI_DEV_FAST
   if(media || mb) { fprintf(stderr, "[mi] internal: development build without the extended kernels\n"); abort(); }
@@ -135,6 +140,11 @@ static const void *path_kernel(bool ptdl, bool media, bool mb, bool fast, unsign
   if(mb) return ptdl ? mi_path_part<true, true, true, false>(which, L) : mi_path_part<false, true, true, false>(which, L);   /* no FAST rounds with moving primitives */
   if(media)
   {
+    if(norg)
+    { /* a scene in a scattering exterior medium: the extended kernels without the exchange between waves */
+      if(fast) return ptdl ? mi_path_part<true, true, false, true, true>(which, L) : mi_path_part<false, true, false, true, true>(which, L);
+      return ptdl ? mi_path_part<true, true, false, false, true>(which, L) : mi_path_part<false, true, false, false, true>(which, L);
+    }
     if(fast) return ptdl ? mi_path_part<true, true, false, true>(which, L) : mi_path_part<false, true, false, true>(which, L);
     return ptdl ? mi_path_part<true, true, false, false>(which, L) : mi_path_part<false, true, false, false>(which, L);
   }
@@ -757,7 +767,10 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
   const bool mb_kernels = s->d_prims_t1 != nullptr;
   const size_t node_bytes = (size_t)(MI_NODE_FIELDS + (mb_kernels && s->d_nodes_t1 ? 6 : 0))*N*16;
   /* (the column of the plain kernels is shorter since round 4: they use the LDS for the pools of mi_regroup.h; s->media is final here) */
-  const int column = mb_kernels ? MI_STACK_LDS_MB : s->media ? MI_STACK_LDS : MI_STACK_LDS_PLAIN;
+  /* a scene in a scattering exterior medium (global fog) runs the extended kernels WITHOUT the exchange: nearly all its vertices are volume
+     vertices, one class (measured: scenes/0056_fog ptdl 124 ms with, 115 without; scenes/0055_media ptdl 35 with, 46 without) */
+  { const DShapeMedium &ext = shape_med[h->num_shapes]; s->norg = s->media && !mb_kernels && (!MI_REGROUP || !MI_REGROUP_MEDIA || (ext.med >= 0 && ext.mu_t[3] > 0.0f && ext.albedo[3] > 0.0f)); }
+  const int column = mb_kernels ? MI_STACK_LDS_MB : s->norg ? MI_STACK_LDS : MI_STACK_LDS_PLAIN;
   const size_t stack_bytes = (size_t)column*MI_BLOCK*sizeof(uint2) + (size_t)(MI_BLOCK/64)*MI_JOBS_LDS;   /* + the waves' job lists */
   const size_t isect_stack_bytes = (size_t)MI_STACK_LDS*MI_BLOCK*sizeof(uint2) + (size_t)(MI_BLOCK/64)*MI_JOBS_LDS;   /* mi_intersect_kernel: full columns, no pools */
   /* the tree lives in LDS next to the traversal stacks when it fits (0010_pt: 50 KB + 96 KB of 160 KB); larger trees are
@@ -777,8 +790,13 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
     if(re && atol(re) >= 0 && (size_t)atol(re) < room) room = (size_t)atol(re);
     if(room > MI_POOL_BYTES_MAX) room = MI_POOL_BYTES_MAX;
     room &= ~(size_t)15;
-    const bool on = MI_REGROUP && num_classes > 1 && !s->media && !mb_kernels && room >= 2048;
-    d.pool_classes = on ? num_classes : 0u;
+    /* extended kernels: volume vertices are one more class when a medium of the scene scatters */
+    bool scatters = false;
+    for(size_t i=0;i<shape_med.size();i++) if(shape_med[i].med >= 0 && shape_med[i].mu_t[3] > 0.0f && shape_med[i].albedo[3] > 0.0f) scatters = true;
+    d.pool_volume_class = num_classes;
+    const uint32_t classes = num_classes + ((s->media && scatters) ? 1u : 0u);
+    const bool on = MI_REGROUP && classes > 1 && !s->norg && !mb_kernels && room >= 2048;
+    d.pool_classes = on ? classes : 0u;
     d.pool_bytes = on ? (uint32_t)room : 0u;
     s->lds_bytes += d.pool_bytes;
     /* one launch size for every kernel of the scene: mi_intersect_kernel keeps full stack columns */
@@ -807,7 +825,7 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
       const unsigned which = ((k & 1u) ? MI_WHICH_RECORD | MI_WHICH_COUNT : 0u) | ((k & 2u) ? MI_WHICH_COUNT : 0u) | (s->nodes_lds ? MI_WHICH_NODES_LDS : 0u) |
                              (h->pointsampler == MI_POINTS_HALTON ? MI_WHICH_HALTON : 0u);
       if(mi_path_which_valid(which))
-        kernels.push_back(path_kernel(h->sampler == MI_SAMPLER_PTDL, s->media, s->d_prims_t1 != nullptr, (k & 4u) != 0, which, nullptr));
+        kernels.push_back(path_kernel(h->sampler == MI_SAMPLER_PTDL, s->media, s->d_prims_t1 != nullptr, (k & 4u) != 0, s->norg, which, nullptr));
     }
     for(const void *k : kernels)
       if(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess)
@@ -909,7 +927,7 @@ static void launch_path_kernel(mi_scene *s, bool record, int grid, uint64_t firs
                          ((s->counting || record) ? MI_WHICH_COUNT : 0u);
   PathLaunch L = { s->d, grid, s->lds_bytes, s->stream, (unsigned long long)first, (unsigned long long)n, (const uint32_t *)s->d_shape_material,
                    (const float *)s->d_shape_L, rec, (uint2 *)s->d_overflow };
-  (void)path_kernel(s->d.sampler == MI_SAMPLER_PTDL, s->media, s->d_prims_t1 != nullptr, s->fast != 0, which, &L);
+  (void)path_kernel(s->d.sampler == MI_SAMPLER_PTDL, s->media, s->d_prims_t1 != nullptr, s->fast != 0, s->norg, which, &L);
 }
 
 extern "C" int mi_render(mi_scene *s, uint64_t first_index, uint64_t count)

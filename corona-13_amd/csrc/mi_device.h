@@ -148,6 +148,7 @@ struct DScene
   const unsigned short *halton_perm;
   /* material queues (mi_regroup.h): bytes of LDS behind the job lists that the pools may use, classes in use (< 2: no exchange) */
   uint32_t pool_bytes, pool_classes;
+  uint32_t pool_volume_class;       /* extended kernels: the class of volume vertices (= number of surface classes) */
 };
 
 #endif

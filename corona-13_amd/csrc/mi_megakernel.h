@@ -66,8 +66,14 @@
 #define MI_PRIO_PTDL_TRACE 0
 #define MI_PRIO_PTDL_SHADE 3
 #endif
+#ifndef MI_REFILL_RUNTIME
+#define MI_REFILL_RUNTIME 1
+#endif
+#ifndef MI_REGROUP_MEDIA
+#define MI_REGROUP_MEDIA 1   /* the exchange in the extended kernels too (media, moving camera): volume vertices are a class of their own */
+#endif
 #ifndef MI_REFILL_MIN
-#define MI_REFILL_MIN (MI_REGROUP ? 12 : 1)   /* with the exchange between waves (mi_regroup.h) the lanes of a wave become free in bursts (a wave that posts all its vertices) and in
+#define MI_REFILL_MIN 12   /* with the exchange between waves (mi_regroup.h) the lanes of a wave become free in bursts (a wave that posts all its vertices) and in
                                   dribbles (one that pulled what the pool had): the dribbles wait. cfg 2 / cfg 3 with 1 / 8 / 16 / 24: 15.94 / 15.74 / 15.77 / 15.89 ms and
                                   30.3 / 29.4 / 29.3 / 29.3; without the exchange a loss (18.7 against 18.4 ms) */
 #endif
@@ -107,26 +113,29 @@
 #endif
 
 /* ======================================================================================= persistent megakernel */
-template<bool RECORD, bool PTDL, bool NODES_LDS, bool HALTON = false, bool MEDIA = false, bool MB = false, bool COUNT = true, bool FAST = false>
+template<bool RECORD, bool PTDL, bool NODES_LDS, bool HALTON = false, bool MEDIA = false, bool MB = false, bool COUNT = true, bool FAST = false, bool NORG = false>
 __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned long long first, unsigned long long count,
                                                            const uint32_t *shape_material, const float *shape_L, mi_path_record *records,
                                                            uint2 *stack_overflow)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int COLUMN = MB ? MI_STACK_LDS_MB : MEDIA ? MI_STACK_LDS : MI_STACK_LDS_PLAIN;      /* stack entries per lane in LDS */
+  constexpr int COLUMN = MB ? MI_STACK_LDS_MB : (NORG || (MEDIA && !MI_REGROUP_MEDIA)) ? MI_STACK_LDS : MI_STACK_LDS_PLAIN;      /* stack entries per lane in LDS */
   const Lds lds = lds_setup<MI_BLOCK, NODES_LDS, HALTON, PTDL && !MEDIA, COLUMN, MB>(sc, smem, stack_overflow);
 
   /* every workgroup owns a contiguous part of the path index range and hands it out through an LDS counter: the
      wave-level refill below then needs no global atomic at all (one shared counter costs ~11 ns per wave refill) */
   __shared__ unsigned int blk_next;
   /* material queues (mi_regroup.h): the plain kernels trade surface vertices between the waves of the workgroup, by class of the material */
-  constexpr bool REGROUP = MI_REGROUP && !MEDIA && !MB;
+  /* NORG: the extended kernels once more WITHOUT the exchange, for scenes in a scattering exterior medium (a global fog): nearly every vertex
+     is a volume vertex there, the exchange has nothing to sort, and its code costs that kernel 26 more spilled registers (fog ptdl 124 against 115 ms) */
+  constexpr bool REGROUP = MI_REGROUP && !MB && !NORG && (!MEDIA || MI_REGROUP_MEDIA);
   __shared__ PoolCtl pool_ctl;
   if(threadIdx.x == 0) blk_next = 0;
   Pool pool;
+  pool.E = 0u;
   if(REGROUP)
   {
-    pool = pool_setup<RECORD, HALTON>(sc, lds.jobs - (threadIdx.x >> 6)*MI_JOBS_LDS + (MI_BLOCK/64)*MI_JOBS_LDS, &pool_ctl);
+    pool = pool_setup<RECORD, HALTON, MEDIA>(sc, lds.jobs - (threadIdx.x >> 6)*MI_JOBS_LDS + (MI_BLOCK/64)*MI_JOBS_LDS, &pool_ctl);
     pool_init(pool, &pool_ctl);
   }
   __syncthreads();
@@ -173,7 +182,12 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
       const unsigned long long m = __ballot(want);
       /* MI_REFILL_MIN: a few idle lanes wait for company -- path_generate costs the wave the same for 3 lanes as for 60 -- unless the wave
          has little else under way */
-      if(m && (MI_REFILL_MIN <= 1 || __popcll(m) >= MI_REFILL_MIN || __popcll(__ballot(tracing || ps.active || ps.sh_pending)) < 64 - 2*MI_REFILL_MIN))
+#if MI_REFILL_RUNTIME
+      const int rmin = (REGROUP && pool.E) ? MI_REFILL_MIN : 1;         /* (only where the exchange runs: without it waiting is a loss) */
+#else
+      constexpr int rmin = REGROUP ? MI_REFILL_MIN : 1;
+#endif
+      if(m && (rmin <= 1 || __popcll(m) >= rmin || __popcll(__ballot(tracing || ps.active || ps.sh_pending)) < 64 - 2*rmin))
       {
         const unsigned n = __popcll(m);
         unsigned int base = 0;
@@ -296,10 +310,12 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
       static_assert(!REGROUP || !CHAIN, "a chained lane's connection is splatted in front of the next vertex's shading");
       const bool fin = tracing && ts.done;
       uint32_t cls = 0u;
-      const bool surf0 = fin && !tr_shadow && hit.prim != MI_NOPRIM;
-      if(surf0 && pool.E) cls = sc.primgeo[hit.prim].cls;       /* under way while the lanes below finish their paths */
+      /* (extended kernels: an extension ray that ended at its sampled free-flight distance has a volume vertex there) */
+      const bool volume = MEDIA && hit.prim == MI_NOPRIM && ps.clip < FLT_MAX;
+      const bool surf0 = fin && !tr_shadow && (hit.prim != MI_NOPRIM || volume);
+      if(surf0 && pool.E) cls = volume ? sc.pool_volume_class : sc.primgeo[hit.prim].cls;       /* under way while the lanes below finish their paths */
 #if MI_REGROUP_EARLY_SHADOW
-      if(fin && (tr_shadow || hit.prim == MI_NOPRIM))
+      if(fin && (tr_shadow || (hit.prim == MI_NOPRIM && !volume)))
       {
         tracing = false;
         mi_path_record *rec = RECORD ? records + (ps.index - first) : nullptr;
@@ -309,7 +325,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
 #else
       /* (the verdict of a finished shadow ray stays where it was, next to path_shade: resolving it first made lanes free that
          almost always owe a splat, at the price of a third divergent region -- cfg 3 +4 % without the exchange) */
-      if(fin && !tr_shadow && hit.prim == MI_NOPRIM)
+      if(fin && !tr_shadow && hit.prim == MI_NOPRIM && !volume)
       {
         tracing = false;
         path_escape<RECORD, MEDIA>(sc, ps, RECORD ? records + (ps.index - first) : nullptr, cnt);
@@ -317,7 +333,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
 #endif
       /* a lane that still owes this iteration a splat keeps its pixel: it is free from the next iteration on */
       const bool freelane = !tracing && !ps.active && !ps.sh_pending && !splat.pending;
-      regroup_exchange<RECORD, PTDL, HALTON, MI_PRIO ? (PTDL ? MI_PRIO_PTDL_SHADE : MI_PRIO_PT_SHADE) : 0>(pool, ps, hit, ts, tracing, tr_shadow, surf0, cls, freelane, exhausted_wave, cnt);
+      regroup_exchange<RECORD, PTDL, HALTON, MEDIA, MI_PRIO ? (PTDL ? MI_PRIO_PTDL_SHADE : MI_PRIO_PT_SHADE) : 0>(pool, ps, hit, ts, tracing, tr_shadow, surf0, cls, freelane, exhausted_wave, cnt);
       if(tracing && ts.done)
       {
         tracing = false;
@@ -325,7 +341,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
         if(PTDL && !MI_REGROUP_EARLY_SHADOW && tr_shadow) shadow_resolve<RECORD>(sc, ps, hit, rec, cnt, splat);
         else
         {
-          __builtin_assume(hit.prim != MI_NOPRIM);     /* paths that left the scene have ended above */
+          if(!MEDIA) __builtin_assume(hit.prim != MI_NOPRIM);     /* paths that left the scene have ended above */
           path_shade<RECORD, PTDL, HALTON, MEDIA, MB>(sc, ps, hit, shape_material, shape_L, rec, cnt, splat);
         }
       }
@@ -445,7 +461,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_intersect_kernel(DScene sc, const
 
 
 /* ---------------------------------------------------------------------------------------- kernel table
- * A part = one (PTDL, MEDIA, MB, FAST); inside it `which` selects bit 0 RECORD, 1 NODES_LDS, 2 HALTON, 3 COUNT. MB implies MEDIA and
+ * A part = one (PTDL, MEDIA, MB, FAST, NORG); inside it `which` selects bit 0 RECORD, 1 NODES_LDS, 2 HALTON, 3 COUNT. MB implies MEDIA and
  * has no FAST rounds (its leaf phase stays per lane); the RECORD kernels always count.
  * MI_DEV_FAST (development builds, tools/variants.sh): only the plain tree-in-LDS kernels (2: with the Halton ones) -- the other
  * parts compile to stubs. L = NULL: return the kernel's address without launching (hipFuncSetAttribute). */
@@ -466,7 +482,7 @@ struct PathLaunch
 #define MI_WHICH_HALTON 4u
 #define MI_WHICH_COUNT 8u
 
-template<bool PTDL, bool MEDIA, bool MB, bool FAST> const void *mi_path_part(unsigned which, const PathLaunch *L);
+template<bool PTDL, bool MEDIA, bool MB, bool FAST, bool NORG = false> const void *mi_path_part(unsigned which, const PathLaunch *L);
 
 static inline bool mi_path_which_valid(unsigned which)
 {
@@ -478,30 +494,30 @@ static inline bool mi_path_which_valid(unsigned which)
 }
 
 #ifdef MI_PART_DEFINE
-template<bool PTDL, bool MEDIA, bool MB, bool FAST, bool R, bool N, bool H, bool C> static const void *mi_path_go(const PathLaunch *L)
+template<bool PTDL, bool MEDIA, bool MB, bool FAST, bool NORG, bool R, bool N, bool H, bool C> static const void *mi_path_go(const PathLaunch *L)
 {
-  constexpr bool valid = !(MB && !MEDIA) && !(MB && FAST) && !(R && !C)
+  constexpr bool valid = !(MB && !MEDIA) && !(MB && FAST) && !(R && !C) && !(NORG && (!MEDIA || MB))
 #ifdef MI_DEV_FAST
                          && (!H || MI_DEV_FAST == 2) && !MEDIA && !MB && N
 #endif
                          ;
   if constexpr(valid)
   {
-    if(L) hipLaunchKernelGGL((mi_path_kernel<R, PTDL, N, H, MEDIA, MB, C, FAST>), dim3(L->grid), dim3(MI_BLOCK), L->lds_bytes, L->stream, L->d, L->first, L->n,
+    if(L) hipLaunchKernelGGL((mi_path_kernel<R, PTDL, N, H, MEDIA, MB, C, FAST, NORG>), dim3(L->grid), dim3(MI_BLOCK), L->lds_bytes, L->stream, L->d, L->first, L->n,
                              L->shape_material, L->shape_L, L->rec, L->overflow);
-    return (const void *)mi_path_kernel<R, PTDL, N, H, MEDIA, MB, C, FAST>;
+    return (const void *)mi_path_kernel<R, PTDL, N, H, MEDIA, MB, C, FAST, NORG>;
   }
   else { fprintf(stderr, "[mi] internal: kernel variant not built\n"); abort(); }
 }
-template<bool PTDL, bool MEDIA, bool MB, bool FAST, int LEFT, bool... B> static const void *mi_path_pick(unsigned which, const PathLaunch *L)
+template<bool PTDL, bool MEDIA, bool MB, bool FAST, bool NORG, int LEFT, bool... B> static const void *mi_path_pick(unsigned which, const PathLaunch *L)
 {
-  if constexpr(LEFT == 0) return mi_path_go<PTDL, MEDIA, MB, FAST, B...>(L);
-  else return (which & 1u) ? mi_path_pick<PTDL, MEDIA, MB, FAST, LEFT - 1, B..., true>(which >> 1, L)
-                           : mi_path_pick<PTDL, MEDIA, MB, FAST, LEFT - 1, B..., false>(which >> 1, L);
+  if constexpr(LEFT == 0) return mi_path_go<PTDL, MEDIA, MB, FAST, NORG, B...>(L);
+  else return (which & 1u) ? mi_path_pick<PTDL, MEDIA, MB, FAST, NORG, LEFT - 1, B..., true>(which >> 1, L)
+                           : mi_path_pick<PTDL, MEDIA, MB, FAST, NORG, LEFT - 1, B..., false>(which >> 1, L);
 }
-template<bool PTDL, bool MEDIA, bool MB, bool FAST> const void *mi_path_part(unsigned which, const PathLaunch *L)
+template<bool PTDL, bool MEDIA, bool MB, bool FAST, bool NORG> const void *mi_path_part(unsigned which, const PathLaunch *L)
 {
-  return mi_path_pick<PTDL, MEDIA, MB, FAST, 4>(which, L);
+  return mi_path_pick<PTDL, MEDIA, MB, FAST, NORG, 4>(which, L);
 }
 #endif
 

@@ -30,9 +30,13 @@
 #ifndef MI_REGROUP
 #define MI_REGROUP 1
 #endif
-#define MI_POOL_CLASSES 3          /* diffuse, dielectric, metal (DPrimGeo.cls: compact index among the bsdfs the scene uses) */
+#define MI_POOL_CLASSES 4          /* diffuse, dielectric, metal (DPrimGeo.cls: compact index among the bsdfs the scene uses) and, in the extended kernels,
+                                      volume vertices (DScene.pool_volume_class) */
 #ifndef MI_POOL_HIGH
 #define MI_POOL_HIGH 48            /* own lanes + pool of a class from which on a wave turns to that class */
+#endif
+#ifndef MI_POOL_PACK16
+#define MI_POOL_PACK16 0
 #endif
 #ifndef MI_POOL_POLICY
 #define MI_POOL_POLICY 2
@@ -49,7 +53,8 @@ typedef __attribute__((address_space(3))) unsigned char lds_u8_t;
 typedef __attribute__((address_space(3))) unsigned short lds_u16_t;
 typedef unsigned int mi_u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) mi_u32x4 lds_uint4;
-#define MI_SEL3(A, I) ((I) == 0 ? (A)[0] : (I) == 1 ? (A)[1] : (A)[2])
+#define MI_SEL3(A, I) ((I) == 0 ? (A)[0] : (I) == 1 ? (A)[1] : (I) == 2 ? (A)[2] : (A)[3])
+#define MI_SUM4(A) ((A)[0] + (A)[1] + (A)[2] + (A)[3])
 
 /* control words. `state` IS the lock: four 16-bit counts {entries listed per class 0..2, free entries} packed into 64 bits while nobody
  * is inside a critical section, all ones while somebody is. A wave enters with ONE atomic exchange (all ones in, the counts out -- or
@@ -61,7 +66,7 @@ typedef __attribute__((address_space(3))) unsigned long long lds_u64_t;
 struct __attribute__((aligned(16))) PoolCtl { unsigned long long state, hint; };
 
 /* 8-byte words of a path vertex on its way through a pool */
-template<bool RECORD, bool HALTON> struct PoolLayout { static constexpr int SLOTS = RECORD ? 16 : HALTON ? 15 : 14; };
+template<bool RECORD, bool HALTON, bool MEDIA = false> struct PoolLayout { static constexpr int BASE = RECORD ? 16 : HALTON ? 15 : 14, SLOTS = BASE + (MEDIA ? 3 : 0); };
 
 /* The pools share their storage: E entries of SLOTS words ([slot][E], so that the lanes of a wave write neighbouring addresses), a list of
  * entry numbers per class, and the list of free entries. A vertex is written / read OUTSIDE the lock (its entry is then on no list); the
@@ -78,10 +83,10 @@ struct Pool
   uint32_t E;               /* entries; 0 = no exchange */
 };
 
-template<bool RECORD, bool HALTON>
+template<bool RECORD, bool HALTON, bool MEDIA>
 __device__ __forceinline__ Pool pool_setup(const DScene &sc, unsigned char *base, PoolCtl *ctl)
 {
-  constexpr uint32_t NS = PoolLayout<RECORD, HALTON>::SLOTS;
+  constexpr uint32_t NS = PoolLayout<RECORD, HALTON, MEDIA>::SLOTS;
   Pool p;
   p.ctl = (lds_u32_t *)ctl;
   uint32_t E = sc.pool_classes > 1u ? sc.pool_bytes/(NS*8u + 2u*(MI_POOL_CLASSES + 1u)) : 0u;
@@ -103,7 +108,7 @@ __device__ __forceinline__ void pool_init(const Pool &p, PoolCtl *ctl)
 __device__ __forceinline__ bool pool_empty(const Pool &p)
 { /* no complete vertex waits in any class (entries a wave is still writing are that wave's business: it is alive and looks again) */
   const unsigned long long h = __hip_atomic_load((lds_u64_t *)p.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  return (h & 0xffffffffffffull) == 0ull;
+  return (h & 0xffffffffffffull) == 0ull;      /* the four classes' counts */
 }
 
 /* enter a critical section: the counts, the same in every lane */
@@ -130,8 +135,15 @@ __device__ __forceinline__ void pool_leave(const Pool &pool, unsigned long long 
     __hip_atomic_store((lds_u64_t *)pool.ctl + 1, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
 }
-#define MI_POOL_UNPACK(ST, P, NFREE) { (P)[0] = (uint32_t)(ST) & 0xffffu; (P)[1] = (uint32_t)((ST) >> 16) & 0xffffu; (P)[2] = (uint32_t)((ST) >> 32) & 0xffffu; (NFREE) = (uint32_t)((ST) >> 48); }
+#if MI_POOL_PACK16     /* experiment: the four 16-bit counts of the three-class version */
+#define MI_POOL_UNPACK(ST, P, NFREE) { (P)[0] = (uint32_t)(ST) & 0xffffu; (P)[1] = (uint32_t)((ST) >> 16) & 0xffffu; (P)[2] = (uint32_t)((ST) >> 32) & 0xffffu; (P)[3] = 0u; (NFREE) = (uint32_t)((ST) >> 48); }
 #define MI_POOL_PACK(P, NFREE) ((unsigned long long)(P)[0] | ((unsigned long long)(P)[1] << 16) | ((unsigned long long)(P)[2] << 32) | ((unsigned long long)(NFREE) << 48))
+#else
+/* five 12-bit counts (at most 1024 entries) */
+#define MI_POOL_UNPACK(ST, P, NFREE) { (P)[0] = (uint32_t)(ST) & 0xfffu; (P)[1] = (uint32_t)((ST) >> 12) & 0xfffu; (P)[2] = (uint32_t)((ST) >> 24) & 0xfffu; \
+                                       (P)[3] = (uint32_t)((ST) >> 36) & 0xfffu; (NFREE) = (uint32_t)((ST) >> 48) & 0xfffu; }
+#define MI_POOL_PACK(P, NFREE) ((unsigned long long)(P)[0] | ((unsigned long long)(P)[1] << 12) | ((unsigned long long)(P)[2] << 24) | ((unsigned long long)(P)[3] << 36) | ((unsigned long long)(NFREE) << 48))
+#endif
 
 /* The exchange of one wave iteration. Call from ALL lanes of the wave.
  *   surf      this lane's extension ray has ended on a primitive and the vertex is not shaded yet (hit, ps are that vertex's)
@@ -142,24 +154,26 @@ __device__ __forceinline__ void pool_leave(const Pool &pool, unsigned long long 
  *             SIMD's other waves run their traversal slices at a higher priority keeps fifteen waves waiting)
  * Afterwards: lanes that posted are free (ps.active = 0, tracing = false); lanes that pulled hold a vertex to shade
  * (tracing = true, ts.done = true, tr_shadow = false). */
-template<bool RECORD, bool PTDL, bool HALTON, int PRIO, class CNT>
+template<bool RECORD, bool PTDL, bool HALTON, bool MEDIA, int PRIO, class CNT>
 __device__ __forceinline__ void regroup_exchange(const Pool &pool, PathState &ps, Hit &hit, TraceState &ts, bool &tracing, bool &tr_shadow,
                                                  bool surf, uint32_t cls, bool freelane, bool drain, CNT &cnt)
 {
-  constexpr int NS = PoolLayout<RECORD, HALTON>::SLOTS;
+  constexpr int NS = PoolLayout<RECORD, HALTON, MEDIA>::SLOTS, NB = PoolLayout<RECORD, HALTON, MEDIA>::BASE;
+  constexpr int NC = MEDIA ? MI_POOL_CLASSES : MI_POOL_CLASSES - 1;      /* the plain kernels have no volume vertices: what belongs to the fourth class folds away */
+  (void)NS;
   const uint32_t E = pool.E;
   if(!E) return;
   mi_u64 mc[MI_POOL_CLASSES];
-  uint32_t n[MI_POOL_CLASSES], p[MI_POOL_CLASSES], nfree;
+  uint32_t n[MI_POOL_CLASSES] = { 0u, 0u, 0u, 0u }, p[MI_POOL_CLASSES], nfree;
 #pragma unroll
-  for(int c=0;c<MI_POOL_CLASSES;c++) { mc[c] = __ballot(surf && cls == (uint32_t)c); n[c] = __popcll(mc[c]); }
+  for(int c=0;c<NC;c++) { mc[c] = __ballot(surf && cls == (uint32_t)c); n[c] = __popcll(mc[c]); }
   const mi_u64 mfree = __ballot(freelane);
   const uint32_t F = __popcll(mfree);
   /* what this wave will do, from the pools' fill: first on an unlocked look -- iterations of a scene with one dominant class often
      have nothing to trade --, then again under the lock. The counts are the same in every lane: as scalars the whole decision runs
      on the scalar unit; no array is indexed at run time. */
   int chosen = -1;
-  uint32_t k[MI_POOL_CLASSES], m = 0;
+  uint32_t k[MI_POOL_CLASSES] = { 0u, 0u, 0u, 0u }, m = 0;
   auto look = [&]()
   { /* from outside: the hint */
     unsigned long long h = __hip_atomic_load((lds_u64_t *)pool.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -170,12 +184,12 @@ __device__ __forceinline__ void regroup_exchange(const Pool &pool, PathState &ps
   {
     chosen = -1; m = 0;
 #pragma unroll
-    for(int c=0;c<MI_POOL_CLASSES;c++) k[c] = 0;
+    for(int c=0;c<NC;c++) k[c] = 0;
     if(drain)
     { /* nothing is posted any more; the fullest pool is emptied into the free lanes */
       uint32_t best = 0;
 #pragma unroll
-      for(int c=0;c<MI_POOL_CLASSES;c++) if(p[c] > 0u && n[c] + p[c] > best) { best = n[c] + p[c]; chosen = c; }
+      for(int c=0;c<NC;c++) if(p[c] > 0u && n[c] + p[c] > best) { best = n[c] + p[c]; chosen = c; }
       if(chosen >= 0) { const uint32_t pc = MI_SEL3(p, chosen); m = pc < F ? pc : F; }
       return;
     }
@@ -184,9 +198,9 @@ __device__ __forceinline__ void regroup_exchange(const Pool &pool, PathState &ps
     /* policy 2: a wave shades a class only when that fills its lanes -- its own vertices of the class plus what the pool holds, as far
        as lanes become free (ended paths + the other classes' vertices, which are posted) --, and otherwise posts ALL its vertices
        while entries are left and goes on tracing: the lanes start new paths together, the vertices are shaded later by full waves */
-    const uint32_t N = n[0] + n[1] + n[2];
+    const uint32_t N = MI_SUM4(n);
 #pragma unroll
-    for(int c=0;c<MI_POOL_CLASSES;c++)
+    for(int c=0;c<NC;c++)
     {
       const uint32_t others = N - n[c] < nfree ? N - n[c] : nfree;
       const uint32_t can = F + others;
@@ -196,12 +210,12 @@ __device__ __forceinline__ void regroup_exchange(const Pool &pool, PathState &ps
     if(chosen < 0 && N > 0u && nfree >= N + MI_POOL_AGE)
     {
 #pragma unroll
-      for(int c=0;c<MI_POOL_CLASSES;c++) k[c] = n[c];
+      for(int c=0;c<NC;c++) k[c] = n[c];
       return;
     }
 #else
 #pragma unroll
-    for(int c=0;c<MI_POOL_CLASSES;c++)
+    for(int c=0;c<NC;c++)
     { /* a full batch: own lanes + pool; when the entries run out the fullest pool counts as one (its vertices must not wait for ever) */
       const uint32_t t = n[c] + p[c];
       if(p[c] > 0u && (t >= MI_POOL_HIGH || nfree < MI_POOL_AGE) && t > best) { best = t; chosen = c; }
@@ -211,17 +225,17 @@ __device__ __forceinline__ void regroup_exchange(const Pool &pool, PathState &ps
     { /* the class most of the wave's own vertices are in */
       best = 0;
 #pragma unroll
-      for(int c=0;c<MI_POOL_CLASSES;c++) if(n[c] > best) { best = n[c]; chosen = c; }
+      for(int c=0;c<NC;c++) if(n[c] > best) { best = n[c]; chosen = c; }
       if(chosen < 0)
       { /* no vertex of its own: the fullest pool */
 #pragma unroll
-        for(int c=0;c<MI_POOL_CLASSES;c++) if(p[c] > best) { best = p[c]; chosen = c; }
+        for(int c=0;c<NC;c++) if(p[c] > best) { best = p[c]; chosen = c; }
         if(chosen < 0) return;
       }
     }
     uint32_t freed = F, room = nfree;
 #pragma unroll
-    for(int c=0;c<MI_POOL_CLASSES;c++) if(c != chosen)
+    for(int c=0;c<NC;c++) if(c != chosen)
     {
       k[c] = n[c] < room ? n[c] : room;
       room -= k[c];
@@ -231,11 +245,11 @@ __device__ __forceinline__ void regroup_exchange(const Pool &pool, PathState &ps
   };
   look();
   decide();
-  if(m + k[0] + k[1] + k[2] == 0u) return;
+  if(m + MI_SUM4(k) == 0u) return;
   /* (what does not depend on the counts is formed before the lock is taken) */
   uint32_t crank = 0;         /* rank of the lane's vertex among the wave's vertices of its class */
 #pragma unroll
-  for(int c=0;c<MI_POOL_CLASSES;c++)
+  for(int c=0;c<NC;c++)
   {
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mc[c] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mc[c], 0u));
     if(cls == (uint32_t)c) crank = rank;
@@ -257,17 +271,17 @@ __device__ __forceinline__ void regroup_exchange(const Pool &pool, PathState &ps
   __builtin_amdgcn_s_sleep(MI_POOL_CS_SLEEP);
 #endif
   /* the plan was made on the hint; inside, the true counts only cut it down */
-  if(chosen >= 0 || k[0] + k[1] + k[2] != 0u)
+  if(chosen >= 0 || MI_SUM4(k) != 0u)
   {
     uint32_t room = nfree, freed = F;
 #pragma unroll
-    for(int c=0;c<MI_POOL_CLASSES;c++) { if(k[c] > room) k[c] = room; room -= k[c]; freed += k[c]; }
+    for(int c=0;c<NC;c++) { if(k[c] > room) k[c] = room; room -= k[c]; freed += k[c]; }
     if(chosen >= 0) { const uint32_t pc = MI_SEL3(p, chosen); if(m > pc) m = pc; if(m > freed) m = freed; }
   }
 #ifdef MI_PROFILE_POOL
   {
     uint32_t posted = 0, left = 0, nmax = 0;
-    for(int c=0;c<MI_POOL_CLASSES;c++) { posted += k[c]; if(c != chosen) left += n[c] - k[c]; if(n[c] > nmax) nmax = n[c]; }
+    for(int c=0;c<NC;c++) { posted += k[c]; if(c != chosen) left += n[c] - k[c]; if(n[c] > nmax) nmax = n[c]; }
     MI_POOLSTAT(cnt, 0, posted, 1)
     MI_POOLSTAT(cnt, 1, m, m ? 1 : 0)
     if(chosen >= 0 && MI_SEL3(n, chosen) < nmax) MI_POOLSTAT(cnt, 2, MI_SEL3(n, chosen) + m, 1)
@@ -277,7 +291,7 @@ __device__ __forceinline__ void regroup_exchange(const Pool &pool, PathState &ps
 #endif
   const bool post = surf && (int)cls != chosen && crank < MI_SEL3(k, cls);
   const mi_u64 mpost = __ballot(post);
-  const uint32_t K = k[0] + k[1] + k[2];
+  const uint32_t K = MI_SUM4(k);
   const uint32_t prank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mpost >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mpost, 0u));
   const mi_u64 mtake = mfree | mpost;
   const uint32_t trank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mtake >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mtake, 0u));
@@ -286,9 +300,9 @@ __device__ __forceinline__ void regroup_exchange(const Pool &pool, PathState &ps
   if(post) id_post = pool.list[MI_POOL_CLASSES*E + (nfree - 1u - prank)];
   if(pull) id_pull = pool.list[(uint32_t)chosen*E + (MI_SEL3(p, chosen) - 1u - trank)];
   {
-    uint32_t q[MI_POOL_CLASSES] = { p[0], p[1], p[2] };
+    uint32_t q[MI_POOL_CLASSES] = { p[0], p[1], p[2], p[3] };
 #pragma unroll
-    for(int c=0;c<MI_POOL_CLASSES;c++) if(c == chosen) q[c] -= m;
+    for(int c=0;c<NC;c++) if(c == chosen) q[c] -= m;
     pool_leave<true>(pool, MI_POOL_PACK(q, nfree - K));
   }
 #ifdef MI_PROFILE_POOL
@@ -319,8 +333,14 @@ __device__ __forceinline__ void regroup_exchange(const Pool &pool, PathState &ps
     e[11*E] = mi_u32x2{__float_as_uint(ps.lambda), __float_as_uint(ps.scramble)};
     e[12*E] = mi_u32x2{(uint32_t)ps.rng.s0, (uint32_t)(ps.rng.s0 >> 32)};
     e[13*E] = mi_u32x2{(uint32_t)ps.rng.s1, (uint32_t)(ps.rng.s1 >> 32)};
-    if constexpr(NS > 14) e[14*E] = mi_u32x2{(uint32_t)ps.index, (uint32_t)(ps.index >> 32)};
-    if constexpr(NS > 15) e[15*E] = mi_u32x2{ps.prev_mode, 0u};
+    if constexpr(NB > 14) e[14*E] = mi_u32x2{(uint32_t)ps.index, (uint32_t)(ps.index >> 32)};
+    if constexpr(NB > 15) e[15*E] = mi_u32x2{ps.prev_mode, 0u};
+    if constexpr(MEDIA)
+    { /* extended kernels: the medium of the edge that ended here, the sampled free-flight distance (a volume vertex lies there), the path's time */
+      e[(NB + 0)*E] = mi_u32x2{__float_as_uint(ps.cur.mu_s), __float_as_uint(ps.cur.mu_t)};
+      e[(NB + 1)*E] = mi_u32x2{__float_as_uint(ps.cur.g), (uint32_t)ps.cur.med};
+      e[(NB + 2)*E] = mi_u32x2{__float_as_uint(ps.clip), __float_as_uint(ps.time)};
+    }
     tracing = false; ps.active = 0; ps.sh_pending = 0;
   }
   if(pull)
@@ -348,8 +368,14 @@ __device__ __forceinline__ void regroup_exchange(const Pool &pool, PathState &ps
     ps.lambda = __uint_as_float(w11.x); ps.scramble = __uint_as_float(w11.y);
     ps.rng.s0 = (unsigned long long)w12.x | ((unsigned long long)w12.y << 32);
     ps.rng.s1 = (unsigned long long)w13.x | ((unsigned long long)w13.y << 32);
-    if constexpr(NS > 14) { const mi_u32x2 w14 = e[14*E]; ps.index = (unsigned long long)w14.x | ((unsigned long long)w14.y << 32); }
-    if constexpr(NS > 15) { const mi_u32x2 w15 = e[15*E]; ps.prev_mode = w15.x; }
+    if constexpr(NB > 14) { const mi_u32x2 w14 = e[14*E]; ps.index = (unsigned long long)w14.x | ((unsigned long long)w14.y << 32); }
+    if constexpr(NB > 15) { const mi_u32x2 w15 = e[15*E]; ps.prev_mode = w15.x; }
+    if constexpr(MEDIA)
+    {
+      const mi_u32x2 a = e[(NB + 0)*E], b = e[(NB + 1)*E], c = e[(NB + 2)*E];
+      ps.cur.mu_s = __uint_as_float(a.x); ps.cur.mu_t = __uint_as_float(a.y); ps.cur.g = __uint_as_float(b.x); ps.cur.med = (int)b.y;
+      ps.clip = __uint_as_float(c.x); ps.time = __uint_as_float(c.y);
+    }
     ps.active = 1; ps.sh_pending = 0;
     if(PTDL) { ps.sh_dir = mk3(0.0f, 0.0f, 0.0f); ps.sh_dist = 0.0f; ps.sh_value = 0.0f; ps.sh_light = 0u; ps.sh_length = 0; }
     tracing = true; tr_shadow = false;
@@ -364,7 +390,7 @@ __device__ __forceinline__ void regroup_exchange(const Pool &pool, PathState &ps
   if(post) pool.list[cls*E + MI_SEL3(p, cls) + crank] = (unsigned short)id_post;
   if(pull) pool.list[MI_POOL_CLASSES*E + nfree + trank] = (unsigned short)id_pull;
   {
-    const uint32_t q[MI_POOL_CLASSES] = { p[0] + k[0], p[1] + k[1], p[2] + k[2] };
+    const uint32_t q[MI_POOL_CLASSES] = { p[0] + k[0], p[1] + k[1], p[2] + k[2], p[3] + k[3] };
     pool_leave<false>(pool, MI_POOL_PACK(q, nfree + m));
   }
   __builtin_amdgcn_s_setprio(PRIO);

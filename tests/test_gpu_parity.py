@@ -13,7 +13,7 @@ import json
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, SCENE_0010, SCENE_ALL, SCENE_CAM_MB, SCENE_FINE, SCENE_FOG, SCENE_MB, SCENE_MB_LIGHT, SCENE_MB_ROUND, SCENE_MEDIA, SCENE_NESTED, SCENE_METAL, SCENE_ROUGH, load_pkg, make_scene, oracle_intersect, oracle_records, oracle_render
+from helpers import oracle_lib, GOLDEN, SCENE_0010, SCENE_ALL, SCENE_CAM_MB, SCENE_FINE, SCENE_FOG, SCENE_MB, SCENE_MB_LIGHT, SCENE_MB_ROUND, SCENE_MEDIA, SCENE_NESTED, SCENE_METAL, SCENE_ROUGH, load_pkg, make_scene, oracle_intersect, oracle_records, oracle_render
 
 pkg = load_pkg()
 pytestmark = pytest.mark.gpu
@@ -44,7 +44,7 @@ def check_work(cnt, ocnt, traversal, tol=1e-3, keys=(0, 1, 2, 3)):
         if traversal == "exact" or k == 0:
             assert abs(cnt[k] - ocnt[k]) <= tol * ocnt[k], (k, cnt[k], ocnt[k])
         else:
-            assert (1 - tol) * ocnt[k] <= cnt[k] <= 1.5 * ocnt[k], (k, cnt[k], ocnt[k])
+            assert (1 - tol) * ocnt[k] <= cnt[k] <= 1.2 * ocnt[k], (k, cnt[k], ocnt[k])      # measured: +7 % node visits, +12 % primitive tests
 
 
 def rel(a, b):
@@ -60,6 +60,10 @@ CASES = [
     ("fine backdrop (tree in HBM) ptdl mv8", SCENE_FINE, pkg.MI_SAMPLER_PTDL, 1280, 720, 8, 10000),
     ("metal pt mv8", SCENE_METAL, pkg.MI_SAMPLER_PT, 1280, 720, 8, 8000),
     ("metal ptdl mv8", SCENE_METAL, pkg.MI_SAMPLER_PTDL, 1280, 720, 8, 8000),
+    # row a19 in the reference BUILD's behaviour (mi_scene_set_metal_reference / oracle_set_reference_metal: the NaN of its compiled
+    # Fresnel term ends 2-4 % of the samples at a gold vertex, src/shaders/metal.c:79-157): the same predicate on both sides, path for path
+    ("metal pt mv8, reference build", SCENE_METAL, pkg.MI_SAMPLER_PT, 1280, 720, 8, 60000),
+    ("metal ptdl mv8, reference build", SCENE_METAL, pkg.MI_SAMPLER_PTDL, 1280, 720, 8, 40000),
     # homogeneous medium inside the glass sphere (`interior`, `medium_rgb`): free-flight sampling, volume
     # vertices, Henyey-Greenstein, transmittance and volume pdfs in next event estimation / MIS; depth 32 = long random walks
     ("media pt mv8", SCENE_MEDIA, pkg.MI_SAMPLER_PT, 1280, 720, 8, 60000),
@@ -106,14 +110,31 @@ def test_paths_match_oracle(name, scene_path, sampler, w, h, mv, n, traversal):
     scene = make_scene(scene_path, width=w, height=h, max_verts=mv, sampler=sampler, pointsampler=points_of(name))
     be = pkg.Backend(scene, traversal=traversal)
     first = 12345
-    gpu = be.trace_paths(first, n)
-    ora = oracle_records(scene, first, n)
+    reference_build = name.endswith("reference build")
+    if reference_build:
+        be.set_metal_reference(True)
+        oracle_lib().oracle_set_reference_metal(1)
+    try:
+        gpu = be.trace_paths(first, n)
+        ora = oracle_records(scene, first, n)
+    finally:
+        oracle_lib().oracle_set_reference_metal(0)
+    if reference_build:
+        # the switch does something: paths end at metal vertices that the formula as written lets go on
+        be.set_metal_reference(False)
+        plain = be.trace_paths(first, n)
+        assert 0.005 * n < (plain["length"] != gpu["length"]).sum() < 0.1 * n
     assert np.array_equal(gpu["index"], ora["index"])
     for f in ("pixel_i", "pixel_j", "lambda", "time", "scramble"):
         assert np.abs(gpu[f] - ora[f]).max() <= 1e-5, f
     # what the build achieves (99.9995 % identical paths on 20 M-path soaks), not a loose bound: at most
     # 2 paths in 100 000 may part ways with the oracle (grazing hits decided by the last ulp of the device libm's sinf / atan2f)
     allowed = max(2, int(np.ceil(2e-5 * n)))
+    if reference_build:
+        # the reference build's NaN is the SIGN of a rounding error of cos theta (oracle/oracle_shade.c:638-663): where the device's cosine
+        # differs from the host's in the last bit (sinf / cosf of the two libms, 1 ulp apart on a few per cent of their arguments) the verdict
+        # is a coin both sides toss. Measured: 27 of 60 000 (pt), i.e. 4.5e-4; every other field of the agreeing paths is held to the usual bounds
+        allowed = int(np.ceil(1e-3 * n))
     same = gpu["length"] == ora["length"]
     assert (~same).sum() <= allowed, (~same).sum()
     # a path's splat count also changes when ONE of its next-event connections flips (a shadow ray grazing an edge, a weight at the
@@ -129,14 +150,16 @@ def test_paths_match_oracle(name, scene_path, sampler, w, h, mv, n, traversal):
         # positions drift with every glossy bounce (libm sin/cos/atan2 differ in the last ulp between host and device)
         # (from the fifth vertex on only a few hundred of the paths are left and the 99.9th percentile is the single most chaotic one --
         # a path bouncing around inside the glass sphere amplifies a last-ulp difference a thousandfold: the 99th is asserted there)
-        q = 0.999 if k <= 4 else 0.99
-        assert np.quantile(dx, q) < (2e-3 if k <= 2 else 1e-2)
+        # Round 4: the 99.9th percentile at every vertex; where fewer than 3000 paths are left, at most three of them may lie outside
+        # (it used to be the 99th percentile for every case from the fifth vertex on: ten times as many outliers as the chaotic path needs)
+        outliers = max(3, int(np.ceil(1e-3 * m.sum())))
+        assert (dx >= (2e-3 if k <= 2 else 1e-2)).sum() <= outliers
         # a moving camera's frame comes out of acosf / sinf per path: the last-ulp libm difference sits on every vertex from the start
-        assert np.quantile(rel(gpu["v"]["throughput"][m, k], ora["v"]["throughput"][m, k]), q) < (2e-2 if name.startswith(("camera motion blur", "moving geometry")) else 1e-3)
+        assert (rel(gpu["v"]["throughput"][m, k], ora["v"]["throughput"][m, k]) >= (2e-2 if name.startswith(("camera motion blur", "moving geometry")) else 1e-3)).sum() <= outliers
         assert (gpu["v"]["flags"][m, k] != ora["v"]["flags"][m, k]).sum() <= allowed
         assert (gpu["v"]["mode"][m, k] != ora["v"]["mode"][m, k]).sum() <= allowed
         assert (gpu["v"]["shader"][m, k] != ora["v"]["shader"][m, k]).sum() <= allowed
-        assert np.quantile(rel(gpu["v"]["pdf"][m, k], ora["v"]["pdf"][m, k]), q) < (2e-2 if name.startswith(("camera motion blur", "moving geometry")) else 5e-3)
+        assert (rel(gpu["v"]["pdf"][m, k], ora["v"]["pdf"][m, k]) >= (2e-2 if name.startswith(("camera motion blur", "moving geometry")) else 5e-3)).sum() <= outliers
     m = same & (gpu["num_splats"] == ora["num_splats"]) & (ora["num_splats"] > 0)
     if m.sum():
         a, b = gpu["splat"]["value"][m, 0], ora["splat"]["value"][m, 0]

@@ -74,7 +74,13 @@ CASES = [
 # few percent of the samples: NaN -> clamp -> R = 0, a black sample that ends the path. The oracle evaluates the same
 # formula with IEEE sqrt and keeps those samples; every such mismatch is a path the REFERENCE ends at a metal vertex
 # with lambda > 600 nm (asserted below).
-MIN_SAME_LENGTH = {"metal_mv8": 0.99, "metal_ptdl_mv8": 0.99}
+MIN_SAME_LENGTH = {"metal_mv8": 0.99, "metal_ptdl_mv8": 0.99,
+                   # with the emulation of the reference build's NaN (METAL_REFERENCE_CASES below): measured 0.9963 / 0.9953. Not the 0.998 of the
+                   # other cases, and it cannot be: the NaN is the SIGN OF A ROUNDING ERROR of cost2r (oracle/oracle_shade.c:638-663), the
+                   # reference's cosr and the oracle's differ in the last bit wherever -ffast-math contracted something on the way, so sample by
+                   # sample the verdict is a coin that both sides toss -- what can be pinned is that they toss it equally often and in the same
+                   # place (test_metal_reference_build_ends_the_references_share_of_paths)
+                   "metal_mv8@reference": 0.994, "metal_ptdl_mv8@reference": 0.994}
 _ = [
 ]
 
@@ -102,9 +108,28 @@ def rel(a, b):
     return np.abs(a - b) / np.maximum(1e-20, np.maximum(np.abs(a), np.abs(b)))
 
 
-@pytest.mark.parametrize("name,sampler,scene_path,etol", CASES)
-def test_oracle_matches_reference_paths(name, sampler, scene_path, etol):
-    g = np.load(GOLDEN / f"paths_{name}.npz")
+# Row a19 pinned to the reference BUILD (round 4): the same two metal fixtures with the oracle's emulation of the reference build's
+# NaN (oracle_set_reference_metal: the compiled Fresnel sequence of src/shaders/metal.c:79-157 restated operation by operation,
+# oracle/oracle_shade.c) -- at the thresholds every other case meets, not the 0.99 the formula as written needs.
+METAL_REFERENCE_CASES = [
+    ("metal_mv8@reference", pkg.MI_SAMPLER_PT, SCENE_METAL, 1.5e-3),
+    ("metal_ptdl_mv8@reference", pkg.MI_SAMPLER_PTDL, SCENE_METAL, 1e-2),
+]
+
+
+class reference_metal:
+    def __enter__(self):
+        oracle_lib().oracle_set_reference_metal(1)
+        return self
+
+    def __exit__(self, *a):
+        oracle_lib().oracle_set_reference_metal(0)
+
+
+def oracle_for_case(name, sampler, scene_path):
+    """(reference records, oracle records) of one case, or None when this host cannot emulate the reference build's rsqrtss"""
+    fixture = name.split("@")[0]
+    g = np.load(GOLDEN / f"paths_{fixture}.npz")
     ref = g["records"]
     s = make_scene(scene_path, width=int(g["width"]), height=int(g["height"]), max_verts=int(g["max_verts"]), sampler=sampler,
                    pointsampler=pkg.MI_POINTS_HALTON if name.startswith("halton_") else pkg.MI_POINTS_RAND)
@@ -112,14 +137,79 @@ def test_oracle_matches_reference_paths(name, sampler, scene_path, etol):
         with reference_rsqrt() as emu:
             ora = oracle_records(s, 0, len(ref))
         if not emu.exact:
-            pytest.skip("rsqrtss of this host differs from the CPU the fixtures were dumped on; thin media need it (see CASES)")
+            return None
+    elif name.endswith("@reference"):
+        with reference_metal():
+            ora = oracle_records(s, 0, len(ref))
     else:
         ora = oracle_records(s, 0, len(ref))
+    return ref, ora
+
+
+def measure(ref, ora):
+    """what the oracle achieves against the reference's dump: the quantities the test bounds"""
+    m = {}
+    same_len = ref["length"] == ora["length"]
+    m["same_length"] = float(same_len.mean())
+    bad_p = bad_m = 0.0
+    for k in range(1, 8):
+        sel = same_len & (ref["length"] > k)
+        if sel.sum():
+            bad_p = max(bad_p, float((ref["v"]["prim"][sel, k] != ora["v"]["prim"][sel, k]).sum()) / float(sel.sum()))
+            bad_m = max(bad_m, float((ref["v"]["mode"][sel, k] != ora["v"]["mode"][sel, k]).sum()) / float(sel.sum()))
+    m["worst_prim_mismatch"] = bad_p
+    m["worst_mode_mismatch"] = bad_m
+    same_splats = ref["num_splats"] == ora["num_splats"]
+    m["same_splats"] = float(same_splats.mean())
+    both = same_len & same_splats
+    devs, nan_same = [], []
+    for k in range(ref["splat"].shape[1]):
+        sel = both & (ref["num_splats"] > k)
+        if sel.sum():
+            a, b = ref["splat"]["value"][sel, k], ora["splat"]["value"][sel, k]
+            nan_same.append(np.isnan(a) == np.isnan(b))
+            fin = np.isfinite(a) & np.isfinite(b)
+            devs.append(rel(a[fin], b[fin]))
+    devs = np.concatenate(devs)
+    m["nan_same"] = float(np.concatenate(nan_same).mean())
+    m["splat_dev_median"] = float(np.median(devs))
+    m["splat_dev_p99"] = float(np.quantile(devs, 0.99))
+    e_ref, e_ora = np.nan_to_num(ref["splat"]["col"][both]).sum(axis=(0, 1)), np.nan_to_num(ora["splat"]["col"][both]).sum(axis=(0, 1))
+    m["energy_dev"] = float(np.abs(e_ref - e_ora).max() / np.abs(e_ref).max())
+    return m
+
+
+def measure_case(name, sampler, scene_path):
+    r = oracle_for_case(name, sampler, scene_path)
+    return None if r is None else measure(*r)
+
+
+with open(GOLDEN / "oracle_vs_reference_measured.json") as _f:
+    MEASURED = json.load(_f)        # written by tests/golden/measure_oracle_vs_reference.py (committed next to it)
+
+
+def bound_fraction(measured, floor):
+    """a fraction of agreeing paths may drop by a quarter of what the measurement misses (other libm, other compiler), never below `floor`"""
+    return max(floor, 1.0 - 1.25 * (1.0 - measured) - 2e-4)
+
+
+def bound_dev(measured, ceiling, slack=1.5):
+    return min(ceiling, slack * measured + 1e-7)
+
+
+@pytest.mark.parametrize("name,sampler,scene_path,etol", CASES + METAL_REFERENCE_CASES)
+def test_oracle_matches_reference_paths(name, sampler, scene_path, etol):
+    r = oracle_for_case(name, sampler, scene_path)
+    if r is None:
+        pytest.skip("rsqrtss of this host differs from the CPU the fixtures were dumped on; thin media need it (see CASES)")
+    ref, ora = r
     for f, tol in (("pixel_i", 1e-4), ("pixel_j", 1e-4), ("lambda", 1e-4), ("time", 1e-6), ("scramble", 1e-6)):
         assert np.abs(ref[f] - ora[f]).max() <= tol, f
+    got, was = measure(ref, ora), MEASURED[name]
     same_len = ref["length"] == ora["length"]
-    assert same_len.mean() >= MIN_SAME_LENGTH.get(name, 0.998)
-    if name in MIN_SAME_LENGTH:
+    # floors: what every case must reach whatever was measured (the module's stated tolerances); bounds: the measurement plus a margin
+    assert got["same_length"] >= bound_fraction(was["same_length"], MIN_SAME_LENGTH.get(name, 0.998)), (got["same_length"], was["same_length"])
+    if name in MIN_SAME_LENGTH and not name.endswith("@reference"):
         bad = np.where(~same_len)[0]
         shorter = ref["length"][bad] < ora["length"][bad]
         last = np.minimum(ref["length"][bad] - 1, 7)
@@ -131,26 +221,47 @@ def test_oracle_matches_reference_paths(name, sampler, scene_path, etol):
             # rough-metal bounce chains: a few hundred paths per depth, one neighbouring backdrop quad is 0.3 %
             # at least the stated fraction, but one stray path is allowed at depths only a few hundred of the fixture's paths reach
             bad_p, bad_m = (ref["v"]["prim"][m, k] != ora["v"]["prim"][m, k]).sum(), (ref["v"]["mode"][m, k] != ora["v"]["mode"][m, k]).sum()
-            assert bad_p <= max(1, (0.005 if name in MIN_SAME_LENGTH else 0.001) * m.sum())
-            assert bad_m <= max(1, (0.005 if name in MIN_SAME_LENGTH else 0.002) * m.sum())
+            metal = name.split("@")[0] in ("metal_mv8", "metal_ptdl_mv8")
+            assert bad_p <= max(1, min(0.005 if metal else 0.001, 1.5 * was["worst_prim_mismatch"] + 2e-4) * m.sum())
+            assert bad_m <= max(1, min(0.005 if metal else 0.002, 1.5 * was["worst_mode_mismatch"] + 2e-4) * m.sum())
+    assert got["same_splats"] >= bound_fraction(was["same_splats"], 0.995), (got["same_splats"], was["same_splats"])
     same_splats = ref["num_splats"] == ora["num_splats"]
-    assert same_splats.mean() >= 0.995
     both = same_len & same_splats
-    devs, nan_same = [], []
     for k in range(ref["splat"].shape[1]):
         m = both & (ref["num_splats"] > k)
         if m.sum():
             assert (ref["splat"]["length"][m, k] == ora["splat"]["length"][m, k]).all()
-            a, b = ref["splat"]["value"][m, k], ora["splat"]["value"][m, k]
-            # the reference's own weights are NaN for a few connections (inf/inf in its MIS products; view_splat drops them)
-            nan_same.append(np.isnan(a) == np.isnan(b))
-            fin = np.isfinite(a) & np.isfinite(b)
-            devs.append(rel(a[fin], b[fin]))
-    devs = np.concatenate(devs)
-    assert np.concatenate(nan_same).mean() >= 0.999
-    assert np.median(devs) < 5e-4 and np.quantile(devs, 0.99) < 5e-2
-    e_ref, e_ora = np.nan_to_num(ref["splat"]["col"][both]).sum(axis=(0, 1)), np.nan_to_num(ora["splat"]["col"][both]).sum(axis=(0, 1))
-    assert np.all(np.abs(e_ref - e_ora) <= etol * np.abs(e_ref).max())
+    # the reference's own weights are NaN for a few connections (inf/inf in its MIS products; view_splat drops them)
+    assert got["nan_same"] >= 0.999
+    assert got["splat_dev_median"] < bound_dev(was["splat_dev_median"], 5e-4), (got["splat_dev_median"], was["splat_dev_median"])
+    assert got["splat_dev_p99"] < bound_dev(was["splat_dev_p99"], 5e-2), (got["splat_dev_p99"], was["splat_dev_p99"])
+    assert got["energy_dev"] <= min(etol, 2.0 * was["energy_dev"] + 1e-4), (got["energy_dev"], was["energy_dev"])
+
+
+@pytest.mark.parametrize("name,sampler", [("metal_mv8", pkg.MI_SAMPLER_PT), ("metal_ptdl_mv8", pkg.MI_SAMPLER_PTDL)])
+def test_metal_reference_build_ends_the_references_share_of_paths(name, sampler):
+    """Row a19 against the reference BUILD. Its metal sample() ends 2-4 % of the samples at a gold vertex with a NaN (src/shaders/metal.c:
+    79-157 as gcc -O3 -ffast-math compiles it); `oracle_set_reference_metal(1)` restates that instruction sequence. The verdict on one
+    sample is the sign of a rounding error, so it cannot agree path for path (see MIN_SAME_LENGTH) -- pinned here: with the formula as
+    written the oracle ends clearly FEWER paths at a metal vertex than the reference's dump does and nearly every mismatching path is
+    one the reference cut short; with the emulation the two end equally many there (within three standard deviations of the
+    number of such verdicts), the mismatches go both ways, and fewer paths mismatch than before."""
+    ref, plain = oracle_for_case(name, sampler, SCENE_METAL)
+    _, emu = oracle_for_case(name + "@reference", sampler, SCENE_METAL)
+
+    def ends_at_metal(r):
+        last = np.minimum(r["length"] - 1, 7)
+        return int(((r["v"]["shader"][np.arange(len(r)), last] == 10) & (r["length"] < 8)).sum())
+
+    n_ref, n_plain, n_emu = ends_at_metal(ref), ends_at_metal(plain), ends_at_metal(emu)
+    killed = n_ref - n_plain                                    # the paths the reference build's NaN ended in this fixture
+    assert killed >= 8, (n_ref, n_plain)
+    assert abs(n_emu - n_ref) <= 3.0 * np.sqrt(2.0 * killed), (n_ref, n_emu, killed)
+    d_plain, d_emu = ref["length"] != plain["length"], ref["length"] != emu["length"]
+    assert (ref["length"][d_plain] < plain["length"][d_plain]).mean() >= 0.85          # one-sided: the reference is the shorter one
+    shorter = (ref["length"][d_emu] < emu["length"][d_emu]).mean()
+    assert 0.2 <= shorter <= 0.8, shorter                                                # both ways now
+    assert d_emu.sum() <= d_plain.sum()
 
 
 def test_first_vertex_geometry_close():

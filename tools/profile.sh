@@ -26,8 +26,8 @@ out = "$OUT"
 build_id = hashlib.sha256(open("$R/corona-13_amd/csrc/libcorona_mi.so", "rb").read()).hexdigest()[:16]
 # the timed kernels: production instantiation (no debug counters), tree in LDS -- pt with the FAST rounds (the bench line) and ptdl with
 # the exact ones (its `secondary`): the library's own choice per scene; bench.py also launches the counting instantiations once, outside its timed regions
-KERNELS = {"pt": "mi_path_kernel<false, false, true, false, false, false, false, %s>" % ("true" if json.load(open(out + "/bench.json"))["config"]["traversal"] == "fast" else "false"),
-           "ptdl": "mi_path_kernel<false, true, true, false, false, false, false, false>"}
+KERNELS = {"pt": "mi_path_kernel<false, false, true, false, false, false, false, %s, false>" % ("true" if json.load(open(out + "/bench.json"))["config"]["traversal"] == "fast" else "false"),
+           "ptdl": "mi_path_kernel<false, true, true, false, false, false, false, false, false>"}
 for tag, kname in KERNELS.items():
     res = {"kernel": kname, "build_id": build_id}
     for f in glob.glob(out + "/pmc_*.csv"):
