@@ -158,8 +158,11 @@ class StubBackend:
     def set_framebuffer_tensor(self, t):
         self.fb = t
 
+    SPLIT = 1 << 20            # float32 framebuffer elements count exactly up to 2^24: element 0 takes count % 2^20, element 1 count // 2^20
+
     def render(self, first, count):
-        self.fb.view(-1)[0] += float(count)
+        self.fb.view(-1)[0] += float(count % self.SPLIT)
+        self.fb.view(-1)[1] += float(count // self.SPLIT)
         self.paths += count
 
     def sync(self):
@@ -387,6 +390,9 @@ def main():
         if dc[4] != nominal:
             raise SystemExit(f"bench.py: the kernel counted {dc[4]} paths, {nominal} were asked for")
         reduced_sum = float(host_fb.double().sum())
+        if args.stub:      # the stub's two counting elements (StubBackend.render), exact for jobs of any size
+            flat = host_fb.view(-1)
+            reduced_sum = float(flat[0].double() + flat[1].double() * StubBackend.SPLIT)
         # the finished frame itself is checked, not only the path count: mean image (gain-scaled XYZ, like the reference's sidecar) of
         # the last frame -- with N ranks under weak scaling the reduced frame holds N x spp samples per pixel
         spp_in_frame = cfg["spp"] * (world if scaling == "weak" else 1)

@@ -930,6 +930,44 @@ static void launch_path_kernel(mi_scene *s, bool record, int grid, uint64_t firs
   (void)path_kernel(s->d.sampler == MI_SAMPLER_PTDL, s->media, s->d_prims_t1 != nullptr, s->fast != 0, s->norg, which, &L);
 }
 
+/* the share of [first, first + count) that member k of n takes: contiguous, remainder indices to the lowest members */
+static inline void group_share(uint64_t first, uint64_t count, int n, int k, uint64_t *start, uint64_t *my)
+{
+  const uint64_t base = count/(uint64_t)n, rem = count%(uint64_t)n;
+  *my = base + ((uint64_t)k < rem ? 1 : 0);
+  *start = first + (uint64_t)k*base + ((uint64_t)k < rem ? (uint64_t)k : rem);
+}
+/* the next launch of a range of `left` path indices on a device with `grid` resident workgroups: every workgroup hands out its part of the
+   launch's range through a 32-bit LDS counter, so a part stays below 2^31 paths; a small range starts fewer workgroups */
+static inline uint64_t launch_chunk(uint64_t left, int grid, int *launch_grid)
+{
+  const uint64_t per_launch = (uint64_t)grid << 31;
+  const uint64_t n = left < per_launch ? left : per_launch;
+  const uint64_t need = (n + MI_BLOCK - 1)/MI_BLOCK;
+  *launch_grid = (uint64_t)grid > need ? (int)need : grid;
+  return n;
+}
+
+extern "C" int mi_plan_launches(uint64_t first_index, uint64_t count, int members, int grid, mi_launch *out, int max_out)
+{
+  if(members < 1 || grid < 1) return fail(MI_ERR_ARG, "mi_plan_launches: bad argument");
+  int num = 0;
+  for(int k=0;k<members;k++)
+  {
+    uint64_t start, my;
+    group_share(first_index, count, members, k, &start, &my);
+    for(uint64_t done = 0; done < my; )
+    {
+      int g;
+      const uint64_t n = launch_chunk(my - done, grid, &g);
+      if(out && num < max_out) { out[num].member = k; out[num].grid = g; out[num].first = start + done; out[num].count = n; }
+      num++;
+      done += n;
+    }
+  }
+  return num;
+}
+
 extern "C" int mi_render(mi_scene *s, uint64_t first_index, uint64_t count)
 {
   MI_ENTER(s, "null scene");
@@ -937,17 +975,14 @@ extern "C" int mi_render(mi_scene *s, uint64_t first_index, uint64_t count)
   { const int e = ensure_halton(s, first_index + count); if(e) return e; }
   HIPCHK(hipEventRecord(s->ev0, s->stream));
   s->kernel_launches_last = 0;
-  /* every workgroup hands out its share of the range through a 32-bit LDS counter: keep a share below 2^31 paths */
-  const uint64_t per_launch = (uint64_t)s->grid << 31;
-  for(uint64_t done = 0; done < count; done += per_launch)
+  for(uint64_t done = 0; done < count; )
   {
-    const uint64_t n = count - done < per_launch ? count - done : per_launch;
-    int grid = s->grid;
-    const uint64_t need = (n + MI_BLOCK - 1)/MI_BLOCK;
-    if((uint64_t)grid > need) grid = (int)need;
+    int grid;
+    const uint64_t n = launch_chunk(count - done, s->grid, &grid);        /* (mi_plan_launches: the same arithmetic, for hosts without a GPU) */
     launch_path_kernel(s, false, grid, first_index + done, n, nullptr);
     HIPCHK(hipGetLastError());
     s->kernel_launches_last++;
+    done += n;
   }
   HIPCHK(hipEventRecord(s->ev1, s->stream));
   s->have_timing = 1;
@@ -1367,11 +1402,10 @@ extern "C" int mi_group_render(mi_group *g, uint64_t first_index, uint64_t count
 { /* member k takes the k-th contiguous share of the range (remainder indices to the lowest members); returns once everything is queued */
   if(!g) return fail(MI_ERR_ARG, "null group");
   DeviceRestore restore;
-  const uint64_t base = count/(uint64_t)g->n, rem = count%(uint64_t)g->n;
   for(int k=0;k<g->n;k++)
   {
-    const uint64_t my = base + ((uint64_t)k < rem ? 1 : 0);
-    const uint64_t start = first_index + (uint64_t)k*base + ((uint64_t)k < rem ? (uint64_t)k : rem);
+    uint64_t start, my;
+    group_share(first_index, count, g->n, k, &start, &my);
     int e = mi_render(g->member[k], start, my);
     if(!e && hipEventRecord(g->rendered[k], g->member[k]->stream) != hipSuccess) e = fail(MI_ERR_DEVICE, "mi_group_render: cannot record an event");
     if(e)

@@ -378,6 +378,14 @@ int  mi_group_sync(mi_group *g);
 int  mi_group_counters(mi_group *g, uint64_t out[8]);
 void mi_group_destroy(mi_group *g);
 
+/* planning hook (no device is touched): the kernel launches mi_group_render(first_index, count) queues on a group of `members` devices whose
+ * scenes run `grid` resident workgroups each -- the arithmetic mi_group_render and mi_render use themselves: member k's contiguous share
+ * (remainder indices to the lowest members, the job counter of src/view.c:618-645 split over devices), cut into launches that keep every
+ * workgroup's part below 2^31 path indices (a workgroup hands its part out through a 32-bit counter). Writes at most max_out entries,
+ * returns the number of launches. Lets a host without GPUs check a configuration (8 x MI355X, 3840x2160, 1024 spp) before it runs. */
+typedef struct mi_launch { int32_t member, grid; uint64_t first, count; } mi_launch;
+int  mi_plan_launches(uint64_t first_index, uint64_t count, int members, int grid, mi_launch *out, int max_out);
+
 /* human readable description of the last error on this thread ("" if none) */
 const char *mi_last_error(void);
 

@@ -53,6 +53,25 @@ def test_single_rank_and_launcher_mismatch():
     assert r.returncode != 0 and "--gpus 4" in (r.stdout + r.stderr)
 
 
+def test_gpus_8_weak_cfg2_and_strong_cfg5():
+    """the driver's 1 -> 8 curve without hardware: eight spawned ranks (gloo), cfg 2 weak (every rank a whole 64-spp frame of its own
+    indices) and cfg 5 strong (configs[4]: 3840x2160, 1024 spp = 8.56 G paths split eight ways, one framebuffer reduce of 100 MB)"""
+    r = run_bench("--gpus", "8", "--stub", "--steps", "2", "--warmup", "1", "--config", "cfg2")
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json_line(r.stdout)
+    per_frame = 64 * 1280 * 736
+    assert out["n_gpus"] == 8 and out["rccl_ranks"] == 8 and out["scaling"] == "weak"
+    assert out["config"]["paths_per_step"] == 8 * per_frame and out["config"]["paths_per_step_per_gpu"] == per_frame
+    assert out["stub"]["reduced_sum_last_frame"] == out["stub"]["expected"] == 8 * per_frame
+    r = run_bench("--gpus", "8", "--stub", "--steps", "1", "--warmup", "0", "--config", "cfg5")
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json_line(r.stdout)
+    job = 1024 * 3840 * 2176
+    assert out["n_gpus"] == 8 and out["scaling"] == "strong"
+    assert out["config"]["paths_per_step"] == job and out["config"]["paths_per_step_per_gpu"] == job // 8
+    assert out["stub"]["reduced_sum_last_frame"] == out["stub"]["expected"] == job        # exact: 8 556 380 160 paths
+
+
 def test_cfg5_defaults_to_strong_scaling():
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench_mod", REPO / "bench.py")
