@@ -460,6 +460,20 @@ def main():
                 "live_work_per_sample": dict(live, rays=dc[0] / paths),
                 "note": "B = 128 N_node + 104 N_prim + 384 N_splat per sample (SURVEY 8(d)) priced with the reference's work counts; served from LDS and L2, not HBM"}
 
+    def valu_floor(config, r):
+        f = Path(__file__).resolve().parent / "profiles" / "r04_valu_floor.json"
+        if not f.exists() or config != "cfg2":
+            return None                      # (cfg 3: the ptdl vertex -- next event estimation, shadow rays -- has no isolated count yet)
+        fl = json.load(open(f))
+        b, vv, mix = fl["blocks"], fl["vertex_valu"], fl["mix"][config]
+        dc, paths = r["dc"], max(r["dc"][4], 1)
+        rays, nodes, prims = dc[0] / paths, dc[1] / paths, dc[3] / paths
+        surf = rays * mix["surface_vertices_per_ray"]
+        vertex = mix["diffuse_share"] * vv["diffuse_on_quad"] + mix["dielectric_share"] * vv["dielectric_on_line"]
+        terms = {"node_visits": nodes * b["node_visit"]["valu"] / 64.0, "prim_tests": prims * b["prim_test"]["valu"] / 64.0,
+                 "generate": b["generate"]["valu"] / 64.0, "surface_vertices": surf * vertex / 64.0}
+        return {"per_path": sum(terms.values()), "terms": terms, "source": "profiles/r04_valu_floor.json x live work counters"}
+
     def roofline_of(config, r):
         """What bounds the kernel: VALU issue (MFMA is not used, DRAM sees 0.2 % of the algorithmic bytes). achieved = wave64 VALU
         instructions per second = SQ_INSTS_VALU per path (committed PMC pass of this command, profiles/) x paths per launch / the live
@@ -489,6 +503,15 @@ def main():
                 # FETCH_SIZE counts 128-B requests as 64 B on gfx950 (MI355X_MICROARCH.md, HBM section); counters are in KiB
                 out["traffic"] = (2.0 * prof["FETCH_SIZE"] + prof["WRITE_SIZE"]) * 1024.0
                 out["hbm_measured_gbs"] = out["traffic"] / (prof_ms * 1e-3) / 1e9 if prof_ms else None
+            # Instruction floor (round 4): the wave instructions the path's WORK needs if every instruction served 64 useful lanes -- the live
+            # work counters priced with the vector instructions one execution of each block takes (static counts of the product's own
+            # functions compiled in isolation: tools/valu_floor.py, tools/micro/floor_blocks.hip -> profiles/r04_valu_floor.json).
+            # floor_over_executed says how much of what the kernel executes is that work; efficiency = frac x floor_over_executed is the share
+            # of the machine's peak issue rate spent on it. A fatter kernel raises `frac` and lowers `floor_over_executed`.
+            floor = valu_floor(config, r)
+            if floor:
+                out.update({"valu_floor_per_path": floor["per_path"], "floor_over_executed": floor["per_path"] / instr_per_path,
+                            "efficiency": achieved / peak * floor["per_path"] / instr_per_path, "valu_floor_terms": floor["terms"], "valu_floor_source": floor["source"]})
             if "SQ_LDS_BANK_CONFLICT" in prof and prof.get("SQ_LDS_IDX_ACTIVE"):
                 out["lds_bank_conflict_share"] = prof["SQ_LDS_BANK_CONFLICT"] / prof["SQ_LDS_IDX_ACTIVE"]
         # LDS line: the node loop reads 7 x 16 B per node visit (six box planes x 4 children + 4 links) and moves about one 8-B stack

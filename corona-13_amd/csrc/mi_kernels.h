@@ -999,6 +999,9 @@ struct RayBox
   float nox, noy, noz, slack;
   float w0, w1;                          /* motion-blur kernels: 1 - time, time of the ray (weights of the shutter-open / -close boxes) */
 };
+#ifndef MI_PUSH_BLIND
+#define MI_PUSH_BLIND 1     /* cfg 2 16.12 -> 16.00 ms (FAST 16.91 -> 16.67), cfg 3 29.35 -> 29.27: 127 -> 102 scalar instructions per node visit (tools/valu_floor.py) */
+#endif
 #ifndef MI_SPEC_FMA
 #define MI_SPEC_FMA 0      /* 0: off. 1: in the ptdl FAST kernel and the ray-level test kernel, 2: in every FAST kernel -- cfg 2 17.71-17.79 against 18.01 ms,
                               cfg 3 (FAST rounds) 37.1 against 38.0; but the relaxed test lets through boxes the reference's test rejects, and a
@@ -1176,9 +1179,17 @@ __device__ __forceinline__ bool node_visit(const Lds &lds, lds_uint2 *lstack, co
     const bool p01 = __builtin_amdgcn_inverse_ballot_w64(H01 & H00);
     if(sp + 3 <= STACK)
     { /* all three slots are in LDS */
+#if MI_PUSH_BLIND
+      /* written whether or not the child is pushed -- an entry above the top of the stack is never read --, the stack pointer moves by the
+         flag: three stores without a divergent region each (each region is two scalar instructions, a branch and an EXEC restore) */
+      lstack[sp*BLOCK] = mi_u32x2{c11, __float_as_uint(t11)}; sp += p11 ? 1 : 0;
+      lstack[sp*BLOCK] = mi_u32x2{c10, __float_as_uint(t10)}; sp += p10 ? 1 : 0;
+      lstack[sp*BLOCK] = mi_u32x2{c01, __float_as_uint(t01)}; sp += p01 ? 1 : 0;
+#else
       if(p11) { lstack[sp*BLOCK] = mi_u32x2{c11, __float_as_uint(t11)}; sp++; }
       if(p10) { lstack[sp*BLOCK] = mi_u32x2{c10, __float_as_uint(t10)}; sp++; }
       if(p01) { lstack[sp*BLOCK] = mi_u32x2{c01, __float_as_uint(t01)}; sp++; }
+#endif
     }
     else
     {
