@@ -219,6 +219,8 @@ static int build_on_device(mi_scene *s, const mi_scene_desc *h, uint32_t *num_no
   BuildBufs b;
   memset(&b, 0, sizeof(b));
   b.n = n;
+  b.leaf_max = s->d_prims_t1 ? MI_BUILD_LEAF : MI_BUILD_LEAF_JOBS;          /* by the kind of leaf phase the scene's kernels run (mi_build.h) */
+  { const char *le = getenv("CORONA_MI_BUILD_LEAF"); if(le && atoi(le) >= 1 && atoi(le) <= 7) b.leaf_max = atoi(le); }
   hipEvent_t t0 = nullptr, t1 = nullptr;
   const bool verbose = getenv("CORONA_MI_VERBOSE") != nullptr;
   if(verbose) { (void)hipEventCreate(&t0); (void)hipEventCreate(&t1); }
@@ -229,6 +231,9 @@ static int build_on_device(mi_scene *s, const mi_scene_desc *h, uint32_t *num_no
   BALLOC(box, float, 8*(size_t)n) BALLOC(key_in, uint32_t, n) BALLOC(key, uint32_t, n) BALLOC(val_in, uint32_t, n) BALLOC(perm, uint32_t, n)
   BALLOC(left, int, n) BALLOC(right, int, n) BALLOC(parent, int, n) BALLOC(leaf_parent, int, n) BALLOC(first, int, n) BALLOC(last, int, n)
   BALLOC(ibox, float, 8*(size_t)n) BALLOC(visits, unsigned int, n)
+  /* moving primitives: a second box set (shutter close), like the reference's aabb1; CORONA_MI_BUILD_T1=0 keeps one box around both states (A/B) */
+  const bool two_states = s->d_prims_t1 != nullptr && !(getenv("CORONA_MI_BUILD_T1") && !atoi(getenv("CORONA_MI_BUILD_T1")));
+  if(two_states) { BALLOC(box1, float, 8*(size_t)n) BALLOC(ibox1, float, 8*(size_t)n) }
 #undef BALLOC
   if(verbose) (void)hipEventRecord(t0, 0);
   hipError_t e = hipMemset(b.visits, 0, sizeof(unsigned int)*n);
@@ -261,6 +266,8 @@ static int build_on_device(mi_scene *s, const mi_scene_desc *h, uint32_t *num_no
   { /* top-down collapse, one launch per level of the 4-wide tree */
     const uint32_t cap = n - 1;
     float4 *tnodes = (float4 *)dev((size_t)MI_NODE_FIELDS*cap*16);
+    float4 *tnodes_t1 = two_states ? (float4 *)dev((size_t)6*cap*16) : nullptr;
+    if(two_states && !tnodes_t1) e = hipErrorOutOfMemory;
     uint32_t *taxes = (uint32_t *)dev((size_t)cap*4);
     int *la = (int *)dev(sizeof(int)*(size_t)n), *lb = (int *)dev(sizeof(int)*(size_t)n);
     unsigned int *qa = (unsigned int *)dev(sizeof(int)*(size_t)n), *qb = (unsigned int *)dev(sizeof(int)*(size_t)n);
@@ -277,7 +284,7 @@ static int build_on_device(mi_scene *s, const mi_scene_desc *h, uint32_t *num_no
       e = hipMemcpy(cnt, hc, 8, hipMemcpyHostToDevice);
       if(e != hipSuccess) break;
       CollapseLists L = { la, qa, lb, qb, cnt, n_in };
-      hipLaunchKernelGGL(bl_collapse, dim3((n_in + BL_BLOCK - 1)/BL_BLOCK), dim3(BL_BLOCK), 0, 0, b, L, tnodes, taxes, cap);
+      hipLaunchKernelGGL(bl_collapse, dim3((n_in + BL_BLOCK - 1)/BL_BLOCK), dim3(BL_BLOCK), 0, 0, b, L, tnodes, taxes, cap, tnodes_t1);
       e = hipGetLastError();
       if(e == hipSuccess) e = hipMemcpy(hc, cnt, 8, hipMemcpyDeviceToHost);
       n_in = hc[1];
@@ -289,8 +296,13 @@ static int build_on_device(mi_scene *s, const mi_scene_desc *h, uint32_t *num_no
     if(e == hipSuccess && (hipMalloc(&s->d_nodes, (size_t)MI_NODE_FIELDS*N*16) != hipSuccess || hipMalloc(&s->d_axes, (size_t)N*4) != hipSuccess)) e = hipErrorOutOfMemory;
     if(e == hipSuccess)
     {
-      hipLaunchKernelGGL(bl_repack, dim3((MI_NODE_FIELDS*N + BL_BLOCK - 1)/BL_BLOCK), dim3(BL_BLOCK), 0, 0, (float4 *)s->d_nodes, (const float4 *)tnodes, N, cap);
+      hipLaunchKernelGGL(bl_repack, dim3((MI_NODE_FIELDS*N + BL_BLOCK - 1)/BL_BLOCK), dim3(BL_BLOCK), 0, 0, (float4 *)s->d_nodes, (const float4 *)tnodes, N, cap, (uint32_t)MI_NODE_FIELDS);
       e = hipGetLastError();
+      if(e == hipSuccess && two_states)
+      {
+        if(hipMalloc(&s->d_nodes_t1, (size_t)6*N*16) != hipSuccess) e = hipErrorOutOfMemory;
+        else { hipLaunchKernelGGL(bl_repack, dim3((6*N + BL_BLOCK - 1)/BL_BLOCK), dim3(BL_BLOCK), 0, 0, (float4 *)s->d_nodes_t1, (const float4 *)tnodes_t1, N, cap, 6u); e = hipGetLastError(); }
+      }
       if(e == hipSuccess) e = hipMemcpy(s->d_axes, taxes, (size_t)N*4, hipMemcpyDeviceToDevice);
     }
   }

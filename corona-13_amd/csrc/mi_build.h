@@ -9,6 +9,9 @@
  * traversal expects (children {0,1} = lower half along axis0, {2,3} = upper half). Primitive records are then gathered
  * into sorted order.
  *
+ * Scenes with moving primitives get the nodes' shutter-close boxes too (round 4: box1 / ibox1, DScene.nodes_t1), refitted on the same
+ * topology as the reference does (src/accel.d/qbvhmp.c:259-283); the traversal interpolates the two box sets at the ray's time.
+ *
  * The tree differs from the reference builder's (binned SAH sweep), so node-visit counters differ; closest hits do not
  * depend on the tree (tests/test_gpu_parity.py: same primitive and distance as the oracle on the host-built tree, bit
  * for bit, apart from exact ties).
@@ -19,19 +22,27 @@
 #include "mi_kernels.h"
 
 #ifndef MI_BUILD_LEAF
-#define MI_BUILD_LEAF 2           /* most primitives in a leaf: 2 measured best (1, 2.2 tests per ray instead of 4; 2/3/4/6/8 tried) */
+#define MI_BUILD_LEAF 2           /* most primitives in a leaf where every lane works through its own leaf (motion-blur kernels): 2 measured best in rounds 1-3
+                                     (2/3/4/6/8 tried) and again in round 4: scenes/0059_mb 26.5 ms with 2, 28.8 with 4 */
+#endif
+#ifndef MI_BUILD_LEAF_JOBS
+#define MI_BUILD_LEAF_JOBS 4      /* ... where the primitive tests of a round are dealt out over all lanes (leaf_jobs: every other kernel): regression/0010_pt
+                                     15.60 ms with 4 (538 nodes: the tree fits LDS), 15.67 with 2 (985 nodes, read from HBM), 16.0 with the reference's tree;
+                                     node visits 1.018 x the reference's count on its own tree (2: 1.089 x), primitive tests 0.73 x (0.44 x) */
 #endif
 #define BL_BLOCK 256
 
 struct BuildBufs
 {
   uint32_t n;                     /* primitives */
+  int leaf_max;                   /* most primitives in a leaf */
   float *box;                     /* [n][8]: lo xyz, pad, hi xyz, pad -- in ORIGINAL order */
   uint32_t *key_in, *key, *val_in, *perm;        /* Morton codes and primitive ids, unsorted / sorted */
   int *left, *right, *parent;     /* binary radix tree: children of internal node i (>= 0: internal, < 0: ~leaf position), parents */
   int *leaf_parent;               /* parent of sorted leaf i */
   int *first, *last;              /* sorted range of internal node i */
   float *ibox;                    /* [n-1][8] boxes of the internal nodes */
+  float *box1, *ibox1;            /* scenes with moving primitives: the same at shutter CLOSE (box / ibox then hold the shutter-open state), else NULL */
   unsigned int *visits;           /* refit arrival counters */
 };
 
@@ -50,20 +61,25 @@ __global__ __launch_bounds__(BL_BLOCK) void bl_boxes(BuildBufs b, const DPrim *p
   if(i >= b.n) return;
   const DPrim &p = prims[i];
   const float *g = geo[i].f;
-  float lo[3], hi[3];
+  float lo[3], hi[3], lo1[3], hi1[3];
+  bool moving = false;
   if(p.type == 0)
-  { /* motion-blurred triangle / quad: the record holds the shutter-open vertices, t1 the shutter-close ones; the box encloses
-       both states, i.e. the whole linear motion */
-    for(int k=0;k<3;k++) lo[k] = hi[k] = p.v[0][k];
+  { /* motion-blurred primitive: the record holds the shutter-open vertices, t1 the shutter-close ones. Round 4: one box per state, as the
+       reference keeps them in its nodes (aabb0 / aabb1, src/accel.d/qbvhmp.c:62-81,259-283) -- the traversal interpolates them at the ray's
+       time (the vertices move linearly, so the interpolated box holds the primitive at every time in between). One box around both
+       states, as before, cost +7 / +14 / +33 % node visits / box hits / primitive tests on scenes/0059_mb. */
+    moving = true;
+    for(int k=0;k<3;k++) { lo[k] = hi[k] = p.v[0][k]; lo1[k] = hi1[k] = t1[i].v[0][k]; }
     for(uint32_t v=0;v<p.pad[0];v++) for(int k=0;k<3;k++)
     {
       const float x0 = p.v[v][k], x1 = t1[i].v[v][k];
-      lo[k] = fminf(lo[k], fminf(x0, x1)); hi[k] = fmaxf(hi[k], fmaxf(x0, x1));
+      lo[k] = fminf(lo[k], x0); hi[k] = fmaxf(hi[k], x0);
+      lo1[k] = fminf(lo1[k], x1); hi1[k] = fmaxf(hi1[k], x1);
     }
     if(p.pad[0] < MI_PRIM_TRI)
     { /* moving sphere / line: pad by the (larger) radius */
       const float r = fmaxf(p.v[2][0], p.v[2][1])*1.0001f + 1e-6f;
-      for(int k=0;k<3;k++) { lo[k] -= r; hi[k] += r; }
+      for(int k=0;k<3;k++) { lo[k] -= r; hi[k] += r; lo1[k] -= r; hi1[k] += r; }
     }
   }
   else if(p.type >= MI_PRIM_TRI)
@@ -83,9 +99,18 @@ __global__ __launch_bounds__(BL_BLOCK) void bl_boxes(BuildBufs b, const DPrim *p
     const float r = fmaxf(f[3], f[4])*1.0001f + 1e-6f;
     for(int k=0;k<3;k++) { lo[k] = fminf(f[k], g[26+k]) - r; hi[k] = fmaxf(f[k], g[26+k]) + r; }
   }
+  if(!moving) for(int k=0;k<3;k++) { lo1[k] = lo[k]; hi1[k] = hi[k]; }
+  if(!b.box1) for(int k=0;k<3;k++) { lo[k] = fminf(lo[k], lo1[k]); hi[k] = fmaxf(hi[k], hi1[k]); }      /* no second box set: one box around both states */
   float *o = b.box + 8*(size_t)i;
   o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = 0.0f; o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = 0.0f;
-  const float cx = ((lo[0] + hi[0])*0.5f - slo.x)*sinv.x, cy = ((lo[1] + hi[1])*0.5f - slo.y)*sinv.y, cz = ((lo[2] + hi[2])*0.5f - slo.z)*sinv.z;
+  if(b.box1)
+  {
+    float *o1 = b.box1 + 8*(size_t)i;
+    o1[0] = lo1[0]; o1[1] = lo1[1]; o1[2] = lo1[2]; o1[3] = 0.0f; o1[4] = hi1[0]; o1[5] = hi1[1]; o1[6] = hi1[2]; o1[7] = 0.0f;
+  }
+  /* the Morton code from the centre of the primitive's whole motion */
+  const float cx = ((fminf(lo[0], lo1[0]) + fmaxf(hi[0], hi1[0]))*0.5f - slo.x)*sinv.x, cy = ((fminf(lo[1], lo1[1]) + fmaxf(hi[1], hi1[1]))*0.5f - slo.y)*sinv.y,
+              cz = ((fminf(lo[2], lo1[2]) + fmaxf(hi[2], hi1[2]))*0.5f - slo.z)*sinv.z;
   const uint32_t qx = (uint32_t)fminf(fmaxf(cx*1024.0f, 0.0f), 1023.0f), qy = (uint32_t)fminf(fmaxf(cy*1024.0f, 0.0f), 1023.0f),
                  qz = (uint32_t)fminf(fmaxf(cz*1024.0f, 0.0f), 1023.0f);
   b.key_in[i] = (bl_expand(qx) << 2) | (bl_expand(qy) << 1) | bl_expand(qz);
@@ -137,6 +162,12 @@ __device__ __forceinline__ void bl_load_box(const BuildBufs &b, int child, float
   lo[0] = p[0]; lo[1] = p[1]; lo[2] = p[2]; hi[0] = p[4]; hi[1] = p[5]; hi[2] = p[6];
 }
 
+__device__ __forceinline__ void bl_load_box1(const BuildBufs &b, int child, float *lo, float *hi)
+{ /* the shutter-close box of a child */
+  const volatile float *p = child >= 0 ? b.ibox1 + 8*(size_t)child : b.box1 + 8*(size_t)b.perm[~child];
+  lo[0] = p[0]; lo[1] = p[1]; lo[2] = p[2]; hi[0] = p[4]; hi[1] = p[5]; hi[2] = p[6];
+}
+
 __global__ __launch_bounds__(BL_BLOCK) void bl_refit(BuildBufs b)
 { /* one thread per leaf walks up; the second thread to arrive at a node forms its box */
   const int i = blockIdx.x*BL_BLOCK + threadIdx.x;
@@ -152,13 +183,20 @@ __global__ __launch_bounds__(BL_BLOCK) void bl_refit(BuildBufs b)
     bl_load_box(b, b.right[node], l1, h1);
     volatile float *o = b.ibox + 8*(size_t)node;
     for(int k=0;k<3;k++) { o[k] = fminf(l0[k], l1[k]); o[4+k] = fmaxf(h0[k], h1[k]); }
+    if(b.box1)
+    { /* the shutter-close boxes are refitted on the same topology (qbvhmp.c:259-283) */
+      bl_load_box1(b, b.left[node], l0, h0);
+      bl_load_box1(b, b.right[node], l1, h1);
+      volatile float *o1 = b.ibox1 + 8*(size_t)node;
+      for(int k=0;k<3;k++) { o1[k] = fminf(l0[k], l1[k]); o1[4+k] = fmaxf(h0[k], h1[k]); }
+    }
     node = b.parent[node];
   }
 }
 
 __device__ __forceinline__ bool bl_large(const BuildBufs &b, int child)
 { /* internal node with more primitives than a leaf may hold */
-  return child >= 0 && b.last[child] - b.first[child] + 1 > MI_BUILD_LEAF;
+  return child >= 0 && b.last[child] - b.first[child] + 1 > b.leaf_max;
 }
 
 __device__ __forceinline__ int bl_split_axis(const float *l0, const float *h0, const float *l1, const float *h1, bool &swap)
@@ -194,7 +232,7 @@ __device__ __forceinline__ float bl_area(const float *lo, const float *hi)
   return dx*dy + dy*dz + dz*dx;
 }
 
-__global__ __launch_bounds__(BL_BLOCK) void bl_collapse(BuildBufs b, CollapseLists L, float4 *nodes, uint32_t *axes, uint32_t stride)
+__global__ __launch_bounds__(BL_BLOCK) void bl_collapse(BuildBufs b, CollapseLists L, float4 *nodes, uint32_t *axes, uint32_t stride, float4 *nodes_t1)
 {
   const unsigned int t = blockIdx.x*BL_BLOCK + threadIdx.x;
   if(t >= L.n_in) return;
@@ -242,17 +280,18 @@ __global__ __launch_bounds__(BL_BLOCK) void bl_collapse(BuildBufs b, CollapseLis
     if(sw) { const int tmp = slot[2*h]; slot[2*h] = slot[2*h+1]; slot[2*h+1] = tmp; }
   }
   uint32_t link[4];
-  float olo[4][3], ohi[4][3];
+  float olo[4][3], ohi[4][3], olo1[4][3], ohi1[4][3];
   for(int c=0;c<4;c++)
   {
     if(slot[c] < 0)
     { /* empty: inverted box (never entered), empty leaf link */
-      for(int k=0;k<3;k++) { olo[c][k] = FLT_MAX; ohi[c][k] = -FLT_MAX; }
+      for(int k=0;k<3;k++) { olo[c][k] = olo1[c][k] = FLT_MAX; ohi[c][k] = ohi1[c][k] = -FLT_MAX; }
       link[c] = MI_LEAF32;
       continue;
     }
     const int j = slot[c], child = cand[j];
     for(int k=0;k<3;k++) { olo[c][k] = lo[j][k]; ohi[c][k] = hi[j][k]; }
+    if(nodes_t1) bl_load_box1(b, child, olo1[c], ohi1[c]);
     if(bl_large(b, child))
     {
       const unsigned int nq = atomicAdd(&L.counters[0], 1u);
@@ -268,15 +307,20 @@ __global__ __launch_bounds__(BL_BLOCK) void bl_collapse(BuildBufs b, CollapseLis
     nodes[(size_t)k*stride + q] = make_float4(olo[0][k], olo[1][k], olo[2][k], olo[3][k]);
     nodes[(size_t)(k+3)*stride + q] = make_float4(ohi[0][k], ohi[1][k], ohi[2][k], ohi[3][k]);
   }
+  if(nodes_t1) for(int k=0;k<3;k++)
+  {
+    nodes_t1[(size_t)k*stride + q] = make_float4(olo1[0][k], olo1[1][k], olo1[2][k], olo1[3][k]);
+    nodes_t1[(size_t)(k+3)*stride + q] = make_float4(ohi1[0][k], ohi1[1][k], ohi1[2][k], ohi1[3][k]);
+  }
   uint4 lk = make_uint4(link[0], link[1], link[2], link[3]);
   nodes[(size_t)6*stride + q] = *(float4 *)&lk;
   axes[q] = (uint32_t)axis0 | ((uint32_t)axis1[0] << 2) | ((uint32_t)axis1[1] << 4);
 }
 
-__global__ __launch_bounds__(BL_BLOCK) void bl_repack(float4 *dst, const float4 *src, uint32_t N, uint32_t stride)
-{ /* [7][stride] -> [7][N] */
+__global__ __launch_bounds__(BL_BLOCK) void bl_repack(float4 *dst, const float4 *src, uint32_t N, uint32_t stride, uint32_t fields)
+{ /* [fields][stride] -> [fields][N] */
   const uint32_t i = blockIdx.x*BL_BLOCK + threadIdx.x;
-  if(i < MI_NODE_FIELDS*N) dst[i] = src[(size_t)(i/N)*stride + i%N];
+  if(i < fields*N) dst[i] = src[(size_t)(i/N)*stride + i%N];
 }
 
 template<class T>

@@ -1151,6 +1151,49 @@ def test_motion_blur_traversal_work_equals_the_reference(scene_path, key):
     assert np.sqrt((((fb - ofb) * scene.gain(1)) ** 2).sum() / n) < 0.05
 
 
+@pytest.mark.parametrize("scene_path,key", [(SCENE_MB, "mb_pt_mv8"), (SCENE_MB_ROUND, "mb_round_pt_mv8")])
+def test_device_built_tree_of_moving_geometry(monkeypatch, scene_path, key):
+    """the device build on a scene with moving primitives (round 4): shutter-open and shutter-close boxes per node, refitted on one topology
+    as the reference does (src/accel.d/qbvhmp.c:259-283) and interpolated per ray -- the same paths as the oracle on the reference's
+    tree; node visits within 12 % of the reference's own -DACCEL_DEBUG count on ITS tree (measured 1.104 x: an LBVH with leaves of at
+    most two primitives visits more nodes than the binned-SAH tree; with leaves of four, CORONA_MI_BUILD_LEAF=4, 1.048 x -- within 10 % --
+    but the motion-blur kernels, whose lanes work through their own leaves, render 9 % slower on it) and fewer primitive tests; with one
+    box around both states (CORONA_MI_BUILD_T1=0, rounds 1-3) clearly more of both."""
+    gold = json.loads((GOLDEN / "counters.json").read_text())[key]
+    scene = make_scene(scene_path, width=1280, height=720, max_verts=8)
+    n = scene.width * scene.height
+    work = {}
+    monkeypatch.setenv("CORONA_MI_BUILD_LEAF", "4")
+    be = pkg.Backend(scene, traversal="exact", device_build=True)
+    c0 = be.counters(); be.render(0, n); be.sync()
+    leaf4 = [b - a for a, b in zip(c0, be.counters())]
+    be.close()
+    assert leaf4[1] <= 1.10 * gold["node_visits"] and leaf4[3] <= gold["prim_tests"], (leaf4, gold)
+    monkeypatch.delenv("CORONA_MI_BUILD_LEAF")
+    for t1 in ("1", "0"):
+        monkeypatch.setenv("CORONA_MI_BUILD_T1", t1)
+        be = pkg.Backend(scene, traversal="exact", device_build=True)
+        assert be.stats()["device_built"]
+        if t1 == "1":
+            m = 20000
+            gpu, ora = be.trace_paths(0, m), oracle_records(scene, 0, m)
+            same = gpu["length"] == ora["length"]
+            for k in range(1, 8):
+                sel = ora["length"] > k
+                same &= ~sel | (gpu["v"]["prim"][:, k] == ora["v"]["prim"][:, k])        # the reference's packed primid: does not depend on the tree
+            assert (~same).sum() <= 2, int((~same).sum())
+        c0 = be.counters()
+        be.render(0, n)
+        be.sync()
+        work[t1] = [b - a for a, b in zip(c0, be.counters())]
+        be.close()
+    assert abs(work["1"][0] - work["0"][0]) <= 1e-5 * work["0"][0]            # the same rays (a tie between two primitives at one distance may fall either way: 1 ray in 2.3 M)
+    assert abs(work["1"][0] - gold["rays"]) <= 3e-3 * gold["rays"]
+    assert work["1"][1] <= 1.12 * gold["node_visits"], (work["1"][1], gold["node_visits"])
+    assert work["1"][3] <= gold["prim_tests"], (work["1"][3], gold["prim_tests"])
+    assert work["0"][1] >= 1.03 * work["1"][1] and work["0"][3] >= 1.10 * work["1"][3], (work["0"], work["1"])
+
+
 @pytest.mark.gpu
 def test_ptdl_scene_without_emitters(tmp_path):
     """a ptdl scene whose shapes emit nothing (lights.num_prims == 0: no emitter records on the device) -- the plain ptdl kernels lay their
