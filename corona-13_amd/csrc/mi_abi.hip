@@ -65,6 +65,17 @@ __global__ void mi_mark_ordered_kernel(const float4 *nodes, uint32_t N, DPrim *p
   }
 }
 
+/* the classes of the primitives (DPrimGeo.cls, mi_regroup.h) two bits each, in the records' final order: a wave asks for the class of its
+   lanes' hits once per iteration, between its traversal slice and the exchange -- from LDS where the table fits (16 primitives per word) */
+__global__ void mi_pack_cls_kernel(const DPrimGeo *geo, uint32_t n, uint32_t *out)
+{
+  const uint32_t w = blockIdx.x*blockDim.x + threadIdx.x;
+  if(16u*w >= n) return;
+  uint32_t v = 0;
+  for(uint32_t k=0;k<16u && 16u*w + k < n;k++) v |= (geo[16u*w + k].cls & 3u) << (2u*k);
+  out[w] = v;
+}
+
 /* ======================================================================================= host side */
 static thread_local char g_err[512] = "";
 static int g_device = -1;
@@ -107,7 +118,7 @@ struct mi_scene
   int fast;                         /* launch the FAST instantiations (mi_scene_set_traversal / CORONA_MI_TRAVERSAL): same hits, other work counters */
   bool media;                       /* some shape is filled with a homogeneous medium: MEDIA instantiations */
   bool norg;                        /* ... of those, the ones without the exchange between waves (scattering exterior medium) */
-  void *d_shape_medium, *d_prims_t1, *d_lights, *d_nodes_t1;
+  void *d_shape_medium, *d_prims_t1, *d_lights, *d_nodes_t1, *d_prim_cls;
   /* Halton point sampler */
   bool halton;
   HaltonTables *halton_tables;
@@ -688,6 +699,16 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
     hipLaunchKernelGGL(mi_mark_ordered_kernel, dim3((4*N + 255)/256), dim3(256), 0, 0, (const float4 *)s->d_nodes, N, (DPrim *)s->d_prims);
     if(hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) e = fail(MI_ERR_DEVICE, "cannot mark the leaves");
   }
+  if(!e && h->num_prims)
+  { /* ... and the primitives' classes for the exchange between waves, packed (mi_pack_cls_kernel) */
+    const uint32_t words = (uint32_t)((h->num_prims + 15)/16);
+    if(hipMalloc(&s->d_prim_cls, (size_t)words*4) != hipSuccess) e = fail(MI_ERR_NOMEM, "cannot allocate the class table");
+    else
+    {
+      hipLaunchKernelGGL(mi_pack_cls_kernel, dim3((words + 255)/256), dim3(256), 0, 0, (const DPrimGeo *)s->d_primgeo, (uint32_t)h->num_prims, (uint32_t *)s->d_prim_cls);
+      if(hipGetLastError() != hipSuccess) e = fail(MI_ERR_DEVICE, "cannot pack the class table");
+    }
+  }
   if(!e && h->lights.num_prims)
   { /* the list is in its final (builder or device-sorted) order now: set the any-hit flags */
     std::vector<uint32_t> cur(h->lights.num_prims);
@@ -743,7 +764,7 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
   s->stream = s->stream_own;
 
   d.nodes = (const float4 *)s->d_nodes; d.nodes_t1 = (const float4 *)s->d_nodes_t1;
-  d.prims = (const DPrim *)s->d_prims; d.primgeo = (const DPrimGeo *)s->d_primgeo;
+  d.prims = (const DPrim *)s->d_prims; d.primgeo = (const DPrimGeo *)s->d_primgeo; d.prim_cls = (const uint32_t *)s->d_prim_cls;
   d.materials = (const DMaterial *)s->d_materials;
   d.shape_medium = (const DShapeMedium *)s->d_shape_medium;
   d.prims_t1 = (const DPrimT1 *)s->d_prims_t1;
@@ -809,8 +830,12 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
     const uint32_t classes = num_classes + ((s->media && scatters) ? 1u : 0u);
     const bool on = MI_REGROUP && classes > 1 && !s->norg && !mb_kernels && room >= 2048;
     d.pool_classes = on ? classes : 0u;
+    /* the class table goes into LDS behind the pools when that costs them at most a fifth of their room (16 primitives per word) */
+    const size_t cls_bytes = (((size_t)h->num_prims + 15)/16)*4;
+    d.pool_cls_bytes = (on && cls_bytes*5 <= room) ? (uint32_t)((cls_bytes + 15) & ~(size_t)15) : 0u;
+    if(on) room -= d.pool_cls_bytes;
     d.pool_bytes = on ? (uint32_t)room : 0u;
-    s->lds_bytes += d.pool_bytes;
+    s->lds_bytes += d.pool_bytes + d.pool_cls_bytes;
     /* one launch size for every kernel of the scene: mi_intersect_kernel keeps full stack columns */
     const size_t isect_bytes = halton_bytes + lights_bytes + (s->nodes_lds ? node_bytes : 0) + isect_stack_bytes;
     if(s->lds_bytes < isect_bytes) s->lds_bytes = isect_bytes;
@@ -1157,7 +1182,7 @@ extern "C" void mi_scene_destroy(mi_scene *s)
   (void)hipSetDevice(s->device);
   void *bufs[] = { s->d_nodes, s->d_axes, s->d_prims, s->d_primgeo, s->d_materials, s->d_light_prim, s->d_light_cdf, s->d_light_L,
                    s->d_cie, s->d_checker, s->d_metal, s->d_counters, s->d_shape_material, s->d_shape_L, s->d_overflow, s->d_fb_own,
-                   s->d_halton_dim, s->d_halton_perm, s->d_shape_medium, s->d_prims_t1, s->d_lights, s->d_nodes_t1 };
+                   s->d_halton_dim, s->d_halton_perm, s->d_shape_medium, s->d_prims_t1, s->d_lights, s->d_nodes_t1, s->d_prim_cls };
   delete s->halton_tables;
   if(s->h_stage) { (void)hipHostFree(s->h_stage); (void)hipEventDestroy(s->ev_stage[0]); (void)hipEventDestroy(s->ev_stage[1]); }
   for(void *b : bufs) if(b) (void)hipFree(b);

@@ -149,6 +149,8 @@ struct DScene
   /* material queues (mi_regroup.h): bytes of LDS behind the job lists that the pools may use, classes in use (< 2: no exchange) */
   uint32_t pool_bytes, pool_classes;
   uint32_t pool_volume_class;       /* extended kernels: the class of volume vertices (= number of surface classes) */
+  uint32_t pool_cls_bytes;          /* bytes of the packed class table staged into LDS behind the pools (0: looked up in prim_cls through L2) */
+  const uint32_t *prim_cls;         /* [ceil(num_prims / 16)]: DPrimGeo.cls of every primitive, two bits each (mi_pack_cls_kernel) */
 };
 
 #endif

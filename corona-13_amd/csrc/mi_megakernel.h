@@ -137,6 +137,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
   {
     pool = pool_setup<RECORD, HALTON, MEDIA>(sc, lds.jobs - (threadIdx.x >> 6)*MI_JOBS_LDS + (MI_BLOCK/64)*MI_JOBS_LDS, &pool_ctl);
     pool_init(pool, &pool_ctl);
+    pool_stage_classes(pool, sc);
   }
   __syncthreads();
   const unsigned long long nb = gridDim.x;
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
       /* (extended kernels: an extension ray that ended at its sampled free-flight distance has a volume vertex there) */
       const bool volume = MEDIA && hit.prim == MI_NOPRIM && ps.clip < FLT_MAX;
       const bool surf0 = fin && !tr_shadow && (hit.prim != MI_NOPRIM || volume);
-      if(surf0 && pool.E) cls = volume ? sc.pool_volume_class : sc.primgeo[hit.prim].cls;       /* under way while the lanes below finish their paths */
+      if(surf0 && pool.E) cls = volume ? sc.pool_volume_class : pool_class_of(pool, sc, hit.prim);
 #if MI_REGROUP_EARLY_SHADOW
       if(fin && (tr_shadow || (hit.prim == MI_NOPRIM && !volume)))
       {
@@ -334,6 +335,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
       /* a lane that still owes this iteration a splat keeps its pixel: it is free from the next iteration on */
       const bool freelane = !tracing && !ps.active && !ps.sh_pending && !splat.pending;
       regroup_exchange<RECORD, PTDL, HALTON, MEDIA, MI_PRIO ? (PTDL ? MI_PRIO_PTDL_SHADE : MI_PRIO_PT_SHADE) : 0>(pool, ps, hit, ts, tracing, tr_shadow, surf0, cls, freelane, exhausted_wave, cnt);
+      MI_TT(cnt, 4)       /* (trav probe: part 4 = the end of the slice + the exchange between waves) */
       if(tracing && ts.done)
       {
         tracing = false;

@@ -80,6 +80,7 @@ struct Pool
   lds_uint2 *data;          /* [slot][E] */
   lds_u16_t *list;          /* [MI_POOL_CLASSES + 1][E]: entry numbers per class, then the free entries */
   lds_u32_t *ctl;           /* PoolCtl */
+  lds_u32_t *cls;           /* the primitives' classes, two bits each, staged behind the pools -- or NULL: DScene.prim_cls through L2 */
   uint32_t E;               /* entries; 0 = no exchange */
 };
 
@@ -96,6 +97,7 @@ __device__ __forceinline__ Pool pool_setup(const DScene &sc, unsigned char *base
   p.E = E;
   p.data = (lds_uint2 *)base;
   p.list = (lds_u16_t *)(base + (size_t)NS*8u*E);
+  p.cls = (E && sc.pool_cls_bytes) ? (lds_u32_t *)(base + sc.pool_bytes) : nullptr;
   return p;
 }
 /* call from all threads of the workgroup before the barrier that starts the kernel */
@@ -103,6 +105,18 @@ __device__ __forceinline__ void pool_init(const Pool &p, PoolCtl *ctl)
 {
   if(threadIdx.x == 0) { ctl->state = (unsigned long long)p.E << 48; ctl->hint = ctl->state; }
   if(threadIdx.x < p.E) p.list[MI_POOL_CLASSES*p.E + threadIdx.x] = (unsigned short)threadIdx.x;
+}
+/* ... with the scene: stages the class table */
+__device__ __forceinline__ void pool_stage_classes(const Pool &p, const DScene &sc)
+{
+  if(p.cls) for(uint32_t i=threadIdx.x;i<(sc.num_prims + 15u)/16u;i+=blockDim.x) p.cls[i] = sc.prim_cls[i];
+}
+/* the class of a primitive (DPrimGeo.cls): one LDS read where the table is staged -- the wave asks between its traversal slice and the
+   exchange, with nothing else to do while the answer is under way */
+__device__ __forceinline__ uint32_t pool_class_of(const Pool &p, const DScene &sc, uint32_t prim)
+{
+  const uint32_t w = p.cls ? p.cls[prim >> 4] : sc.prim_cls[prim >> 4];
+  return (w >> ((prim & 15u)*2u)) & 3u;
 }
 
 __device__ __forceinline__ bool pool_empty(const Pool &p)
@@ -165,6 +179,8 @@ __device__ __forceinline__ void regroup_exchange(const Pool &pool, PathState &ps
   if(!E) return;
   mi_u64 mc[MI_POOL_CLASSES];
   uint32_t n[MI_POOL_CLASSES] = { 0u, 0u, 0u, 0u }, p[MI_POOL_CLASSES], nfree;
+  /* (the look at the pools' fill is issued before the classes of the lanes' hits are needed: the two LDS reads travel together) */
+  unsigned long long hint = __hip_atomic_load((lds_u64_t *)pool.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
   for(int c=0;c<NC;c++) { mc[c] = __ballot(surf && cls == (uint32_t)c); n[c] = __popcll(mc[c]); }
   const mi_u64 mfree = __ballot(freelane);
@@ -176,7 +192,7 @@ __device__ __forceinline__ void regroup_exchange(const Pool &pool, PathState &ps
   uint32_t k[MI_POOL_CLASSES] = { 0u, 0u, 0u, 0u }, m = 0;
   auto look = [&]()
   { /* from outside: the hint */
-    unsigned long long h = __hip_atomic_load((lds_u64_t *)pool.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    unsigned long long h = hint;
     h = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)h) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(h >> 32)) << 32);
     MI_POOL_UNPACK(h, p, nfree)
   };

@@ -4,7 +4,7 @@ import sys
 sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parent.parent / "tests"))
 from helpers import *
 pkg = load_pkg()
-names = ["node loop", "job set-up", "job passes", "owner epilogue", "slice rest", "refill+shade", "splat"]
+names = ["node loop", "job set-up", "job passes", "owner epilogue", "exchange", "refill+shade", "splat"]
 for name, sampler in (("pt", 0), ("ptdl", 1)):
     scene = make_scene(SCENE_0010, width=1280, height=720, max_verts=8, sampler=sampler)
     for mode in ("exact", "fast"):
