@@ -813,7 +813,11 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
   /* plain ptdl kernels: emitter records in LDS. The same predicate as the kernel's (lds_setup<..., LIGHTS = PTDL && !MEDIA> advances by these
      bytes whether or not the scene has emitter records: a ptdl scene without emitters still needs them allocated) */
   const size_t lights_bytes = (h->sampler == MI_SAMPLER_PTDL && !s->media) ? (size_t)MI_LIGHTS_LDS*sizeof(DLight) : 0;
-  s->nodes_lds = halton_bytes + lights_bytes + node_bytes + (stack_bytes > isect_stack_bytes ? stack_bytes : isect_stack_bytes) <= 160*1024 && !(nodes_env && !strcmp(nodes_env, "global"));
+  /* (both kinds of kernel must find room: the path kernels with their columns -- and the shutter-close boxes in a motion-blur scene --, the
+     ray-level test kernel with full columns and the shutter-open boxes only) */
+  const size_t isect_node_bytes = (size_t)MI_NODE_FIELDS*N*16;
+  s->nodes_lds = halton_bytes + lights_bytes + node_bytes + stack_bytes <= 160*1024 && isect_node_bytes + isect_stack_bytes <= 160*1024 &&
+                 !(nodes_env && !strcmp(nodes_env, "global"));
   s->lds_bytes = halton_bytes + lights_bytes + (s->nodes_lds ? node_bytes : 0) + stack_bytes;
   { /* material queues (mi_regroup.h): the pools take what is left of the CU's LDS behind the job lists (plain kernels only: the extended
        ones carry more path state than an entry holds). CORONA_MI_REGROUP=0 switches the exchange off, =<bytes> limits the pools. */
@@ -837,7 +841,7 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
     d.pool_bytes = on ? (uint32_t)room : 0u;
     s->lds_bytes += d.pool_bytes + d.pool_cls_bytes;
     /* one launch size for every kernel of the scene: mi_intersect_kernel keeps full stack columns */
-    const size_t isect_bytes = halton_bytes + lights_bytes + (s->nodes_lds ? node_bytes : 0) + isect_stack_bytes;
+    const size_t isect_bytes = (s->nodes_lds ? isect_node_bytes : 0) + isect_stack_bytes;
     if(s->lds_bytes < isect_bytes) s->lds_bytes = isect_bytes;
   }
   s->device_built = device_build; s->stack_need = stack_need;
