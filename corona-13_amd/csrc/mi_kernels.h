@@ -794,18 +794,25 @@ __device__ __forceinline__ void trace_begin(const Lds &lds, TraceState &ts, cons
 }
 
 /* what follows a leaf in accel_intersect: pop the next subtree that starts in front of the closest hit (qbvhmp.c:1357-1364,1380-1386) */
+#ifndef MI_POP_PREFETCH
+#define MI_POP_PREFETCH 1     /* cfg 2 16.17 -> 16.07 ms, cfg 3 28.82 -> 28.67 (same-box A/B, gpurun_out/ab_pre.txt) */
+#endif
+/* (top / has_top: the stack's top entry, read by the caller earlier -- together with the leaf's results, so that the pop does not start a
+   second round trip through LDS when the results have arrived; only entries that live in LDS are read ahead) */
 template<int BLOCK, int STACK, bool ANYHIT>
-__device__ __forceinline__ void leaf_finish(const Lds &lds, const Hit &hit, TraceState &ts)
+__device__ __forceinline__ void leaf_finish(const Lds &lds, const Hit &hit, TraceState &ts, const mi_u32x2 top = mi_u32x2{0u, 0u}, bool has_top = false)
 {
   lds_uint2 *lstack = (lds_uint2 *)lds.stack;
   int sp = ts.sp;
   uint32_t current = MI_LEAF32;
   bool done = true;
   if(ANYHIT && ts.anyhit && hit.prim != MI_NOPRIM) sp = 0;   /* an occluder is all a shadow ray needs to know (MI_LIGHT_ANYHIT) */
+  bool first = has_top;
   while(sp > 0)
   {
     sp--;
-    const uint2 e = stack_top<BLOCK, STACK>(lds, lstack, sp);
+    const uint2 e = first ? make_uint2(top.x, top.y) : stack_top<BLOCK, STACK>(lds, lstack, sp);
+    first = false;
     if(!(__uint_as_float(e.y) > hit.dist)) { current = e.x; done = false; break; }
   }
   ts.sp = sp; ts.current = current; ts.done = done;
@@ -958,6 +965,9 @@ __device__ __forceinline__ void leaf_jobs(const Lds &lds, const DPrim *prims, co
   MI_TT(cnt, 2)
   if(own)
   {
+    const bool has_top = MI_POP_PREFETCH && ts.sp > 0 && ts.sp <= STACK;
+    mi_u32x2 top = mi_u32x2{0u, 0u};
+    if(has_top) top = ((lds_uint2 *)lds.stack)[(ts.sp - 1)*BLOCK];       /* the pop's first read travels with the results */
     const mi_u64 res = fits ? *best : 0;
     if(res == 0)
     { /* a folded quad crossed twice: what it yields depends on the running distance -- this lane's leaf in the reference's order */
@@ -983,7 +993,7 @@ __device__ __forceinline__ void leaf_jobs(const Lds &lds, const DPrim *prims, co
         analytic &= analytic - 1;
         analytic_intersect<MB>(prims, idxp + i, o, d, ignore, hit, MB ? ts.time : 0.0f, MB ? ts.prims_t1 : nullptr);
       }
-      leaf_finish<BLOCK, STACK, ANYHIT>(lds, hit, ts);
+      leaf_finish<BLOCK, STACK, ANYHIT>(lds, hit, ts, top, has_top);
     }
   }
   MI_TT(cnt, 3)
@@ -1232,14 +1242,21 @@ __device__ __forceinline__ void trace_round(const Lds &lds, const DPrim *prims, 
 #ifdef MI_PROFILE_LOOPS
       if(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) cnt.c[8] += MI_PROFILE_LOOPS == 2 ? nround : 1;   /* wave-level inner iterations (2: lanes still under way) */
 #endif
+      /* MI_POP_PREFETCH: the stack's top entry is read together with the node's planes -- if no child is hit the pop has it already
+         instead of starting a round trip of its own (a visit that hits a child pushes above it and leaves it alone) */
+      const bool has_top = MI_POP_PREFETCH && sp > 0 && sp <= STACK;
+      mi_u32x2 top = mi_u32x2{0u, 0u};
+      if(has_top) top = lstack[(sp - 1)*BLOCK];
       node_visit<BLOCK, STACK, false, MB>(lds, lstack, rb, o, hit.dist, current, sp, cnt, [&]()
       { /* pop, skipping entries that start behind the current hit (qbvhmp.c:1357-1364) */
         current = MI_LEAF32;          /* empty leaf: falls out of this loop; `done` if the stack runs dry */
         done = true;
+        bool first = has_top;
         while(sp > 0)
         {
           sp--;
-          const uint2 e = stack_top<BLOCK, STACK>(lds, lstack, sp);
+          const uint2 e = first ? make_uint2(top.x, top.y) : stack_top<BLOCK, STACK>(lds, lstack, sp);
+          first = false;
           if(!(__uint_as_float(e.y) > hit.dist)) { current = e.x; done = false; break; }
         }
       });

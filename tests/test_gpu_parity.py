@@ -530,6 +530,74 @@ def test_fast_rounds_give_the_exact_rounds_paths():
         ex.close(); fa.close()
 
 
+def _three_class_scene(tmp_path):
+    """0010 with the cylinder in gold: diffuse, dielectric and metal vertices in one scene (three classes of the exchange between waves)"""
+    import shutil
+    dst = tmp_path / "0010_three"
+    shutil.copytree(SCENE_0010.parent, dst)
+    lines = (dst / "test.nra2").read_text().splitlines()
+    n = int(lines[1])
+    assert lines[2 + n - 1].startswith("mult 2 11 3 0") and lines[2 + n + 1 + 4].endswith("../geo/cylinder")
+    lines[1] = str(n + 2)
+    lines[2 + n:2 + n] = ["metal Au # %d" % n, "mult 1 7 %d # %d gold" % (n, n + 1)]
+    k = 2 + (n + 2) + 1 + 4
+    lines[k] = "%d ../geo/cylinder" % (n + 1)
+    text = "\n".join(lines) + "\n"
+    (dst / "test.nra2").write_text(text.replace("../geo/", str(SCENE_0010.parent.parent / "geo") + "/"))       # the geometry stays where it is
+    return dst / "test.nra2"
+
+
+def test_exchange_between_waves_changes_no_path(monkeypatch, tmp_path):
+    """The material queues (csrc/mi_regroup.h): the waves of a workgroup trade path vertices by class of the material -- which lane
+    finishes a path must not matter to the path. Path records with the exchange (the default) and without it (CORONA_MI_REGROUP=0) are
+    the same BYTES: plain pt / ptdl, a scene with three classes (diffuse, dielectric, metal: the cylinder of 0010 in gold) against the oracle
+    too, the extended kernels (volume vertices as a class of their own), the Halton sampler (the path index travels with the vertex), a tree
+    in HBM (bigger pools), launches smaller than a wave and smaller than a workgroup (the pools must run empty before the last wave leaves);
+    rendered frames agree to the order of the float atomics and count every path."""
+    three = _three_class_scene(tmp_path)
+    cases = [(SCENE_0010, pkg.MI_SAMPLER_PT, "rand", 8, 400000), (SCENE_0010, pkg.MI_SAMPLER_PTDL, "rand", 8, 300000),
+             (three, pkg.MI_SAMPLER_PT, "rand", 8, 300000), (three, pkg.MI_SAMPLER_PTDL, "rand", 8, 200000),
+             (SCENE_MEDIA, pkg.MI_SAMPLER_PTDL, "rand", 32, 200000), (SCENE_CAM_MB, pkg.MI_SAMPLER_PT, "rand", 8, 200000),
+             (SCENE_0010, pkg.MI_SAMPLER_PTDL, "halton", 8, 200000), (SCENE_FINE, pkg.MI_SAMPLER_PT, "rand", 8, 200000),
+             (SCENE_ROUGH, pkg.MI_SAMPLER_PT, "rand", 32, 200000)]
+    for path, sampler, points, mv, n in cases:
+        scene = make_scene(path, width=1280, height=720, max_verts=mv, sampler=sampler,
+                           pointsampler=pkg.MI_POINTS_HALTON if points == "halton" else pkg.MI_POINTS_RAND)
+        monkeypatch.setenv("CORONA_MI_REGROUP", "0")
+        off = pkg.Backend(scene)
+        monkeypatch.delenv("CORONA_MI_REGROUP")
+        on = pkg.Backend(scene)
+        for first, count in ((5, n), (123456789, 1), (77, 63), (1000, 1000), (2 ** 33 + 9, 70000)):
+            a, b = off.trace_paths(first, count), on.trace_paths(first, count)
+            assert a.tobytes() == b.tobytes(), (str(path), sampler, points, first, count)
+        if path == three:
+            ora = oracle_records(scene, 5, 50000)
+            g = on.trace_paths(5, 50000)
+            same = (g["length"] == ora["length"]) & (g["num_splats"] == ora["num_splats"])
+            for k in range(1, 8):
+                sel = ora["length"] > k
+                same &= ~sel | (g["v"]["prim"][:, k] == ora["v"]["prim"][:, k])
+            assert (~same).sum() <= 2, int((~same).sum())
+            assert len(np.unique(g["v"]["shader"][g["length"] > 2, 1])) >= 3          # the three materials are all hit
+        off.close(); on.close()
+        # production kernels: every path counted, the same frame up to the order of the float atomics
+        per = 4 * scene.width * scene.height
+        frames = []
+        for env in ("0", None):
+            if env is None:
+                monkeypatch.delenv("CORONA_MI_REGROUP", raising=False)
+            else:
+                monkeypatch.setenv("CORONA_MI_REGROUP", env)
+            be = pkg.Backend(scene, counters=False)
+            c0 = be.counters()
+            be.render(9 * per, per)
+            frames.append(be.fb_read())
+            assert be.counters()[4] - c0[4] == per
+            be.close()
+        monkeypatch.delenv("CORONA_MI_REGROUP", raising=False)
+        assert np.abs(frames[0] - frames[1]).max() <= 2e-4 * np.abs(frames[0]).max(), (str(path), sampler)
+
+
 def test_cfg5_film_3840x2160(counters):
     """BASELINE config 5's film (3840x2160, padded to 3840x2176; 100 MB framebuffer): one sample per pixel, sharded over two
     path-index ranges like two ranks would, against the oracle's image of the same indices"""
@@ -1204,9 +1272,9 @@ def test_ptdl_scene_without_emitters(tmp_path):
     dst = tmp_path / "0010_dark"
     shutil.copytree(src, dst)
     nra = (dst / "test.nra2").read_text().replace("color e 3200 3200 3200 1.", "color d 0.5 0.5 0.5").replace("color e 10 10 10 1.", "color d 0.5 0.5 0.5")
-    (dst / "test.nra2").write_text(nra)
+    (dst / "test.nra2").write_text(nra.replace("../geo/", str(SCENE_0010.parent.parent / "geo") + "/"))       # the geometry stays where it is
     scene = make_scene(dst / "test.nra2", width=256, height=144, max_verts=8, sampler=pkg.MI_SAMPLER_PTDL)
-    assert scene.desc.lights.num_prims == 0
+    assert scene.desc.lights.num_prims == 0 and scene.desc.num_shapes == 6 and scene.desc.num_prims > 4000
     n = 20000
     ora = oracle_records(scene, 0, n)
     for mode in ("exact", "fast"):
