@@ -462,16 +462,23 @@ def main():
 
     def valu_floor(config, r):
         f = Path(__file__).resolve().parent / "profiles" / "r04_valu_floor.json"
-        if not f.exists() or config != "cfg2":
-            return None                      # (cfg 3: the ptdl vertex -- next event estimation, shadow rays -- has no isolated count yet)
+        if not f.exists() or config not in ("cfg2", "cfg3"):
+            return None
         fl = json.load(open(f))
-        b, vv, mix = fl["blocks"], fl["vertex_valu"], fl["mix"][config]
+        ptdl = config == "cfg3"
+        if ptdl and "vertex_valu_ptdl" not in fl:
+            return None
+        b, vv, mix = fl["blocks"], fl["vertex_valu_ptdl" if ptdl else "vertex_valu"], fl["mix"][config]
         dc, paths = r["dc"], max(r["dc"][4], 1)
         rays, nodes, prims = dc[0] / paths, dc[1] / paths, dc[3] / paths
-        surf = rays * mix["surface_vertices_per_ray"]
+        ext = dc[6] / paths - 1.0 if ptdl else rays            # every extension ray makes one vertex (surface or environment); the sensor's is the first
+        surf = ext * mix["surface_vertices_per_extension_ray" if ptdl else "surface_vertices_per_ray"]
         vertex = mix["diffuse_share"] * vv["diffuse_on_quad"] + mix["dielectric_share"] * vv["dielectric_on_line"]
         terms = {"node_visits": nodes * b["node_visit"]["valu"] / 64.0, "prim_tests": prims * b["prim_test"]["valu"] / 64.0,
                  "generate": b["generate"]["valu"] / 64.0, "surface_vertices": surf * vertex / 64.0}
+        if ptdl:       # shadow rays = rays - extension rays: each ends in a verdict; a splat is a quarter of a cooperative pass (64 lanes at work)
+            terms["shadow_verdicts"] = max(rays - ext, 0.0) * b["shadow_resolve"]["valu"] / 64.0
+            terms["splats"] = dc[5] / paths * b["splat_pass_of_four"]["valu"] / 4.0
         return {"per_path": sum(terms.values()), "terms": terms, "source": "profiles/r04_valu_floor.json x live work counters"}
 
     def roofline_of(config, r):

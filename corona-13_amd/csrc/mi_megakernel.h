@@ -66,9 +66,6 @@
 #define MI_PRIO_PTDL_TRACE 0
 #define MI_PRIO_PTDL_SHADE 3
 #endif
-#ifndef MI_REFILL_RUNTIME
-#define MI_REFILL_RUNTIME 1
-#endif
 #ifndef MI_REGROUP_MEDIA
 #define MI_REGROUP_MEDIA 1   /* the exchange in the extended kernels too (media, moving camera): volume vertices are a class of their own */
 #endif
@@ -183,11 +180,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
       const unsigned long long m = __ballot(want);
       /* MI_REFILL_MIN: a few idle lanes wait for company -- path_generate costs the wave the same for 3 lanes as for 60 -- unless the wave
          has little else under way */
-#if MI_REFILL_RUNTIME
       const int rmin = (REGROUP && pool.E) ? MI_REFILL_MIN : 1;         /* (only where the exchange runs: without it waiting is a loss) */
-#else
-      constexpr int rmin = REGROUP ? MI_REFILL_MIN : 1;
-#endif
       if(m && (rmin <= 1 || __popcll(m) >= rmin || __popcll(__ballot(tracing || ps.active || ps.sh_pending)) < 64 - 2*rmin))
       {
         const unsigned n = __popcll(m);

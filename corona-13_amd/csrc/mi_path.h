@@ -871,11 +871,7 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
         PointSampler<HALTON> pts(sc, ps.rng, ps.index, rand_beg_extend<PTDL>(v + 1));   /* the vertex the sample leads to */
         if(mat_bsdf == MI_BSDF_DIFFUSE) { MI_BLK(cnt, 5) sample_diffuse(pts, sf, sh, mode, bs); }
         else if(mat_bsdf == MI_BSDF_DIELECTRIC) { MI_BLK(cnt, 6) sample_dielectric(pts, sf, sh, omega, eta_ratio, mode, bs); }
-#ifdef MI_EXP_NO_METAL      /* experiment: how much the mere presence of never-executed code costs (instruction cache) */
-        else __builtin_unreachable();
-#else
         else { MI_BLK(cnt, 7) sample_metal(sc, pts, sf, sh, omega, ps.cur_ior, (int)mat_p0, ps.lambda, mode, bs); }
-#endif
         MI_PHASE(cnt, 7)
         /* shader_sample tail, src/shader.c:582-589 */
         bs.omega = normalise3(bs.omega);

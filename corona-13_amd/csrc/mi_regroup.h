@@ -35,9 +35,6 @@
 #ifndef MI_POOL_HIGH
 #define MI_POOL_HIGH 48            /* own lanes + pool of a class from which on a wave turns to that class */
 #endif
-#ifndef MI_POOL_PACK16
-#define MI_POOL_PACK16 0
-#endif
 #ifndef MI_POOL_POLICY
 #define MI_POOL_POLICY 2
 #endif
@@ -149,15 +146,10 @@ __device__ __forceinline__ void pool_leave(const Pool &pool, unsigned long long 
     __hip_atomic_store((lds_u64_t *)pool.ctl + 1, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
 }
-#if MI_POOL_PACK16     /* experiment: the four 16-bit counts of the three-class version */
-#define MI_POOL_UNPACK(ST, P, NFREE) { (P)[0] = (uint32_t)(ST) & 0xffffu; (P)[1] = (uint32_t)((ST) >> 16) & 0xffffu; (P)[2] = (uint32_t)((ST) >> 32) & 0xffffu; (P)[3] = 0u; (NFREE) = (uint32_t)((ST) >> 48); }
-#define MI_POOL_PACK(P, NFREE) ((unsigned long long)(P)[0] | ((unsigned long long)(P)[1] << 16) | ((unsigned long long)(P)[2] << 32) | ((unsigned long long)(NFREE) << 48))
-#else
 /* five 12-bit counts (at most 1024 entries) */
 #define MI_POOL_UNPACK(ST, P, NFREE) { (P)[0] = (uint32_t)(ST) & 0xfffu; (P)[1] = (uint32_t)((ST) >> 12) & 0xfffu; (P)[2] = (uint32_t)((ST) >> 24) & 0xfffu; \
                                        (P)[3] = (uint32_t)((ST) >> 36) & 0xfffu; (NFREE) = (uint32_t)((ST) >> 48) & 0xfffu; }
 #define MI_POOL_PACK(P, NFREE) ((unsigned long long)(P)[0] | ((unsigned long long)(P)[1] << 12) | ((unsigned long long)(P)[2] << 24) | ((unsigned long long)(P)[3] << 36) | ((unsigned long long)(NFREE) << 48))
-#endif
 
 
 /* a vertex into / out of an entry: the whole path state that is live between two rays (NS 8-byte words, [word][E]) */
@@ -248,9 +240,7 @@ template<bool RECORD, bool PTDL, bool HALTON, bool MEDIA, int PRIO, class CNT>
 __device__ __forceinline__ void regroup_exchange(const Pool &pool, PathState &ps, Hit &hit, TraceState &ts, bool &tracing, bool &tr_shadow,
                                                  bool surf, uint32_t cls, bool freelane, bool drain, CNT &cnt)
 {
-  constexpr int NS = PoolLayout<RECORD, HALTON, MEDIA>::SLOTS, NB = PoolLayout<RECORD, HALTON, MEDIA>::BASE;
   constexpr int NC = MEDIA ? MI_POOL_CLASSES : MI_POOL_CLASSES - 1;      /* the plain kernels have no volume vertices: what belongs to the fourth class folds away */
-  (void)NS;
   const uint32_t E = pool.E;
   if(!E) return;
   mi_u64 mc[MI_POOL_CLASSES];

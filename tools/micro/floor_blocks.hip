@@ -75,7 +75,7 @@ template<int N> __global__ __launch_bounds__(FB_BLOCK) void fb_generate(DScene s
 
 /* ---- one surface vertex of the pt sampler: everything path_shade does between two rays (all material branches present in the code;
  *      valu_floor.py subtracts the bsdf blocks a vertex of a given class does not run) */
-template<int N> __global__ __launch_bounds__(FB_BLOCK) void fb_vertex(DScene sc, FbIO *io, const uint32_t *shape_material, const float *shape_L)
+template<int N, bool PTDL> __global__ __launch_bounds__(FB_BLOCK) void fb_vertex(DScene sc, FbIO *io, const uint32_t *shape_material, const float *shape_L)
 {
   FbIO &q = io[threadIdx.x];
   Counters<false> cnt;
@@ -87,11 +87,68 @@ template<int N> __global__ __launch_bounds__(FB_BLOCK) void fb_vertex(DScene sc,
   for(int k=0;k<N;k++)
   {
     __builtin_assume(hit.prim != MI_NOPRIM);
-    path_shade<false, false, false, false, false>(sc, ps, hit, shape_material, shape_L, nullptr, cnt, splat);
-    hit.prim = ps.ignore + 1u; hit.dist = ps.pdf + 1.0f; hit.u = ps.dir.x; hit.v = ps.dir.y;
+    path_shade<false, PTDL, false, false, false>(sc, ps, hit, shape_material, shape_L, nullptr, cnt, splat);
+    hit.prim = ps.ignore + 1u; hit.dist = ps.pdf + 1.0f + (PTDL ? ps.sh_dist + ps.sh_value + ps.sh_dir.x + ps.sh_dir.y + ps.sh_dir.z + (float)ps.sh_light + (float)ps.sh_pending : 0.0f); hit.u = ps.dir.x; hit.v = ps.dir.y;
   }
   q.f[0] = ps.org.x + ps.org.y + ps.org.z + ps.dir.z + ps.throughput + ps.prev_cos + splat.c0 + splat.c1 + splat.c2 + (float)ps.pdfprod + ps.cur_ior;
   q.u[0] = ps.active | (splat.pending ? 2u : 0u) | ((uint32_t)ps.media.ids << 2) | ((uint32_t)ps.rng.s0 << 8);
+}
+
+/* ---- ptdl: the verdict of a finished shadow ray and the splat of its connection (shadow_resolve) */
+template<int N> __global__ __launch_bounds__(FB_BLOCK) void fb_shadow(DScene sc, FbIO *io)
+{
+  FbIO &q = io[threadIdx.x];
+  Counters<false> cnt;
+  PathState ps;
+  path_generate<false, false, false>(sc, ps, q.u[0], nullptr, cnt);
+  ps.sh_dist = q.f[0]; ps.sh_value = q.f[1]; ps.sh_light = q.u[1]; ps.sh_length = 3;
+  Hit hit; hit.prim = q.u[2]; hit.dist = q.f[2]; hit.u = hit.v = 0.0f;
+  SplatReq splat; splat.pending = false; splat.c0 = splat.c1 = splat.c2 = 0.0f;
+  float acc = 0.0f;
+#pragma unroll
+  for(int k=0;k<N;k++)
+  {
+    shadow_resolve<false>(sc, ps, hit, nullptr, cnt, splat);
+    acc += splat.c0 + splat.c1 + splat.c2; ps.sh_value = acc; hit.dist = acc; ps.lambda += splat.c0;
+  }
+  q.f[0] = acc; q.u[0] = splat.pending ? 1u : 0u;
+}
+
+/* ---- one pass of the cooperative splat: four splats, sixteen lanes each (splat_wave) */
+template<int N> __global__ __launch_bounds__(FB_BLOCK) void fb_splat(DScene sc, FbIO *io)
+{
+  FbIO &q = io[threadIdx.x];
+  float pi = q.f[0], pj = q.f[1], c0 = q.f[2], c1 = q.f[3], c2 = q.f[4];
+#pragma unroll
+  for(int k=0;k<N;k++)
+  { /* exactly four lanes of the wave hold a splat: one pass */
+    splat_wave(sc, (__lane_id() & 15u) == (unsigned)k, pi, pj, c0, c1, c2);
+    pi += 1.0f;
+  }
+}
+
+/* ---- ptdl: bsdf and pdf of a connection (the next-event block evaluates the vertex's own bsdf) */
+template<int N, int WHICH> __global__ __launch_bounds__(FB_BLOCK) void fb_eval(DScene sc, FbIO *io)
+{
+  FbIO &q = io[threadIdx.x];
+  Surf sf;
+  sf.n = mk3(q.f[0], q.f[1], q.f[2]); sf.gn = sf.n; sf.x = mk3(0, 0, 0); sf.u = sf.v = sf.s = sf.t = 0.0f; sf.flags = q.u[2];
+  get_scrambled_onb(q.f[3], sf.n, sf.a, sf.b);
+  Shading sh; sh.roughness = q.f[4]; sh.rs = q.f[5]; sh.rd = q.f[6]; sh.rg = q.f[7]; sh.em = 0.0f;
+  V3 wi = mk3(q.f[8], q.f[9], q.f[10]), wo = mk3(q.f[13], q.f[14], q.f[15]);
+  float acc = 0.0f;
+#pragma unroll
+  for(int k=0;k<N;k++)
+  {
+    BsdfEval be;
+    float pb;
+    if(WHICH == 0) { be = brdf_diffuse(sf, sh, wo); pb = (float)(1.0f/MI_PI_D); }
+    else if(WHICH == 1) { be = brdf_dielectric(sf, sh, wi, wo, q.f[11]); pb = pdf_dielectric(sf, sh, wi, wo, q.f[11], be.mode); }
+    else { be = brdf_metal(sc, sf, sh, wi, wo, 1.0f, (int)q.u[3], q.f[12]); pb = pdf_metal(sf, sh, wi, wo, be.mode); }
+    acc += be.value + pb + (float)be.mode;
+    wo = mk3(wo.y + acc, wo.z, wo.x);
+  }
+  q.f[0] = acc;
 }
 
 /* ---- surface set-up alone, for one kind of primitive (TYPE = vertex count: 1 sphere, 2 line, 4 quad; 0 = whatever the record says: every kind's code) */
@@ -145,8 +202,14 @@ template __global__ void fb_prim_test<1>(DScene, FbIO *);
 template __global__ void fb_prim_test<2>(DScene, FbIO *);
 template __global__ void fb_generate<1>(DScene, FbIO *);
 template __global__ void fb_generate<2>(DScene, FbIO *);
-template __global__ void fb_vertex<1>(DScene, FbIO *, const uint32_t *, const float *);
-template __global__ void fb_vertex<2>(DScene, FbIO *, const uint32_t *, const float *);
+template __global__ void fb_vertex<1, false>(DScene, FbIO *, const uint32_t *, const float *);
+template __global__ void fb_vertex<2, false>(DScene, FbIO *, const uint32_t *, const float *);
+template __global__ void fb_vertex<1, true>(DScene, FbIO *, const uint32_t *, const float *);
+template __global__ void fb_vertex<2, true>(DScene, FbIO *, const uint32_t *, const float *);
+template __global__ void fb_shadow<1>(DScene, FbIO *);
+template __global__ void fb_shadow<2>(DScene, FbIO *);
+template __global__ void fb_splat<1>(DScene, FbIO *);
+template __global__ void fb_splat<2>(DScene, FbIO *);
 template __global__ void fb_sample<1, 0>(DScene, FbIO *);
 template __global__ void fb_sample<2, 0>(DScene, FbIO *);
 template __global__ void fb_sample<1, 1>(DScene, FbIO *);
@@ -161,3 +224,9 @@ template __global__ void fb_setup<1, 2>(DScene, FbIO *);
 template __global__ void fb_setup<2, 2>(DScene, FbIO *);
 template __global__ void fb_setup<1, 4>(DScene, FbIO *);
 template __global__ void fb_setup<2, 4>(DScene, FbIO *);
+template __global__ void fb_eval<1, 0>(DScene, FbIO *);
+template __global__ void fb_eval<2, 0>(DScene, FbIO *);
+template __global__ void fb_eval<1, 1>(DScene, FbIO *);
+template __global__ void fb_eval<2, 1>(DScene, FbIO *);
+template __global__ void fb_eval<1, 2>(DScene, FbIO *);
+template __global__ void fb_eval<2, 2>(DScene, FbIO *);

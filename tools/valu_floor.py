@@ -37,7 +37,9 @@ def main():
         return {k: b[k] - a[k] for k in a}
 
     blocks = {"node_visit": per_exec("fb_node_visit"), "prim_test": per_exec("fb_prim_test"), "generate": per_exec("fb_generate"),
-              "vertex_all_branches": per_exec("fb_vertex"), "sample_diffuse": per_exec("fb_sample", "0"), "sample_dielectric": per_exec("fb_sample", "1"),
+              "vertex_all_branches": per_exec("fb_vertex", "false"), "vertex_ptdl_all_branches": per_exec("fb_vertex", "true"),
+              "eval_diffuse": per_exec("fb_eval", "0"), "eval_dielectric": per_exec("fb_eval", "1"), "eval_metal": per_exec("fb_eval", "2"),
+              "shadow_resolve": per_exec("fb_shadow"), "splat_pass_of_four": per_exec("fb_splat"), "sample_diffuse": per_exec("fb_sample", "0"), "sample_dielectric": per_exec("fb_sample", "1"),
               "sample_metal": per_exec("fb_sample", "2"),
               "setup_all_kinds": per_exec("fb_setup", "0"), "setup_sphere": per_exec("fb_setup", "1"), "setup_line": per_exec("fb_setup", "2"), "setup_quad": per_exec("fb_setup", "4")}
     v = blocks["vertex_all_branches"]["valu"]
@@ -48,6 +50,9 @@ def main():
            # a vertex runs ONE bsdf's sample block and the surface set-up of ONE kind of primitive: the all-branches count minus what it does not run
            "vertex_valu": {"diffuse_on_quad": v - t - me - sa + blocks["setup_quad"]["valu"], "dielectric_on_line": v - d - me - sa + blocks["setup_line"]["valu"],
                            "dielectric_on_sphere": v - d - me - sa + blocks["setup_sphere"]["valu"], "metal_on_line": v - d - t - sa + blocks["setup_line"]["valu"]},
+           # ptdl: the same vertex with next event estimation (nee_sample + the bsdf and pdf of the connection; both bsdfs' brdf / pdf code is counted)
+           "vertex_valu_ptdl": {"diffuse_on_quad": blocks["vertex_ptdl_all_branches"]["valu"] - t - me - sa + blocks["setup_quad"]["valu"] - blocks["eval_dielectric"]["valu"] - blocks["eval_metal"]["valu"],
+                                "dielectric_on_line": blocks["vertex_ptdl_all_branches"]["valu"] - d - me - sa + blocks["setup_line"]["valu"] - blocks["eval_diffuse"]["valu"] - blocks["eval_metal"]["valu"]},
            "note": "vertex = path_shade of the pt sampler between two rays (surface set-up, material ops, emitter hit, Russian roulette, bsdf sample, next ray) "
                    "with the bsdf blocks and the set-up of the primitive kinds it does not run taken out; the emitter / roulette / nested-media branches a given "
                    "vertex skips are still counted, so the vertex figures are upper estimates and the floor errs on the high side"}
