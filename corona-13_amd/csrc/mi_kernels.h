@@ -197,7 +197,9 @@ enum { MI_DIM_IMAGE_X = 0, MI_DIM_IMAGE_Y = 1, MI_DIM_LAMBDA = 2, MI_DIM_TIME = 
  * two or three path vertices' -- the dimensions every path draws) are staged into LDS at the start of the workgroup's dynamic
  * LDS by the HALTON instantiations (lds_setup); the rest of the 387 KB stays in L2. 0 = everything from L2 (A/B switch). */
 #ifndef MI_HALTON_LDS
-#define MI_HALTON_LDS 4096
+#define MI_HALTON_LDS 0      /* entries of the Halton permutation tables' head staged into LDS. Rounds 2-3: 4096 (+0.2 % pt, +0.5 % ptdl against L2: the look-ups are in
+                                flight together anyway). Round 4: the 8 KB are worth more to the pools of the exchange between waves (mi_regroup.h): 0010 Halton pt
+                                17.92 -> 17.26 ms, ptdl 33.2 -> 31.5 with the tables left in L2 */
 #endif
 __device__ __forceinline__ const unsigned short *halton_lds()
 {
