@@ -570,6 +570,9 @@ __device__ __forceinline__ void path_shade(const DScene &sc, PathState &ps, cons
     run_prepare_ops(sc, mat, mhead.y, sf, ps.lambda, sh);
     uint32_t material_modes = 0;
     float eta_ratio = 1.0f;      /* path_eta_ratio(v): e[v].vol.ior / ior behind the interface, src/pathspace.c:117-124 */
+    /* (only the dielectric and the metal read it -- and the path records: a wave of diffuse vertices, which the exchange between waves
+       makes the common case, skips the medium stack's walk and the look-up of the ior behind the interface) */
+    if(RECORD || mat_bsdf != MI_BSDF_DIFFUSE)
     {
       Media hyp = ps.media;
       media_apply(hyp, shape, (sf.flags & s_inside) != 0);
