@@ -9,16 +9,20 @@
  * workgroup barrier per iteration was measured first: +30 % kernel time on cfg 2, +21 % on cfg 3 -- the waves' traversal slices are too
  * uneven for lock step, profiles/r04_regroup_ab.txt):
  *
- *   after its traversal slice a wave looks at the surface vertices its lanes have arrived at (class = the material's bsdf, one
- *   word per primitive, DPrimGeo.cls) and at the pools; it picks ONE class to shade in this iteration -- a class whose pool plus
- *   its own lanes make a full batch if there is one, else the class most of its own lanes are in --, POSTS the vertices of the other
- *   classes into their pools (the whole path state that is live between two rays: MI_POOL_SLOTS 8-byte words) and PULLS vertices of
- *   the chosen class into the lanes that have become free (those whose path has just ended + those that posted).
- *   path_shade then runs as before; its other classes' blocks find no lane and are skipped. A full pool means "shade in place",
- *   which is what every kernel did before -- the exchange is an optimisation on top of the same code, not a second pipeline.
+ *   after its traversal slice a wave looks at the vertices its lanes have arrived at (class = the material's bsdf, two bits per
+ *   primitive in a table staged into LDS; in the extended kernels volume vertices are a class of their own) and at the pools. If its own
+ *   vertices of a class plus what that class's pool holds FILL the wave's lanes -- as far as lanes become free: ended paths + the other
+ *   classes' vertices, which are posted --, it SHADES THAT CLASS: posts the others, pulls from the pool. Otherwise it POSTS ALL its
+ *   vertices while entries are left, shades nothing and goes on tracing: its lanes start new paths together, and the vertices are shaded
+ *   later by a wave they fill (MI_POOL_POLICY 2; policy 1 -- always shade the class most own lanes are in -- is the first version).
+ *   What travels is the whole path state that is live between two rays (PoolLayout::SLOTS 8-byte words). path_shade then runs as before;
+ *   the blocks of the classes the wave does not hold find no lane and are skipped. A full pool means "shade in place", which is what
+ *   every kernel did before -- the exchange is an optimisation on top of the same code, not a second pipeline.
  *
  * Which lane finishes a path does not matter to the path: its generator, pixel, wavelength and throughput travel with it, counters are
- * summed over all lanes. The pools are guarded by ONE spin lock in LDS taken by a wave for the ~30 LDS instructions of an exchange.
+ * summed over all lanes (tests/test_gpu_parity.py::test_exchange_between_waves_changes_no_path: byte-identical path records with and
+ * without the exchange). The lists of entries are guarded by ONE lock word in LDS that carries the pools' counts (below); a wave holds
+ * it twice per exchange for a handful of instructions, the vertices are copied outside.
  * End of the launch: a wave whose index range has run dry posts nothing and pulls from any pool; it only leaves once the pools
  * are empty, and a wave that posts is alive and will check again -- so the last wave out sees them empty.
  */
@@ -53,7 +57,7 @@ typedef __attribute__((address_space(3))) mi_u32x4 lds_uint4;
 #define MI_SEL3(A, I) ((I) == 0 ? (A)[0] : (I) == 1 ? (A)[1] : (I) == 2 ? (A)[2] : (A)[3])
 #define MI_SUM4(A) ((A)[0] + (A)[1] + (A)[2] + (A)[3])
 
-/* control words. `state` IS the lock: four 16-bit counts {entries listed per class 0..2, free entries} packed into 64 bits while nobody
+/* control words. `state` IS the lock: five 12-bit counts {entries listed per class 0..3, free entries} packed into 64 bits while nobody
  * is inside a critical section, all ones while somebody is. A wave enters with ONE atomic exchange (all ones in, the counts out -- or
  * all ones out: spin) and leaves by storing the new counts: lock, look and unlock cost one LDS round trip together (as three
  * separate operations each was a round trip through an LDS that fifteen other waves traverse a tree in: 6 000 ticks held per
