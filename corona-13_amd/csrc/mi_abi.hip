@@ -241,7 +241,7 @@ static int build_on_device(mi_scene *s, const mi_scene_desc *h, uint32_t *num_no
 #define BALLOC(field, type, count) if(!(b.field = (type *)dev(sizeof(type)*(size_t)(count)))) { release(); return fail(MI_ERR_NOMEM, "device build: out of memory"); }
   BALLOC(box, float, 8*(size_t)n) BALLOC(key_in, uint32_t, n) BALLOC(key, uint32_t, n) BALLOC(val_in, uint32_t, n) BALLOC(perm, uint32_t, n)
   BALLOC(left, int, n) BALLOC(right, int, n) BALLOC(parent, int, n) BALLOC(leaf_parent, int, n) BALLOC(first, int, n) BALLOC(last, int, n)
-  BALLOC(ibox, float, 8*(size_t)n) BALLOC(visits, unsigned int, n)
+  BALLOC(ibox, float, 8*(size_t)n) BALLOC(visits, unsigned int, n) BALLOC(count, int, n) BALLOC(perm2, uint32_t, n)
   /* moving primitives: a second box set (shutter close), like the reference's aabb1; CORONA_MI_BUILD_T1=0 keeps one box around both states (A/B) */
   const bool two_states = s->d_prims_t1 != nullptr && !(getenv("CORONA_MI_BUILD_T1") && !atoi(getenv("CORONA_MI_BUILD_T1")));
   if(two_states) { BALLOC(box1, float, 8*(size_t)n) BALLOC(ibox1, float, 8*(size_t)n) }
@@ -271,8 +271,24 @@ static int build_on_device(mi_scene *s, const mi_scene_desc *h, uint32_t *num_no
     hipLaunchKernelGGL(bl_refit, dim3(grid), dim3(BL_BLOCK), 0, 0, b);
     e = hipGetLastError();
   }
-  uint32_t N = 0;
   unsigned int stats[4] = {0, 0, 0, 0};
+  { /* SAH refinement: passes of tree rotations over the binary tree (mi_build.h); CORONA_MI_BUILD_SAH=0 keeps the plain LBVH (A/B) */
+    int passes = 3;
+    { const char *pe = getenv("CORONA_MI_BUILD_SAH"); if(pe && atoi(pe) >= 0 && atoi(pe) <= 16) passes = atoi(pe); }
+    unsigned int *rot = passes ? (unsigned int *)dev(4) : nullptr;
+    if(passes && !rot) e = hipErrorOutOfMemory;
+    if(e == hipSuccess && rot) e = hipMemset(rot, 0, 4);
+    for(int k=0;k<passes && e == hipSuccess && n > 2;k++)
+    {
+      e = hipMemset(b.visits, 0, sizeof(unsigned int)*n);
+      if(e != hipSuccess) break;
+      hipLaunchKernelGGL(bl_rotate, dim3(grid), dim3(BL_BLOCK), 0, 0, b, rot);
+      e = hipGetLastError();
+    }
+    if(e == hipSuccess && rot && verbose) e = hipMemcpy(&stats[1], rot, 4, hipMemcpyDeviceToHost);
+    stats[2] = (unsigned int)passes;
+  }
+  uint32_t N = 0;
   if(e == hipSuccess)
   { /* top-down collapse, one launch per level of the 4-wide tree */
     const uint32_t cap = n - 1;
@@ -282,24 +298,26 @@ static int build_on_device(mi_scene *s, const mi_scene_desc *h, uint32_t *num_no
     uint32_t *taxes = (uint32_t *)dev((size_t)cap*4);
     int *la = (int *)dev(sizeof(int)*(size_t)n), *lb = (int *)dev(sizeof(int)*(size_t)n);
     unsigned int *qa = (unsigned int *)dev(sizeof(int)*(size_t)n), *qb = (unsigned int *)dev(sizeof(int)*(size_t)n);
+    unsigned int *fa = (unsigned int *)dev(sizeof(int)*(size_t)n), *fb = (unsigned int *)dev(sizeof(int)*(size_t)n);
     unsigned int *cnt = (unsigned int *)dev(8);
-    if(!tnodes || !taxes || !la || !lb || !qa || !qb || !cnt) e = hipErrorOutOfMemory;
+    if(!tnodes || !taxes || !la || !lb || !qa || !qb || !fa || !fb || !cnt) e = hipErrorOutOfMemory;
     unsigned int hc[2] = {1, 0};
     const int zero = 0;
     if(e == hipSuccess) e = hipMemcpy(la, &zero, 4, hipMemcpyHostToDevice);
     if(e == hipSuccess) e = hipMemcpy(qa, &zero, 4, hipMemcpyHostToDevice);
+    if(e == hipSuccess) e = hipMemcpy(fa, &zero, 4, hipMemcpyHostToDevice);
     unsigned int n_in = 1, levels = 0;
     while(e == hipSuccess && n_in)
     {
       hc[1] = 0;
       e = hipMemcpy(cnt, hc, 8, hipMemcpyHostToDevice);
       if(e != hipSuccess) break;
-      CollapseLists L = { la, qa, lb, qb, cnt, n_in };
+      CollapseLists L = { la, qa, fa, lb, qb, fb, cnt, n_in };
       hipLaunchKernelGGL(bl_collapse, dim3((n_in + BL_BLOCK - 1)/BL_BLOCK), dim3(BL_BLOCK), 0, 0, b, L, tnodes, taxes, cap, tnodes_t1);
       e = hipGetLastError();
       if(e == hipSuccess) e = hipMemcpy(hc, cnt, 8, hipMemcpyDeviceToHost);
       n_in = hc[1];
-      std::swap(la, lb); std::swap(qa, qb);
+      std::swap(la, lb); std::swap(qa, qb); std::swap(fa, fb);
       levels++;
     }
     N = hc[0]; stats[0] = levels;
@@ -325,10 +343,10 @@ static int build_on_device(mi_scene *s, const mi_scene_desc *h, uint32_t *num_no
     if(e == hipSuccess && s->d_prims_t1 && hipMalloc(&nt, sizeof(DPrimT1)*(size_t)n) != hipSuccess) e = hipErrorOutOfMemory;
     if(e == hipSuccess)
     {
-      if(nt) hipLaunchKernelGGL(bl_gather<DPrimT1>, dim3(grid), dim3(BL_BLOCK), 0, 0, (DPrimT1 *)nt, (const DPrimT1 *)s->d_prims_t1, (const uint32_t *)b.perm, n);
-      hipLaunchKernelGGL(bl_gather<DPrim>, dim3(grid), dim3(BL_BLOCK), 0, 0, (DPrim *)np, (const DPrim *)s->d_prims, (const uint32_t *)b.perm, n);
-      hipLaunchKernelGGL(bl_gather<DPrimGeo>, dim3(grid), dim3(BL_BLOCK), 0, 0, (DPrimGeo *)ng, (const DPrimGeo *)s->d_primgeo, (const uint32_t *)b.perm, n);
-      hipLaunchKernelGGL(bl_invert, dim3(grid), dim3(BL_BLOCK), 0, 0, inv, (const uint32_t *)b.perm, n);
+      if(nt) hipLaunchKernelGGL(bl_gather<DPrimT1>, dim3(grid), dim3(BL_BLOCK), 0, 0, (DPrimT1 *)nt, (const DPrimT1 *)s->d_prims_t1, (const uint32_t *)b.perm2, n);
+      hipLaunchKernelGGL(bl_gather<DPrim>, dim3(grid), dim3(BL_BLOCK), 0, 0, (DPrim *)np, (const DPrim *)s->d_prims, (const uint32_t *)b.perm2, n);
+      hipLaunchKernelGGL(bl_gather<DPrimGeo>, dim3(grid), dim3(BL_BLOCK), 0, 0, (DPrimGeo *)ng, (const DPrimGeo *)s->d_primgeo, (const uint32_t *)b.perm2, n);
+      hipLaunchKernelGGL(bl_invert, dim3(grid), dim3(BL_BLOCK), 0, 0, inv, (const uint32_t *)b.perm2, n);
       if(h->lights.num_prims)
         hipLaunchKernelGGL(bl_remap, dim3((h->lights.num_prims + BL_BLOCK - 1)/BL_BLOCK), dim3(BL_BLOCK), 0, 0, (uint32_t *)s->d_light_prim, (const uint32_t *)inv,
                            h->lights.num_prims);
@@ -350,7 +368,7 @@ static int build_on_device(mi_scene *s, const mi_scene_desc *h, uint32_t *num_no
   {
     float ms = 0.0f;
     if(e == hipSuccess && hipEventElapsedTime(&ms, t0, t1) == hipSuccess)
-      fprintf(stderr, "[mi] device build: %u primitives -> %u 4-wide nodes, %u levels, %.3f ms on the device\n", n, N, stats[0], ms);
+      fprintf(stderr, "[mi] device build: %u primitives -> %u 4-wide nodes, %u levels, %u rotations in %u passes, %.3f ms on the device\n", n, N, stats[0], stats[1], stats[2], ms);
     (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
   }
   release();

@@ -12,6 +12,14 @@
  * Scenes with moving primitives get the nodes' shutter-close boxes too (round 4: box1 / ibox1, DScene.nodes_t1), refitted on the same
  * topology as the reference does (src/accel.d/qbvhmp.c:259-283); the traversal interpolates the two box sets at the ray's time.
  *
+ * SAH refinement (round 4, bl_rotate): between refit and collapse the binary tree is improved by tree rotations (Kensler 2008) -- bottom
+ * up, every node tries to trade one of its children for a grandchild on the other side and keeps the trade that shrinks the surface
+ * area of the node in between the most (the SAH cost of the binary tree is the sum of its inner nodes' areas); a few passes
+ * (CORONA_MI_BUILD_SAH, default 3; 0 = the plain LBVH). The reference gets its quality from a binned SAH sweep at build time
+ * (src/accel.d/qbvhmp.c:425-525, 854-873); here the Morton order gives the topology in one sort and the rotations repair its worst
+ * splits. Rotated subtrees no longer cover contiguous ranges of the Morton order: the collapse hands out the final positions top
+ * down (a node's range is split among its children by their primitive counts) and writes the final permutation (perm2).
+ *
  * The tree differs from the reference builder's (binned SAH sweep), so node-visit counters differ; closest hits do not
  * depend on the tree (tests/test_gpu_parity.py: same primitive and distance as the oracle on the host-built tree, bit
  * for bit, apart from exact ties).
@@ -40,7 +48,9 @@ struct BuildBufs
   uint32_t *key_in, *key, *val_in, *perm;        /* Morton codes and primitive ids, unsorted / sorted */
   int *left, *right, *parent;     /* binary radix tree: children of internal node i (>= 0: internal, < 0: ~leaf position), parents */
   int *leaf_parent;               /* parent of sorted leaf i */
-  int *first, *last;              /* sorted range of internal node i */
+  int *first, *last;              /* sorted range of internal node i (as built: not kept up by the rotations) */
+  int *count;                     /* primitives below internal node i */
+  uint32_t *perm2;                /* final order of the primitives: position -> original primitive (written by the collapse) */
   float *ibox;                    /* [n-1][8] boxes of the internal nodes */
   float *box1, *ibox1;            /* scenes with moving primitives: the same at shutter CLOSE (box / ibox then hold the shutter-open state), else NULL */
   unsigned int *visits;           /* refit arrival counters */
@@ -149,7 +159,7 @@ __global__ __launch_bounds__(BL_BLOCK) void bl_hierarchy(BuildBufs b)
   const int lo = i < j ? i : j, hi = i < j ? j : i;
   const int lc = lo == gamma ? ~gamma : gamma;
   const int rc = hi == gamma + 1 ? ~(gamma + 1) : gamma + 1;
-  b.left[i] = lc; b.right[i] = rc; b.first[i] = lo; b.last[i] = hi;
+  b.left[i] = lc; b.right[i] = rc; b.first[i] = lo; b.last[i] = hi; b.count[i] = hi - lo + 1;
   if(lc >= 0) b.parent[lc] = i; else b.leaf_parent[~lc] = i;
   if(rc >= 0) b.parent[rc] = i; else b.leaf_parent[~rc] = i;
   if(i == 0) b.parent[0] = -1;
@@ -194,9 +204,89 @@ __global__ __launch_bounds__(BL_BLOCK) void bl_refit(BuildBufs b)
   }
 }
 
+__device__ __forceinline__ int bl_count(const BuildBufs &b, int child) { return child >= 0 ? b.count[child] : 1; }
 __device__ __forceinline__ bool bl_large(const BuildBufs &b, int child)
 { /* internal node with more primitives than a leaf may hold */
-  return child >= 0 && b.last[child] - b.first[child] + 1 > b.leaf_max;
+  return child >= 0 && b.count[child] > b.leaf_max;
+}
+
+/* ---- SAH refinement: tree rotations, bottom up (one thread per leaf walks up; the second thread to arrive at a node works on it, so
+ * both subtrees below are final for this pass and nobody else touches them). At node N with children X and S (S an inner node with
+ * children G and K) the trade "X <-> G" leaves N's box as it is and makes S = {X, K}: the tree's cost changes by area(X u K) - area(S).
+ * All (up to four) trades are priced, the best one that lowers the cost is carried out. Scenes with two box sets (moving primitives)
+ * price the sum of the areas at shutter open and close. */
+struct BlBox { float lo[3], hi[3], lo1[3], hi1[3]; };
+__device__ __forceinline__ int bl_ldi(const int *p) { return *(const volatile int *)p; }
+__device__ __forceinline__ BlBox bl_box_of(const BuildBufs &b, int child)
+{
+  BlBox x;
+  bl_load_box(b, child, x.lo, x.hi);
+  if(b.box1) bl_load_box1(b, child, x.lo1, x.hi1);
+  else for(int k=0;k<3;k++) { x.lo1[k] = x.lo[k]; x.hi1[k] = x.hi[k]; }
+  return x;
+}
+__device__ __forceinline__ BlBox bl_union(const BlBox &a, const BlBox &c)
+{
+  BlBox x;
+  for(int k=0;k<3;k++) { x.lo[k] = fminf(a.lo[k], c.lo[k]); x.hi[k] = fmaxf(a.hi[k], c.hi[k]); x.lo1[k] = fminf(a.lo1[k], c.lo1[k]); x.hi1[k] = fmaxf(a.hi1[k], c.hi1[k]); }
+  return x;
+}
+__device__ __forceinline__ float bl_area2(const BlBox &x)
+{
+  const float dx = x.hi[0]-x.lo[0], dy = x.hi[1]-x.lo[1], dz = x.hi[2]-x.lo[2];
+  const float ex = x.hi1[0]-x.lo1[0], ey = x.hi1[1]-x.lo1[1], ez = x.hi1[2]-x.lo1[2];
+  return (dx*dy + dy*dz + dz*dx) + (ex*ey + ey*ez + ez*ex);
+}
+__device__ __forceinline__ void bl_set_parent(const BuildBufs &b, int child, int parent)
+{
+  if(child >= 0) b.parent[child] = parent; else b.leaf_parent[~child] = parent;
+}
+
+__global__ __launch_bounds__(BL_BLOCK) void bl_rotate(BuildBufs b, unsigned int *rotations)
+{
+  const int i = blockIdx.x*BL_BLOCK + threadIdx.x;
+  if(i >= (int)b.n) return;
+  int node = bl_ldi(b.leaf_parent + i);
+  while(node >= 0)
+  {
+    __threadfence();
+    if(atomicAdd(&b.visits[node], 1u) == 0) return;
+    __threadfence();
+    const int c[2] = { bl_ldi(b.left + node), bl_ldi(b.right + node) };
+    const BlBox cb[2] = { bl_box_of(b, c[0]), bl_box_of(b, c[1]) };
+    float best = 0.0f;
+    int bx = -1, bg = -1;           /* trade child c[bx] of `node` for grandchild number bg of its sibling c[1-bx] */
+    BlBox bbox;
+    for(int x=0;x<2;x++)
+    {
+      const int sgl = c[1-x];
+      if(sgl < 0) continue;
+      const int g[2] = { bl_ldi(b.left + sgl), bl_ldi(b.right + sgl) };
+      const float as = bl_area2(cb[1-x]);
+      for(int k=0;k<2;k++)
+      { /* X = c[x] takes the place of G = g[k]; K = g[1-k] stays */
+        const BlBox u = bl_union(cb[x], bl_box_of(b, g[1-k]));
+        const float d = bl_area2(u) - as;
+        if(d < best - 1e-6f*as) { best = d; bx = x; bg = k; bbox = u; }
+      }
+    }
+    if(bx >= 0)
+    {
+      const int X = c[bx], S = c[1-bx];
+      const int g[2] = { bl_ldi(b.left + S), bl_ldi(b.right + S) };
+      const int G = g[bg], K = g[1-bg];
+      if(bx == 0) b.left[node] = G; else b.right[node] = G;
+      if(bg == 0) b.left[S] = X; else b.right[S] = X;
+      bl_set_parent(b, G, node);
+      bl_set_parent(b, X, S);
+      volatile float *o = b.ibox + 8*(size_t)S;
+      for(int k=0;k<3;k++) { o[k] = bbox.lo[k]; o[4+k] = bbox.hi[k]; }
+      if(b.box1) { volatile float *o1 = b.ibox1 + 8*(size_t)S; for(int k=0;k<3;k++) { o1[k] = bbox.lo1[k]; o1[4+k] = bbox.hi1[k]; } }
+      *(volatile int *)(b.count + S) = (X >= 0 ? bl_ldi(b.count + X) : 1) + (K >= 0 ? bl_ldi(b.count + K) : 1);
+      atomicAdd(rotations, 1u);
+    }
+    node = bl_ldi(b.parent + node);
+  }
 }
 
 __device__ __forceinline__ int bl_split_axis(const float *l0, const float *h0, const float *l1, const float *h1, bool &swap)
@@ -220,8 +310,10 @@ struct CollapseLists
 {
   const int *in;                  /* binary node of every 4-wide node of this level */
   const unsigned int *in_q;       /* its 4-wide index */
+  const unsigned int *in_first;   /* first position of its primitives in the final order */
   int *out;
   unsigned int *out_q;
+  unsigned int *out_first;
   unsigned int *counters;         /* [0] nodes allocated so far, [1] entries in `out` */
   unsigned int n_in;
 };
@@ -279,6 +371,9 @@ __global__ __launch_bounds__(BL_BLOCK) void bl_collapse(BuildBufs b, CollapseLis
     axis1[h] = bl_split_axis(lo[slot[2*h]], hi[slot[2*h]], lo[slot[2*h+1]], hi[slot[2*h+1]], sw);
     if(sw) { const int tmp = slot[2*h]; slot[2*h] = slot[2*h+1]; slot[2*h+1] = tmp; }
   }
+  /* final positions: this node's range is dealt out to the candidates by their primitive counts */
+  unsigned int cfirst[4] = {0, 0, 0, 0};
+  { unsigned int pos = L.in_first[t]; for(int j=0;j<m;j++) { cfirst[j] = pos; pos += (unsigned int)bl_count(b, cand[j]); } }
   uint32_t link[4];
   float olo[4][3], ohi[4][3], olo1[4][3], ohi1[4][3];
   for(int c=0;c<4;c++)
@@ -296,11 +391,22 @@ __global__ __launch_bounds__(BL_BLOCK) void bl_collapse(BuildBufs b, CollapseLis
     {
       const unsigned int nq = atomicAdd(&L.counters[0], 1u);
       const unsigned int pos = atomicAdd(&L.counters[1], 1u);
-      L.out[pos] = child; L.out_q[pos] = nq;
+      L.out[pos] = child; L.out_q[pos] = nq; L.out_first[pos] = cfirst[j];
       link[c] = nq;
     }
-    else if(child < 0) link[c] = MI_LEAF32 | ((uint32_t)(~child) << 5) | 1u;
-    else link[c] = MI_LEAF32 | ((uint32_t)b.first[child] << 5) | (uint32_t)(b.last[child] - b.first[child] + 1);
+    else
+    { /* a leaf: the primitives below `child` take the positions cfirst[j] ... in the final order */
+      int stk[8], sp = 0;
+      unsigned int k = 0;
+      stk[sp++] = child;
+      while(sp)
+      {
+        const int e = stk[--sp];
+        if(e < 0) b.perm2[cfirst[j] + k++] = b.perm[~e];
+        else { stk[sp++] = b.right[e]; stk[sp++] = b.left[e]; }
+      }
+      link[c] = MI_LEAF32 | ((uint32_t)cfirst[j] << 5) | k;
+    }
   }
   for(int k=0;k<3;k++)
   {
