@@ -241,7 +241,7 @@ static int build_on_device(mi_scene *s, const mi_scene_desc *h, uint32_t *num_no
 #define BALLOC(field, type, count) if(!(b.field = (type *)dev(sizeof(type)*(size_t)(count)))) { release(); return fail(MI_ERR_NOMEM, "device build: out of memory"); }
   BALLOC(box, float, 8*(size_t)n) BALLOC(key_in, uint32_t, n) BALLOC(key, uint32_t, n) BALLOC(val_in, uint32_t, n) BALLOC(perm, uint32_t, n)
   BALLOC(left, int, n) BALLOC(right, int, n) BALLOC(parent, int, n) BALLOC(leaf_parent, int, n) BALLOC(first, int, n) BALLOC(last, int, n)
-  BALLOC(ibox, float, 8*(size_t)n) BALLOC(visits, unsigned int, n) BALLOC(count, int, n) BALLOC(perm2, uint32_t, n)
+  BALLOC(ibox, float, 8*(size_t)n) BALLOC(visits, unsigned int, n) BALLOC(count, int, n) BALLOC(perm2, uint32_t, n) BALLOC(cost, float, n)
   /* moving primitives: a second box set (shutter close), like the reference's aabb1; CORONA_MI_BUILD_T1=0 keeps one box around both states (A/B) */
   const bool two_states = s->d_prims_t1 != nullptr && !(getenv("CORONA_MI_BUILD_T1") && !atoi(getenv("CORONA_MI_BUILD_T1")));
   if(two_states) { BALLOC(box1, float, 8*(size_t)n) BALLOC(ibox1, float, 8*(size_t)n) }
@@ -273,8 +273,11 @@ static int build_on_device(mi_scene *s, const mi_scene_desc *h, uint32_t *num_no
   }
   unsigned int stats[4] = {0, 0, 0, 0};
   { /* SAH refinement: passes of tree rotations over the binary tree (mi_build.h); CORONA_MI_BUILD_SAH=0 keeps the plain LBVH (A/B) */
-    int passes = 3;
+    int passes = 2;                 /* measured on regression/0010_pt and scenes/0059_mb (profiles/r04_devtree.txt): 1 / 2 / 3 (= converged) passes -> node visits 0.999 /
+                                       0.957 / 0.951 and 1.050 / 1.016 / 1.025 x the reference's on its own tree, 64 spp in 15.48 / 15.53 / 15.91 and 25.65 / 25.57 / 26.33 ms */
+    float ct = 1.0f;                /* cost of a primitive test in units of an inner (binary) node's box test: 2 and 4 buy fewer primitive tests with more node visits (no gain) */
     { const char *pe = getenv("CORONA_MI_BUILD_SAH"); if(pe && atoi(pe) >= 0 && atoi(pe) <= 16) passes = atoi(pe); }
+    { const char *ce = getenv("CORONA_MI_BUILD_CT"); if(ce && atof(ce) > 0.0 && atof(ce) <= 64.0) ct = (float)atof(ce); }
     unsigned int *rot = passes ? (unsigned int *)dev(4) : nullptr;
     if(passes && !rot) e = hipErrorOutOfMemory;
     if(e == hipSuccess && rot) e = hipMemset(rot, 0, 4);
@@ -282,7 +285,7 @@ static int build_on_device(mi_scene *s, const mi_scene_desc *h, uint32_t *num_no
     {
       e = hipMemset(b.visits, 0, sizeof(unsigned int)*n);
       if(e != hipSuccess) break;
-      hipLaunchKernelGGL(bl_rotate, dim3(grid), dim3(BL_BLOCK), 0, 0, b, rot);
+      hipLaunchKernelGGL(bl_rotate, dim3(grid), dim3(BL_BLOCK), 0, 0, b, rot, ct);
       e = hipGetLastError();
     }
     if(e == hipSuccess && rot && verbose) e = hipMemcpy(&stats[1], rot, 4, hipMemcpyDeviceToHost);

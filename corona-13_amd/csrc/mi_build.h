@@ -50,6 +50,7 @@ struct BuildBufs
   int *leaf_parent;               /* parent of sorted leaf i */
   int *first, *last;              /* sorted range of internal node i (as built: not kept up by the rotations) */
   int *count;                     /* primitives below internal node i */
+  float *cost;                    /* SAH cost of the subtree below internal node i (bl_rotate) */
   uint32_t *perm2;                /* final order of the primitives: position -> original primitive (written by the collapse) */
   float *ibox;                    /* [n-1][8] boxes of the internal nodes */
   float *box1, *ibox1;            /* scenes with moving primitives: the same at shutter CLOSE (box / ibox then hold the shutter-open state), else NULL */
@@ -211,10 +212,11 @@ __device__ __forceinline__ bool bl_large(const BuildBufs &b, int child)
 }
 
 /* ---- SAH refinement: tree rotations, bottom up (one thread per leaf walks up; the second thread to arrive at a node works on it, so
- * both subtrees below are final for this pass and nobody else touches them). At node N with children X and S (S an inner node with
- * children G and K) the trade "X <-> G" leaves N's box as it is and makes S = {X, K}: the tree's cost changes by area(X u K) - area(S).
- * All (up to four) trades are priced, the best one that lowers the cost is carried out. Scenes with two box sets (moving primitives)
- * price the sum of the areas at shutter open and close. */
+ * both subtrees below are final for this pass and nobody else touches them). The cost of a subtree is what the collapse will make of
+ * it: a leaf of n primitives (n <= leaf_max) costs ct * n * area, an inner node area + the cost of its two children (areas are not
+ * divided by the root's: only differences are compared). At node N with children X and S (S an inner node with children G and K) the
+ * trade "X <-> G" leaves N's box as it is and makes S = {X, K}; all (up to four) trades are priced, the best one that lowers the cost
+ * is carried out. Scenes with two box sets (moving primitives) price the sum of the areas at shutter open and close. */
 struct BlBox { float lo[3], hi[3], lo1[3], hi1[3]; };
 __device__ __forceinline__ int bl_ldi(const int *p) { return *(const volatile int *)p; }
 __device__ __forceinline__ BlBox bl_box_of(const BuildBufs &b, int child)
@@ -242,7 +244,16 @@ __device__ __forceinline__ void bl_set_parent(const BuildBufs &b, int child, int
   if(child >= 0) b.parent[child] = parent; else b.leaf_parent[~child] = parent;
 }
 
-__global__ __launch_bounds__(BL_BLOCK) void bl_rotate(BuildBufs b, unsigned int *rotations)
+__device__ __forceinline__ float bl_cost_of(const BuildBufs &b, int child, const BlBox &box, float ct)
+{ /* cost of the subtree below a child of the node under work (its own pass through bl_rotate is over) */
+  return child >= 0 ? *(const volatile float *)(b.cost + child) : ct*bl_area2(box);
+}
+__device__ __forceinline__ float bl_cost_node(const BuildBufs &b, int n, float area, float cl, float cr, float ct)
+{
+  return n <= b.leaf_max ? ct*(float)n*area : area + cl + cr;
+}
+
+__global__ __launch_bounds__(BL_BLOCK) void bl_rotate(BuildBufs b, unsigned int *rotations, float ct)
 {
   const int i = blockIdx.x*BL_BLOCK + threadIdx.x;
   if(i >= (int)b.n) return;
@@ -254,37 +265,53 @@ __global__ __launch_bounds__(BL_BLOCK) void bl_rotate(BuildBufs b, unsigned int 
     __threadfence();
     const int c[2] = { bl_ldi(b.left + node), bl_ldi(b.right + node) };
     const BlBox cb[2] = { bl_box_of(b, c[0]), bl_box_of(b, c[1]) };
-    float best = 0.0f;
-    int bx = -1, bg = -1;           /* trade child c[bx] of `node` for grandchild number bg of its sibling c[1-bx] */
-    BlBox bbox;
-    for(int x=0;x<2;x++)
-    {
-      const int sgl = c[1-x];
-      if(sgl < 0) continue;
-      const int g[2] = { bl_ldi(b.left + sgl), bl_ldi(b.right + sgl) };
-      const float as = bl_area2(cb[1-x]);
-      for(int k=0;k<2;k++)
-      { /* X = c[x] takes the place of G = g[k]; K = g[1-k] stays */
-        const BlBox u = bl_union(cb[x], bl_box_of(b, g[1-k]));
-        const float d = bl_area2(u) - as;
-        if(d < best - 1e-6f*as) { best = d; bx = x; bg = k; bbox = u; }
+    float cc[2] = { bl_cost_of(b, c[0], cb[0], ct), bl_cost_of(b, c[1], cb[1], ct) };
+    const int ncount = bl_ldi(b.count + node);
+    const float narea = bl_area2(bl_union(cb[0], cb[1]));
+    if(ncount > b.leaf_max)
+    { /* (a node that ends up inside a leaf has nothing to gain) */
+      float best = cc[0] + cc[1];
+      const float margin = 1e-6f*best;
+      int bx = -1, bg = -1;           /* trade child c[bx] of `node` for grandchild number bg of its sibling c[1-bx] */
+      BlBox bbox;
+      float bcost = 0.0f;
+      int bcount = 0;
+      for(int x=0;x<2;x++)
+      {
+        const int sgl = c[1-x];
+        if(sgl < 0) continue;
+        const int g[2] = { bl_ldi(b.left + sgl), bl_ldi(b.right + sgl) };
+        for(int k=0;k<2;k++)
+        { /* X = c[x] takes the place of G = g[k]; K = g[1-k] stays */
+          const BlBox gb = bl_box_of(b, g[k]), kb = bl_box_of(b, g[1-k]);
+          const BlBox u = bl_union(cb[x], kb);
+          const int n2 = (c[x] >= 0 ? bl_ldi(b.count + c[x]) : 1) + (g[1-k] >= 0 ? bl_ldi(b.count + g[1-k]) : 1);
+          const float c2 = bl_cost_node(b, n2, bl_area2(u), cc[x], bl_cost_of(b, g[1-k], kb, ct), ct);
+          const float total = bl_cost_of(b, g[k], gb, ct) + c2;
+          if(total < best - margin) { best = total; bx = x; bg = k; bbox = u; bcost = c2; bcount = n2; }
+        }
+      }
+      if(bx >= 0)
+      {
+        const int X = c[bx], S = c[1-bx];
+        const int g[2] = { bl_ldi(b.left + S), bl_ldi(b.right + S) };
+        const int G = g[bg];
+        if(bx == 0) b.left[node] = G; else b.right[node] = G;
+        if(bg == 0) b.left[S] = X; else b.right[S] = X;
+        bl_set_parent(b, G, node);
+        bl_set_parent(b, X, S);
+        volatile float *o = b.ibox + 8*(size_t)S;
+        for(int k=0;k<3;k++) { o[k] = bbox.lo[k]; o[4+k] = bbox.hi[k]; }
+        if(b.box1) { volatile float *o1 = b.ibox1 + 8*(size_t)S; for(int k=0;k<3;k++) { o1[k] = bbox.lo1[k]; o1[4+k] = bbox.hi1[k]; } }
+        *(volatile int *)(b.count + S) = bcount;
+        *(volatile float *)(b.cost + S) = bcost;
+        atomicAdd(rotations, 1u);
+        /* the node's children are now G and S */
+        const BlBox gb = bl_box_of(b, G);
+        cc[bx] = bl_cost_of(b, G, gb, ct); cc[1-bx] = bcost;
       }
     }
-    if(bx >= 0)
-    {
-      const int X = c[bx], S = c[1-bx];
-      const int g[2] = { bl_ldi(b.left + S), bl_ldi(b.right + S) };
-      const int G = g[bg], K = g[1-bg];
-      if(bx == 0) b.left[node] = G; else b.right[node] = G;
-      if(bg == 0) b.left[S] = X; else b.right[S] = X;
-      bl_set_parent(b, G, node);
-      bl_set_parent(b, X, S);
-      volatile float *o = b.ibox + 8*(size_t)S;
-      for(int k=0;k<3;k++) { o[k] = bbox.lo[k]; o[4+k] = bbox.hi[k]; }
-      if(b.box1) { volatile float *o1 = b.ibox1 + 8*(size_t)S; for(int k=0;k<3;k++) { o1[k] = bbox.lo1[k]; o1[4+k] = bbox.hi1[k]; } }
-      *(volatile int *)(b.count + S) = (X >= 0 ? bl_ldi(b.count + X) : 1) + (K >= 0 ? bl_ldi(b.count + K) : 1);
-      atomicAdd(rotations, 1u);
-    }
+    *(volatile float *)(b.cost + node) = bl_cost_node(b, ncount, narea, cc[0], cc[1], ct);
     node = bl_ldi(b.parent + node);
   }
 }
