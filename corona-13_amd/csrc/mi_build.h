@@ -13,9 +13,8 @@
  * topology as the reference does (src/accel.d/qbvhmp.c:259-283); the traversal interpolates the two box sets at the ray's time.
  *
  * SAH refinement (round 4, bl_rotate): between refit and collapse the binary tree is improved by tree rotations (Kensler 2008) -- bottom
- * up, every node tries to trade one of its children for a grandchild on the other side and keeps the trade that shrinks the surface
- * area of the node in between the most (the SAH cost of the binary tree is the sum of its inner nodes' areas); a few passes
- * (CORONA_MI_BUILD_SAH, default 3; 0 = the plain LBVH). The reference gets its quality from a binned SAH sweep at build time
+ * up, every node tries to trade one of its children for a grandchild on the other side and keeps the trade that lowers the SAH cost
+ * of what the collapse will make of the subtree the most; a few passes (CORONA_MI_BUILD_SAH, default 2; 0 = the plain LBVH). The reference gets its quality from a binned SAH sweep at build time
  * (src/accel.d/qbvhmp.c:425-525, 854-873); here the Morton order gives the topology in one sort and the rotations repair its worst
  * splits. Rotated subtrees no longer cover contiguous ranges of the Morton order: the collapse hands out the final positions top
  * down (a node's range is split among its children by their primitive counts) and writes the final permutation (perm2).

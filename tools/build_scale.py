@@ -1,6 +1,7 @@
 """development helper (GPU box): device BVH build against the host (reference-style SAH) build at growing primitive counts.
-Backdrops of 4096 * k^2 quads are generated with tools/make_geo.py into a scratch directory."""
-import shutil, subprocess, sys, tempfile, time
+Backdrops of 4096 * k^2 quads are generated with tools/make_geo.py into a scratch directory. MI_SCALE_SAH="0 2": the device build once per
+number of rotation passes (CORONA_MI_BUILD_SAH); default: the library's default only."""
+import os, shutil, subprocess, sys, tempfile, time
 from pathlib import Path
 REPO = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(REPO / "tests"))
@@ -25,23 +26,31 @@ for k in ks:
     t1 = time.perf_counter()
     host = pkg.Backend(scene); host.sync()
     t2 = time.perf_counter()
-    devb = pkg.Backend(scene, device_build=True); devb.sync()
-    t3 = time.perf_counter()
     rng = np.random.default_rng(1)
     n = 100000
     pos = rng.uniform(-4, 4, size=(n, 3)).astype(np.float32) + np.float32([0, 0, 2])
     d = rng.normal(size=(n, 3)); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
-    a = host.intersect(pos, d); b = devb.intersect(pos, d)
-    same = a["primid"] == b["primid"]
+    a = host.intersect(pos, d)
     per = scene.width * scene.height
-    res = []
-    for be in (host, devb):
+
+    def measure(be):
         be.render(0, per); be.sync()
         c0 = be.counters(); t = time.perf_counter(); be.render(per, 8 * per); be.sync(); ms = (time.perf_counter() - t) * 1e3; c1 = be.counters()
         dc = [y - x for x, y in zip(c0, c1)]
-        res.append((8 * per / ms / 1e3, dc[1] / dc[0], dc[3] / dc[0]))
-    print("%8d prims: host load+SAH build %8.1f ms | backend with host tree %7.1f ms | backend with device build %7.1f ms | same hits %.6f | "
-          "render host tree %7.1f Msamples/s (%.2f nodes, %.2f prims per ray), device tree %7.1f (%.2f, %.2f)" %
-          (scene.desc.num_prims, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, same.mean(), *res[0], *res[1]), flush=True)
-    host.close(); devb.close()
+        return (8 * per / ms / 1e3, dc[1] / dc[0], dc[3] / dc[0])
+    res_host = measure(host)
+    print("%8d prims: host load+SAH build %8.1f ms | backend with host tree %7.1f ms | render host tree %7.1f Msamples/s (%.2f nodes, %.2f prims per ray)" %
+          (scene.desc.num_prims, (t1 - t0) * 1e3, (t2 - t1) * 1e3, *res_host), flush=True)
+    host.close()
+    for sah in (os.environ.get("MI_SCALE_SAH", "").split() or [None]):
+        if sah is not None:
+            os.environ["CORONA_MI_BUILD_SAH"] = sah
+        t2 = time.perf_counter()
+        devb = pkg.Backend(scene, device_build=True); devb.sync()
+        t3 = time.perf_counter()
+        b = devb.intersect(pos, d)
+        same = a["primid"] == b["primid"]
+        print("%8s        device build%s: backend %7.1f ms, %d nodes | same hits %.6f | render %7.1f Msamples/s (%.2f nodes, %.2f prims per ray)" %
+              ("", "" if sah is None else " sah=" + sah, (t3 - t2) * 1e3, devb.stats()["nodes"], same.mean(), *measure(devb)), flush=True)
+        devb.close()
 shutil.rmtree(work, ignore_errors=True)
