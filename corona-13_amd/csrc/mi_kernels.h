@@ -2388,11 +2388,43 @@ __device__ __forceinline__ V3 tri_retime(const V3 v0, const V3 v1, const V3 v2, 
   return mk3(w*v0.x + v*v1.x + u*v2.x, w*v0.y + v*v1.y + u*v2.y, w*v0.z + v*v1.z + u*v2.z);
 }
 
+/* a point on a sphere / on the mantle of a cone or cylinder (geo_sphere_retime, include/geo/sphere.h:38-49; geo_line_retime, include/geo/line.h:88-121) */
+__device__ __forceinline__ V3 sphere_sample_at(const V3 c, float radius, float r0, float r1, float &hu, float &hv)
+{
+  hu = r0; hv = (float)((double)acosf(r1)/MI_PI_D);
+  const float x1 = (float)((double)(-(mi_cosf((float)((double)hv*MI_PI_D))-1.f))/2.0), x2 = hu;
+  const float z = 1.f - 2.f*x1, rr = mi_sqrt(1.f - z*z);
+  const float phi = (float)(2.f*MI_PI_D*(double)x2);
+  return mk3(c.x + radius*(rr*mi_cosf(phi)), c.y + radius*(rr*mi_sinf(phi)), c.z + radius*z);
+}
+__device__ __forceinline__ V3 line_sample_at(const V3 v0, const V3 v1, float lr0, float lr1, float r0, float r1, float &hu, float &hv)
+{
+  hu = r0; hv = r1;
+  float y;
+  if(fabsf(lr1-lr0) < 1e-3f) y = hu;
+  else y = (mi_sqrt((lr1*lr1 - lr0*lr0)*hu + lr0*lr0) - lr0)/(lr1-lr0);
+  const float phi = (float)(2.0*MI_PI_D*(double)hv);
+  float sinphi, cosphi; mi_sincosf(phi, &sinphi, &cosphi);
+  V3 d = sub3(v1, v0);
+  d = scale3(d, mi_rcp(mi_sqrt(dot3(d, d))));
+  V3 a, b; get_onb(d, a, b);
+  return mk3(v0.x + (v1.x - v0.x)*y + a.x*sinphi + b.x*cosphi, v0.y + (v1.y - v0.y)*y + a.y*sinphi + b.y*cosphi,
+             v0.z + (v1.z - v0.z)*y + a.z*sinphi + b.z*cosphi);
+}
+
 template<bool MB = false>
 __device__ __forceinline__ V3 prim_sample(const DPrim &p, const DPrimGeo &geo, float r0, float r1, float &hu, float &hv,
                                           const DPrimT1 *t1 = nullptr, float time = 0.0f)
 { /* prims_sample + prims_retime, src/prims.c:178-252 */
   const bool ordered = p.type == 0 && p.pad[1] == MI_PRIM_ORDERED;     /* a static triangle / quad under its leaf-order mark (mi_mark_ordered_kernel) */
+  if(MB && p.type == 0 && !ordered && p.pad[0] < MI_PRIM_TRI)
+  { /* moving emitter (sphere / cone / cylinder): centre / end points at the path's time (geo_get_vertex_time), the radii of the shutter-open
+       vertices -- the record moving_analytic_at makes for the intersection */
+    V3 a0, a1;
+    (void)moving_analytic_at(p, *t1, time, a0, a1);
+    if(p.pad[0] == MI_PRIM_SPHERE) return sphere_sample_at(a0, p.v[2][0], r0, r1, hu, hv);
+    return line_sample_at(a0, a1, p.v[2][0], p.v[2][1], r0, r1, hu, hv);
+  }
   if(MB && p.type == 0 && !ordered)
   { /* moving emitter (triangle / quad): the record holds the shutter-open vertices, *t1 the shutter-close ones; sample the
        primitive as it is at the path's time */
@@ -2423,30 +2455,9 @@ __device__ __forceinline__ V3 prim_sample(const DPrim &p, const DPrimGeo &geo, f
     hu = r1*a; hv = (1.0f-r1)*a;
     return tri_retime(ld3(p.v[0]), ld3(gv), ld3(gv + 3), hu, hv);
   }
-  if(type == MI_PRIM_SPHERE)
-  { /* geo_sphere_retime, include/geo/sphere.h:38-49 */
-    hu = r0; hv = (float)((double)acosf(r1)/MI_PI_D);
-    const float x1 = (float)((double)(-(mi_cosf((float)((double)hv*MI_PI_D))-1.f))/2.0), x2 = hu;
-    const float z = 1.f - 2.f*x1, rr = mi_sqrt(1.f - z*z);
-    const float phi = (float)(2.f*MI_PI_D*(double)x2);
-    const float radius = p.v[1][0];
-    return mk3(p.v[0][0] + radius*(rr*mi_cosf(phi)), p.v[0][1] + radius*(rr*mi_sinf(phi)), p.v[0][2] + radius*z);
-  }
-  /* line: geo_line_retime, include/geo/line.h:88-121 */
-  hu = r0; hv = r1;
+  if(type == MI_PRIM_SPHERE) return sphere_sample_at(ld3(p.v[0]), p.v[1][0], r0, r1, hu, hv);
   const float *f = &p.v[0][0];
-  const V3 v0 = mk3(f[0], f[1], f[2]), v1 = mk3(geo.f[26], geo.f[27], geo.f[28]);
-  const float lr0 = f[3], lr1 = f[4];
-  float y;
-  if(fabsf(lr1-lr0) < 1e-3f) y = hu;
-  else y = (mi_sqrt((lr1*lr1 - lr0*lr0)*hu + lr0*lr0) - lr0)/(lr1-lr0);
-  const float phi = (float)(2.0*MI_PI_D*(double)hv);
-  float sinphi, cosphi; mi_sincosf(phi, &sinphi, &cosphi);
-  V3 d = sub3(v1, v0);
-  d = scale3(d, mi_rcp(mi_sqrt(dot3(d, d))));
-  V3 a, b; get_onb(d, a, b);
-  return mk3(v0.x + (v1.x - v0.x)*y + a.x*sinphi + b.x*cosphi, v0.y + (v1.y - v0.y)*y + a.y*sinphi + b.y*cosphi,
-             v0.z + (v1.z - v0.z)*y + a.z*sinphi + b.z*cosphi);
+  return line_sample_at(mk3(f[0], f[1], f[2]), mk3(geo.f[26], geo.f[27], geo.f[28]), f[3], f[4], r0, r1, hu, hv);
 }
 
 /* ------------------------------------------------------------------------------------------ splat */

@@ -476,8 +476,6 @@ static int init_lights(ch_scene *s)
       const float L = m->op[k].mul*(ch_coeff_eval(c, 400.0f) + ch_coeff_eval(c, 480.0f) + ch_coeff_eval(c, 560.0f) + ch_coeff_eval(c, 660.0f))/4.0f;
       for(uint32_t i=0;i<sh->num_prims;i++)
       { /* list.c:56-74 */
-        if(MI_PRIMID_MB(s->primid[prim_base + i]) && MI_PRIMID_VCNT(s->primid[prim_base + i]) < 3)
-        { fprintf(stderr, "[ch] shape %u: moving spheres / lines as emitters are outside the scope of this backend\n", sid); return MI_ERR_UNSUPPORTED; }
         s->light_primid[off+i] = s->primid[prim_base + i];
         s->light_cdf[off+i] = ch_prim_area(&s->geo, s->primid[prim_base + i])*L;
         s->light_L[off+i] = L;

@@ -10,7 +10,7 @@ sources under /root/reference) and writes small data files that are committed:
   counters.json              -DACCEL_DEBUG work counters (rays, node visits, box hits, prim tests) for 1 spp
   tilemeans_<cfg>.npz        32x32 tile means + image means of high-spp reference renders (statistical oracle)
 
-Usage: python3 tests/golden/make_golden.py [quick|paths|mb|images|all]
+Usage: python3 tests/golden/make_golden.py [quick|paths|mb|mbrl|images|all]
 """
 import json
 import os
@@ -179,6 +179,10 @@ def main():
         dump_paths("mb_round_ptdl_mv8", "dump_ptdl_xs_mv8", 8, "0062_mb_round", 1280, 720, 6000)
         dump_paths("mb_light_pt_mv8", "dump_pt_xs_mv8", 8, "0060_mb_light", 1280, 720, 6000)        # moving emitter
         dump_paths("mb_light_ptdl_mv8", "dump_ptdl_xs_mv8", 8, "0060_mb_light", 1280, 720, 6000)
+    if what in ("paths", "all", "mbrl"):
+        dump_paths("mb_round_light_pt_mv8", "dump_pt_xs_mv8", 8, "0063_mb_round_light", 1280, 720, 6000)   # moving sphere and cone as emitters
+        dump_paths("mb_round_light_ptdl_mv8", "dump_ptdl_xs_mv8", 8, "0063_mb_round_light", 1280, 720, 6000)
+    if what in ("paths", "all"):
         dump_paths("halton_all_ptdl_mv8", "dump_ptdl_halton_mv8", 8, "0061_all", 1280, 720, 6000)    # every feature in one scene
         dump_paths("all_pt_mv32", "dump_pt_xs_mv32", 32, "0061_all", 1280, 720, 4000)
         # MOD_pointsampler=halton; the mv32 ptdl case reaches dimensions >= 256 (fallback to the per-path generator)

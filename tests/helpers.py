@@ -26,6 +26,7 @@ SCENE_MB = REPO / "scenes" / "0059_mb" / "test.nra2"           # 0010 with the b
 SCENE_MB_LIGHT = REPO / "scenes" / "0060_mb_light" / "test.nra2"   # 0059 with the emitter moving and turning as well
 SCENE_ALL = REPO / "scenes" / "0061_all" / "test.nra2"         # fog, media in sphere and cone, moving camera, moving backdrop / cap / emitter
 SCENE_MB_ROUND = REPO / "scenes" / "0062_mb_round" / "test.nra2"   # 0059 with sphere, cone and cylinder moving as well
+SCENE_MB_ROUND_LIGHT = REPO / "scenes" / "0063_mb_round_light" / "test.nra2"   # 0062 with the moving sphere and cone as emitters
 SCENE_METAL = REPO / "scenes" / "0053_metal" / "test.nra2"     # 0052 with `metal Au`, roughness 0.3 on cone/sphere/cylinder
 
 

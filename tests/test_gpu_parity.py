@@ -13,7 +13,7 @@ import json
 import numpy as np
 import pytest
 
-from helpers import oracle_lib, GOLDEN, SCENE_0010, SCENE_ALL, SCENE_CAM_MB, SCENE_FINE, SCENE_FOG, SCENE_MB, SCENE_MB_LIGHT, SCENE_MB_ROUND, SCENE_MEDIA, SCENE_NESTED, SCENE_METAL, SCENE_ROUGH, load_pkg, make_scene, oracle_intersect, oracle_records, oracle_render
+from helpers import oracle_lib, GOLDEN, SCENE_0010, SCENE_ALL, SCENE_CAM_MB, SCENE_FINE, SCENE_FOG, SCENE_MB, SCENE_MB_LIGHT, SCENE_MB_ROUND, SCENE_MB_ROUND_LIGHT, SCENE_MEDIA, SCENE_NESTED, SCENE_METAL, SCENE_ROUGH, load_pkg, make_scene, oracle_intersect, oracle_records, oracle_render
 
 pkg = load_pkg()
 pytestmark = pytest.mark.gpu
@@ -86,6 +86,8 @@ CASES = [
     ("moving geometry and emitter ptdl mv8", SCENE_MB_LIGHT, pkg.MI_SAMPLER_PTDL, 1280, 720, 8, 30000),
     ("moving geometry: sphere, cone, cylinder pt mv8", SCENE_MB_ROUND, pkg.MI_SAMPLER_PT, 1280, 720, 8, 40000),
     ("moving geometry: sphere, cone, cylinder ptdl mv8", SCENE_MB_ROUND, pkg.MI_SAMPLER_PTDL, 1280, 720, 8, 20000),
+    ("moving sphere and cone as emitters pt mv8", SCENE_MB_ROUND_LIGHT, pkg.MI_SAMPLER_PT, 1280, 720, 8, 20000),
+    ("moving sphere and cone as emitters ptdl mv8", SCENE_MB_ROUND_LIGHT, pkg.MI_SAMPLER_PTDL, 1280, 720, 8, 20000),
     # MOD_pointsampler = halton; ptdl at depth 32 reaches dimensions >= 256 (generator fall-back)
     ("halton pt mv8", SCENE_0010, pkg.MI_SAMPLER_PT, 1280, 720, 8, 60000),
     ("halton ptdl mv8", SCENE_0010, pkg.MI_SAMPLER_PTDL, 1280, 720, 8, 40000),

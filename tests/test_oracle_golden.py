@@ -18,7 +18,7 @@ import json
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, SCENE_0010, SCENE_ALL, SCENE_CAM_MB, SCENE_FINE, SCENE_FOG, SCENE_MB, SCENE_MB_LIGHT, SCENE_MB_ROUND, SCENE_MEDIA, SCENE_NESTED, SCENE_METAL, SCENE_ROUGH, load_pkg, make_scene, oracle_lib, oracle_records, oracle_render
+from helpers import GOLDEN, SCENE_0010, SCENE_ALL, SCENE_CAM_MB, SCENE_FINE, SCENE_FOG, SCENE_MB, SCENE_MB_LIGHT, SCENE_MB_ROUND, SCENE_MB_ROUND_LIGHT, SCENE_MEDIA, SCENE_NESTED, SCENE_METAL, SCENE_ROUGH, load_pkg, make_scene, oracle_lib, oracle_records, oracle_render
 
 pkg = load_pkg()
 
@@ -59,6 +59,9 @@ CASES = [
     ("mb_round_ptdl_mv8", pkg.MI_SAMPLER_PTDL, SCENE_MB_ROUND, 1e-2),
     ("mb_light_pt_mv8", pkg.MI_SAMPLER_PT, SCENE_MB_LIGHT, 1.5e-3),          # the emitter moves too: prims_sample / prims_retime at the path's time
     ("mb_light_ptdl_mv8", pkg.MI_SAMPLER_PTDL, SCENE_MB_LIGHT, 1e-2),
+    # moving sphere and cone AS EMITTERS (round 4; src/prims.c:216-252 prims_sample -> geo_sphere_retime / geo_line_retime at the path's time)
+    ("mb_round_light_pt_mv8", pkg.MI_SAMPLER_PT, SCENE_MB_ROUND_LIGHT, 1.5e-3),
+    ("mb_round_light_ptdl_mv8", pkg.MI_SAMPLER_PTDL, SCENE_MB_ROUND_LIGHT, 1e-2),
     ("halton_pt_mv8", pkg.MI_SAMPLER_PT, SCENE_0010, 1.5e-3),
     ("halton_ptdl_mv8", pkg.MI_SAMPLER_PTDL, SCENE_0010, 1e-2),
     ("halton_ptdl_rough_mv32", pkg.MI_SAMPLER_PTDL, SCENE_ROUGH, 1e-2),
