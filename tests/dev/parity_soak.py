@@ -14,6 +14,7 @@ CASES = {"base": (("cfg2 pt mv8", SCENE_0010, pkg.MI_SAMPLER_PT, 8), ("cfg3 ptdl
                  ("nested pt mv32", SCENE_NESTED, pkg.MI_SAMPLER_PT, 32), ("cam mb ptdl mv8", SCENE_CAM_MB, pkg.MI_SAMPLER_PTDL, 8),
                  ("mb ptdl mv8", SCENE_MB, pkg.MI_SAMPLER_PTDL, 8), ("halton ptdl mv8", SCENE_0010, pkg.MI_SAMPLER_PTDL, 8),
                  ("mb light ptdl mv8", SCENE_MB_LIGHT, pkg.MI_SAMPLER_PTDL, 8), ("mb round ptdl mv8", SCENE_MB_ROUND, pkg.MI_SAMPLER_PTDL, 8),
+                 ("mb round light ptdl mv8", SCENE_MB_ROUND_LIGHT, pkg.MI_SAMPLER_PTDL, 8),
                  ("halton all ptdl mv32", SCENE_ALL, pkg.MI_SAMPLER_PTDL, 32))}
 for name, path, sampler, mv in CASES[sys.argv[2] if len(sys.argv) > 2 else "base"]:
     scene = make_scene(path, width=1280, height=720, max_verts=mv, sampler=sampler,
