@@ -403,6 +403,7 @@ def main():
         # afterwards (`kernel_ms_separate`: their average; with one rank the two agree to the launch-to-launch scatter). The roofline is
         # computed on the timed launch.
         kms_timed = be.last_kernel_ms() if not args.stub else 0.0
+        kernel = be.kernel_name() if not args.stub else "stub"      # the instantiation the timed launches ran: the library's own answer
         first, count = pkg.shard_range(0, job, rank, world)
         durs = []
         extra_frames = max(3, min(steps, 5))
@@ -431,18 +432,12 @@ def main():
         res = dict(cfg=cfg, scene_wh=(scene.width, scene.height), per_frame=per_frame, job=job, elapsed=elapsed, dc=dc, kms=kms,
                    launch_paths=count, nodes_in_lds=be.nodes_in_lds(), reduced_sum=reduced_sum, steps=steps, image_mean=image_mean,
                    image_mean_many=image_mean_many, image_mean_many_spp=cfg["spp"] * (1 + extra_frames), kms_separate=kms_separate, kms_is_timed=kms_timed > 0.0,
-                   traversal="stub" if args.stub else be.traversal())
+                   traversal="stub" if args.stub else be.traversal(), kernel=kernel)
         be.close()
         return res
 
     def kernel_name(r):
-        cfg = r["cfg"]
-        inst = ("false", "true" if cfg["sampler"] == "ptdl" else "false", "true" if r["nodes_in_lds"] else "false",
-                "true" if args.points == "halton" else "false",
-                "true" if cfg["scene"] in ("0055_media", "0056_fog", "0058_cam_mb", "0059_mb") else "false", "true" if cfg["scene"] == "0059_mb" else "false", "false",
-                "true" if r["traversal"] == "fast" else "false",
-                "true" if cfg["scene"] == "0056_fog" else "false")
-        return "mi_path_kernel<%s> (RECORD, PTDL, NODES_LDS, HALTON, MEDIA, MB, COUNT, FAST, NORG)" % ",".join(inst)
+        return r["kernel"] + " (RECORD, PTDL, NODES_LDS, HALTON, MEDIA, MB, COUNT, FAST, NORG)"
 
     def work_rate_of(config, r):
         """SURVEY 8(d)'s figure under its own name: algorithmic bytes per launch / launch duration, beside the HBM peak. The 0.5 MB scene

@@ -303,6 +303,8 @@ def mi_lib():
         m.mi_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         m.mi_last_kernel_launches.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         m.mi_scene_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        m.mi_scene_kernel_name.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        m.mi_scene_lds_nodes.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         m.mi_scene_destroy.argtypes = [C.c_void_p]
         m.mi_scene_destroy.restype = None
         m.mi_shutdown.restype = None
@@ -328,7 +330,7 @@ def mi_lib():
 
 MI_SYMBOLS = ["mi_init", "mi_scene_create", "mi_scene_set_framebuffer", "mi_scene_set_stream", "mi_render",
               "mi_sync", "mi_fb_read", "mi_fb_clear", "mi_fb_device_ptr", "mi_counters", "mi_scene_set_counters", "mi_scene_set_traversal", "mi_scene_get_traversal", "mi_scene_set_metal_reference", "mi_trace_paths", "mi_intersect", "mi_plan_launches",
-              "mi_last_kernel_ms", "mi_last_kernel_launches", "mi_scene_stats", "mi_scene_destroy", "mi_shutdown", "mi_last_error", "mi_current_device", "mi_bsdf_test_run",
+              "mi_last_kernel_ms", "mi_last_kernel_launches", "mi_scene_stats", "mi_scene_lds_nodes", "mi_scene_kernel_name", "mi_scene_destroy", "mi_shutdown", "mi_last_error", "mi_current_device", "mi_bsdf_test_run",
               "mi_group_create", "mi_group_size", "mi_group_scene", "mi_group_uses_rccl", "mi_group_render", "mi_group_fb_reduce", "mi_group_fb_read",
               "mi_group_fb_clear", "mi_group_sync", "mi_group_counters", "mi_group_destroy"]
 
@@ -467,6 +469,18 @@ class Backend:
 
     def nodes_in_lds(self):
         return self.stats()["nodes_in_lds"]
+
+    def lds_nodes(self):
+        """nodes of the tree (breadth first from the root) staged in LDS (mi_scene_lds_nodes)"""
+        out = C.c_uint32(0)
+        self._check(self.m.mi_scene_lds_nodes(self._ptr, C.byref(out)), "mi_scene_lds_nodes")
+        return int(out.value)
+
+    def kernel_name(self):
+        """the instantiation the next render() launches, as rocprofv3 prints it (mi_scene_kernel_name)"""
+        buf = C.create_string_buffer(256)
+        self._check(self.m.mi_scene_kernel_name(self._ptr, buf, len(buf)), "mi_scene_kernel_name")
+        return buf.value.decode()
 
     def close(self):
         if self._ptr:

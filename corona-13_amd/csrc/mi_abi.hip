@@ -17,16 +17,19 @@
 #include <vector>
 
 /* ======================================================================================= upload-time kernels */
-/* Upload-time pass over the child links (one thread per link): an inner link takes the split axes of the node it points to into
- * bits 24..29, so that a node visit needs no separate look-up of its axes (one LDS read less per visit, and no second round trip in
- * front of the box reads). `axes` = axis0 | axis00 << 2 | axis01 << 4 per node, as the host builder / the device build leave them. */
-__global__ void mi_fold_axes_kernel(float4 *nodes, const uint32_t *axes, uint32_t N)
+/* Upload-time pass over the child links (one thread per link), once the scene knows how many nodes it stages in LDS: an inner link
+ * (node index until now) becomes the child's RECORD OFFSET in 16-byte lanes (mi_device.h: n < K ? n SL : K SL + (n - K) SH) with the
+ * child's split axes in bits 24..29 -- a node visit then needs neither a multiplication by the record size nor a separate look-up of
+ * its axes. `axes` = axis0 | axis00 << 2 | axis01 << 4 per node, as the host builder / the device build leave them. */
+__global__ void mi_bake_links_kernel(float4 *nodes, const uint32_t *axes, uint32_t N, uint32_t K, uint32_t SL, uint32_t SH)
 {
   const uint32_t i = blockIdx.x*blockDim.x + threadIdx.x;
   if(i >= 4u*N) return;
-  uint32_t *link = (uint32_t *)(nodes + (size_t)6*N) + i;
+  uint32_t *link = (uint32_t *)(nodes + (size_t)(i >> 2)*SH + 6) + (i & 3u);
   const uint32_t l = *link;
-  if(!(l & MI_LEAF32)) *link = (l & MI_NODE_MASK) | (axes[l & MI_NODE_MASK] << MI_AXES_SHIFT);
+  if(l & MI_LEAF32) return;
+  const uint32_t n = l & MI_NODE_MASK;
+  *link = (n < K ? n*SL : K*SL + (n - K)*SH) | (axes[n] << MI_AXES_SHIFT);
 }
 
 /* Upload-time pass over the leaves (one thread per child link of the tree, after the primitive records are in place -- for a
@@ -35,11 +38,11 @@ __global__ void mi_fold_axes_kernel(float4 *nodes, const uint32_t *axes, uint32_
  * quad: a static quad whose fourth vertex leaves the plane of the first three by more than 1e-5 of its size and which follows a
  * primitive that is put off, or anything that follows a moving quad. From there to the end of its leaf every triangle / quad
  * is put off too (type 0, pad[0] = vertex count, pad[1] = MI_PRIM_ORDERED): the put-off tests run in the leaf's order. */
-__global__ void mi_mark_ordered_kernel(const float4 *nodes, uint32_t N, DPrim *prims)
+__global__ void mi_mark_ordered_kernel(const float4 *nodes, uint32_t N, uint32_t SH, DPrim *prims)
 {
   const uint32_t i = blockIdx.x*blockDim.x + threadIdx.x;
   if(i >= 4u*N) return;
-  const uint32_t link = ((const uint32_t *)(nodes + (size_t)6*N))[i];
+  const uint32_t link = ((const uint32_t *)(nodes + (size_t)(i >> 2)*SH + 6))[i & 3u];
   if(!(link & MI_LEAF32)) return;
   const uint32_t first = (link ^ MI_LEAF32) >> 5, num = link & 31u;
   bool deferred = false, ordered = false;
@@ -108,7 +111,8 @@ struct mi_scene
   hipEvent_t ev0, ev1;
   int have_timing;
   size_t lds_bytes;
-  bool nodes_lds;                   /* BVH staged in LDS (fits next to the stacks) or read from HBM */
+  bool nodes_lds;                   /* the whole BVH is staged in LDS (fits next to the stacks); else its first d.nodes_lds nodes are, the rest is read from HBM */
+  bool nodes_t1;                    /* the node records carry the child boxes at shutter close */
   bool device_built;                /* tree made by mi_build.h */
   int stack_need;                   /* stack entries a ray may need */
   int grid;
@@ -118,7 +122,7 @@ struct mi_scene
   int fast;                         /* launch the FAST instantiations (mi_scene_set_traversal / CORONA_MI_TRAVERSAL): same hits, other work counters */
   bool media;                       /* some shape is filled with a homogeneous medium: MEDIA instantiations */
   bool norg;                        /* ... of those, the ones without the exchange between waves (scattering exterior medium) */
-  void *d_shape_medium, *d_prims_t1, *d_lights, *d_nodes_t1, *d_prim_cls;
+  void *d_shape_medium, *d_prims_t1, *d_lights, *d_prim_cls;
   /* Halton point sampler */
   bool halton;
   HaltonTables *halton_tables;
@@ -325,15 +329,19 @@ static int build_on_device(mi_scene *s, const mi_scene_desc *h, uint32_t *num_no
     }
     N = hc[0]; stats[0] = levels;
     if(e == hipSuccess && (!N || N >= MI_LEAF32 || N > cap)) e = hipErrorInvalidValue;
-    if(e == hipSuccess && (hipMalloc(&s->d_nodes, (size_t)MI_NODE_FIELDS*N*16) != hipSuccess || hipMalloc(&s->d_axes, (size_t)N*4) != hipSuccess)) e = hipErrorOutOfMemory;
+    const uint32_t SH = two_states ? 2u*MI_NODE_STRIDE : MI_NODE_STRIDE;       /* lanes of a node record (mi_device.h) */
+    if(e == hipSuccess && (hipMalloc(&s->d_nodes, (size_t)SH*N*16) != hipSuccess || hipMalloc(&s->d_axes, (size_t)N*4) != hipSuccess)) e = hipErrorOutOfMemory;
+    if(e == hipSuccess) e = hipMemset(s->d_nodes, 0, (size_t)SH*N*16);
     if(e == hipSuccess)
     {
-      hipLaunchKernelGGL(bl_repack, dim3((MI_NODE_FIELDS*N + BL_BLOCK - 1)/BL_BLOCK), dim3(BL_BLOCK), 0, 0, (float4 *)s->d_nodes, (const float4 *)tnodes, N, cap, (uint32_t)MI_NODE_FIELDS);
+      hipLaunchKernelGGL(bl_repack, dim3((MI_NODE_FIELDS*N + BL_BLOCK - 1)/BL_BLOCK), dim3(BL_BLOCK), 0, 0, (float4 *)s->d_nodes, (const float4 *)tnodes, N, cap, (uint32_t)MI_NODE_FIELDS, SH);
       e = hipGetLastError();
       if(e == hipSuccess && two_states)
       {
-        if(hipMalloc(&s->d_nodes_t1, (size_t)6*N*16) != hipSuccess) e = hipErrorOutOfMemory;
-        else { hipLaunchKernelGGL(bl_repack, dim3((6*N + BL_BLOCK - 1)/BL_BLOCK), dim3(BL_BLOCK), 0, 0, (float4 *)s->d_nodes_t1, (const float4 *)tnodes_t1, N, cap, 6u); e = hipGetLastError(); }
+        hipLaunchKernelGGL(bl_repack, dim3((MI_NODE_T1_FIELDS*N + BL_BLOCK - 1)/BL_BLOCK), dim3(BL_BLOCK), 0, 0, (float4 *)s->d_nodes + MI_NODE_T1_HBM, (const float4 *)tnodes_t1, N, cap,
+                           (uint32_t)MI_NODE_T1_FIELDS, SH);
+        e = hipGetLastError();
+        s->nodes_t1 = true;
       }
       if(e == hipSuccess) e = hipMemcpy(s->d_axes, taxes, (size_t)N*4, hipMemcpyDeviceToDevice);
     }
@@ -428,22 +436,41 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
     d.far_dist = 2.0f*(ez > m1 ? ez : m1);
   }
 
-  /* nodes: SoA of 16-byte lanes, children as 32-bit links */
+  /* nodes: one record of SH 16-byte lanes per node (mi_device.h), children as 32-bit links -- node indices here, record offsets once the
+     scene knows how many nodes it stages in LDS (mi_bake_links_kernel). Nodes are renumbered breadth first from the root, so that the
+     first K nodes are the top of the tree whatever order the caller's builder numbered them in (the reference's: depth first). */
   uint32_t N = device_build ? 0 : h->num_nodes;
-  std::vector<float> nodes((size_t)MI_NODE_FIELDS*N*4);
+  const bool host_t1 = !device_build && h->nodes_t1;
+  const uint32_t SH_host = host_t1 ? 2u*MI_NODE_STRIDE : MI_NODE_STRIDE;
+  std::vector<float> nodes((size_t)SH_host*N*4, 0.0f);
   std::vector<uint32_t> axes(N);
   std::vector<bool> in_leaf(device_build ? 0 : (size_t)h->num_prims, false);
-  for(uint32_t n=0;n<N;n++)
+  std::vector<uint32_t> bfs, newid(N, 0xffffffffu);        /* bfs[new] = old, newid[old] = new */
+  if(N)
+  { /* (tree_depth above has checked the links: every node is reachable at most once) */
+    bfs.reserve(N);
+    bfs.push_back(0); newid[0] = 0;
+    for(size_t q=0;q<bfs.size();q++)
+      for(int c=0;c<4;c++)
+      {
+        const uint64_t ch = h->nodes[bfs[q]].child[c];
+        if(!(ch & MI_NODE_LEAF) && ch < N && newid[ch] == 0xffffffffu) { newid[ch] = (uint32_t)bfs.size(); bfs.push_back((uint32_t)ch); }
+      }
+    for(uint32_t n=0;n<N;n++) if(newid[n] == 0xffffffffu) { newid[n] = (uint32_t)bfs.size(); bfs.push_back(n); }     /* unreachable nodes keep a place behind the tree */
+  }
+  for(uint32_t nn=0;nn<N;nn++)
   {
+    const uint32_t n = bfs[nn];
     const mi_node &nd = h->nodes[n];
-    /* fields 0..2 hold the lower, 3..5 the upper plane per axis. The reference marks empty children by an inverted box
+    float *rec = &nodes[(size_t)nn*SH_host*4];
+    /* lanes 0..2 hold the lower, 3..5 the upper plane per axis. The reference marks empty children by an inverted box
        (min = FLT_MAX, max = -FLT_MAX, qbvhmp.c:1095-1112) and evaluates min(t0,t1)/max(t0,t1), which is symmetric in the two
        planes; the kernel picks entry/exit planes by ray sign instead, so inverted slabs are stored in ascending order */
     for(int k=0;k<3;k++) for(int c=0;c<4;c++)
     {
       const float b0 = nd.aabb[k][c], b1 = nd.aabb[k+3][c];
-      nodes[((size_t)k*N + n)*4 + c]     = b0 > b1 ? b1 : b0;
-      nodes[((size_t)(k+3)*N + n)*4 + c] = b0 > b1 ? b0 : b1;
+      rec[k*4 + c]     = b0 > b1 ? b1 : b0;
+      rec[(k+3)*4 + c] = b0 > b1 ? b0 : b1;
     }
     for(int c=0;c<4;c++)
     {
@@ -459,23 +486,19 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
         }
         link = MI_LEAF32 | (uint32_t)(first << 5) | (uint32_t)cntp;
       }
-      else link = (uint32_t)nd.child[c];
-      memcpy(&nodes[((size_t)6*N + n)*4 + c], &link, 4);
+      else link = newid[(uint32_t)nd.child[c]];
+      memcpy(&rec[6*4 + c], &link, 4);
     }
-    axes[n] = (uint32_t)(nd.axis0 & 3) | ((uint32_t)(nd.axis00 & 3) << 2) | ((uint32_t)(nd.axis01 & 3) << 4);
-  }
-  /* the shutter-close boxes, if the caller's tree carries them: same SoA, same treatment of empty children */
-  std::vector<float> nodes_t1;
-  if(!device_build && h->nodes_t1)
-  {
-    nodes_t1.resize((size_t)6*N*4);
-    for(uint32_t n=0;n<N;n++) for(int k=0;k<3;k++) for(int c=0;c<4;c++)
+    axes[nn] = (uint32_t)(nd.axis0 & 3) | ((uint32_t)(nd.axis00 & 3) << 2) | ((uint32_t)(nd.axis01 & 3) << 4);
+    /* the shutter-close boxes, if the caller's tree carries them: lanes 8..13, same treatment of empty children */
+    if(host_t1) for(int k=0;k<3;k++) for(int c=0;c<4;c++)
     {
       const float b0 = h->nodes_t1[n].aabb[k][c], b1 = h->nodes_t1[n].aabb[k+3][c];
-      nodes_t1[((size_t)k*N + n)*4 + c]     = b0 > b1 ? b1 : b0;
-      nodes_t1[((size_t)(k+3)*N + n)*4 + c] = b0 > b1 ? b0 : b1;
+      rec[(MI_NODE_T1_HBM + k)*4 + c]     = b0 > b1 ? b1 : b0;
+      rec[(MI_NODE_T1_HBM + k+3)*4 + c] = b0 > b1 ? b0 : b1;
     }
   }
+  s->nodes_t1 = host_t1;
   /* primitives: resolve primid -> vtxidx -> vtx once */
   std::vector<DPrim> prims(h->num_prims ? h->num_prims : 1);
   std::vector<DPrimGeo> pgeo(h->num_prims ? h->num_prims : 1);
@@ -679,7 +702,6 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
   {
     UP(d_nodes, nodes.data(), nodes.size());
     UP(d_axes, axes.data(), axes.size());
-    if(!nodes_t1.empty()) { UP(d_nodes_t1, nodes_t1.data(), nodes_t1.size()); }
   }
   UP(d_prims, prims.data(), prims.size());
   UP(d_primgeo, pgeo.data(), pgeo.size());
@@ -706,18 +728,12 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
     e = build_on_device(s, h, &N, &stack_need);
     d.num_nodes = N;
   }
-  if(!e && N >= (1u << MI_AXES_SHIFT)) e = fail(MI_ERR_UNSUPPORTED, "more than 2^24 nodes");
-  if(!e && N)
-  { /* the split axes of every node move into the links that point to it (mi_fold_axes_kernel); the root's go into the scene */
-    uint32_t root_axes = 0;
-    hipLaunchKernelGGL(mi_fold_axes_kernel, dim3((4*N + 255)/256), dim3(256), 0, 0, (float4 *)s->d_nodes, (const uint32_t *)s->d_axes, N);
-    if(hipGetLastError() != hipSuccess || hipMemcpy(&root_axes, s->d_axes, 4, hipMemcpyDeviceToHost) != hipSuccess) e = fail(MI_ERR_DEVICE, "cannot fold the split axes into the links");
-    d.root_link = root_axes << MI_AXES_SHIFT;
-  }
+  /* (a link holds a record offset in 24 bits, mi_device.h: 2^24 lanes of 16 bytes) */
+  if(!e && (uint64_t)N*(s->nodes_t1 ? 2u*MI_NODE_STRIDE : MI_NODE_STRIDE) >= (1ull << MI_AXES_SHIFT)) e = fail(MI_ERR_UNSUPPORTED, "more nodes than a link can address (2^24 lanes of 16 bytes)");
   if(!e && N)
   { /* tree and primitive records are in their final order: leaves in which the order of the tests matters (a folded quad behind a
        primitive the leaf loops put off) are marked, see mi_mark_ordered_kernel */
-    hipLaunchKernelGGL(mi_mark_ordered_kernel, dim3((4*N + 255)/256), dim3(256), 0, 0, (const float4 *)s->d_nodes, N, (DPrim *)s->d_prims);
+    hipLaunchKernelGGL(mi_mark_ordered_kernel, dim3((4*N + 255)/256), dim3(256), 0, 0, (const float4 *)s->d_nodes, N, (uint32_t)(s->nodes_t1 ? 2u*MI_NODE_STRIDE : MI_NODE_STRIDE), (DPrim *)s->d_prims);
     if(hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) e = fail(MI_ERR_DEVICE, "cannot mark the leaves");
   }
   if(!e && h->num_prims)
@@ -784,7 +800,7 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
   { mi_scene_destroy(s); return fail(MI_ERR_DEVICE, "cannot create stream/events"); }
   s->stream = s->stream_own;
 
-  d.nodes = (const float4 *)s->d_nodes; d.nodes_t1 = (const float4 *)s->d_nodes_t1;
+  d.nodes = (const float4 *)s->d_nodes; d.nodes_t1 = s->nodes_t1 ? 1u : 0u;
   d.prims = (const DPrim *)s->d_prims; d.primgeo = (const DPrimGeo *)s->d_primgeo; d.prim_cls = (const uint32_t *)s->d_prim_cls;
   d.materials = (const DMaterial *)s->d_materials;
   d.shape_medium = (const DShapeMedium *)s->d_shape_medium;
@@ -819,7 +835,9 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
 
   /* a scene with moving primitives runs the motion-blur kernels: shallower stack columns, and both box sets of the nodes in LDS */
   const bool mb_kernels = s->d_prims_t1 != nullptr;
-  const size_t node_bytes = (size_t)(MI_NODE_FIELDS + (mb_kernels && s->d_nodes_t1 ? 6 : 0))*N*16;
+  /* lanes of a node record in LDS / in HBM: the links are baked for them (mi_device.h) */
+  const uint32_t SL = s->nodes_t1 ? MI_NODE_FIELDS + MI_NODE_T1_FIELDS : MI_NODE_FIELDS, SH = s->nodes_t1 ? 2u*MI_NODE_STRIDE : MI_NODE_STRIDE;
+  const size_t node_bytes = (size_t)SL*N*16;
   /* (the column of the plain kernels is shorter since round 4: they use the LDS for the pools of mi_regroup.h; s->media is final here) */
   /* a scene in a scattering exterior medium (global fog) runs the extended kernels WITHOUT the exchange: nearly all its vertices are volume
      vertices, one class (measured: scenes/0056_fog ptdl 124 ms with, 115 without; scenes/0055_media ptdl 35 with, 46 without) */
@@ -827,24 +845,49 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
   const int column = mb_kernels ? MI_STACK_LDS_MB : s->norg ? MI_STACK_LDS : MI_STACK_LDS_PLAIN;
   const size_t stack_bytes = (size_t)column*MI_BLOCK*sizeof(uint2) + (size_t)(MI_BLOCK/64)*MI_JOBS_LDS;   /* + the waves' job lists */
   const size_t isect_stack_bytes = (size_t)MI_STACK_LDS*MI_BLOCK*sizeof(uint2) + (size_t)(MI_BLOCK/64)*MI_JOBS_LDS;   /* mi_intersect_kernel: full columns, no pools */
-  /* the tree lives in LDS next to the traversal stacks when it fits (0010_pt: 50 KB + 96 KB of 160 KB); larger trees are
-     read from HBM / L2 by the NODES_LDS = false instantiations (CORONA_MI_NODES=global forces that, for tests) */
+  /* The tree lives in LDS next to the traversal stacks when it fits (0010_pt: 48 KB + 80 KB of 160 KB). Of a larger tree the TOP is
+     staged -- as many of its breadth-first numbered nodes as the LDS takes next to stacks, job lists and the pools' share
+     (MI_NODES_TOP_POOL) -- and the NODES_LDS = false instantiations read the rest from HBM / L2, one 128-byte record per visit.
+     CORONA_MI_NODES=global forces that for a tree that would fit (tests), CORONA_MI_NODES_TOP=<nodes> limits the staged top (0: none). */
   const char *nodes_env = getenv("CORONA_MI_NODES");
   const size_t halton_bytes = h->pointsampler == MI_POINTS_HALTON ? (size_t)2*MI_HALTON_LDS : 0;     /* staged head of the permutation tables */
   /* plain ptdl kernels: emitter records in LDS. The same predicate as the kernel's (lds_setup<..., LIGHTS = PTDL && !MEDIA> advances by these
      bytes whether or not the scene has emitter records: a ptdl scene without emitters still needs them allocated) */
   const size_t lights_bytes = (h->sampler == MI_SAMPLER_PTDL && !s->media) ? (size_t)MI_LIGHTS_LDS*sizeof(DLight) : 0;
-  /* (both kinds of kernel must find room: the path kernels with their columns -- and the shutter-close boxes in a motion-blur scene --, the
-     ray-level test kernel with full columns and the shutter-open boxes only) */
-  const size_t isect_node_bytes = (size_t)MI_NODE_FIELDS*N*16;
-  s->nodes_lds = halton_bytes + lights_bytes + node_bytes + stack_bytes <= 160*1024 && isect_node_bytes + isect_stack_bytes <= 160*1024 &&
-                 !(nodes_env && !strcmp(nodes_env, "global"));
-  s->lds_bytes = halton_bytes + lights_bytes + (s->nodes_lds ? node_bytes : 0) + stack_bytes;
+  /* (both kinds of kernel must find room: the path kernels with their columns, the ray-level test kernel with full columns -- one K for
+     both, the links are baked for it) */
+  const size_t lds_total = 160*1024, static_bytes = 256;    /* blk_next, the pools' control words, alignment */
+  const size_t fixed_path = halton_bytes + lights_bytes + stack_bytes + static_bytes, fixed_isect = isect_stack_bytes + static_bytes;
+  s->nodes_lds = fixed_path + node_bytes <= lds_total && fixed_isect + node_bytes <= lds_total && !(nodes_env && !strcmp(nodes_env, "global"));
+  uint32_t K = N;
+  if(!s->nodes_lds)
+  {
+    bool scatters_ = false;
+    for(size_t i=0;i<shape_med.size();i++) if(shape_med[i].med >= 0 && shape_med[i].mu_t[3] > 0.0f && shape_med[i].albedo[3] > 0.0f) scatters_ = true;
+    const bool pools_wanted = MI_REGROUP && !s->norg && !mb_kernels && num_classes + ((s->media && scatters_) ? 1u : 0u) > 1u;   /* (the predicate of the pools below) */
+    const size_t pool_share = pools_wanted ? (size_t)MI_NODES_TOP_POOL : 0;
+    const size_t room_path = fixed_path + pool_share < lds_total ? lds_total - fixed_path - pool_share : 0;
+    const size_t room_isect = fixed_isect < lds_total ? lds_total - fixed_isect : 0;
+    K = (uint32_t)((room_path < room_isect ? room_path : room_isect)/((size_t)SL*16));
+    if(K > N) K = N;
+    const char *te = getenv("CORONA_MI_NODES_TOP");
+    if(te && atol(te) >= 0 && (uint32_t)atol(te) < K) K = (uint32_t)atol(te);
+    if(nodes_env && !strcmp(nodes_env, "global") && !te) K = 0;       /* the all-or-nothing switch of rounds 1-4, for tests */
+  }
+  d.nodes_lds = K;
+  s->lds_bytes = halton_bytes + lights_bytes + (size_t)SL*K*16 + stack_bytes;
+  if(N)
+  { /* now that K is known: node indices in the links become record offsets, with the child's split axes (mi_bake_links_kernel) */
+    uint32_t root_axes = 0;
+    hipLaunchKernelGGL(mi_bake_links_kernel, dim3((4*N + 255)/256), dim3(256), 0, 0, (float4 *)s->d_nodes, (const uint32_t *)s->d_axes, N, K, SL, SH);
+    if(hipGetLastError() != hipSuccess || hipMemcpy(&root_axes, s->d_axes, 4, hipMemcpyDeviceToHost) != hipSuccess)
+    { mi_scene_destroy(s); return fail(MI_ERR_DEVICE, "cannot bake the child links"); }
+    d.root_link = root_axes << MI_AXES_SHIFT;       /* node 0: record offset 0 */
+  }
   { /* material queues (mi_regroup.h): the pools take what is left of the CU's LDS behind the job lists (plain kernels only: the extended
        ones carry more path state than an entry holds). CORONA_MI_REGROUP=0 switches the exchange off, =<bytes> limits the pools. */
     const char *re = getenv("CORONA_MI_REGROUP");
-    const size_t static_bytes = 256;                        /* blk_next, the pools' control words, alignment */
-    size_t room = s->lds_bytes + static_bytes < 160*1024 ? 160*1024 - s->lds_bytes - static_bytes : 0;
+    size_t room = s->lds_bytes + static_bytes < lds_total ? lds_total - s->lds_bytes - static_bytes : 0;
     if(re && atol(re) >= 0 && (size_t)atol(re) < room) room = (size_t)atol(re);
     if(room > MI_POOL_BYTES_MAX) room = MI_POOL_BYTES_MAX;
     room &= ~(size_t)15;
@@ -853,16 +896,22 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
     for(size_t i=0;i<shape_med.size();i++) if(shape_med[i].med >= 0 && shape_med[i].mu_t[3] > 0.0f && shape_med[i].albedo[3] > 0.0f) scatters = true;
     d.pool_volume_class = num_classes;
     const uint32_t classes = num_classes + ((s->media && scatters) ? 1u : 0u);
-    const bool on = MI_REGROUP && classes > 1 && !s->norg && !mb_kernels && room >= 2048;
-    d.pool_classes = on ? classes : 0u;
     /* the class table goes into LDS behind the pools when that costs them at most a fifth of their room (16 primitives per word) */
     const size_t cls_bytes = (((size_t)h->num_prims + 15)/16)*4;
-    d.pool_cls_bytes = (on && cls_bytes*5 <= room) ? (uint32_t)((cls_bytes + 15) & ~(size_t)15) : 0u;
+    const size_t cls_lds = cls_bytes*5 <= room ? ((cls_bytes + 15) & ~(size_t)15) : 0;
+    /* the exchange runs only if EVERY kernel the scene can launch gets its 32 entries: the same formula as pool_setup (mi_regroup.h) with the
+       widest entry among them (the RECORD kernels', three more words in the extended kernels). A scene in the gap -- room for the pools of
+       some kernels but not of others -- used to pay for pools (shorter stack columns, no FAST rounds) that traded nothing. */
+    const uint32_t ns_max = (uint32_t)PoolLayout<true, true, false>::SLOTS + (s->media ? 3u : 0u);
+    const uint32_t e_min = (uint32_t)((room - cls_lds)/(ns_max*8u + 2u*(MI_POOL_CLASSES + 1u))) & ~7u;
+    const bool on = MI_REGROUP && classes > 1 && !s->norg && !mb_kernels && e_min >= 32u;
+    d.pool_classes = on ? classes : 0u;
+    d.pool_cls_bytes = on ? (uint32_t)cls_lds : 0u;
     if(on) room -= d.pool_cls_bytes;
     d.pool_bytes = on ? (uint32_t)room : 0u;
     s->lds_bytes += d.pool_bytes + d.pool_cls_bytes;
     /* one launch size for every kernel of the scene: mi_intersect_kernel keeps full stack columns */
-    const size_t isect_bytes = (s->nodes_lds ? isect_node_bytes : 0) + isect_stack_bytes;
+    const size_t isect_bytes = (size_t)SL*K*16 + isect_stack_bytes;
     if(s->lds_bytes < isect_bytes) s->lds_bytes = isect_bytes;
   }
   s->device_built = device_build; s->stack_need = stack_need;
@@ -1201,13 +1250,30 @@ extern "C" int mi_scene_stats(mi_scene *s, uint32_t out[4])
   return MI_OK;
 }
 
+extern "C" int mi_scene_lds_nodes(mi_scene *s, uint32_t *staged)
+{
+  if(!s || !staged) return fail(MI_ERR_ARG, "null argument");
+  *staged = s->nodes_lds ? s->d.num_nodes : s->d.nodes_lds;
+  return MI_OK;
+}
+
+extern "C" int mi_scene_kernel_name(mi_scene *s, char *buf, size_t len)
+{ /* the instantiation launch_path_kernel picks for a plain mi_render (RECORD = false), spelled as rocprofv3 spells it */
+  if(!s || !buf || len == 0) return fail(MI_ERR_ARG, "null argument");
+  const bool mb = s->d_prims_t1 != nullptr;
+  auto tf = [](bool b) { return b ? "true" : "false"; };
+  const int n = snprintf(buf, len, "mi_path_kernel<false, %s, %s, %s, %s, %s, %s, %s, %s>", tf(s->d.sampler == MI_SAMPLER_PTDL), tf(s->nodes_lds), tf(s->halton),
+                         tf(s->media), tf(mb), tf(s->counting != 0), tf(s->fast != 0 && !mb), tf(s->norg));
+  return (n < 0 || (size_t)n >= len) ? fail(MI_ERR_ARG, "mi_scene_kernel_name: buffer too small") : MI_OK;
+}
+
 extern "C" void mi_scene_destroy(mi_scene *s)
 {
   if(!s) return;
   (void)hipSetDevice(s->device);
   void *bufs[] = { s->d_nodes, s->d_axes, s->d_prims, s->d_primgeo, s->d_materials, s->d_light_prim, s->d_light_cdf, s->d_light_L,
                    s->d_cie, s->d_checker, s->d_metal, s->d_counters, s->d_shape_material, s->d_shape_L, s->d_overflow, s->d_fb_own,
-                   s->d_halton_dim, s->d_halton_perm, s->d_shape_medium, s->d_prims_t1, s->d_lights, s->d_nodes_t1, s->d_prim_cls };
+                   s->d_halton_dim, s->d_halton_perm, s->d_shape_medium, s->d_prims_t1, s->d_lights, s->d_prim_cls };
   delete s->halton_tables;
   if(s->h_stage) { (void)hipHostFree(s->h_stage); (void)hipEventDestroy(s->ev_stage[0]); (void)hipEventDestroy(s->ev_stage[1]); }
   for(void *b : bufs) if(b) (void)hipFree(b);

@@ -449,10 +449,10 @@ __global__ __launch_bounds__(BL_BLOCK) void bl_collapse(BuildBufs b, CollapseLis
   axes[q] = (uint32_t)axis0 | ((uint32_t)axis1[0] << 2) | ((uint32_t)axis1[1] << 4);
 }
 
-__global__ __launch_bounds__(BL_BLOCK) void bl_repack(float4 *dst, const float4 *src, uint32_t N, uint32_t stride, uint32_t fields)
-{ /* [fields][stride] -> [fields][N] */
+__global__ __launch_bounds__(BL_BLOCK) void bl_repack(float4 *dst, const float4 *src, uint32_t N, uint32_t stride, uint32_t fields, uint32_t dst_stride)
+{ /* [fields][stride] -> the first `fields` lanes of N node records of dst_stride lanes (mi_device.h) */
   const uint32_t i = blockIdx.x*BL_BLOCK + threadIdx.x;
-  if(i < fields*N) dst[i] = src[(size_t)(i/N)*stride + i%N];
+  if(i < fields*N) dst[(size_t)(i%N)*dst_stride + i/N] = src[(size_t)(i/N)*stride + i%N];
 }
 
 template<class T>

@@ -1,12 +1,21 @@
 /* mi_device.h -- device-resident scene layout of the MI355X backend (HBM / LDS).
  *
- *  nodes      SoA of 16-byte lanes, node-major inside each field (stage to LDS; a wave whose lanes sit in
- *             different nodes then spreads over all sixteen 16-B LDS slots instead of two):
- *               field 0..2  min x,y,z of the 4 children       field 3..5  max x,y,z
- *               field 6     4 child links: bit31 leaf | first_prim<<5 | count, else node index | the CHILD's split axes << 24
- *                           (axis0 | axis00<<2 | axis01<<4, MI_AXES_SHIFT: a visit knows its node's axes from the link it arrived
- *                           by -- no second LDS read per visit, folded in at upload by mi_fold_axes_kernel)
- *             = 112 B per node (reference qbvh_node_t: 256 B, src/accel.d/qbvhmp.c:62-81)
+ *  nodes      one 128-byte record per node = ONE cache line of HBM / L2 (round 5; rounds 1-4: field-major SoA, seven lines per visit):
+ *               lane 0..2  min x,y,z of the 4 children (16 B each)       lane 3..5  max x,y,z
+ *               lane 6     4 child links: bit31 leaf | first_prim<<5 | count, else the child's RECORD OFFSET (below) | the CHILD's split
+ *                          axes << 24 (axis0 | axis00<<2 | axis01<<4, MI_AXES_SHIFT: a visit knows its node's axes from the link it
+ *                          arrived by -- no second read per visit; baked at upload by mi_bake_links_kernel)
+ *               lane 7     pad
+ *             (reference qbvh_node_t: 256 B, src/accel.d/qbvhmp.c:62-81). A tree with moving primitives carries the child boxes at shutter
+ *             close in the same record: 256 B, lanes 8..13 (same order as 0..5), 14..15 pad.
+ *             Nodes are numbered breadth first (renumbered at upload; the device build numbers by level), so "the first K nodes" are the
+ *             top of the tree: those are staged into LDS without the pad lanes (112 / 208 B) -- all of them when the tree fits, else as
+ *             many as the LDS takes next to stacks and pools; the rest is read from HBM / L2, one (two) line(s) per visit.
+ *             RECORD OFFSET of node n, in 16-byte lanes: n < K ? n * SL : K * SL + (n - K) * SH  with SL = 7 (13) lanes in LDS, SH = 8 (16)
+ *             in HBM: the LDS address of a staged record is base + 16 * offset (one v_mad_u32_u24, the axes bits fall off), the HBM address
+ *             of any record is (nodes + 16 K (SH - SL)) + 16 * offset, "staged" is offset < K * SL -- a visit never multiplies by a record
+ *             size. Its seven 16-byte reads then have compile-time offsets from that ONE address; the entry / exit plane of an axis
+ *             is picked by adding +-48 bytes per lane. 24 offset bits: 2 M nodes of a tree that is traversed from HBM.
  *  prims      one 64-B record per primitive in builder (leaf) order, pre-resolved at upload so an
  *             intersection test is ONE aligned fetch instead of primid -> vtxidx -> vtx
  *             (src/prims.c:638-672, include/geo.h:120-138)
@@ -20,7 +29,11 @@
 #define MI_LEAF32 0x80000000u
 #define MI_AXES_SHIFT 24           /* inner link: node index in bits 0..23, the node's split axes in bits 24..29 */
 #define MI_NODE_MASK 0x00ffffffu
-#define MI_NODE_FIELDS 7
+#define MI_NODE_FIELDS 7           /* 16-byte lanes of a node record in LDS (112 B) */
+#define MI_NODE_STRIDE 8           /* ... in HBM (128 B: one cache line per node) */
+#define MI_NODE_T1_FIELDS 6        /* lanes of a node's shutter-close boxes: LDS lanes 7..12, HBM lanes 8..13 of a record of 13 / 16 lanes */
+#define MI_NODE_T1_LDS 7           /* first shutter-close lane of a record in LDS */
+#define MI_NODE_T1_HBM 8           /* ... in HBM */
 #define MI_COUNTER_SHARDS 256
 /* light_prim[] bit 31: a shadow ray towards this emitter primitive may stop at the FIRST occluder it finds (any-hit) instead of
  * running the closest-hit traversal to its end like the reference's live path_visible (src/pathspace.c:311-344 -> accel_intersect;
@@ -115,8 +128,10 @@ struct DScene
   uint64_t frame;
   /* accel */
   uint32_t num_nodes, num_prims;
-  const float4  *nodes;            /* [MI_NODE_FIELDS][num_nodes] */
-  const float4  *nodes_t1;         /* [6][num_nodes] or NULL: the child boxes at shutter close, same field order (mi_scene_desc.nodes_t1) */
+  const float4  *nodes;            /* [num_nodes][SH] records, SH = MI_NODE_STRIDE lanes (2 MI_NODE_STRIDE with shutter-close boxes) */
+  uint32_t nodes_t1;               /* 1: the records carry the child boxes at shutter close (mi_scene_desc.nodes_t1) */
+  uint32_t nodes_lds;              /* K: the first K nodes (breadth-first numbering: the top of the tree) are staged into LDS; = num_nodes in the
+                                      NODES_LDS instantiations, fewer (or 0) in the others, which read the rest from HBM / L2 */
   uint32_t root_link;              /* link of node 0: its split axes << MI_AXES_SHIFT */
   uint32_t metal_reference;        /* metal sample() ends the paths the reference BUILD's NaN ends (mi_scene_set_metal_reference) */
   const DPrim  *prims;

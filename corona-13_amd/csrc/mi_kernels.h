@@ -664,10 +664,13 @@ __device__ __forceinline__ void analytic_intersect(const DPrim *prims, uint32_t 
 #endif
 struct Lds
 {
-  const float4 *nodes;      /* [MI_NODE_FIELDS][num_nodes] in LDS (or in HBM when the tree does not fit, see lds_setup) */
-  bool nodes_in_lds;        /* compile-time constant after inlining (lds_setup<NODES_LDS>) */
-  uint32_t root;            /* link of node 0 (its split axes << MI_AXES_SHIFT) */
-  const float4 *nodes_t1;   /* [6][num_nodes] in HBM / L2 or NULL: the child boxes at shutter close (motion-blur kernels, DScene.nodes_t1) */
+  /* node records (mi_device.h): a link carries the record's OFFSET in 16-byte lanes, valid for both homes */
+  const float4 *nodes_adj;  /* HBM / L2: the record at offset L starts at nodes_adj + L */
+  uint32_t nodes_lds_addr;  /* LDS byte address of the staged records: the one at offset L < top_off starts at nodes_lds_addr + 16 L */
+  bool nodes_in_lds;        /* the WHOLE tree is staged: compile-time constant after inlining (lds_setup<NODES_LDS>) */
+  uint32_t top_off;         /* offsets below this are staged in LDS (may be 0) */
+  uint32_t root;            /* link of node 0 (offset 0 | its split axes << MI_AXES_SHIFT) */
+  bool has_t1;              /* the records carry the child boxes at shutter close (motion-blur kernels read them) */
   uint2 *stack;             /* [STACK][BLOCK] in LDS, this thread's column */
   uint2 *overflow;          /* [extra][total threads] in HBM: entries beyond STACK (rare). The workgroup's row; the thread's column is
                                added where it is used, so that no per-thread 64-bit pointer lives in registers through the kernel */
@@ -734,24 +737,26 @@ __device__ __forceinline__ Lds lds_setup(const DScene &sc, unsigned char *smem, 
     smem += MI_LIGHTS_LDS*sizeof(DLight);
     if(!NODES_LDS) __syncthreads();
   }
-  if(NODES_LDS)
-  {
-    float4 *lds_nodes = (float4 *)smem;
-    /* motion-blur kernels: the shutter-close boxes of the nodes (six more fields) behind the shutter-open ones, if the tree has them */
-    const bool t1 = T1 && sc.nodes_t1 != nullptr;
-    const size_t stack_off = (size_t)(MI_NODE_FIELDS + (t1 ? 6 : 0))*N*16;
-    lds_stack = (uint2 *)(smem + stack_off);
-    for(uint32_t i=threadIdx.x;i<MI_NODE_FIELDS*N;i+=BLOCK) lds_nodes[i] = sc.nodes[i];
-    if(t1) for(uint32_t i=threadIdx.x;i<6*N;i+=BLOCK) lds_nodes[MI_NODE_FIELDS*N + i] = sc.nodes_t1[i];
+  { /* the top of the tree (all of it in the NODES_LDS instantiations): the first K records, pad lanes dropped -- 7 of 8 lanes, with the
+       shutter-close boxes 13 of 16 (which only the motion-blur kernels stage: T1) */
+    const uint32_t K = NODES_LDS ? N : sc.nodes_lds;
+    const bool t1 = sc.nodes_t1 != 0u;
+    const uint32_t SH = t1 ? 2u*MI_NODE_STRIDE : MI_NODE_STRIDE;
+    const uint32_t SL = t1 ? MI_NODE_FIELDS + MI_NODE_T1_FIELDS : MI_NODE_FIELDS;      /* the links are baked for these strides (mi_bake_links_kernel) */
+    mi_f32x4 *lds_nodes = (mi_f32x4 *)smem;
+    lds_stack = (uint2 *)(smem + (size_t)SL*K*16);
+    const mi_f32x4 *src = (const mi_f32x4 *)sc.nodes;
+    if(!t1) for(uint32_t i=threadIdx.x;i<MI_NODE_FIELDS*K;i+=BLOCK) { const uint32_t n = i/MI_NODE_FIELDS, f = i - n*MI_NODE_FIELDS; lds_nodes[i] = src[(size_t)n*MI_NODE_STRIDE + f]; }
+    else for(uint32_t i=threadIdx.x;i<(MI_NODE_FIELDS + MI_NODE_T1_FIELDS)*K;i+=BLOCK)
+    { /* (kernels that never read the second box set still keep the records' layout: the links are baked for it) */
+      const uint32_t n = i/(MI_NODE_FIELDS + MI_NODE_T1_FIELDS), f = i - n*(MI_NODE_FIELDS + MI_NODE_T1_FIELDS);
+      lds_nodes[i] = src[(size_t)n*2u*MI_NODE_STRIDE + (f < MI_NODE_FIELDS ? f : f + (MI_NODE_T1_HBM - MI_NODE_T1_LDS))];
+    }
     __syncthreads();
-    lds.nodes = lds_nodes; lds.nodes_in_lds = true;
-    lds.nodes_t1 = t1 ? lds_nodes + (size_t)MI_NODE_FIELDS*N : nullptr;
-  }
-  else
-  {
-    lds_stack = (uint2 *)smem;
-    lds.nodes = sc.nodes; lds.nodes_in_lds = false;
-    lds.nodes_t1 = sc.nodes_t1;
+    lds.nodes_in_lds = NODES_LDS; lds.top_off = K*SL;
+    lds.nodes_adj = sc.nodes + (size_t)K*(SH - SL);
+    lds.nodes_lds_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    lds.has_t1 = T1 && t1;
   }
   lds.stack = lds_stack + threadIdx.x; lds.num_nodes = N; lds.root = sc.root_link;
   lds.jobs = (unsigned char *)(lds_stack + (size_t)COLUMN*BLOCK) + (threadIdx.x >> 6)*MI_JOBS_LDS;
@@ -1004,7 +1009,7 @@ __device__ __forceinline__ void leaf_jobs(const Lds &lds, const DPrim *prims, co
 /* the ray geometry a node visit needs, fixed for the length of a round */
 struct RayBox
 {
-  uint32_t nearbits, offx, offy, offz;   /* sign bits of the direction; near-plane field of each axis: max planes (fields 3..5) for negative directions */
+  uint32_t nearbits, offx, offy, offz;   /* sign bits of the direction; byte offset of each axis' entry plane inside a node record: 48 (the upper planes, lanes 3..5) for negative directions */
   float idx, idy, idz;
   bool slow;                             /* a lane of the wave has an infinite 1/dir: literal SSE-semantics slab test for the whole wave */
   /* FMA slabs (FAST rounds only, MI_SPEC_FMA): -o/d per axis, and the absolute part of the slack of the box test */
@@ -1029,7 +1034,7 @@ __device__ __forceinline__ RayBox raybox_setup(const V3 o, const V3 d, const Tra
   rb.nearbits = near_x | (near_y << 1) | (near_z << 2);
   rb.idx = ts.idx; rb.idy = ts.idy; rb.idz = ts.idz;
   rb.w0 = 1.0f - ts.time; rb.w1 = ts.time;
-  rb.offx = near_x ? 3u*N : 0u; rb.offy = near_y ? 3u*N : 0u; rb.offz = near_z ? 3u*N : 0u;
+  rb.offx = near_x ? 48u : 0u; rb.offy = near_y ? 48u : 0u; rb.offz = near_z ? 48u : 0u;       /* bytes: three lanes from the lower to the upper plane of an axis */
   if(FMA)
   { /* huge 1/dir (a component of the direction below 1e-30) go the literal way too: plane/d - o/d may be inf - inf there */
     rb.slow = __any(!(fabsf(rb.idx) < 1e30f) || !(fabsf(rb.idy) < 1e30f) || !(fabsf(rb.idz) < 1e30f));
@@ -1057,59 +1062,64 @@ __device__ __forceinline__ bool node_visit(const Lds &lds, lds_uint2 *lstack, co
      difference), so the box counts as hit when lo <= hi (1 + 2^-19) + 2^-21 max|o/d|: every box the reference's test passes passes
      here (and a few more: counted work, not results), and the entry distances pushed with the subtrees are compared with the same
      slack when they are popped (cull_distance). */
-  const uint32_t N = lds.num_nodes;
-  const uint32_t nearbits = rb.nearbits, offx = rb.offx, offy = rb.offy, offz = rb.offz;
+  const uint32_t nearbits = rb.nearbits;
   const float idx = rb.idx, idy = rb.idy, idz = rb.idz;
   const bool slow = rb.slow;
-  /* byte offset of the node inside a field: a 24-bit multiply reads only the link's index bits, so the axes in front of them need no
-     mask in the chain pop -> address -> LDS read (v_mad_u32_u24 with the field's base as addend) */
-  const uint32_t ax = (current >> MI_AXES_SHIFT) & 63u;        /* the node's split axes travel in the link (mi_fold_axes_kernel) */
-  auto at = [&](const float4 *base, uint32_t f) -> float4
+  const uint32_t ax = (current >> MI_AXES_SHIFT) & 63u;        /* the node's split axes travel in the link (mi_bake_links_kernel) */
+  /* The node's record: seven 16-byte lanes at compile-time offsets from ONE address. bx / by / bz = byte offset of the lane that holds
+     the ray's ENTRY plane of each axis (0: the lower planes, 48: the upper ones); the exit plane sits 48 bytes to the other side.
+     MB, if the tree carries the shutter-close boxes (lds.has_t1): the planes at the ray's time, aabb0 (1 - t) + aabb1 t (qbvhmp.c:1208-1224:
+     two products and a sum as there). Rounding is monotonic, so the interpolated lower plane of a box never lies above its upper one and
+     the sign-selected slabs below stay what the reference's min / max of the two plane distances evaluate to. */
+  float4 nx, ny, nz, fx, fy, fz, child4;
+  const float w0 = rb.w0, w1 = rb.w1;
+  auto mix = [&](const float4 a_, const float4 b_) { return make_float4(a_.x*w0 + b_.x*w1, a_.y*w0 + b_.y*w1, a_.z*w0 + b_.z*w1, a_.w*w0 + b_.w*w1); };
+  auto fetch = [&](uint32_t bx, uint32_t by, uint32_t bz)
   {
-    if(lds.nodes_in_lds)
-    { /* (written as the instruction: the compiler turns a 24-bit multiply by 16 back into shift + mask) */
-      const uint32_t b = (uint32_t)(uintptr_t)(lds_f32x4 *)(base + f);
+    auto from_lds = [&]()
+    { /* byte address of the record: a 24-bit multiply reads only the link's offset bits, so the axes in front of them need no mask in the
+         chain pop -> address -> LDS read (written as the instruction: the compiler turns a 24-bit multiply by 16 back into shift + mask) */
       uint32_t a;
-      asm("v_mad_u32_u24 %0, %1, 16, %2" : "=v"(a) : "v"(current), "v"(b));
-      const mi_f32x4 q = *(lds_f32x4 *)(uintptr_t)a;
-      return make_float4(q.x, q.y, q.z, q.w);
-    }
-    return base[f + (current & MI_NODE_MASK)];
+      asm("v_mad_u32_u24 %0, %1, 16, %2" : "=v"(a) : "v"(current), "s"(lds.nodes_lds_addr));
+#define MI_LDS_LANE(ADDR, OFF) ({ const mi_f32x4 q_ = *(lds_f32x4 *)(uintptr_t)((ADDR) + (uint32_t)(OFF)); make_float4(q_.x, q_.y, q_.z, q_.w); })
+      const uint32_t ax_ = a + bx, ay_ = a + by, az_ = a + bz, cx_ = a - bx, cy_ = a - by, cz_ = a - bz;
+      child4 = MI_LDS_LANE(a, 96);
+      nx = MI_LDS_LANE(ax_, 0);  ny = MI_LDS_LANE(ay_, 16); nz = MI_LDS_LANE(az_, 32);
+      fx = MI_LDS_LANE(cx_, 48); fy = MI_LDS_LANE(cy_, 64); fz = MI_LDS_LANE(cz_, 80);
+      if(MB && lds.has_t1)
+      {
+        constexpr uint32_t T = 16u*MI_NODE_T1_LDS;
+        nx = mix(nx, MI_LDS_LANE(ax_, T + 0));  ny = mix(ny, MI_LDS_LANE(ay_, T + 16)); nz = mix(nz, MI_LDS_LANE(az_, T + 32));
+        fx = mix(fx, MI_LDS_LANE(cx_, T + 48)); fy = mix(fy, MI_LDS_LANE(cy_, T + 64)); fz = mix(fz, MI_LDS_LANE(cz_, T + 80));
+      }
+#undef MI_LDS_LANE
+    };
+    auto from_hbm = [&]()
+    { /* one 128-byte line (two with the shutter-close boxes) */
+      const unsigned char *r = (const unsigned char *)(lds.nodes_adj + (current & MI_NODE_MASK));
+#define MI_HBM_LANE(P, OFF) (*(const float4 *)((P) + (OFF)))
+      const unsigned char *ax_ = r + bx, *ay_ = r + by, *az_ = r + bz, *cx_ = r - bx, *cy_ = r - by, *cz_ = r - bz;
+      child4 = MI_HBM_LANE(r, 96);
+      nx = MI_HBM_LANE(ax_, 0);  ny = MI_HBM_LANE(ay_, 16); nz = MI_HBM_LANE(az_, 32);
+      fx = MI_HBM_LANE(cx_, 48); fy = MI_HBM_LANE(cy_, 64); fz = MI_HBM_LANE(cz_, 80);
+      if(MB && lds.has_t1)
+      {
+        constexpr uint32_t T = 16u*MI_NODE_T1_HBM;
+        nx = mix(nx, MI_HBM_LANE(ax_, T + 0));  ny = mix(ny, MI_HBM_LANE(ay_, T + 16)); nz = mix(nz, MI_HBM_LANE(az_, T + 32));
+        fx = mix(fx, MI_HBM_LANE(cx_, T + 48)); fy = mix(fy, MI_HBM_LANE(cy_, T + 64)); fz = mix(fz, MI_HBM_LANE(cz_, T + 80));
+      }
+#undef MI_HBM_LANE
+    };
+    if(lds.nodes_in_lds) from_lds();
+    else if(!lds.top_off) from_hbm();
+    else if((current & MI_NODE_MASK) < lds.top_off) from_lds();      /* the top of the tree is staged, the rest is not (per lane) */
+    else from_hbm();
   };
-  auto at_uniform = [&](const float4 *base, uint32_t f) -> float4
-  { /* the same with a wave-uniform field offset: the base stays in a scalar register */
-    if(lds.nodes_in_lds)
-    {
-      const uint32_t b = (uint32_t)(uintptr_t)(lds_f32x4 *)(base + f);
-      uint32_t a;
-      asm("v_mad_u32_u24 %0, %1, 16, %2" : "=v"(a) : "v"(current), "s"(b));
-      const mi_f32x4 q = *(lds_f32x4 *)(uintptr_t)a;
-      return make_float4(q.x, q.y, q.z, q.w);
-    }
-    return base[f + (current & MI_NODE_MASK)];
-  };
-  const float4 child4 = at_uniform(lds.nodes, 6*N);
-  const uint4 child = make_uint4(__float_as_uint(child4.x), __float_as_uint(child4.y), __float_as_uint(child4.z), __float_as_uint(child4.w));
   float tm0, tm1, tm2, tm3;
   mi_u64 M0, M1, M2, M3;    /* child c is hit: lane masks (the compares' own results) in scalar registers, combined by scalar instructions below */
-  /* one field of the node: the planes of the four children -- in a motion-blur kernel whose tree carries the shutter-close boxes too
-     (lds.nodes_t1), the planes at the ray's time, aabb0 (1 - t) + aabb1 t (qbvhmp.c:1208-1224: two products and a sum as there).
-     Rounding is monotonic, so the interpolated lower plane of a box never lies above its upper one and the sign-selected slabs
-     below stay what the reference's min / max of the two plane distances evaluate to. */
-  const float4 *t1p = MB ? lds.nodes_t1 : nullptr;
-  const float w0 = rb.w0, w1 = rb.w1;
-  auto field = [&](uint32_t f, bool uniform = false) -> float4
-  {
-    const float4 a_ = uniform ? at_uniform(lds.nodes, f) : at(lds.nodes, f);
-    if(!MB || !t1p) return a_;
-    const float4 b_ = uniform ? at_uniform(t1p, f) : at(t1p, f);
-    return make_float4(a_.x*w0 + b_.x*w1, a_.y*w0 + b_.y*w1, a_.z*w0 + b_.z*w1, a_.w*w0 + b_.w*w1);
-  };
   if(FMA && !slow)
   {
-    const float4 nx = at(lds.nodes, offx),       fx = at(lds.nodes, 3*N - offx);
-    const float4 ny = at(lds.nodes, N + offy),   fy = at(lds.nodes, 4*N - offy);
-    const float4 nz = at(lds.nodes, 2*N + offz), fz = at(lds.nodes, 5*N - offz);
+    fetch(rb.offx, rb.offy, rb.offz);
 #define SLAB(J, C, TM) { \
     const float lo = fmaxf(fmaxf(fmaxf(__builtin_fmaf(nx.C, idx, rb.nox), __builtin_fmaf(ny.C, idy, rb.noy)), __builtin_fmaf(nz.C, idz, rb.noz)), 0.0f); \
     const float hi = fminf(fminf(fminf(__builtin_fmaf(fx.C, idx, rb.nox), __builtin_fmaf(fy.C, idy, rb.noy)), __builtin_fmaf(fz.C, idz, rb.noz)), dist); \
@@ -1122,9 +1132,7 @@ __device__ __forceinline__ bool node_visit(const Lds &lds, lds_uint2 *lstack, co
        the reference's min(t0,t1) / max(t0,t1) evaluate to for finite 1/dir and b_min <= b_max (rounding is monotonic;
        empty children are uploaded as [-FLT_MAX, FLT_MAX], see upload_nodes). That leaves v_max3/v_min3 chains
        instead of 48 compare+select pairs (each pair costs a VCC hazard nop on gfx950). */
-    const float4 nx = field(offx),       fx = field(3*N - offx);
-    const float4 ny = field(N + offy),   fy = field(4*N - offy);
-    const float4 nz = field(2*N + offz), fz = field(5*N - offz);
+    fetch(rb.offx, rb.offy, rb.offz);
 #define SLAB(J, C, TM) { \
     const float lo = fmaxf(fmaxf(fmaxf((nx.C - o.x)*idx, (ny.C - o.y)*idy), (nz.C - o.z)*idz), 0.0f); \
     const float hi = fminf(fminf(fminf((fx.C - o.x)*idx, (fy.C - o.y)*idy), (fz.C - o.z)*idz), dist); \
@@ -1135,8 +1143,7 @@ __device__ __forceinline__ bool node_visit(const Lds &lds, lds_uint2 *lstack, co
   else
   { /* a lane of this wave has a zero direction component (1/dir infinite): 0*inf NaNs are possible and the reference's
        SSE min/max semantics (second operand on NaN) decide; evaluate them literally with ordered compares */
-    const float4 mnx = field(0*N, true), mny = field(1*N, true), mnz = field(2*N, true);
-    const float4 mxx = field(3*N, true), mxy = field(4*N, true), mxz = field(5*N, true);
+    fetch(0u, 0u, 0u);       /* n* = the lower planes, f* = the upper ones */
 #define SLAB(J, X0, X1, Y0, Y1, Z0, Z1, TM) { \
     float lo = 0.0f, hi = dist; \
     float t0 = ((X0) - o.x)*idx, t1 = ((X1) - o.x)*idx; \
@@ -1149,12 +1156,13 @@ __device__ __forceinline__ bool node_visit(const Lds &lds, lds_uint2 *lstack, co
     mn = t0 < t1 ? t0 : t1; mx = t0 > t1 ? t0 : t1; \
     lo = lo > mn ? lo : mn; hi = hi < mx ? hi : mx; \
     TM = lo; J = __ballot(lo <= hi); }
-    SLAB(M0, mnx.x, mxx.x, mny.x, mxy.x, mnz.x, mxz.x, tm0)
-    SLAB(M1, mnx.y, mxx.y, mny.y, mxy.y, mnz.y, mxz.y, tm1)
-    SLAB(M2, mnx.z, mxx.z, mny.z, mxy.z, mnz.z, mxz.z, tm2)
-    SLAB(M3, mnx.w, mxx.w, mny.w, mxy.w, mnz.w, mxz.w, tm3)
+    SLAB(M0, nx.x, fx.x, ny.x, fy.x, nz.x, fz.x, tm0)
+    SLAB(M1, nx.y, fx.y, ny.y, fy.y, nz.y, fz.y, tm1)
+    SLAB(M2, nx.z, fx.z, ny.z, fy.z, nz.z, fz.z, tm2)
+    SLAB(M3, nx.w, fx.w, ny.w, fy.w, nz.w, fz.w, tm3)
 #undef SLAB
   }
+  const uint4 child = make_uint4(__float_as_uint(child4.x), __float_as_uint(child4.y), __float_as_uint(child4.z), __float_as_uint(child4.w));
   const bool any_child = __builtin_amdgcn_inverse_ballot_w64(M0 | M1 | M2 | M3);
   if(any_child)
   {

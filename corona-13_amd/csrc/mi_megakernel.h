@@ -66,6 +66,9 @@
 #define MI_PRIO_PTDL_TRACE 0
 #define MI_PRIO_PTDL_SHADE 3
 #endif
+#ifndef MI_SCENE_LAZY
+#define MI_SCENE_LAZY 0
+#endif
 #ifndef MI_REGROUP_MEDIA
 #define MI_REGROUP_MEDIA 1   /* the exchange in the extended kernels too (media, moving camera): volume vertices are a class of their own */
 #endif
@@ -173,6 +176,20 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
 #endif
   while(true)
   {
+#if MI_SCENE_LAZY
+    /* the scene descriptor is the kernel's first by-value argument, i.e. it lives in the kernarg segment. Read through the plain argument,
+       every field is loaded at the kernel's entry and stays in a scalar register (or a spill lane) for the whole launch; read through a
+       pointer the compiler cannot see through, a field is s_load'ed in the iteration that uses it (lever 1a; A/B in
+       profiles/r05_levers_ab.txt) */
+    const DScene *sc_lazy;
+    {
+      typedef __attribute__((address_space(4))) const unsigned char *mi_kernarg_ptr;
+      mi_kernarg_ptr k = (mi_kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(k));
+      sc_lazy = (const DScene *)k;
+    }
+    const DScene &sc = *sc_lazy;
+#endif
     /* ------------------------------------------------------------ refill idle lanes (wave-level compaction of the work queue) */
     if(!exhausted)
     {

@@ -45,6 +45,10 @@
 #ifndef MI_POOL_AGE
 #define MI_POOL_AGE 24             /* ... or when fewer than this many entries are still free */
 #endif
+#ifndef MI_NODES_TOP_POOL
+#define MI_NODES_TOP_POOL (24*1024)   /* a tree that does not fit LDS: bytes the pools keep when the TOP of the tree is staged (mi_abi.hip); the rest of the
+                                         LDS behind stacks and job lists goes to node records. Sweep: profiles/r05_large_tree.txt */
+#endif
 #ifndef MI_POOL_BYTES_MAX
 #define MI_POOL_BYTES_MAX (48*1024)   /* trees that are traversed from HBM leave more LDS than the pools can use */
 #endif
@@ -137,17 +141,21 @@ __device__ __forceinline__ unsigned long long pool_enter(const Pool &pool)
   __builtin_amdgcn_wave_barrier();
   return st;
 }
-/* leave it with new counts. LDS operations of a wave are carried out in order: the list entries written in the section are in place
-   before the store that opens it; the fence waits for the section's READS (another wave may overwrite those list entries afterwards) */
+/* leave it with new counts. The fence waits for the section's READS (another wave may overwrite those list entries afterwards) and
+   makes its WRITES (list entries) visible before the store that opens the lock: a workgroup-scope release in both cases -- one
+   s_waitcnt lgkmcnt(0); the round-4 version relied on a wave's DS operations being carried out in order for the writes, which is what
+   the hardware does but not what the memory model promises (A/B of the two: profiles/r05_levers_ab.txt).
+   The hint is stored FIRST, i.e. while the lock is still held: written after the store that opens the lock, a wave that stalled between
+   the two stores could overwrite a newer hint of the next holder with its stale counts -- and a stale hint that shows empty classes
+   lets draining waves leave the kernel (pool_empty) while vertices are still listed. */
 template<bool READS>
 __device__ __forceinline__ void pool_leave(const Pool &pool, unsigned long long st)
 {
-  if(READS) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-  else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");       /* order for the compiler only */
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   if(__lane_id() == 0)
   {
-    __hip_atomic_store((lds_u64_t *)pool.ctl, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __hip_atomic_store((lds_u64_t *)pool.ctl + 1, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store((lds_u64_t *)pool.ctl, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
 }
 /* five 12-bit counts (at most 1024 entries) */

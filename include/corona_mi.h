@@ -351,6 +351,16 @@ int  mi_last_kernel_launches(mi_scene *s, uint64_t *launches);
  * out[2] traversal stack entries a ray may need, out[3] 1 if the tree was built on the device (mi_scene_desc.nodes == NULL).
  * No reference counterpart (the reference prints accel statistics to its log, src/accel.d/qbvhmp.c:1121-1144). */
 int  mi_scene_stats(mi_scene *s, uint32_t out[4]);
+/* how many of the tree's nodes (numbered breadth first: the top of the tree) the kernels stage in LDS: all of them if out[1] of
+ * mi_scene_stats is 1, else as many as fit next to the traversal stacks and the material queues' pools -- the rest is read from
+ * HBM / L2, one 128-byte record per node visit (qbvh_node_t, src/accel.d/qbvhmp.c:62-81, is what the reference reads per visit).
+ * CORONA_MI_NODES_TOP=<n> limits it, CORONA_MI_NODES=global forces 0 (tests). */
+int  mi_scene_lds_nodes(mi_scene *s, uint32_t *staged);
+/* the name of the kernel instantiation the next mi_render of this scene launches, as a profiler prints it
+ * ("mi_path_kernel<false, PTDL, NODES_LDS, HALTON, MEDIA, MB, COUNT, FAST, NORG>"): the library picks it from the scene (media, moving
+ * primitives, exterior fog, LDS residency of the tree, traversal mode, debug counters) -- bench.py and tools/profile.sh attach counter
+ * profiles to the kernel by this name instead of re-deriving the choice. No reference counterpart. */
+int  mi_scene_kernel_name(mi_scene *s, char *buf, size_t len);
 
 void mi_scene_destroy(mi_scene *s);
 void mi_shutdown(void);

@@ -26,3 +26,10 @@ def pytest_configure(config):
     import hashlib
     digest = hashlib.sha256(fine.read_bytes()).hexdigest()
     assert digest == "5ab97b31c13baef90daac0af6367b1fae8e764d591f5da9e895a698a19d6410f", "scenes/geo/plane_fine.geo differs from the file the goldens were made with"
+    # ... and the 262 144-quad backdrop of scenes/0064_large (27 MB, 0.7 s to generate): a tree of which only the top fits LDS
+    large = REPO / "scenes" / "geo" / "plane_k8.geo"
+    if not large.exists():
+        subprocess.check_call([sys.executable, str(REPO / "tools" / "make_geo.py"), "subdivide",
+                               str(REPO / "scenes" / "geo" / "plane.geo"), str(large), "8"])
+    digest = hashlib.sha256(large.read_bytes()).hexdigest()
+    assert digest == "42233bc5affc7449029a09de780bc65b7e7450ebd8c214d4c6d9fc6590a1c166", "scenes/geo/plane_k8.geo differs from the file the tests were written with"

@@ -17,6 +17,7 @@ REPO = Path(__file__).resolve().parent.parent
 GOLDEN = REPO / "tests" / "golden"
 SCENE_0010 = REPO / "scenes" / "0010_pt" / "test.nra2"
 SCENE_ROUGH = REPO / "scenes" / "0052_rough" / "test.nra2"
+SCENE_LARGE = REPO / "scenes" / "0064_large" / "test.nra2"     # 0010 with every backdrop quad split 8x8: 262 156 primitives, the top of the tree in LDS, the rest in HBM
 SCENE_FINE = REPO / "scenes" / "0054_fine" / "test.nra2"       # 0010 with every backdrop quad split 2x2 (tools/make_geo.py): 1711 nodes, too big for LDS
 SCENE_MEDIA = REPO / "scenes" / "0055_media" / "test.nra2"     # 0010 with a scattering medium inside the glass sphere (`interior`, `medium_rgb`)
 SCENE_FOG = REPO / "scenes" / "0056_fog" / "test.nra2"         # 0010 in a thin global fog (`exterior <medium> 0`)

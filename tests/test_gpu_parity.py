@@ -13,7 +13,7 @@ import json
 import numpy as np
 import pytest
 
-from helpers import oracle_lib, GOLDEN, SCENE_0010, SCENE_ALL, SCENE_CAM_MB, SCENE_FINE, SCENE_FOG, SCENE_MB, SCENE_MB_LIGHT, SCENE_MB_ROUND, SCENE_MB_ROUND_LIGHT, SCENE_MEDIA, SCENE_NESTED, SCENE_METAL, SCENE_ROUGH, load_pkg, make_scene, oracle_intersect, oracle_records, oracle_render
+from helpers import oracle_lib, GOLDEN, SCENE_0010, SCENE_ALL, SCENE_CAM_MB, SCENE_FINE, SCENE_LARGE, SCENE_FOG, SCENE_MB, SCENE_MB_LIGHT, SCENE_MB_ROUND, SCENE_MB_ROUND_LIGHT, SCENE_MEDIA, SCENE_NESTED, SCENE_METAL, SCENE_ROUGH, load_pkg, make_scene, oracle_intersect, oracle_records, oracle_render
 
 pkg = load_pkg()
 pytestmark = pytest.mark.gpu
@@ -644,6 +644,45 @@ def test_tree_larger_than_lds_is_read_from_hbm(traversal, counters):
     ofb, _, _ = oracle_render(scene, 0, npx, threads=8)
     rmse = np.sqrt((((fb - ofb) * scene.gain(1)) ** 2).sum() / npx)
     assert rmse < 0.05, rmse
+    be.close()
+
+
+@pytest.mark.parametrize("top", [None, "0", "37"], ids=["top that fits", "nothing staged", "37 nodes staged"])
+def test_large_tree_top_in_lds_rest_from_hbm(monkeypatch, traversal, counters, top):
+    """scenes/0064_large: 262 156 primitives (the backdrop split 8 x 8, tools/make_geo.py, hash-checked in conftest.py), a QBVH of 27 104
+    nodes = 3.5 MB of 128-byte records (qbvh_node_t of src/accel.d/qbvhmp.c:62-81 in 128 instead of 256 bytes). Only the top of the tree
+    -- as many breadth-first numbered nodes as the LDS takes next to stacks and pools -- is staged; everything below is read from
+    HBM / L2, one record per visit. Ray-level results bit-exact against the oracle (same counters in exact mode), the image against the
+    oracle's; the same with no node staged and with a top that ends in the middle of a level (CORONA_MI_NODES_TOP)."""
+    if top is not None:
+        monkeypatch.setenv("CORONA_MI_NODES_TOP", top)
+    scene = make_scene(SCENE_LARGE, width=640, height=352, max_verts=8)
+    assert scene.desc.num_prims == 262156 and scene.desc.num_nodes * 128 > 3 << 20
+    be = pkg.Backend(scene, traversal=traversal, counters=counters)
+    staged = be.lds_nodes()
+    assert not be.nodes_in_lds()
+    if top is None:
+        assert 128 <= staged < scene.desc.num_nodes, staged           # at least the first four levels of the 4-wide tree
+    else:
+        assert staged == int(top)
+    assert "mi_path_kernel<false, false, false," in be.kernel_name()
+    rng = np.random.default_rng(11)
+    n = 60000
+    pos = rng.uniform(-4, 4, size=(n, 3)).astype(np.float32) + np.float32([0, 0, 2])
+    d = rng.normal(size=(n, 3))
+    d[::50, 1] = 0.0                                       # some rays with an infinite 1/dir: the literal slab test
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    _compare_hits(scene, be, pos, d, traversal=traversal)
+    if top is None or (traversal == "exact" and counters):
+        npx = scene.width * scene.height
+        be.render(0, npx)
+        fb = be.fb_read()
+        ofb, _, _ = oracle_render(scene, 0, npx, threads=8)
+        rmse = np.sqrt((((fb - ofb) * scene.gain(1)) ** 2).sum() / npx)
+        assert rmse < 0.05, rmse
+        gpu = be.trace_paths(0, 4000)
+        ora = oracle_records(scene, 0, 4000)
+        assert (gpu["length"] == ora["length"]).mean() >= 0.999
     be.close()
 
 
