@@ -53,6 +53,10 @@ CONFIGS = {
     "cam_mb": dict(scene="0058_cam_mb", sampler="pt", w=1280, h=720, spp=64, mv=8, name="0010 scene seen by a moving camera (scenes/0058_cam_mb), pt, 1280x720, 64 spp"),
     "fog": dict(scene="0056_fog", sampler="pt", w=1280, h=720, spp=64, mv=8, name="0010 scene in a thin global fog (scenes/0056_fog), pt, 1280x720, 64 spp"),
     "fog_ptdl": dict(scene="0056_fog", sampler="ptdl", w=1280, h=720, spp=64, mv=8, name="scenes/0056_fog, ptdl, 1280x720, 64 spp"),
+    # trees that do not fit LDS (round 5): the top is staged, the rest is read from HBM / L2, one 128-byte record per node visit
+    "fine": dict(scene="0054_fine", sampler="pt", w=1280, h=720, spp=64, mv=8, name="0010 scene, backdrop split 2x2 (scenes/0054_fine: 16 396 primitives, 1711 nodes), pt, 1280x720, 64 spp"),
+    "large": dict(scene="0064_large", sampler="pt", w=1280, h=720, spp=64, mv=8, name="0010 scene, backdrop split 8x8 (scenes/0064_large: 262 156 primitives, 27 104 nodes = 3.5 MB of node records), pt, 1280x720, 64 spp"),
+    "large_ptdl": dict(scene="0064_large", sampler="ptdl", w=1280, h=720, spp=64, mv=8, name="scenes/0064_large, ptdl, 1280x720, 64 spp"),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 LDS_PEAK_TBS = 150.0           # MI355X_MICROARCH.md, LDS section: ds_read_b64 / b128 streaming, all 256 CUs (~2.4 GHz)
@@ -128,6 +132,15 @@ def cpu_baseline(width, height):
     secs = o.oracle_render(scene.desc_ptr, 0, n, fb.ctypes.data, cores, (C.c_uint64 * 8)())
     return {"value": n / secs / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
             "sample": f"4 spp of the same 1280x736 frame ({n} paths), oracle/liboracle.so, {secs:.2f} s"}
+
+
+def ensure_generated_geometry(scene_name):
+    """the finer backdrops of scenes/0054_fine and scenes/0064_large are generated (tools/make_geo.py subdivide: deterministic, the test
+    suite checks their hashes, tests/conftest.py), not committed"""
+    k = {"0054_fine": ("plane_fine", 2), "0064_large": ("plane_k8", 8)}.get(scene_name)
+    if k and not (REPO / "scenes" / "geo" / (k[0] + ".geo")).exists():
+        subprocess.check_call([sys.executable, str(REPO / "tools" / "make_geo.py"), "subdivide", str(REPO / "scenes" / "geo" / "plane.geo"),
+                               str(REPO / "scenes" / "geo" / (k[0] + ".geo")), str(k[1])])
 
 
 def library_build_id():
@@ -325,6 +338,10 @@ def main():
         """W untimed + K timed steps of `config`; returns a dict of raw results (rank-local except `elapsed`, the max over ranks)"""
         cfg = CONFIGS[config]
         # the scene as the host library loads it: its colours carry the reference table's coefficients (scenes/*/test.rgb2spec)
+        if rank == 0:
+            ensure_generated_geometry(cfg["scene"])
+        if use_dist:
+            dist.barrier()
         scene = pkg.Scene(REPO / "scenes" / cfg["scene"] / "test.nra2", width=cfg["w"], height=cfg["h"], max_verts=cfg["mv"],
                           sampler=pkg.MI_SAMPLER_PTDL if cfg["sampler"] == "ptdl" else pkg.MI_SAMPLER_PT,
                           pointsampler=pkg.MI_POINTS_HALTON if args.points == "halton" else pkg.MI_POINTS_RAND)

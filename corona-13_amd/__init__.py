@@ -303,8 +303,12 @@ def mi_lib():
         m.mi_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         m.mi_last_kernel_launches.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         m.mi_scene_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
-        m.mi_scene_kernel_name.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
-        m.mi_scene_lds_nodes.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        try:
+            m.mi_scene_kernel_name.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+            m.mi_scene_lds_nodes.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        except AttributeError:
+            if "CORONA_MI_LIB" not in os.environ:      # only a kernel-variant library of an older round (same-box A/B) may lack these two getters
+                raise
         m.mi_scene_destroy.argtypes = [C.c_void_p]
         m.mi_scene_destroy.restype = None
         m.mi_shutdown.restype = None
@@ -479,6 +483,8 @@ class Backend:
     def kernel_name(self):
         """the instantiation the next render() launches, as rocprofv3 prints it (mi_scene_kernel_name)"""
         buf = C.create_string_buffer(256)
+        if "CORONA_MI_LIB" in os.environ and not hasattr(self.m, "mi_scene_kernel_name"):
+            return "mi_path_kernel<a library of an earlier round>"       # same-box A/B against an older build only
         self._check(self.m.mi_scene_kernel_name(self._ptr, buf, len(buf)), "mi_scene_kernel_name")
         return buf.value.decode()
 

@@ -857,21 +857,27 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
   /* (both kinds of kernel must find room: the path kernels with their columns, the ray-level test kernel with full columns -- one K for
      both, the links are baked for it) */
   const size_t lds_total = 160*1024, static_bytes = 256;    /* blk_next, the pools' control words, alignment */
-  const size_t fixed_path = halton_bytes + lights_bytes + stack_bytes + static_bytes, fixed_isect = isect_stack_bytes + static_bytes;
+  /* (mi_intersect refuses scenes with moving primitives -- its rays carry no time --, so the ray-level kernel's full columns do not count there:
+     the motion-blur kernels keep both box sets of cfg-sized trees in LDS next to their 7-entry columns) */
+  const size_t fixed_path = halton_bytes + lights_bytes + stack_bytes + static_bytes, fixed_isect = mb_kernels ? 0 : isect_stack_bytes + static_bytes;
   s->nodes_lds = fixed_path + node_bytes <= lds_total && fixed_isect + node_bytes <= lds_total && !(nodes_env && !strcmp(nodes_env, "global"));
+  bool scatters_ = false;
+  for(size_t i=0;i<shape_med.size();i++) if(shape_med[i].med >= 0 && shape_med[i].mu_t[3] > 0.0f && shape_med[i].albedo[3] > 0.0f) scatters_ = true;
+  const bool pools_wanted = MI_REGROUP && !s->norg && (!mb_kernels || MI_REGROUP_MB) && num_classes + ((s->media && scatters_) ? 1u : 0u) > 1u;   /* (the predicate of the pools below) */
+  /* motion-blur kernels (round 5): both box sets of a cfg-sized tree fill the LDS next to the stacks -- no room for the pools of the exchange
+     between waves. With the top of the tree staged instead of all of it (the lowest levels from L2) the pools fit: MI_REGROUP_MB */
+  if(mb_kernels && pools_wanted && s->nodes_lds && fixed_path + node_bytes + (size_t)MI_NODES_TOP_POOL > lds_total && !getenv("CORONA_MI_MB_ALL_LDS")) s->nodes_lds = false;
   uint32_t K = N;
   if(!s->nodes_lds)
   {
-    bool scatters_ = false;
-    for(size_t i=0;i<shape_med.size();i++) if(shape_med[i].med >= 0 && shape_med[i].mu_t[3] > 0.0f && shape_med[i].albedo[3] > 0.0f) scatters_ = true;
-    const bool pools_wanted = MI_REGROUP && !s->norg && !mb_kernels && num_classes + ((s->media && scatters_) ? 1u : 0u) > 1u;   /* (the predicate of the pools below) */
-    const size_t pool_share = pools_wanted ? (size_t)MI_NODES_TOP_POOL : 0;
+    const char *pe = getenv("CORONA_MI_NODES_POOL");              /* (experiments: the pools' share in bytes) */
+    const size_t pool_share = !pools_wanted ? 0 : (pe && pe[0] && atol(pe) >= 0) ? (size_t)atol(pe) : (size_t)MI_NODES_TOP_POOL;
     const size_t room_path = fixed_path + pool_share < lds_total ? lds_total - fixed_path - pool_share : 0;
     const size_t room_isect = fixed_isect < lds_total ? lds_total - fixed_isect : 0;
     K = (uint32_t)((room_path < room_isect ? room_path : room_isect)/((size_t)SL*16));
     if(K > N) K = N;
     const char *te = getenv("CORONA_MI_NODES_TOP");
-    if(te && atol(te) >= 0 && (uint32_t)atol(te) < K) K = (uint32_t)atol(te);
+    if(te && te[0] && atol(te) >= 0 && (uint32_t)atol(te) < K) K = (uint32_t)atol(te);
     if(nodes_env && !strcmp(nodes_env, "global") && !te) K = 0;       /* the all-or-nothing switch of rounds 1-4, for tests */
   }
   d.nodes_lds = K;
@@ -904,14 +910,14 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
        some kernels but not of others -- used to pay for pools (shorter stack columns, no FAST rounds) that traded nothing. */
     const uint32_t ns_max = (uint32_t)PoolLayout<true, true, false>::SLOTS + (s->media ? 3u : 0u);
     const uint32_t e_min = (uint32_t)((room - cls_lds)/(ns_max*8u + 2u*(MI_POOL_CLASSES + 1u))) & ~7u;
-    const bool on = MI_REGROUP && classes > 1 && !s->norg && !mb_kernels && e_min >= 32u;
+    const bool on = MI_REGROUP && classes > 1 && !s->norg && (!mb_kernels || MI_REGROUP_MB) && e_min >= 32u;
     d.pool_classes = on ? classes : 0u;
     d.pool_cls_bytes = on ? (uint32_t)cls_lds : 0u;
     if(on) room -= d.pool_cls_bytes;
     d.pool_bytes = on ? (uint32_t)room : 0u;
     s->lds_bytes += d.pool_bytes + d.pool_cls_bytes;
     /* one launch size for every kernel of the scene: mi_intersect_kernel keeps full stack columns */
-    const size_t isect_bytes = (size_t)SL*K*16 + isect_stack_bytes;
+    const size_t isect_bytes = mb_kernels ? 0 : (size_t)SL*K*16 + isect_stack_bytes;
     if(s->lds_bytes < isect_bytes) s->lds_bytes = isect_bytes;
   }
   s->device_built = device_build; s->stack_need = stack_need;

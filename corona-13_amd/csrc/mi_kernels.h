@@ -1007,6 +1007,9 @@ __device__ __forceinline__ void leaf_jobs(const Lds &lds, const DPrim *prims, co
 }
 
 /* the ray geometry a node visit needs, fixed for the length of a round */
+#ifndef MI_HYBRID
+#define MI_HYBRID 1       /* 0 (experiments): the NODES_LDS = false instantiations read every node from HBM / L2, as in rounds 1-4 */
+#endif
 struct RayBox
 {
   uint32_t nearbits, offx, offy, offz;   /* sign bits of the direction; byte offset of each axis' entry plane inside a node record: 48 (the upper planes, lanes 3..5) for negative directions */
@@ -1111,7 +1114,7 @@ __device__ __forceinline__ bool node_visit(const Lds &lds, lds_uint2 *lstack, co
 #undef MI_HBM_LANE
     };
     if(lds.nodes_in_lds) from_lds();
-    else if(!lds.top_off) from_hbm();
+    else if(!MI_HYBRID || !lds.top_off) from_hbm();
     else if((current & MI_NODE_MASK) < lds.top_off) from_lds();      /* the top of the tree is staged, the rest is not (per lane) */
     else from_hbm();
   };

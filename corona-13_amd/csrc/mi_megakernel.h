@@ -67,7 +67,11 @@
 #define MI_PRIO_PTDL_SHADE 3
 #endif
 #ifndef MI_SCENE_LAZY
-#define MI_SCENE_LAZY 0
+#define MI_SCENE_LAZY 1     /* A/B (profiles/r05_levers_ab.txt): cfg 2 15.82 -> 15.48 ms, cfg 3 28.46 -> 28.21; spilled SGPRs 89 -> 24 (pt), 151 -> 82 (ptdl) */
+#endif
+#ifndef MI_REGROUP_MB
+#define MI_REGROUP_MB 0      /* ... in the motion-blur kernels (round 5 experiment): the pools take the place of the lowest levels of the tree, which are then read from L2.
+                                0059_mb, same box: 30.31 ms with (33-59 spilled registers more, hybrid node fetch), 26.73 ms without, the whole tree in LDS: off */
 #endif
 #ifndef MI_REGROUP_MEDIA
 #define MI_REGROUP_MEDIA 1   /* the exchange in the extended kernels too (media, moving camera): volume vertices are a class of their own */
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
   /* material queues (mi_regroup.h): the plain kernels trade surface vertices between the waves of the workgroup, by class of the material */
   /* NORG: the extended kernels once more WITHOUT the exchange, for scenes in a scattering exterior medium (a global fog): nearly every vertex
      is a volume vertex there, the exchange has nothing to sort, and its code costs that kernel 26 more spilled registers (fog ptdl 124 against 115 ms) */
-  constexpr bool REGROUP = MI_REGROUP && !MB && !NORG && (!MEDIA || MI_REGROUP_MEDIA);
+  constexpr bool REGROUP = MI_REGROUP && (!MB || MI_REGROUP_MB) && !NORG && (!MEDIA || MI_REGROUP_MEDIA);
   __shared__ PoolCtl pool_ctl;
   if(threadIdx.x == 0) blk_next = 0;
   Pool pool;
