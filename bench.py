@@ -56,6 +56,7 @@ CONFIGS = {
     # trees that do not fit LDS (round 5): the top is staged, the rest is read from HBM / L2, one 128-byte record per node visit
     "fine": dict(scene="0054_fine", sampler="pt", w=1280, h=720, spp=64, mv=8, name="0010 scene, backdrop split 2x2 (scenes/0054_fine: 16 396 primitives, 1711 nodes), pt, 1280x720, 64 spp"),
     "large": dict(scene="0064_large", sampler="pt", w=1280, h=720, spp=64, mv=8, name="0010 scene, backdrop split 8x8 (scenes/0064_large: 262 156 primitives, 27 104 nodes = 3.5 MB of node records), pt, 1280x720, 64 spp"),
+    "huge": dict(scene="0065_huge", sampler="pt", w=1280, h=720, spp=64, mv=8, name="0010 scene, backdrop split 16x16 (scenes/0065_huge: 1 048 588 primitives, node records beyond one XCD's L2), pt, 1280x720, 64 spp"),
     "large_ptdl": dict(scene="0064_large", sampler="ptdl", w=1280, h=720, spp=64, mv=8, name="scenes/0064_large, ptdl, 1280x720, 64 spp"),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
@@ -137,7 +138,7 @@ def cpu_baseline(width, height):
 def ensure_generated_geometry(scene_name):
     """the finer backdrops of scenes/0054_fine and scenes/0064_large are generated (tools/make_geo.py subdivide: deterministic, the test
     suite checks their hashes, tests/conftest.py), not committed"""
-    k = {"0054_fine": ("plane_fine", 2), "0064_large": ("plane_k8", 8)}.get(scene_name)
+    k = {"0054_fine": ("plane_fine", 2), "0064_large": ("plane_k8", 8), "0065_huge": ("plane_k16", 16)}.get(scene_name)
     if k and not (REPO / "scenes" / "geo" / (k[0] + ".geo")).exists():
         subprocess.check_call([sys.executable, str(REPO / "tools" / "make_geo.py"), "subdivide", str(REPO / "scenes" / "geo" / "plane.geo"),
                                str(REPO / "scenes" / "geo" / (k[0] + ".geo")), str(k[1])])
