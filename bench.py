@@ -166,8 +166,8 @@ class StubBackend:
     sharding, reduce and JSON logic of this file can run under gloo. It renders nothing: it adds the number of path indices it
     was handed to element 0 of the framebuffer (so the reduced frame must sum to the job size) and counts them."""
 
-    def __init__(self):
-        self.fb, self.paths = None, 0
+    def __init__(self, tiles=0):
+        self.fb, self.paths, self.tiles = None, 0, tiles
 
     def set_framebuffer_tensor(self, t):
         self.fb = t
@@ -178,6 +178,13 @@ class StubBackend:
         self.fb.view(-1)[0] += float(count % self.SPLIT)
         self.fb.view(-1)[1] += float(count // self.SPLIT)
         self.paths += count
+
+    def set_pixels(self, on):
+        self.pixels = on
+
+    def render_tiles(self, first_frame, frames, member, members, tiles=None):
+        local = (self.tiles - member + members - 1) // members if member < self.tiles else 0
+        self.render(0, frames * local * 1024)
 
     def sync(self):
         pass
@@ -278,6 +285,11 @@ def main():
                     help="auto (the library's choice per scene: fast for the plain pt kernels, exact otherwise); fast: leaves put aside while a lane "
                          "descends on, same hits; exact: the reference's order of operations per ray, work counters equal its -DACCEL_DEBUG totals "
                          "(corona_mi.h, MI_TRAVERSAL_*)")
+    ap.add_argument("--shard", default="indices", choices=["indices", "tiles"],
+                    help="how the GPUs of the job share a step's paths. indices (default): rank r renders the r-th contiguous block of the step's path "
+                         "indices, pixels are sampled (regression/0010_pt as the reference renders it: path for path the reference's paths). tiles: "
+                         "rank r renders the 32 x 32 film tiles t = r (mod N) of every frame, pixels come from the path indices (the tiled branch of "
+                         "the reference's render_sample_path, src/render.d/gi.c:88-95; mi_render_tiles) -- every rank splats into its own pixels")
     ap.add_argument("--reduce", default="torch", choices=["torch", "c"],
                     help="torch: one process per GPU, torch.distributed (RCCL) all-reduce of the framebuffer (what the driver launches); c: ONE process, "
                          "the N GPUs behind the C ABI (mi_group_*: index ranges split in the library, ncclReduce from the library)")
@@ -351,7 +363,7 @@ def main():
         fb = torch.zeros((scene.height, scene.width, 3), dtype=torch.float32, device=device)
         host_fb = torch.zeros((scene.height, scene.width, 3), dtype=torch.float32, pin_memory=not args.stub)
         if args.stub:
-            be = StubBackend()
+            be = StubBackend(tiles=(scene.width // 32) * (scene.height // 32))
             be.set_framebuffer_tensor(fb)
         else:
             # the timed kernels carry no debug counters (only the path count), like the reference without -DACCEL_DEBUG
@@ -369,9 +381,17 @@ def main():
                 dist.barrier()
             sync_device()
 
+        tiles = (scene.width // 32) * (scene.height // 32)
+        frames_per_step = job // (scene.width * scene.height)          # tile sharding: a step = this many one-sample-per-pixel frames
+        my_tiles = (tiles - rank + world - 1) // world if rank < tiles else 0
+        if args.shard == "tiles":
+            be.set_pixels(True)
+
         def step(k):
-            # rank r renders its own contiguous block of the step's path indices: no data-path collective
+            # rank r renders its own contiguous block of the step's path indices (or its own tiles of the step's frames): no data-path collective
             first, count = pkg.shard_range(k * job, job, rank, world)
+            if args.shard == "tiles":
+                count = frames_per_step * my_tiles * 1024
             if use_dist:
                 buf = reducer.begin(k)                         # cleared: the reduce works on this step's partial sums only
                 if args.stub:
@@ -380,7 +400,10 @@ def main():
                     be.set_framebuffer(buf.data_ptr())
             else:
                 fb.zero_()                                     # every step renders its own frame (the multi-rank path clears per step too)
-            be.render(first, count)
+            if args.shard == "tiles":
+                be.render_tiles(k * frames_per_step, frames_per_step, rank, world)
+            else:
+                be.render(first, count)
             if use_dist:
                 reducer.end(k)                                 # framebuffer reduce over xGMI (RCCL), asynchronous
             return count
@@ -423,12 +446,21 @@ def main():
         kms_timed = be.last_kernel_ms() if not args.stub else 0.0
         kernel = be.kernel_name() if not args.stub else "stub"      # the instantiation the timed launches ran: the library's own answer
         first, count = pkg.shard_range(0, job, rank, world)
+        if args.shard == "tiles":
+            count = frames_per_step * my_tiles * 1024
+
+        def render_share(k):
+            """this rank's share of job number k, outside the timed region"""
+            if args.shard == "tiles":
+                be.render_tiles(k * frames_per_step, frames_per_step, rank, world)
+            else:
+                be.render(k * job + first, count)
         durs = []
         extra_frames = max(3, min(steps, 5))
         if not use_dist and not args.stub:
             be.set_framebuffer(fb.data_ptr())
         for k in range(extra_frames):
-            be.render((1000 + k) * job + first, count)      # (added on top of the last timed frame in `fb`: the converged-mean check below)
+            render_share(1000 + k)                          # (added on top of the last timed frame in `fb`: the converged-mean check below)
             be.sync()
             durs.append(be.last_kernel_ms())
         kms_separate = sum(durs) / len(durs)
@@ -444,7 +476,7 @@ def main():
         if not args.stub:
             be.set_counters(True)
         w0 = be.counters()
-        be.render(2000 * job + first, count)
+        render_share(2000)
         be.sync()
         dc = [b - a for a, b in zip(w0, be.counters())]
         res = dict(cfg=cfg, scene_wh=(scene.width, scene.height), per_frame=per_frame, job=job, elapsed=elapsed, dc=dc, kms=kms,
@@ -515,10 +547,18 @@ def main():
             peak = CUS * SIMDS_PER_CU * clock_ghz / 2.0
             lane = prof["SQ_THREAD_CYCLES_VALU"] / (64.0 * prof["SQ_ACTIVE_INST_VALU"])
             build = library_build_id()
+            fresh = prof.get("build_id") == build and prof.get("kernel", "").split(" (")[0] == r["kernel"]
             out.update({"achieved": achieved, "peak": peak, "frac": achieved / peak, "lane_utilisation": lane, "useful_lane_frac": achieved / peak * lane,
                         "valu_instr_per_path": instr_per_path, "clock_ghz": clock_ghz, "source": prof_name,
-                        # the instruction count belongs to the build the profile was taken from: flagged when that is not the loaded library
-                        "profile_build_id": prof.get("build_id"), "library_build_id": build, "profile_matches_library": prof.get("build_id") == build})
+                        # the instruction count belongs to the build the profile was taken from
+                        "profile_build_id": prof.get("build_id"), "library_build_id": build, "profile_matches_library": fresh})
+            if not fresh:
+                # never a stale fraction: the committed counters are of another build (or of another instantiation than the
+                # one this run launched) -- the live fields (kernel_ms, traffic-free LDS line, algorithmic_hbm_frac) stay, the counter-derived ones go
+                for k in ("achieved", "frac", "useful_lane_frac", "valu_instr_per_path", "lane_utilisation"):
+                    out[k] = None
+                out["stale_profile"] = (f"{prof_name} was taken from library build {prof.get('build_id')} / kernel {prof.get('kernel')}; this run loaded build {build} and launched "
+                                        f"{r['kernel']}: re-run tools/profile.sh and commit its summary")
             if "FETCH_SIZE" in prof and "WRITE_SIZE" in prof:
                 # FETCH_SIZE counts 128-B requests as 64 B on gfx950 (MI355X_MICROARCH.md, HBM section); counters are in KiB
                 out["traffic"] = (2.0 * prof["FETCH_SIZE"] + prof["WRITE_SIZE"]) * 1024.0
@@ -528,12 +568,14 @@ def main():
             # functions compiled in isolation: tools/valu_floor.py, tools/micro/floor_blocks.hip -> profiles/r04_valu_floor.json).
             # floor_over_executed says how much of what the kernel executes is that work; efficiency = frac x floor_over_executed is the share
             # of the machine's peak issue rate spent on it. A fatter kernel raises `frac` and lowers `floor_over_executed`.
-            floor = valu_floor(config, r)
+            floor = valu_floor(config, r) if fresh else None
             if floor:
                 out.update({"valu_floor_per_path": floor["per_path"], "floor_over_executed": floor["per_path"] / instr_per_path,
                             "efficiency": achieved / peak * floor["per_path"] / instr_per_path, "valu_floor_terms": floor["terms"], "valu_floor_source": floor["source"]})
             if "SQ_LDS_BANK_CONFLICT" in prof and prof.get("SQ_LDS_IDX_ACTIVE"):
                 out["lds_bank_conflict_share"] = prof["SQ_LDS_BANK_CONFLICT"] / prof["SQ_LDS_IDX_ACTIVE"]
+        # SURVEY 8(d)'s figure beside the binding one: algorithmic bytes per launch / launch duration over the HBM peak (work_rate_vs_hbm has the terms)
+        out["algorithmic_hbm_frac"] = work_rate_of(config, r)["rate_over_hbm_peak"]
         # LDS line: the node loop reads 7 x 16 B per node visit (six box planes x 4 children + 4 links) and moves about one 8-B stack
         # entry in and out per visit; live node visits of the counting launch
         paths = max(r["dc"][4], 1)
@@ -593,7 +635,8 @@ def main():
             "data": "synthetic: regression/0010_pt scene (6 of 7 shapes, scenes/0010_pt), per-path xorshift128+ seeds",
             "config": {"workload": cfg["name"], "tree": args.tree, "pointsampler": args.points, "traversal": main_r["traversal"],
                        "paths_per_step": main_r["job"], "paths_per_step_per_gpu": main_r["launch_paths"],
-                       "sharding": f"path-index ranges x{world} ({scaling}), framebuffer all-reduce + read-back of the last frame in the timed region"},
+                       "sharding": (f"32x32 film tiles t = rank (mod {world}), pixels from path indices (mi_render_tiles; {scaling})" if args.shard == "tiles"
+                                    else f"path-index ranges x{world} ({scaling})") + ", framebuffer all-reduce + read-back of the last frame in the timed region"},
             # the timed kernel counts paths only; live_work_per_sample comes from one launch of the counting instantiation outside the timed region
             "counters_compiled_in": False,
             "roofline": roofline_of(args.config, main_r),

@@ -23,6 +23,7 @@ REPO_DIR = PKG_DIR.parent
 HOST_LIB = Path(os.environ.get("CORONA_HOST_LIB", PKG_DIR / "host" / "libcorona_host.so"))   # override: the sanitizer build (make sanitize)
 MI_LIB = Path(os.environ.get("CORONA_MI_LIB", PKG_DIR / "csrc" / "libcorona_mi.so"))   # override: kernel-variant experiments only
 
+MI_PIXELS_SAMPLED, MI_PIXELS_FROM_INDEX = 0, 1
 MI_SAMPLER_PT, MI_SAMPLER_PTDL = 0, 1
 MI_POINTS_RAND, MI_POINTS_HALTON = 0, 1
 MI_TRAVERSAL_EXACT, MI_TRAVERSAL_FAST = 0, 1
@@ -304,6 +305,13 @@ def mi_lib():
         m.mi_last_kernel_launches.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         m.mi_scene_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         try:
+            m.mi_scene_set_pixels.argtypes = [C.c_void_p, C.c_int]
+            m.mi_render_tiles.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
+            m.mi_group_render_tiles.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+        except AttributeError:
+            if "CORONA_MI_LIB" not in os.environ:
+                raise
+        try:
             m.mi_scene_kernel_name.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
             m.mi_scene_lds_nodes.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         except AttributeError:
@@ -334,7 +342,7 @@ def mi_lib():
 
 MI_SYMBOLS = ["mi_init", "mi_scene_create", "mi_scene_set_framebuffer", "mi_scene_set_stream", "mi_render",
               "mi_sync", "mi_fb_read", "mi_fb_clear", "mi_fb_device_ptr", "mi_counters", "mi_scene_set_counters", "mi_scene_set_traversal", "mi_scene_get_traversal", "mi_scene_set_metal_reference", "mi_trace_paths", "mi_intersect", "mi_plan_launches",
-              "mi_last_kernel_ms", "mi_last_kernel_launches", "mi_scene_stats", "mi_scene_lds_nodes", "mi_scene_kernel_name", "mi_scene_destroy", "mi_shutdown", "mi_last_error", "mi_current_device", "mi_bsdf_test_run",
+              "mi_last_kernel_ms", "mi_last_kernel_launches", "mi_scene_stats", "mi_scene_lds_nodes", "mi_scene_kernel_name", "mi_scene_set_pixels", "mi_render_tiles", "mi_group_render_tiles", "mi_scene_destroy", "mi_shutdown", "mi_last_error", "mi_current_device", "mi_bsdf_test_run",
               "mi_group_create", "mi_group_size", "mi_group_scene", "mi_group_uses_rccl", "mi_group_render", "mi_group_fb_reduce", "mi_group_fb_read",
               "mi_group_fb_clear", "mi_group_sync", "mi_group_counters", "mi_group_destroy"]
 
@@ -403,6 +411,14 @@ class Backend:
 
     def render(self, first, count):
         self._check(self.m.mi_render(self._ptr, first, count), "mi_render")
+
+    def set_pixels(self, from_index: bool):
+        """True: path i starts inside pixel (i mod W H) (MI_PIXELS_FROM_INDEX, the hook of the reference's tiled branch of render_sample_path); False: sampled"""
+        self._check(self.m.mi_scene_set_pixels(self._ptr, MI_PIXELS_FROM_INDEX if from_index else MI_PIXELS_SAMPLED), "mi_scene_set_pixels")
+
+    def render_tiles(self, first_frame, frames, member=0, members=1):
+        """the paths of frames [first_frame, first_frame + frames) whose pixel lies in a 32 x 32 tile t = member (mod members)"""
+        self._check(self.m.mi_render_tiles(self._ptr, first_frame, frames, member, members), "mi_render_tiles")
 
     def sync(self):
         self._check(self.m.mi_sync(self._ptr), "mi_sync")
@@ -528,6 +544,10 @@ class Group:
 
     def render(self, first, count):
         self._check(self.m.mi_group_render(self._ptr, first, count), "mi_group_render")
+
+    def render_tiles(self, first_frame, frames):
+        """member k renders the tiles t = k (mod n) of every frame (mi_group_render_tiles)"""
+        self._check(self.m.mi_group_render_tiles(self._ptr, first_frame, frames), "mi_group_render_tiles")
 
     def reduce(self):
         self._check(self.m.mi_group_fb_reduce(self._ptr), "mi_group_fb_reduce")

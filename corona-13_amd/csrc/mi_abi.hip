@@ -1107,6 +1107,47 @@ extern "C" int mi_render(mi_scene *s, uint64_t first_index, uint64_t count)
   return MI_OK;
 }
 
+extern "C" int mi_scene_set_pixels(mi_scene *s, int mode)
+{
+  MI_ENTER(s, "null scene");
+  if(mode != MI_PIXELS_SAMPLED && mode != MI_PIXELS_FROM_INDEX) return fail(MI_ERR_ARG, "mi_scene_set_pixels: unknown mode");
+  s->d.pixels_from_index = mode == MI_PIXELS_FROM_INDEX ? 1u : 0u;
+  return MI_OK;
+}
+
+extern "C" int mi_render_tiles(mi_scene *s, uint64_t first_frame, uint64_t frames, uint32_t member, uint32_t members)
+{ /* the paths of frames [first_frame, first_frame + frames) whose pixel lies in a tile t = member (mod members): the launch's work items are
+     (frame, local tile, pixel of the tile) triples in that order, 1024 per tile; tile_path() (mi_path.h) names the path of an item */
+  MI_ENTER(s, "null scene");
+  if(!members || member >= members) return fail(MI_ERR_ARG, "mi_render_tiles: member must be below members");
+  if(!s->d.pixels_from_index) return fail(MI_ERR_ARG, "mi_render_tiles: the scene samples its pixels (mi_scene_set_pixels(s, MI_PIXELS_FROM_INDEX) first)");
+  const uint32_t tiles_x = s->width/32u, tiles = tiles_x*(s->height/32u);
+  const uint32_t local = member < tiles ? (tiles - member + members - 1u)/members : 0u;
+  if(!frames || !local) return MI_OK;
+  if(frames > (~0ull >> 11)/local) return fail(MI_ERR_ARG, "mi_render_tiles: too many frames");
+  { const int e = ensure_halton(s, (first_frame + frames)*(uint64_t)s->width*s->height); if(e) return e; }
+  DScene &d = s->d;
+  d.tile_members = members; d.tile_member = member; d.tiles_local = local; d.tiles_x = tiles_x;
+  const uint64_t first_item = first_frame*local*1024u, count = frames*local*1024u;
+  hipError_t err = hipEventRecord(s->ev0, s->stream);
+  s->kernel_launches_last = 0;
+  for(uint64_t done = 0; done < count && err == hipSuccess; )
+  {
+    int grid;
+    const uint64_t n = launch_chunk(count - done, s->grid, &grid);
+    launch_path_kernel(s, false, grid, first_item + done, n, nullptr);
+    err = hipGetLastError();
+    s->kernel_launches_last++;
+    done += n;
+  }
+  d.tile_members = 0;          /* (the descriptor travels by value with every launch: mi_render and mi_trace_paths see a plain scene again) */
+  if(err == hipSuccess) err = hipEventRecord(s->ev1, s->stream);
+  if(err != hipSuccess) { snprintf(g_err, sizeof(g_err), "mi_render_tiles: %s", hipGetErrorString(err)); fprintf(stderr, "[mi] %s\n", g_err); return MI_ERR_DEVICE; }
+  s->have_timing = 1;
+  s->launches += s->kernel_launches_last;
+  return MI_OK;
+}
+
 extern "C" int mi_sync(mi_scene *s)
 {
   MI_ENTER(s, "null scene");
@@ -1545,6 +1586,26 @@ extern "C" int mi_group_render(mi_group *g, uint64_t first_index, uint64_t count
     if(e)
     { /* the members before k have their shares queued: let them finish, and refuse to reduce or read the partial frame (mi_group_fb_clear
          makes the group usable again) */
+      for(int j=0;j<k;j++) (void)mi_sync(g->member[j]);
+      g->broken = true;
+      return e;
+    }
+  }
+  return MI_OK;
+}
+
+extern "C" int mi_group_render_tiles(mi_group *g, uint64_t first_frame, uint64_t frames)
+{ /* member k renders the tiles t = k (mod n) of every frame: no member touches another's pixels except through the filter's 4 x 4 footprint
+     at tile borders, which the reduce adds up like everything else */
+  if(!g) return fail(MI_ERR_ARG, "null group");
+  DeviceRestore restore;
+  for(int k=0;k<g->n;k++)
+  {
+    int e = g->member[k]->d.pixels_from_index ? MI_OK : mi_scene_set_pixels(g->member[k], MI_PIXELS_FROM_INDEX);
+    if(!e) e = mi_render_tiles(g->member[k], first_frame, frames, (uint32_t)k, (uint32_t)g->n);
+    if(!e && hipEventRecord(g->rendered[k], g->member[k]->stream) != hipSuccess) e = fail(MI_ERR_DEVICE, "mi_group_render_tiles: cannot record an event");
+    if(e)
+    {
       for(int j=0;j<k;j++) (void)mi_sync(g->member[j]);
       g->broken = true;
       return e;

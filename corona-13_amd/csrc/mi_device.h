@@ -166,6 +166,10 @@ struct DScene
   uint32_t pool_volume_class;       /* extended kernels: the class of volume vertices (= number of surface classes) */
   uint32_t pool_cls_bytes;          /* bytes of the packed class table staged into LDS behind the pools (0: looked up in prim_cls through L2) */
   const uint32_t *prim_cls;         /* [ceil(num_prims / 16)]: DPrimGeo.cls of every primitive, two bits each (mi_pack_cls_kernel) */
+  /* pixels from path indices (mi_scene_set_pixels) and tile-owned sharding (mi_render_tiles): see mi_path.h, tile_path() */
+  uint32_t pixels_from_index;       /* 1: path i starts inside pixel (i mod W H) -- the hook of render_sample_path's tiled branch, src/render.d/gi.c:88-95 (mi_scene_set_pixels) */
+  uint32_t tile_members;            /* > 0 during mi_render_tiles: the launch enumerates the pixels of the 32 x 32 tiles t = tile_member (mod tile_members) */
+  uint32_t tile_member, tiles_local, tiles_x;
 };
 
 #endif

@@ -183,6 +183,20 @@ __device__ __forceinline__ void rng_seed(Rng &r, unsigned long long index, unsig
   r.s1 = 2 + frame;
   for(int k=0;k<10;k++) (void)rng_next(r);
 }
+__device__ __forceinline__ unsigned long long mi_splitmix64(unsigned long long z)
+{
+  z = (z ^ (z >> 30))*0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27))*0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ void rng_seed_hashed(Rng &r, unsigned long long index, unsigned long long frame)
+{ /* MI_PIXELS_FROM_INDEX only (corona_mi.h), NOT the reference's seeding: both state words through the splitmix64 finaliser, then the same ten
+     rounds. Seeded as above, the first numbers of paths i and i + 1 are correlated (their wavelengths: r = 0.96) -- harmless while a path's
+     pixel is one of those numbers, a colour cast that takes thousands of samples to average out once neighbouring indices are neighbouring pixels */
+  r.s0 = mi_splitmix64(1 + index + 0x9e3779b97f4a7c15ull);
+  r.s1 = mi_splitmix64(2 + frame + 2*0x9e3779b97f4a7c15ull + r.s0);
+  if(!(r.s0 | r.s1)) r.s0 = 1;
+  for(int k=0;k<10;k++) (void)rng_next(r);
+}
 
 /* ---------------------------------------------------------------------------------- point sampler
  * pointsampler(path, dim), MOD_pointsampler = rand (src/pointsampler.d/rand.c:48-55: the next number of the per-path

@@ -212,7 +212,16 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
         {
           const unsigned rank = __popcll(m & ((1ull << lane) - 1ull));
           const unsigned long long i = blk_lo + base + rank;
-          if(i < blk_hi) path_generate<RECORD, HALTON, MEDIA>(sc, ps, first + i, RECORD ? records + i : nullptr, cnt);
+          if(i < blk_hi)
+          {
+            if(!RECORD && sc.tile_members)
+            { /* tile-owned sharding (mi_render_tiles): the launch's items are pixels of this member's tiles, tile_path() names their paths */
+              float px, py;
+              const unsigned long long index = tile_path(sc, first + i, px, py);
+              path_generate<RECORD, HALTON, MEDIA>(sc, ps, index, nullptr, cnt, px, py);
+            }
+            else path_generate<RECORD, HALTON, MEDIA>(sc, ps, first + i, RECORD ? records + i : nullptr, cnt);
+          }
           else exhausted = true;
         }
       }

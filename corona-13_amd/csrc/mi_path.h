@@ -127,13 +127,37 @@ __device__ __forceinline__ void camera_frame_at(const mi_camera &cam, float time
 }
 
 /* start path `index`: afterwards ps holds the camera ray as the pending extension ray */
-template<bool RECORD, bool HALTON, bool MEDIA = false, class CNT>
-__device__ __forceinline__ void path_generate(const DScene &sc, PathState &ps, unsigned long long index, mi_path_record *rec, CNT &cnt)
+/* Tile-owned sharding (mi_render_tiles): work item j of a launch -> the path it stands for. Member g of G owns the 32 x 32 tiles
+ * t = g (mod G), tiles counted row by row (the reference's tile size, include/render_tiles.h:156). Items walk the member's tiles round robin:
+ * item j is pixel (j / T) mod 1024 of local tile j mod T in frame j / (1024 T) (T = the member's tile count) -- neighbouring items, i.e. the
+ * lanes of a wave and the waves of a workgroup, work in DIFFERENT tiles. Dealt out tile by tile instead (a wave inside one tile, a workgroup
+ * inside one stretch of the film) the same launch took 19.0 instead of 15.6 ms on cfg 2 and 49.9 instead of 28.4 ms on cfg 3: the workgroups'
+ * contiguous item ranges then cover regions of different cost (sky against glass), and the sixteen taps of a tile's splats queue up at the
+ * same framebuffer addresses (profiles/r05_tiles.txt).
+ * The path's INDEX is what render_sample_path's pixel branch (src/render.d/gi.c:88-93) inverts: frame * W H + y W + x -- so a path has the
+ * same index, generator state and pixel whichever member renders it, and G members together render exactly the paths
+ * [first_frame W H, (first_frame + frames) W H). */
+__device__ __forceinline__ unsigned long long tile_path(const DScene &sc, unsigned long long j, float &px, float &py)
+{
+  const unsigned long long r = j/sc.tiles_local;
+  const uint32_t lt = (uint32_t)(j - r*sc.tiles_local);
+  const uint32_t p = (uint32_t)r & 1023u;
+  const unsigned long long f = r >> 10;
+  const uint32_t t = sc.tile_member + lt*sc.tile_members;
+  const uint32_t ty = t/sc.tiles_x, tx = t - ty*sc.tiles_x;
+  const uint32_t x = tx*32u + (p & 31u), y = ty*32u + (p >> 5);
+  px = (float)x; py = (float)y;
+  return (f*sc.height + y)*sc.width + x;
+}
+
+template<bool RECORD, bool HALTON, bool MEDIA, class CNT>
+__device__ __forceinline__ void path_generate(const DScene &sc, PathState &ps, unsigned long long index, mi_path_record *rec, CNT &cnt, float px = -1.0f, float py = -1.0f)
 {
   /* path_init + first half of path_extend (length == 0), src/pathspace.c:13-28,210-249 */
   MI_BLK(cnt, 0)
   ps.index = index;
-  rng_seed(ps.rng, ps.index, sc.frame);
+  if(sc.pixels_from_index) rng_seed_hashed(ps.rng, ps.index, sc.frame);     /* (why: mi_kernels.h) */
+  else rng_seed(ps.rng, ps.index, sc.frame);
   PointSampler<HALTON> pts(sc, ps.rng, index, 0);
   ps.scramble = 0.1f + rng_next(ps.rng)*(0.9f-0.1f);          /* points_rand, not the point sampler: src/pathspace.c:213 */
   const float lf0 = pts.template camera<MI_DIM_LAMBDA>() + 0/(float)1;
@@ -145,8 +169,21 @@ __device__ __forceinline__ void path_generate(const DScene &sc, PathState &ps, u
   const mi_camera &cam = sc.cam;
   const DCamConst &cc = sc.cc;
   const float W = cc.W, H = cc.H;
-  const float ci = pts.template camera<MI_DIM_IMAGE_X>()*W;
-  const float cj = pts.template camera<MI_DIM_IMAGE_Y>()*H;
+  /* the film position: sampled -- or, DScene.pixels_from_index, inside the pixel the path's index names (path_set_pixel, include/pathspace.h:355-360:
+     camera_sample takes a caller's position instead of asking the point sampler, src/camera.d/thinlens.c:117-118). The position inside the
+     pixel comes from the two numbers that would have been the sampled position, so the rest of the path's numbers stay where they are. */
+  float ci = pts.template camera<MI_DIM_IMAGE_X>(), cj = pts.template camera<MI_DIM_IMAGE_Y>();
+  if(sc.pixels_from_index)
+  {
+    if(px < 0.0f)
+    { /* gi.c:88-93: frame = index / (W H), y = rest / W, x = rest - y W (contiguous index ranges: mi_render, mi_trace_paths) */
+      const unsigned long long wh = (unsigned long long)sc.width*sc.height, rest = index - (index/wh)*wh;
+      const uint32_t y = (uint32_t)(rest/sc.width);
+      py = (float)y; px = (float)(uint32_t)(rest - (unsigned long long)y*sc.width);
+    }
+    ci += px; cj += py;
+  }
+  else { ci *= W; cj *= H; }
   const float r1 = pts.template camera<MI_DIM_APERTURE_X>();
   const float r2 = pts.template camera<MI_DIM_APERTURE_Y>();
   const float ang = (float)(2*MI_PI_D*(double)r1);

@@ -347,6 +347,33 @@ int  mi_last_kernel_ms(mi_scene *s, float *ms);
  * workgroup); mi_last_kernel_ms then spans the whole sequence */
 int  mi_last_kernel_launches(mi_scene *s, uint64_t *launches);
 
+/* Pixels from path indices, and tile-owned sharding.
+ * replaces: the branch of render_sample_path that the reference keeps for tiled rendering (src/render.d/gi.c:88-95: frame = index / (W H),
+ * y, x from the rest, pointsampler_mutate_with_pixel -> path_set_pixel, include/pathspace.h:355-360; camera_sample then takes the caller's
+ * position instead of two numbers of the point sampler, src/camera.d/thinlens.c:117-118) and the tile scheme of include/render_tiles.h:148-170
+ * (32 x 32 pixel tiles handed to workers, src/render_tiles.c:29-88).
+ *   mi_scene_set_pixels(s, MI_PIXELS_FROM_INDEX): from now on path i of mi_render / mi_trace_paths starts inside pixel (x, y) = (q mod W, q / W),
+ *   q = i mod W H (gi.c:89-92) -- one sample per pixel per W H consecutive indices. MI_PIXELS_SAMPLED (default): the film position is
+ *   sampled, as regression/0010_pt renders. Two things differ from the reference's (dead, `#if 0`) branch, both measured with the oracle's
+ *   literal restatement of it (tests/test_oracle_golden.py::test_pixels_from_indices_*):
+ *     - the position is (x + u, y + v) with u, v the two numbers the sampled mode turns into the film position, not the pixel's corner
+ *       (x, y): the film is sampled as densely as in the default mode and the path's other numbers stay what they are;
+ *     - the path's generator is seeded through a 64-bit hash (splitmix64) of the index. The reference seeds with 1 + index and ten warm-up
+ *       rounds (points_set_state, src/points.d/xorshift128p.c:53-59), which leaves the first numbers of CONSECUTIVE indices correlated
+ *       (the wavelengths of paths i and i + 1: r = 0.96). Sampled film positions hide that; with neighbouring indices on neighbouring
+ *       pixels whole rows share their wavelengths, and a 256-spp mean of cfg 3 is still 1.5 % off in X and Z.
+ *   This mode has no path-for-path reference (the branch never runs in the reference's builds): it is pinned statistically, against the
+ *   reference's converged render of the same film (tests/test_gpu_parity.py::test_tile_sharding_statistics_against_the_reference_render).
+ *   mi_render_tiles(s, first_frame, frames, member, members): of the paths [first_frame W H, (first_frame + frames) W H) those whose
+ *   pixel lies in a tile t = member (mod members), tiles counted row by row. A path has the same index, random numbers and pixel
+ *   whichever member renders it: `members` scenes (GPUs) together splat exactly what one mi_render of the range splats, each into
+ *   its own pixels (+ the two-pixel rim of the 4 x 4 filter footprint) -- the framebuffers are then summed as with index sharding.
+ * Asynchronous like mi_render. */
+#define MI_PIXELS_SAMPLED    0
+#define MI_PIXELS_FROM_INDEX 1
+int  mi_scene_set_pixels(mi_scene *s, int mode);
+int  mi_render_tiles(mi_scene *s, uint64_t first_frame, uint64_t frames, uint32_t member, uint32_t members);
+
 /* what the backend made of the scene: out[0] 4-wide nodes, out[1] 1 if the tree is staged in LDS (0: traversed from HBM),
  * out[2] traversal stack entries a ray may need, out[3] 1 if the tree was built on the device (mi_scene_desc.nodes == NULL).
  * No reference counterpart (the reference prints accel statistics to its log, src/accel.d/qbvhmp.c:1121-1144). */
@@ -381,6 +408,9 @@ int  mi_group_size(mi_group *g);
 mi_scene *mi_group_scene(mi_group *g, int k);
 int  mi_group_uses_rccl(mi_group *g);                                    /* 1: ncclReduce, 0: peer copies + add kernel */
 int  mi_group_render(mi_group *g, uint64_t first_index, uint64_t count); /* queues the shares on the members' streams, returns */
+/* ... by tiles: member k renders the 32 x 32 tiles t = k (mod n) of frames [first_frame, first_frame + frames) (mi_render_tiles; switches
+ * the members to MI_PIXELS_FROM_INDEX) */
+int  mi_group_render_tiles(mi_group *g, uint64_t first_frame, uint64_t frames);
 int  mi_group_fb_reduce(mi_group *g);                                    /* member 0 += members 1..n-1, which are cleared; stream ordered */
 int  mi_group_fb_read(mi_group *g, float *host_fb, int accumulate);      /* reduce, wait, mi_fb_read of member 0 */
 int  mi_group_fb_clear(mi_group *g);

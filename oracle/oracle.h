@@ -29,6 +29,21 @@ void oracle_trace_path(const mi_scene_desc *s, uint64_t index, float *fb, mi_pat
  * common_atomic_add, include/corona_common.h:316-329). returns seconds spent. */
 double oracle_render(const mi_scene_desc *s, uint64_t first, uint64_t count, float *fb, int threads, uint64_t *counters);
 
+/* Pixels from path indices -- the tiled branch of render_sample_path, src/render.d/gi.c:88-95 (`#if 0` in the reference's default build):
+ * the pixel of path `index` is q = index mod W H, (x, y) = (q mod W, q / W), handed to camera_sample through path_set_pixel, which then asks the
+ * point sampler for no film position (src/camera.d/thinlens.c:117-118). A process-wide switch; affects every entry point.
+ *   mode 0: sampled (default).
+ *   mode 1: THE REFERENCE'S BRANCH, literally: position = the pixel's corner (x, y), generator seeded as always (points_set_state).
+ *   mode 2: MI_PIXELS_FROM_INDEX as the product defines it (corona_mi.h): position (x + u, y + v) with u, v the path's two film numbers, generator
+ *           seeded through splitmix64. This is a restatement of the PRODUCT's mode, kept here as the checker of its kernels.
+ * PARITY OF BOTH MODES IS UNPINNED path for path: the reference's builds never run the branch, no golden dumps exist. Mode 2 is pinned statistically
+ * (tile means against the reference's converged render of the same film); mode 1 serves to show why the product departs from it
+ * (tests/test_oracle_golden.py::test_pixels_from_indices_*). */
+void oracle_set_pixels_from_index(int mode);
+/* ... and of the frames [first_frame, first_frame + frames) the paths whose pixel lies in a 32 x 32 tile t = member (mod members) (tile scheme
+ * of include/render_tiles.h:148-170): what mi_render_tiles renders. Switches mode 2 on if the pixels are sampled. Returns seconds. */
+double oracle_render_tiles(const mi_scene_desc *s, uint64_t first_frame, uint64_t frames, uint32_t member, uint32_t members, float *fb, int threads, uint64_t *counters);
+
 /* fill records for [first, first+count) */
 void oracle_trace_records(const mi_scene_desc *s, uint64_t first, uint64_t count, mi_path_record *out);
 

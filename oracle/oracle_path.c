@@ -23,11 +23,27 @@ float o_rand(o_ctx *c)
   return f - 1.0f;
 }
 
+static int o_pixels_from_index = 0;       /* oracle_set_pixels_from_index: 0 the pixel is sampled; 1 it is given by the path's index exactly as the reference's
+                                             tiled branch does it (gi.c:88-95: integer pixel, the reference's seeding); 2 MI_PIXELS_FROM_INDEX as the product
+                                             defines it (corona_mi.h): the same pixel, a position inside it from the path's own two image-plane numbers,
+                                             hashed seeding */
+void oracle_set_pixels_from_index(int mode) { o_pixels_from_index = mode; }
+
 void o_rand_seed(o_ctx *c, uint64_t index, uint64_t frame)
 { /* points_set_state, src/points.d/xorshift128p.c:53-59, called from render_sample_path with
      (tid, index, rt.anim_frame), src/render.d/gi.c:88; thread id 0 */
   c->rng0 = 1 + index;
   c->rng1 = 2 + frame;
+  if(o_pixels_from_index == 2)
+  { /* MI_PIXELS_FROM_INDEX (corona_mi.h), NOT the reference: the two state words go through the splitmix64 finaliser first. Seeded as above, paths
+       i and i + 1 draw correlated first numbers (their wavelengths: r = 0.96) -- harmless while the pixel is one of those numbers, a colour cast
+       that takes thousands of samples to average out once neighbouring indices are neighbouring pixels (oracle_set_pixels_from_index(1) shows it) */
+    uint64_t z = c->rng0 + 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30))*0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27))*0x94d049bb133111ebull; c->rng0 = z ^ (z >> 31);
+    z = c->rng1 + 2*0x9e3779b97f4a7c15ull + c->rng0;
+    z = (z ^ (z >> 30))*0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27))*0x94d049bb133111ebull; c->rng1 = z ^ (z >> 31);
+    if(!(c->rng0 | c->rng1)) c->rng0 = 1;
+  }
   for(int k=0;k<10;k++) (void)o_rand(c);
 }
 
@@ -144,8 +160,28 @@ static float o_camera_sample(o_ctx *c, o_path *p)
   const mi_scene_desc *s = c->s;
   const mi_camera *cam = &s->cam;
   const float W = (float)s->width, H = (float)s->height;
-  const float i = o_point(c, p, 0, o_dim_image_x)*W;
-  const float j = o_point(c, p, 0, o_dim_image_y)*H;
+  /* the pixel: two numbers of the point sampler -- or, when the path's pixel has been set (path_set_pixel, include/pathspace.h:355-360), that
+     pixel and NO numbers for the two image dimensions (thinlens.c:117-118: `p->sensor.pixel_set ? p->sensor.pixel_i : pointsampler(...)`).
+     The pixel of path `index` is what render_sample_path's tiled branch computes, src/render.d/gi.c:88-95 (oracle_set_pixels_from_index). */
+  float i, j;
+  if(o_pixels_from_index == 1 || o_pixels_from_index == 2)
+  {
+    const uint64_t w = s->width, h = s->height;                                     /* gi.c:89-92, literally */
+    const uint64_t frame = p->index / (w*h);
+    const uint64_t y = (p->index - frame * (w*h))/w;
+    const uint64_t x = (p->index - frame * (w*h) - y * w);
+    i = (float)x; j = (float)y;
+    if(o_pixels_from_index == 2)
+    { /* the product's mode: the position inside the pixel from the two numbers camera_sample would have turned into the pixel itself */
+      i += o_point(c, p, 0, o_dim_image_x);
+      j += o_point(c, p, 0, o_dim_image_y);
+    }
+  }
+  else
+  {
+    i = o_point(c, p, 0, o_dim_image_x)*W;
+    j = o_point(c, p, 0, o_dim_image_y)*H;
+  }
   const float r1 = o_point(c, p, 0, o_dim_aperture_x);
   const float r2 = o_point(c, p, 0, o_dim_aperture_y);
   const float lens_radius = (.5f/cam->f_stop)*cam->focal_length;
@@ -795,6 +831,59 @@ static void *o_worker(void *arg)
   }
   memcpy(j->cnt, c.cnt, sizeof(c.cnt));
   return 0;
+}
+
+/* The paths of frames [first_frame, first_frame + frames) whose pixel lies in a 32 x 32 tile t = member (mod members), tiles counted row by
+ * row (tile size: include/render_tiles.h:156; the walk over a tile's pixels: src/render_tiles.c:71-81, here row by row -- the order does not
+ * matter to the sum). Sets the pixels-from-index mode. Single-threaded per call unless threads > 1 (then one tile row of work at a time). */
+typedef struct o_tilejob { const mi_scene_desc *s; float *fb; uint64_t *counter, items, first_frame; uint32_t member, members, local, tiles_x; uint64_t cnt[8]; int atomic_fb; } o_tilejob;
+static void *o_tile_worker(void *arg)
+{
+  o_tilejob *j = (o_tilejob *)arg;
+  o_ctx c;
+  memset(&c, 0, sizeof(c));
+  c.s = j->s; c.fb = j->fb; c.atomic_fb = j->atomic_fb;
+  const uint64_t W = j->s->width, H = j->s->height;
+  while(1)
+  {
+    const uint64_t it = __sync_fetch_and_add(j->counter, 1);
+    if(it >= j->items) break;
+    const uint64_t p = it & 1023u, r = it >> 10, f = r / j->local, lt = r - f*j->local;
+    const uint64_t t = j->member + lt*j->members, ty = t / j->tiles_x, tx = t - ty*j->tiles_x;
+    const uint64_t x = tx*32 + (p & 31), y = ty*32 + (p >> 5);
+    o_trace(&c, ((j->first_frame + f)*H + y)*W + x);           /* the index gi.c:88-93 turns back into (frame, y, x) */
+  }
+  memcpy(j->cnt, c.cnt, sizeof(c.cnt));
+  return 0;
+}
+double oracle_render_tiles(const mi_scene_desc *s, uint64_t first_frame, uint64_t frames, uint32_t member, uint32_t members, float *fb, int threads, uint64_t *counters)
+{
+  if(threads < 1) threads = 1;
+  if(threads > 256) threads = 256;
+  if(!o_pixels_from_index) oracle_set_pixels_from_index(2);
+  const uint32_t tiles_x = s->width/32, tiles = tiles_x*(s->height/32);
+  const uint32_t local = member < tiles ? (tiles - member + members - 1)/members : 0;
+  struct timeval t0, t1;
+  o_prepare_points(s, (first_frame + frames)*(uint64_t)s->width*s->height);
+  gettimeofday(&t0, 0);
+  uint64_t counter = 0;
+  o_tilejob job[256];
+  pthread_t th[256];
+  for(int k=0;k<threads;k++)
+  {
+    memset(job + k, 0, sizeof(o_tilejob));
+    job[k].s = s; job[k].fb = fb; job[k].counter = &counter; job[k].items = frames*local*1024u; job[k].first_frame = first_frame;
+    job[k].member = member; job[k].members = members; job[k].local = local ? local : 1; job[k].tiles_x = tiles_x; job[k].atomic_fb = threads > 1;
+  }
+  if(threads == 1) o_tile_worker(job);
+  else
+  {
+    for(int k=0;k<threads;k++) pthread_create(th + k, 0, o_tile_worker, job + k);
+    for(int k=0;k<threads;k++) pthread_join(th[k], 0);
+  }
+  if(counters) for(int k=0;k<threads;k++) for(int i=0;i<8;i++) counters[i] += job[k].cnt[i];
+  gettimeofday(&t1, 0);
+  return (t1.tv_sec - t0.tv_sec) + 1e-6*(t1.tv_usec - t0.tv_usec);
 }
 
 double oracle_render(const mi_scene_desc *s, uint64_t first, uint64_t count, float *fb, int threads, uint64_t *counters)

@@ -60,6 +60,10 @@ def oracle_lib():
         o.oracle_intersect.restype = None
         o.oracle_rand_sequence.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
         o.oracle_rand_sequence.restype = C.c_float
+        o.oracle_set_pixels_from_index.argtypes = [C.c_int]
+        o.oracle_set_pixels_from_index.restype = None
+        o.oracle_render_tiles.argtypes = [C.POINTER(pkg.MiSceneDesc), C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
+        o.oracle_render_tiles.restype = C.c_double
         _oracle = o
     return _oracle
 
@@ -94,6 +98,25 @@ def oracle_render(scene, first, count, threads=1):
     cnt = (C.c_uint64 * 8)()
     secs = oracle_lib().oracle_render(scene.desc_ptr, first, count, fb.ctypes.data, threads, cnt)
     return fb, list(cnt), secs
+
+
+def oracle_render_tiles(scene, first_frame, frames, member=0, members=1, threads=1):
+    """the member's tiles of the frames, pixels from path indices (oracle.h); leaves that mode ON in the oracle: see oracle_pixels()"""
+    fb = np.zeros((scene.height, scene.width, 3), dtype=np.float32)
+    cnt = (C.c_uint64 * 8)()
+    secs = oracle_lib().oracle_render_tiles(scene.desc_ptr, first_frame, frames, member, members, fb.ctypes.data, threads, cnt)
+    return fb, list(cnt), secs
+
+
+class oracle_pixels:
+    """with oracle_pixels(mode): ... -- the oracle takes every path's pixel from its index inside (1: row by row, gi.c:88-95; 2: the scattered order of
+    MI_PIXELS_SCATTERED), samples it again outside"""
+    def __init__(self, mode=2):
+        self.mode = mode
+    def __enter__(self):
+        oracle_lib().oracle_set_pixels_from_index(self.mode)
+    def __exit__(self, *a):
+        oracle_lib().oracle_set_pixels_from_index(0)
 
 
 def golden_coeffs():

@@ -79,3 +79,21 @@ def test_cfg5_defaults_to_strong_scaling():
     spec.loader.exec_module(mod)
     assert mod.CONFIGS["cfg5"]["scaling"] == "strong" and mod.CONFIGS["cfg5"]["spp"] == 1024
     assert abs(128 * mod.REFERENCE_WORK["cfg2"]["node_visits"] + 104 * mod.REFERENCE_WORK["cfg2"]["prim_tests"] + 384 * mod.REFERENCE_WORK["cfg2"]["splats"] - 2822) < 2
+
+
+def test_gpus_2_tile_owned_sharding():
+    """--shard tiles: rank r renders the 32 x 32 film tiles t = r (mod N) of every frame of the step (mi_render_tiles): cfg 1's 256 x 256 film has
+    64 tiles, 32 per rank; strong scaling splits the frame's 4 spp x 64 tiles, weak gives the step N x 4 frames"""
+    r = run_bench("--gpus", "2", "--stub", "--steps", "2", "--warmup", "1", "--config", "cfg1", "--shard", "tiles", "--scaling", "strong")
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json_line(r.stdout)
+    per_frame = 4 * 256 * 256
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and "tiles" in out["config"]["sharding"]
+    assert out["config"]["paths_per_step"] == per_frame and out["config"]["paths_per_step_per_gpu"] == per_frame // 2
+    assert out["stub"]["reduced_sum_last_frame"] == per_frame
+    r = run_bench("--gpus", "3", "--stub", "--steps", "1", "--warmup", "0", "--config", "cfg1", "--shard", "tiles")
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json_line(r.stdout)
+    # weak: 3 x 4 frames; 64 tiles over three ranks = 22 + 21 + 21 -- rank 0 holds 22 of them
+    assert out["scaling"] == "weak" and out["config"]["paths_per_step"] == 3 * per_frame and out["config"]["paths_per_step_per_gpu"] == 12 * 22 * 1024
+    assert out["stub"]["reduced_sum_last_frame"] == 3 * per_frame

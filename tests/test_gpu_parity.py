@@ -13,7 +13,7 @@ import json
 import numpy as np
 import pytest
 
-from helpers import oracle_lib, GOLDEN, SCENE_0010, SCENE_ALL, SCENE_CAM_MB, SCENE_FINE, SCENE_LARGE, SCENE_FOG, SCENE_MB, SCENE_MB_LIGHT, SCENE_MB_ROUND, SCENE_MB_ROUND_LIGHT, SCENE_MEDIA, SCENE_NESTED, SCENE_METAL, SCENE_ROUGH, load_pkg, make_scene, oracle_intersect, oracle_records, oracle_render
+from helpers import oracle_lib, GOLDEN, SCENE_0010, SCENE_ALL, SCENE_CAM_MB, SCENE_FINE, SCENE_LARGE, SCENE_FOG, SCENE_MB, SCENE_MB_LIGHT, SCENE_MB_ROUND, SCENE_MB_ROUND_LIGHT, SCENE_MEDIA, SCENE_NESTED, SCENE_METAL, SCENE_ROUGH, load_pkg, make_scene, oracle_intersect, oracle_records, oracle_render, oracle_render_tiles, oracle_pixels
 
 pkg = load_pkg()
 pytestmark = pytest.mark.gpu
@@ -1234,6 +1234,124 @@ def test_group_behind_the_c_abi(monkeypatch, reduce):
         with pytest.raises(RuntimeError, match="not distinct"):
             pkg.Group(scene, [0, 0])                   # RCCL needs distinct devices: asked for explicitly, that is an error, not a silent fallback
     single.close()
+
+
+@pytest.mark.parametrize("sampler,points", [(pkg.MI_SAMPLER_PT, pkg.MI_POINTS_RAND), (pkg.MI_SAMPLER_PTDL, pkg.MI_POINTS_RAND), (pkg.MI_SAMPLER_PT, pkg.MI_POINTS_HALTON)],
+                         ids=["pt", "ptdl", "pt halton"])
+def test_pixels_from_path_indices(sampler, points, traversal):
+    """MI_PIXELS_FROM_INDEX, the hook of render_sample_path's tiled branch (src/render.d/gi.c:88-95; path_set_pixel, include/pathspace.h:355-360;
+    camera_sample, src/camera.d/thinlens.c:117-118): path i starts inside pixel (i mod W H), at the position its two film numbers name there, with
+    its generator seeded through a hash of the index (corona_mi.h says why). Path for path against the oracle's restatement of the mode; the
+    sampled mode is back afterwards."""
+    scene = make_scene(SCENE_0010, width=640, height=352, max_verts=8, sampler=sampler, pointsampler=points)
+    W, H = scene.width, scene.height
+    be = pkg.Backend(scene, traversal=traversal)
+    be.set_pixels(True)
+    first, n = 3 * W * H - 7000, 40000                    # across a frame boundary
+    gpu = be.trace_paths(first, n)
+    with oracle_pixels():
+        ora = oracle_records(scene, first, n)
+    idx = (first + np.arange(n)) % (W * H)
+    assert np.array_equal(np.floor(gpu["pixel_i"]), (idx % W).astype(np.float32)) and np.array_equal(np.floor(gpu["pixel_j"]), (idx // W).astype(np.float32))
+    assert np.abs(gpu["pixel_i"] - ora["pixel_i"]).max() <= 1e-4 and np.abs(gpu["pixel_j"] - ora["pixel_j"]).max() <= 1e-4
+    frac = gpu["pixel_i"] - np.floor(gpu["pixel_i"])
+    assert 0.45 < frac.mean() < 0.55 and frac.std() > 0.25           # ... somewhere inside the pixel, not at its corner
+    for f in ("lambda", "time", "scramble"):
+        assert np.abs(gpu[f] - ora[f]).max() <= 1e-5, f
+    same = gpu["length"] == ora["length"]
+    assert (~same).sum() <= 2, (~same).sum()
+    assert (gpu["num_splats"] != ora["num_splats"]).sum() <= (2 if sampler == pkg.MI_SAMPLER_PT else 8)
+    for k in range(1, 8):
+        m = same & (ora["length"] > k)
+        if m.sum():
+            assert (gpu["v"]["prim"][m, k] != ora["v"]["prim"][m, k]).sum() <= 2
+            assert (rel(gpu["v"]["throughput"][m, k], ora["v"]["throughput"][m, k]) >= 1e-3).sum() <= max(3, int(1e-3 * m.sum()))
+    # ... and the paths differ from the sampled mode's (other pixels, other random numbers)
+    be.set_pixels(False)
+    sampled = be.trace_paths(first, n)
+    assert (sampled["pixel_i"] != gpu["pixel_i"]).mean() > 0.99
+    assert (sampled["length"] != oracle_records(scene, first, n)["length"]).sum() <= 2
+    be.close()
+
+
+@pytest.mark.parametrize("sampler", [pkg.MI_SAMPLER_PT, pkg.MI_SAMPLER_PTDL], ids=["pt", "ptdl"])
+def test_tile_owned_sharding(sampler, counters):
+    """mi_render_tiles: member g of G renders the 32 x 32 tiles t = g (mod G) (tile scheme of include/render_tiles.h:148-170); the members'
+    framebuffers add up to the render of the frames' index range in MI_PIXELS_FROM_INDEX mode -- the same paths, whoever renders them --,
+    a member's own image is empty outside its tiles and their two-pixel rim (the 4 x 4 filter footprint), and both equal the oracle's."""
+    scene = make_scene(SCENE_0010, width=320, height=224, max_verts=8, sampler=sampler)
+    W, H = scene.width, scene.height
+    frames, G = 6, 3
+    be = pkg.Backend(scene, counters=counters)
+    with pytest.raises(RuntimeError, match="samples its pixels"):
+        be.render_tiles(0, 1)
+    be.set_pixels(True)
+    be.render(2 * W * H, frames * W * H)
+    whole = be.fb_read()
+    c0 = be.counters()
+    parts = []
+    for g in range(G):
+        be.fb_clear()
+        be.render_tiles(2, frames, g, G)
+        parts.append(be.fb_read())
+    c1 = be.counters()
+    assert c1[4] - c0[4] == frames * W * H                   # every path of the frames exactly once
+    if counters:
+        assert all(abs((c1[k] - c0[k]) - c0[k]) <= 1e-6 * c0[k] for k in (0, 1, 3))      # ... with the same rays, node visits, primitive tests
+    total = sum(parts)
+    assert np.abs(total - whole).max() <= 2e-4 * whole.max()
+    ty, tx = np.arange(H) // 32, np.arange(W) // 32
+    owner = (ty[:, None] * (W // 32) + tx[None, :]) % G
+    for g in range(G):
+        inside = owner == g
+        rim = np.zeros_like(inside)
+        for dy in range(-2, 3):
+            for dx in range(-2, 3):
+                rim |= np.roll(np.roll(inside, dy, axis=0), dx, axis=1)
+        assert parts[g][~rim].sum() == 0.0                    # nothing lands further than the filter reaches
+        assert parts[g][inside].sum() > 0.8 * parts[g].sum()
+    with oracle_pixels():
+        ofb = sum(oracle_render_tiles(scene, 2, frames, g, G, threads=8)[0] for g in range(G))
+    gain = scene.gain(frames)
+    assert np.sqrt((((total - ofb) * gain) ** 2).sum() / (W * H)) < 0.05
+    assert np.allclose(total.sum(axis=(0, 1)), ofb.sum(axis=(0, 1)), rtol=2e-3)
+    # one member of one: all tiles; more members than tiles: the surplus members render nothing
+    be.fb_clear(); be.render_tiles(2, frames, 0, 1)
+    assert np.abs(be.fb_read() - whole).max() <= 2e-4 * whole.max()
+    be.fb_clear(); be.render_tiles(2, frames, 100, 101)
+    assert be.fb_read().sum() == 0.0
+    with pytest.raises(RuntimeError):
+        be.render_tiles(0, 1, 3, 3)
+    be.close()
+
+
+def test_tile_sharding_statistics_against_the_reference_render():
+    """the tiled branch is `#if 0` in the reference's default build, so there are no reference dumps of its paths: it is pinned statistically.
+    2048 spp rendered through mi_group_render_tiles (two members on this GPU, tiles 0 / 1 (mod 2), framebuffers reduced) against the real
+    reference's 2048-spp render of the same film (tests/golden/tilemeans_pt_mv8.npz, sampled pixels): tile means as unit noise around the
+    reference's, the same robust statistics as test_full_size_properties_cfg2 asserts for the sampled mode."""
+    g = np.load(GOLDEN / "tilemeans_pt_mv8.npz")
+    scene = make_scene(SCENE_0010, width=int(g["width"]), height=int(g["height"]), max_verts=int(g["max_verts"]))
+    assert (scene.height // 32, scene.width // 32, 3) == g["tiles"].shape
+    two = pkg.Group(scene, [0, 0])
+    rspp, Q = int(g["spp"]), 8
+    parts = []
+    for q in range(Q):
+        two.fb_clear()
+        two.render_tiles(q * rspp // Q, rspp // Q)
+        parts.append((two.fb_read() * scene.gain(rspp // Q)).reshape(scene.height // 32, 32, scene.width // 32, 32, 3).mean(axis=(1, 3)))
+    assert two.counters()[4] == rspp * scene.width * scene.height
+    parts = np.array(parts)
+    tiles = parts.mean(axis=0)
+    var = parts.var(axis=0, ddof=1) / Q
+    z = (tiles - g["tiles"]) / np.sqrt(2 * var)
+    width = 1.4826 * np.median(np.abs(z - np.median(z)))
+    assert abs(np.median(z)) < 0.1, np.median(z)
+    assert 0.85 < width < 1.25, width
+    assert (np.abs(z) > 4).mean() < 0.012             # (sampled mode: < 0.01; one frame per pixel and step leaves the fireflies of a tile a little less averaged)
+    assert np.all(np.abs(tiles.mean(axis=(0, 1)) / g["tiles"].mean(axis=(0, 1)) - 1) < 3e-3)
+    assert np.corrcoef(tiles[8:, :, 1].ravel(), g["tiles"][8:, :, 1].ravel())[0, 1] > 0.995
+    two.close()
 
 
 def test_bsdf_battle_test_on_the_device():

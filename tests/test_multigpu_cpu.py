@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from helpers import REPO, SCENE_0010, load_pkg, make_scene, oracle_render
+from helpers import REPO, SCENE_0010, load_pkg, make_scene, oracle_lib, oracle_pixels, oracle_render, oracle_render_tiles
 
 
 def _worker(rank, world, port, outdir):
@@ -63,3 +63,63 @@ def test_two_ranks_equal_single_process():
     single, _, _ = oracle_render(scene, 0, 3 * world * per_frame, threads=1)
     assert np.allclose(reduced, single, rtol=1e-5, atol=1e-4)
     assert reduced.sum() > 0
+
+
+def _tile_worker(rank, world, port, outdir):
+    """tile-owned sharding (mi_render_tiles / bench.py --shard tiles): rank r renders the 32 x 32 tiles t = r (mod world) of every frame,
+    then the same framebuffer all-reduce"""
+    sys.path.insert(0, str(REPO / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = load_pkg()
+    scene = make_scene(SCENE_0010, width=96, height=64, max_verts=4)
+    shape = (scene.height, scene.width, 3)
+    reducer = pkg.FrameReducer([torch.zeros(shape), torch.zeros(shape)], dist)
+    total = np.zeros(shape, dtype=np.float32)
+    steps, spp = 2, 3
+    for k in range(steps):
+        buf = reducer.begin(k)
+        with oracle_pixels():
+            fb, cnt, _ = oracle_render_tiles(scene, k * spp, spp, rank, world, threads=1)
+        # this rank splats into its own tiles and at most two pixels beyond them (the 4 x 4 filter footprint)
+        ty, tx = np.arange(scene.height) // 32, np.arange(scene.width) // 32
+        mine = (ty[:, None] * (scene.width // 32) + tx[None, :]) % world == rank
+        rim = np.zeros_like(mine)
+        for dy in range(-2, 3):
+            for dx in range(-2, 3):
+                rim |= np.roll(np.roll(mine, dy, axis=0), dx, axis=1)
+        assert fb[~rim].sum() == 0.0 and cnt[4] == spp * mine.sum()
+        buf += torch.from_numpy(fb)
+        reducer.end(k)
+        if k >= 1:
+            total += reducer.finished(k - 1).numpy()
+    total += reducer.finished(steps - 1).numpy()
+    reducer.drain()
+    if rank == 0:
+        np.save(os.path.join(outdir, "reduced_tiles.npy"), total)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_owning_tiles_equal_single_process():
+    """... and equal the single-process render of the frames' index range with the pixels taken from the path indices
+    (render_sample_path's tiled branch, src/render.d/gi.c:88-95): the same paths, whoever renders them"""
+    world = 2
+    port = 31500 + (os.getpid() % 2000)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_tile_worker, args=(world, port, d), nprocs=world, join=True)
+        reduced = np.load(os.path.join(d, "reduced_tiles.npy"))
+    scene = make_scene(SCENE_0010, width=96, height=64, max_verts=4)
+    with oracle_pixels():
+        single, cnt, _ = oracle_render(scene, 0, 6 * scene.width * scene.height, threads=1)
+        # the pixel of path i is (i mod W H): one sample per pixel per frame
+        from helpers import oracle_records
+        rec = oracle_records(scene, 5 * scene.width * scene.height - 3, 6)
+    assert np.array_equal(np.floor(rec["pixel_i"]), np.float32([93, 94, 95, 0, 1, 2])) and np.array_equal(np.floor(rec["pixel_j"]), np.float32([63, 63, 63, 0, 0, 0]))
+    assert np.allclose(reduced, single, rtol=1e-5, atol=1e-4)
+    assert reduced.sum() > 0
+    # three tile owners, one of them without a tile in the last row: still every pixel exactly once
+    with oracle_pixels():
+        three = sum(oracle_render_tiles(scene, 0, 6, g, 3, threads=2)[0] for g in range(3))
+    assert np.allclose(three, single, rtol=1e-5, atol=1e-4)

@@ -315,7 +315,8 @@ def _tile_stats(fb, gain):
 @pytest.mark.parametrize("name,sampler,scene_path,mv,w,h,spp", [
     ("pt_mv4_256", pkg.MI_SAMPLER_PT, SCENE_0010, 4, 256, 256, 64),
 ])
-def test_oracle_image_statistics_vs_reference_render(name, sampler, scene_path, mv, w, h, spp):
+@pytest.mark.parametrize("pixels", ["sampled", "from path indices"])
+def test_oracle_image_statistics_vs_reference_render(name, sampler, scene_path, mv, w, h, spp, pixels):
     """Statistical oracle: high-spp render of the real reference (sfmt, all cores) reduced to 32x32 tile means.
     The oracle's `spp` render must agree in the image mean within 3 standard errors estimated from the
     tile-to-tile scatter (pure pt with a tiny emitter is firefly dominated, hence the robust statistic)."""
@@ -324,7 +325,15 @@ def test_oracle_image_statistics_vs_reference_render(name, sampler, scene_path, 
         pytest.skip("tile-mean fixture not generated")
     g = np.load(fn)
     s = make_scene(scene_path, width=w, height=h, max_verts=mv, sampler=sampler)
-    fb, _, _ = oracle_render(s, 0, spp * s.width * s.height, threads=8)
+    if pixels == "sampled":
+        fb, _, _ = oracle_render(s, 0, spp * s.width * s.height, threads=8)
+    else:
+        # the tiled branch of render_sample_path (gi.c:88-95, `#if 0` in the reference's default build: no path dumps exist for it) is pinned
+        # against the same converged reference render: two tile owners, every pixel sampled spp times
+        from helpers import oracle_render_tiles
+        from helpers import oracle_pixels
+        with oracle_pixels():
+            fb = sum(oracle_render_tiles(s, 0, spp, g, 2, threads=8)[0] for g in range(2))
     tiles = _tile_stats(fb, s.gain(spp))
     ref = g["tiles"]
     # compare medians of tile luminance (robust against fireflies)
@@ -404,3 +413,26 @@ def test_motion_blur_work_counters_equal_the_reference():
     assert cnt[4] == n
     for k, key in ((0, "rays"), (1, "node_visits"), (2, "box_hits"), (3, "prim_tests")):
         assert abs(4 * cnt[k] / gold[key] - 1) < 1e-2, (key, 4 * cnt[k], gold[key])
+
+
+def test_pixels_from_indices_why_not_the_reference_branch_literally():
+    """render_sample_path's tiled branch (src/render.d/gi.c:88-95) is dead code in the reference's builds; MI_PIXELS_FROM_INDEX uses its hook
+    (path_set_pixel) but departs from it in two ways (corona_mi.h). The oracle restates BOTH (oracle_set_pixels_from_index 1 / 2); this is the
+    measurement behind the departure, on the reference's own generator:
+      - points_set_state seeds path i with 1 + i and ten warm-up rounds: the first numbers of consecutive indices stay correlated;
+      - with the branch's row-by-row pixels that puts (nearly) one wavelength on a whole stretch of neighbouring pixels per frame (on the
+        GPU, cfg 3: the 256-spp image mean 1.5 % off in X and Z, profiles/r05_tiles.txt);
+      - the product's mode (hashed seed, position inside the pixel) has neither."""
+    from helpers import oracle_pixels
+    s = make_scene(SCENE_0010, width=160, height=96, max_verts=8, sampler=pkg.MI_SAMPLER_PTDL)
+    W, H = s.width, s.height
+    lam = {}
+    for mode in (0, 1, 2):
+        with oracle_pixels(mode):
+            lam[mode] = oracle_records(s, 0, 4000)["lambda"]
+    corr = {m: abs(np.corrcoef(l[:-1], l[1:])[0, 1]) for m, l in lam.items()}
+    assert corr[0] > 0.9 and corr[1] > 0.9 and corr[2] < 0.05, corr            # the reference's seeding / the hashed one
+    # what that does to a 32-pixel stretch of a tile's row: the literal branch lights it with (nearly) one wavelength per frame -- a spread of a few
+    # nanometres where independent samples of [360, 830] nm spread 136 nm
+    spread = {m: l[:3968].reshape(-1, 32).std(axis=1).mean() for m, l in lam.items()}
+    assert spread[1] < 20.0 and spread[2] > 110.0, spread

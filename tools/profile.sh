@@ -18,16 +18,20 @@ pmc sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU 
 pmc mem SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS
 pmc l2 TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum
 pmc grbm GRBM_GUI_ACTIVE
+# instruction classes (round 5): gfx950 issues the plain f32 add / mul / fma of a wave64 in 2 cycles, most other vector ops in 4, transcendentals in 8
+# (tools/micro/valu_cost.hip) -- the mix says how busy the vector pipes are, which SQ_INSTS_VALU x 2 cycles underestimates
+pmc mix SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_SMEM
+pmc mix2 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_BRANCH SQ_INSTS_FLAT SQ_WAIT_INST_LDS
 python3 $R/tools/hbm_copy.py > $OUT/hbm_copy.json 2>/dev/null
 rm -rf $OUT/trace $OUT/pmc_*/ $OUT/*.log
 python3 - <<PY
 import csv, glob, json, collections, hashlib
 out = "$OUT"
 build_id = hashlib.sha256(open("$R/corona-13_amd/csrc/libcorona_mi.so", "rb").read()).hexdigest()[:16]
-# the timed kernels: production instantiation (no debug counters), tree in LDS -- pt with the FAST rounds (the bench line) and ptdl with
-# the exact ones (its `secondary`): the library's own choice per scene; bench.py also launches the counting instantiations once, outside its timed regions
-KERNELS = {"pt": "mi_path_kernel<false, false, true, false, false, false, false, %s, false>" % ("true" if json.load(open(out + "/bench.json"))["config"]["traversal"] == "fast" else "false"),
-           "ptdl": "mi_path_kernel<false, true, true, false, false, false, false, false, false>"}
+# the timed kernels: the instantiations the library chose for cfg 2 and cfg 3 (its `secondary`), by the names bench.py got from
+# mi_scene_kernel_name; bench.py also launches the counting instantiations once, outside its timed regions
+_bench = json.load(open(out + "/bench.json"))
+KERNELS = {"pt": _bench["roofline"]["kernel"].split(" (")[0], "ptdl": _bench["secondary"]["roofline"]["kernel"].split(" (")[0]}
 for tag, kname in KERNELS.items():
     res = {"kernel": kname, "build_id": build_id}
     for f in glob.glob(out + "/pmc_*.csv"):
@@ -56,6 +60,17 @@ for tag, kname in KERNELS.items():
         res["valu_busy_pct_simd32"] = 100.0 * res["SQ_ACTIVE_INST_VALU"] * 2 / simds / cycles
         res["lane_utilisation"] = res["SQ_THREAD_CYCLES_VALU"] / (64.0 * res["SQ_ACTIVE_INST_VALU"])
         res["valu_instr_per_path"] = res["SQ_INSTS_VALU"] / res["paths_per_launch"]
+        res["salu_instr_per_path"] = res.get("SQ_INSTS_SALU", 0.0) / res["paths_per_launch"]
+        if "SQ_INSTS_VALU_FMA_F32" in res:
+            # vector pipe occupancy from the instruction mix: plain f32 add / mul / fma 2 cycles per wave64 instruction, transcendentals 8, f64 8 (quarter
+            # rate), everything else 4 (min / max / compare / select / integer / conversions: tools/micro/valu_cost.hip measured 4.4 against 2.5)
+            f32 = res.get("SQ_INSTS_VALU_ADD_F32", 0.0) + res.get("SQ_INSTS_VALU_MUL_F32", 0.0) + res["SQ_INSTS_VALU_FMA_F32"]
+            trans = res.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+            f64 = res.get("SQ_INSTS_VALU_ADD_F64", 0.0) + res.get("SQ_INSTS_VALU_MUL_F64", 0.0) + res.get("SQ_INSTS_VALU_FMA_F64", 0.0)
+            other = res["SQ_INSTS_VALU"] - f32 - trans - f64
+            res["valu_mix"] = {"f32_add_mul_fma": f32 / res["SQ_INSTS_VALU"], "transcendental": trans / res["SQ_INSTS_VALU"], "f64": f64 / res["SQ_INSTS_VALU"], "other": other / res["SQ_INSTS_VALU"]}
+            res["valu_pipe_cycles_model"] = 2.0 * f32 + 8.0 * trans + 8.0 * f64 + 4.0 * other
+            res["valu_pipe_busy_model"] = res["valu_pipe_cycles_model"] / simds / cycles
     json.dump(res, open(out + ("/pmc_summary.json" if tag == "pt" else "/pmc_summary_ptdl.json"), "w"), indent=1)
     print(json.dumps(res))
 PY
