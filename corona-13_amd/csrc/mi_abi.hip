@@ -841,7 +841,9 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
   /* (the column of the plain kernels is shorter since round 4: they use the LDS for the pools of mi_regroup.h; s->media is final here) */
   /* a scene in a scattering exterior medium (global fog) runs the extended kernels WITHOUT the exchange: nearly all its vertices are volume
      vertices, one class (measured: scenes/0056_fog ptdl 124 ms with, 115 without; scenes/0055_media ptdl 35 with, 46 without) */
-  { const DShapeMedium &ext = shape_med[h->num_shapes]; s->norg = s->media && !mb_kernels && (!MI_REGROUP || !MI_REGROUP_MEDIA || (ext.med >= 0 && ext.mu_t[3] > 0.0f && ext.albedo[3] > 0.0f)); }
+  { const DShapeMedium &ext = shape_med[h->num_shapes]; s->norg = s->media && !mb_kernels && (!MI_REGROUP || !MI_REGROUP_MEDIA || (ext.med >= 0 && ext.mu_t[3] > 0.0f && ext.albedo[3] > 0.0f));
+    const char *ne = getenv("CORONA_MI_NORG");        /* (experiments: 0 = the exchange also in a global fog, 1 = never in the extended kernels) */
+    if(ne && ne[0] && s->media && !mb_kernels) s->norg = atoi(ne) != 0; }
   const int column = mb_kernels ? MI_STACK_LDS_MB : s->norg ? MI_STACK_LDS : MI_STACK_LDS_PLAIN;
   const size_t stack_bytes = (size_t)column*MI_BLOCK*sizeof(uint2) + (size_t)(MI_BLOCK/64)*MI_JOBS_LDS;   /* + the waves' job lists */
   const size_t isect_stack_bytes = (size_t)MI_STACK_LDS*MI_BLOCK*sizeof(uint2) + (size_t)(MI_BLOCK/64)*MI_JOBS_LDS;   /* mi_intersect_kernel: full columns, no pools */

@@ -192,22 +192,35 @@ def test_soak_two_million_paths(traversal):
     assert worst < 1e-3, worst
 
 
-def test_paths_match_reference_golden(traversal):
-    """directly against the records dumped from the real reference"""
-    g = np.load(GOLDEN / "paths_pt_mv8.npz")
+with open(GOLDEN / "gpu_vs_reference_measured.json") as _f:
+    GPU_VS_REFERENCE = json.load(_f)          # written by tests/dev/measure_gpu_vs_reference.py on the GPU box (committed next to the goldens)
+
+
+@pytest.mark.parametrize("name,scene_path,sampler,mv,points", [
+    ("pt_mv8", SCENE_0010, pkg.MI_SAMPLER_PT, 8, pkg.MI_POINTS_RAND), ("ptdl_mv8", SCENE_0010, pkg.MI_SAMPLER_PTDL, 8, pkg.MI_POINTS_RAND),
+    ("rough_mv32", SCENE_ROUGH, pkg.MI_SAMPLER_PT, 32, pkg.MI_POINTS_RAND), ("halton_ptdl_mv8", SCENE_0010, pkg.MI_SAMPLER_PTDL, 8, pkg.MI_POINTS_HALTON)])
+def test_paths_match_reference_golden(name, scene_path, sampler, mv, points, traversal):
+    """directly against the records dumped from the real reference. The bounds are what the build was MEASURED to reach against these very
+    dumps (tests/golden/gpu_vs_reference_measured.json) plus a margin -- a quarter of the measured miss, at least one path in 5000 -- not round
+    numbers: pt 3000 of 3000 identical, ptdl 2999 of 3000 (one grazing next-event connection), depth 32 1998 of 2000."""
+    g = np.load(GOLDEN / f"paths_{name}.npz")
     ref = g["records"]
-    scene = make_scene(SCENE_0010, width=1280, height=720, max_verts=8)
+    was = GPU_VS_REFERENCE[f"{name}@{traversal}"]
+
+    def bound(measured):
+        return 1.0 - 1.25 * (1.0 - measured) - 2e-4
+    scene = make_scene(scene_path, width=int(g["width"]), height=int(g["height"]), max_verts=mv, sampler=sampler, pointsampler=points)
     be = pkg.Backend(scene, traversal=traversal)
     gpu = be.trace_paths(0, len(ref))
     same = gpu["length"] == ref["length"]
-    assert same.mean() >= 0.998
-    assert (gpu["num_splats"] == ref["num_splats"]).mean() >= 0.995
+    assert same.mean() >= bound(was["same_length"]), (same.mean(), was["same_length"])
+    assert (gpu["num_splats"] == ref["num_splats"]).mean() >= bound(was["same_splats"])
     for k in range(1, 8):
         m = same & (ref["length"] > k)
         if m.sum():
-            assert (gpu["v"]["prim"][m, k] == ref["v"]["prim"][m, k]).mean() >= 0.999
-    e_ref, e_gpu = ref["splat"]["col"].sum(axis=(0, 1)), gpu["splat"]["col"].sum(axis=(0, 1))
-    assert np.all(np.abs(e_ref - e_gpu) <= 2e-3 * np.abs(e_ref).max())
+            assert (gpu["v"]["prim"][m, k] == ref["v"]["prim"][m, k]).mean() >= bound(was["worst_same_prim"])
+    e_ref, e_gpu = np.nan_to_num(ref["splat"]["col"]).sum(axis=(0, 1)), np.nan_to_num(gpu["splat"]["col"]).sum(axis=(0, 1))
+    assert np.abs(e_ref - e_gpu).max() / np.abs(e_ref).max() <= 1.5 * was["energy_dev"] + 1e-5
     be.close()
 
 
