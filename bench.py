@@ -506,7 +506,7 @@ def main():
                 "note": "B = 128 N_node + 104 N_prim + 384 N_splat per sample (SURVEY 8(d)) priced with the reference's work counts; served from LDS and L2, not HBM"}
 
     def valu_floor(config, r):
-        f = Path(__file__).resolve().parent / "profiles" / "r04_valu_floor.json"
+        f = Path(__file__).resolve().parent / "profiles" / "r05_valu_floor.json"
         if not f.exists() or config not in ("cfg2", "cfg3"):
             return None
         fl = json.load(open(f))
@@ -524,7 +524,7 @@ def main():
         if ptdl:       # shadow rays = rays - extension rays: each ends in a verdict; a splat is a quarter of a cooperative pass (64 lanes at work)
             terms["shadow_verdicts"] = max(rays - ext, 0.0) * b["shadow_resolve"]["valu"] / 64.0
             terms["splats"] = dc[5] / paths * b["splat_pass_of_four"]["valu"] / 4.0
-        return {"per_path": sum(terms.values()), "terms": terms, "source": "profiles/r04_valu_floor.json x live work counters"}
+        return {"per_path": sum(terms.values()), "terms": terms, "source": "profiles/r05_valu_floor.json x live work counters"}
 
     def roofline_of(config, r):
         """What bounds the kernel: VALU issue (MFMA is not used, DRAM sees 0.2 % of the algorithmic bytes). achieved = wave64 VALU
@@ -552,10 +552,17 @@ def main():
                         "valu_instr_per_path": instr_per_path, "clock_ghz": clock_ghz, "source": prof_name,
                         # the instruction count belongs to the build the profile was taken from
                         "profile_build_id": prof.get("build_id"), "library_build_id": build, "profile_matches_library": fresh})
+            if "valu_pipe_cycles_model" in prof:
+                # the same instructions priced with what gfx950 charges for them (tools/micro/valu_cost.hip: a wave64 f32 add / mul / fma occupies a SIMD for
+                # 2 cycles, min / max / compare / select / integer / conversion ops for 4, transcendentals and f64 for 8; mix from the SQ_INSTS_VALU_* counters of
+                # the same committed passes): the share of the vector pipes' cycles this launch fills. `frac` counts every instruction as 2 cycles.
+                cyc = prof["valu_pipe_cycles_model"] / prof_paths * r["launch_paths"]
+                out["frac_cycle_weighted"] = cyc / (CUS * SIMDS_PER_CU) / (r["kms"] * 1e-3 * clock_ghz * 1e9)
+                out["valu_mix"] = prof.get("valu_mix")
             if not fresh:
                 # never a stale fraction: the committed counters are of another build (or of another instantiation than the
                 # one this run launched) -- the live fields (kernel_ms, traffic-free LDS line, algorithmic_hbm_frac) stay, the counter-derived ones go
-                for k in ("achieved", "frac", "useful_lane_frac", "valu_instr_per_path", "lane_utilisation"):
+                for k in ("achieved", "frac", "useful_lane_frac", "valu_instr_per_path", "lane_utilisation", "frac_cycle_weighted", "valu_mix"):
                     out[k] = None
                 out["stale_profile"] = (f"{prof_name} was taken from library build {prof.get('build_id')} / kernel {prof.get('kernel')}; this run loaded build {build} and launched "
                                         f"{r['kernel']}: re-run tools/profile.sh and commit its summary")
@@ -565,7 +572,7 @@ def main():
                 out["hbm_measured_gbs"] = out["traffic"] / (prof_ms * 1e-3) / 1e9 if prof_ms else None
             # Instruction floor (round 4): the wave instructions the path's WORK needs if every instruction served 64 useful lanes -- the live
             # work counters priced with the vector instructions one execution of each block takes (static counts of the product's own
-            # functions compiled in isolation: tools/valu_floor.py, tools/micro/floor_blocks.hip -> profiles/r04_valu_floor.json).
+            # functions compiled in isolation: tools/valu_floor.py, tools/micro/floor_blocks.hip -> profiles/r05_valu_floor.json).
             # floor_over_executed says how much of what the kernel executes is that work; efficiency = frac x floor_over_executed is the share
             # of the machine's peak issue rate spent on it. A fatter kernel raises `frac` and lowers `floor_over_executed`.
             floor = valu_floor(config, r) if fresh else None

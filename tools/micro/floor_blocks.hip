@@ -63,6 +63,7 @@ template<int N> __global__ __launch_bounds__(FB_BLOCK) void fb_generate(DScene s
   PathState ps;
   unsigned long long index = q.u[0];
   float acc = 0.0f;
+  if(sc.pixels_from_index) return;      /* the floor is that of the sampled film position (the bench configuration): the other mode's branch folds away */
 #pragma unroll
   for(int k=0;k<N;k++)
   {

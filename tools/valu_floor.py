@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """development helper (build container, nothing runs on a GPU): the vector instructions ONE execution of each block of the hot path needs,
 read from the code of tools/micro/floor_blocks.hip (the product's own functions compiled in isolation, one and two executions each: the
-difference has no prologue, epilogue or loop control in it).  python3 tools/valu_floor.py > profiles/r04_valu_floor.json
+difference has no prologue, epilogue or loop control in it).  python3 tools/valu_floor.py > profiles/r05_valu_floor.json
 bench.py prices the live work counters with these numbers (roofline.valu_floor_per_path)."""
 import json
 import re
