@@ -40,7 +40,7 @@ W, H, SPP, MAX_VERTS = 1280, 720, 64, 8
 # The others can be timed with --config (development / DESIGN.md table); their CPU baseline leg is not run.
 CONFIGS = {
     "cfg1": dict(scene="0010_pt", sampler="pt", w=256, h=256, spp=4, mv=4, name="configs[0]: regression/0010_pt, pt, 256x256, 4 spp, max depth 4"),
-    "cfg2": dict(scene="0010_pt", sampler="pt", w=W, h=H, spp=SPP, mv=MAX_VERTS,
+    "cfg2": dict(scene="0010_pt", sampler="pt", w=W, h=H, spp=SPP, mv=MAX_VERTS, scaling="strong",
                  name="configs[1]: regression/0010_pt test.nra2, pt sampler, 1280x720 (padded 1280x736), 64 spp, max depth 8"),
     "cfg3": dict(scene="0010_pt", sampler="ptdl", w=1280, h=720, spp=64, mv=8, name="configs[2]: regression/0011_ptdl (0010 scene, ptdl sampler), 1280x720, 64 spp"),
     "cfg4": dict(scene="0052_rough", sampler="pt", w=1280, h=720, spp=256, mv=32, name="configs[3]: regression/0052 parameters (rough dielectric), max depth 32, 1280x720, 256 spp"),
@@ -274,8 +274,8 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the short configs[2] (ptdl) measurement reported as `secondary`")
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
-                    help="weak: every GPU renders a whole frame of distinct path indices (job = N frames); strong: the frame's indices are "
-                         "split over the GPUs (job fixed). Default weak, strong for cfg5")
+                    help="strong: the step's frame is split over the GPUs (job fixed: the headline configuration is ONE 64-spp frame, BASELINE.json; default "
+                         "for cfg2 and cfg5); weak: every GPU renders a whole frame of distinct path indices (job = N frames; default for the other configs)")
     ap.add_argument("--tree", default="reference", choices=["reference", "device"],
                     help="reference: the QBVH the reference's builder makes, handed over through the ABI (default, the drop-in contract); "
                          "device: no tree handed over, the backend builds its own (csrc/mi_build.h)")

@@ -56,7 +56,7 @@ def test_single_rank_and_launcher_mismatch():
 def test_gpus_8_weak_cfg2_and_strong_cfg5():
     """the driver's 1 -> 8 curve without hardware: eight spawned ranks (gloo), cfg 2 weak (every rank a whole 64-spp frame of its own
     indices) and cfg 5 strong (configs[4]: 3840x2160, 1024 spp = 8.56 G paths split eight ways, one framebuffer reduce of 100 MB)"""
-    r = run_bench("--gpus", "8", "--stub", "--steps", "2", "--warmup", "1", "--config", "cfg2")
+    r = run_bench("--gpus", "8", "--stub", "--steps", "2", "--warmup", "1", "--config", "cfg2", "--scaling", "weak")
     assert r.returncode == 0, r.stdout + r.stderr
     out = json_line(r.stdout)
     per_frame = 64 * 1280 * 736
@@ -78,6 +78,7 @@ def test_cfg5_defaults_to_strong_scaling():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.CONFIGS["cfg5"]["scaling"] == "strong" and mod.CONFIGS["cfg5"]["spp"] == 1024
+    assert mod.CONFIGS["cfg2"]["scaling"] == "strong"        # the headline configuration is one fixed 64-spp frame: N GPUs split it
     assert abs(128 * mod.REFERENCE_WORK["cfg2"]["node_visits"] + 104 * mod.REFERENCE_WORK["cfg2"]["prim_tests"] + 384 * mod.REFERENCE_WORK["cfg2"]["splats"] - 2822) < 2
 
 
@@ -97,3 +98,14 @@ def test_gpus_2_tile_owned_sharding():
     # weak: 3 x 4 frames; 64 tiles over three ranks = 22 + 21 + 21 -- rank 0 holds 22 of them
     assert out["scaling"] == "weak" and out["config"]["paths_per_step"] == 3 * per_frame and out["config"]["paths_per_step_per_gpu"] == 12 * 22 * 1024
     assert out["stub"]["reduced_sum_last_frame"] == 3 * per_frame
+
+
+def test_gpus_4_default_is_strong_scaling_of_the_headline_frame():
+    """python bench.py --gpus N as the driver launches it: configs[1] is ONE 64-spp frame, four ranks render a quarter of its path indices each"""
+    r = run_bench("--gpus", "4", "--stub", "--steps", "2", "--warmup", "1")
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json_line(r.stdout)
+    per_frame = 64 * 1280 * 736
+    assert out["n_gpus"] == 4 and out["scaling"] == "strong"
+    assert out["config"]["paths_per_step"] == per_frame and out["config"]["paths_per_step_per_gpu"] == per_frame // 4
+    assert out["stub"]["reduced_sum_last_frame"] == per_frame
