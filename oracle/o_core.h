@@ -81,8 +81,10 @@ typedef struct o_edge
   o_volume vol;
 } o_edge;
 
+struct o_ctx;
 typedef struct o_path
 { /* path_t */
+  struct o_ctx *ctx;             /* (hero wavelengths: the lane's context, for the group hooks below; NULL = scalar) */
   float lambda, throughput;
   int length;
   float time;
@@ -93,15 +95,80 @@ typedef struct o_path
   o_edge   e[O_MAX_VERTS+1];
 } o_path;
 
+/* Hero wavelengths (the reference built with -DMF_COUNT=4, include/mf.h:280-423): every spectral quantity of a path is a vector of four, one per
+ * wavelength; geometry and every decision follow component 0, the hero. The restatement runs FOUR scalar lanes in lock step -- one thread per
+ * wavelength, each executing the scalar code above and below with its own lambda -- and the few places where the reference looks across the
+ * components (mf_any / mf_all / mf(x, 0) / mf_hsum) are group hooks: every lane contributes its value, a barrier, every lane reads the result.
+ * All four lanes draw the same random numbers and take the same branches (every wavelength-dependent branch goes through a hook), so they meet
+ * at the same hooks in the same order. Scalar mode (grp == NULL, everything before round 5): a hook is the identity on the lane's own value. */
+#include <pthread.h>
+#define O_MF 4
+typedef struct o_group
+{
+  volatile int arrived, sense;   /* sense-reversing spin barrier: the lanes meet twice per hook, a futex sleep each time cost 2 ms per path */
+  volatile float f[O_MF];
+  volatile double d[O_MF];
+  volatile int b[O_MF];
+  volatile float col[O_MF][3];
+} o_group;
+
 typedef struct o_ctx
 {
   const mi_scene_desc *s;
+  o_group *grp;                  /* hero wavelengths: the four lanes' meeting point, NULL in scalar mode */
+  int lane;                      /* 0 = hero */
+  int sense;                     /* this lane's side of the barrier */
   uint64_t rng0, rng1;           /* xorshift128+ state */
   float *fb;
   int atomic_fb;
   mi_path_record *rec;
+  oracle_hero_ext *hero_ext;     /* hero wavelengths: all components of the finished path (every lane writes its own column) */
+  int hero_splats;
   uint64_t cnt[8];
 } o_ctx;
+
+#include <sched.h>
+static inline void o_g_meet(o_ctx *c)
+{
+  o_group *g = c->grp;
+  const int s = c->sense ^= 1;
+  if(__sync_add_and_fetch(&g->arrived, 1) == O_MF) { g->arrived = 0; __sync_synchronize(); g->sense = s; }
+  else { int spins = 0; while(g->sense != s) { if(++spins > 4000) sched_yield(); else __builtin_ia32_pause(); } }
+  __sync_synchronize();
+}
+static inline int o_g_any(o_ctx *c, int cond)       /* mf_any */
+{
+  if(!c || !c->grp) return cond;
+  c->grp->b[c->lane] = cond; o_g_meet(c);
+  const int r = c->grp->b[0] | c->grp->b[1] | c->grp->b[2] | c->grp->b[3];
+  o_g_meet(c);
+  return r;
+}
+static inline int o_g_all(o_ctx *c, int cond)       /* mf_all */
+{
+  if(!c || !c->grp) return cond;
+  c->grp->b[c->lane] = cond; o_g_meet(c);
+  const int r = c->grp->b[0] & c->grp->b[1] & c->grp->b[2] & c->grp->b[3];
+  o_g_meet(c);
+  return r;
+}
+static inline float o_g_hero(o_ctx *c, float x)     /* mf(x, 0) */
+{
+  if(!c || !c->grp) return x;
+  c->grp->f[c->lane] = x; o_g_meet(c);
+  const float r = c->grp->f[0];
+  o_g_meet(c);
+  return r;
+}
+static inline float o_g_hsum(o_ctx *c, float x)     /* mf_hsum: _mm_hadd_ps twice = (a0 + a1) + (a2 + a3), include/mf.h:301-306 */
+{
+  if(!c || !c->grp) return x;
+  c->grp->f[c->lane] = x; o_g_meet(c);
+  const float r = (c->grp->f[0] + c->grp->f[1]) + (c->grp->f[2] + c->grp->f[3]);
+  o_g_meet(c);
+  return r;
+}
+#define O_CTX(p) ((p)->ctx)
 
 /* oracle_rng: src/points.d/xorshift128p.c */
 float o_rand(o_ctx *c);

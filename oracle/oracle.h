@@ -44,6 +44,21 @@ void oracle_set_pixels_from_index(int mode);
  * of include/render_tiles.h:148-170): what mi_render_tiles renders. Switches mode 2 on if the pixels are sampled. Returns seconds. */
 double oracle_render_tiles(const mi_scene_desc *s, uint64_t first_frame, uint64_t frames, uint32_t member, uint32_t members, float *fb, int threads, uint64_t *counters);
 
+/* Hero wavelengths: the path tracers as the reference built with -DMF_COUNT=4 runs them (include/mf.h:280-423: four wavelengths per path, geometry and
+ * decisions by component 0; src/pathspace.c:215-221, src/sampler.d/pt.c:30-38, ptdl.c:78-88, src/shaders/dielectric.c:240-415). Pinned against per-path
+ * dumps of that build (`make -C oracle mf4`, tests/golden/make_golden_mf4.py -> tests/golden/paths_mf4_*.npz, tests/test_oracle_golden.py).
+ * out[i]: the record of path first + i with the HERO component of every spectral quantity; ext[i] (or NULL): all four components, the layout of the
+ * dump harness' extension block; fb (or NULL): framebuffer to splat into; counters (or NULL): += the hero lane's. Plain scenes only (no media). */
+#define ORACLE_MF 4
+typedef struct oracle_hero_ext
+{
+  float lambda[ORACLE_MF];
+  float throughput[MI_REC_MAX_VERTS][ORACLE_MF], pdf[MI_REC_MAX_VERTS][ORACLE_MF];
+  float rd[MI_REC_MAX_VERTS][ORACLE_MF], rg[MI_REC_MAX_VERTS][ORACLE_MF], em[MI_REC_MAX_VERTS][ORACLE_MF], eta[MI_REC_MAX_VERTS][ORACLE_MF];
+  float splat_value[MI_REC_MAX_SPLATS][ORACLE_MF];
+} oracle_hero_ext;
+void oracle_hero_trace(const mi_scene_desc *s, uint64_t first, uint64_t count, mi_path_record *out, oracle_hero_ext *ext, float *fb, uint64_t *counters);
+
 /* fill records for [first, first+count) */
 void oracle_trace_records(const mi_scene_desc *s, uint64_t first, uint64_t count, mi_path_record *out);
 

@@ -81,7 +81,7 @@ static float o_path_G(const o_path *p, int e)
 /* ---------------------------------------------------------------- emitters */
 static float o_lights_eval_vertex(const o_path *path, int v)
 { /* lights_eval_vertex, src/lights.d/list.c:242-275 (path tracing direction) */
-  if(path->v[v].shading.em <= 0.0f) return 0.0f;
+  if(o_g_all(O_CTX(path), path->v[v].shading.em <= 0.0f)) return 0.0f;       /* mf_all(mf_lte(em, 0)), list.c:246 */
   float edf = 1.0f;
   const float *omega = path->e[v].omega;
   if(path->v[v].hit.prim != MI_PRIMID_INVALID)
@@ -333,7 +333,9 @@ static int o_path_propagate(o_ctx *c, o_path *path, int v)
     const float far = 2.0f*OMAX(aabb[5] - aabb[2], OMAX(aabb[4] - aabb[1], aabb[3] - aabb[0]));
     for(int k=0;k<3;k++) hit->x[k] = path->v[v-1].hit.x[k] + far*path->e[v].omega[k];
   }
-  if(path->e[v].contribution > 0.0f || (path->v[v].shading.em > 0.0f && !(path->v[v].flags & s_inside)))
+  /* (mf_any on either, src/pathspace.c:876-877; both hooks are always called: the four lanes of a hero path meet at the same hooks) */
+  const int any_contribution = o_g_any(c, path->e[v].contribution > 0.0f), any_em = o_g_any(c, path->v[v].shading.em > 0.0f);
+  if(any_contribution || (any_em && !(path->v[v].flags & s_inside)))
     path->v[v].material_modes = path->v[v].mode = s_emit;
   path->v[v].pdf = path->v[v].pdf*path->e[v].pdf;
   return 0;
@@ -352,7 +354,7 @@ static int o_path_extend(o_ctx *c, o_path *path)
   if(path->length)
   {
     if(path->v[v-1].flags & s_environment) return 1;
-    if(!(path->v[v-1].throughput > 0.0f))
+    if(!o_g_any(c, path->v[v-1].throughput > 0.0f))          /* !mf_any(mf_gt(throughput, 0)), src/pathspace.c:189 */
     {
       path->v[v-1].throughput = 0.0f;
       path->v[v-1].mode = s_absorb;
@@ -369,7 +371,15 @@ static int o_path_extend(o_ctx *c, o_path *path)
     /* draw order: scramble, lambda, time, camid (path_extend), camid again (view_cam_sample,
        src/view.c:846-847), then image x/y, aperture x/y (thinlens.c:117-121) */
     path->scramble = 0.1f + o_rand(c)*(0.9f-0.1f);
-    const float lf = fmodf(o_point(c, path, 0, o_dim_lambda) + 0/(float)1, 1.0f);
+    float lf = fmodf(o_point(c, path, 0, o_dim_lambda) + 0/(float)1, 1.0f);
+    if(c->grp)
+    { /* MF_COUNT = 4, src/pathspace.c:218-221: the point sampler is asked once PER COMPONENT -- with the `rand` sampler four numbers --, component l
+         takes fmodf(number l + l / 4, 1). Every lane draws all four (the lanes' generators stay in step) and keeps its own. */
+      float lfs[O_MF];
+      lfs[0] = lf;
+      for(int l=1;l<O_MF;l++) lfs[l] = fmodf(o_point(c, path, 0, o_dim_lambda) + l/(float)O_MF, 1.0f);
+      lf = lfs[c->lane];
+    }
     path->lambda = 360 + (830 - 360)*lf;                          /* spectrum_sample_lambda, include/spectrum.h:206-210 */
     path->time = o_point(c, path, 0, o_dim_time)*s->cam.time_scale; /* view_sample_time, src/view.c:881-891 */
     (void)o_point(c, path, 0, o_dim_camid);                        /* view_sample_camid: one camera */
@@ -394,7 +404,7 @@ static int o_path_extend(o_ctx *c, o_path *path)
     path->v[0].tech = s_tech_extend;
     v++;
   }
-  if((path->v[v].throughput <= 0.0f) || o_path_propagate(c, path, v))
+  if(o_g_all(c, path->v[v].throughput <= 0.0f) || o_path_propagate(c, path, v))       /* mf_all(mf_lte(throughput, 0)), src/pathspace.c:253 */
   {
     if(!(path->v[v-1].mode & s_emit)) path->v[v-1].mode = s_absorb;
     path->v[v].throughput = -0.0f;
@@ -462,13 +472,25 @@ static void o_splat(o_ctx *c, const o_path *path, float value)
      -> filter_blackmanharris_splat, include/filter/blackmanharris.h:43-77 */
   const mi_scene_desc *s = c->s;
   float col[3] = {0.0f, 0.0f, 0.0f};
-  const int ok = (value > 0.0f) && (value < FLT_MAX) && (value == value);
+  /* hero wavelengths: mf_any(value > 0), mf_all(value < FLT_MAX), mf_all(value == value) -- all three hooks always (the lanes meet) */
+  const int any_pos = o_g_any(c, value > 0.0f), all_fin = o_g_all(c, value < FLT_MAX), all_num = o_g_all(c, value == value);
+  const int ok = any_pos && all_fin && all_num;
   if(ok)
   {
     float f = (path->lambda - 360)/5;
     const int i = (int)f;
     f -= i;
     for(int k=0;k<3;k++) col[k] = ((1-f)*s->cie_xyz[3*i+k] + f*s->cie_xyz[3*(i+1)+k])*value;
+  }
+  if(c->grp)
+  { /* spectrum_p_to_xyz, include/spectrum.h:185-195: xyz[k] += b[k] * p[l] for l = 0 .. 3 in that order; the hero lane splats the sum */
+    for(int k=0;k<3;k++) c->grp->col[c->lane][k] = col[k];
+    o_g_meet(c);
+    for(int k=0;k<3;k++) { col[k] = 0.0f; for(int l=0;l<O_MF;l++) col[k] += c->grp->col[l][k]; }
+    o_g_meet(c);
+    if(c->hero_ext && c->hero_splats < MI_REC_MAX_SPLATS) c->hero_ext->splat_value[c->hero_splats][c->lane] = value;
+    c->hero_splats++;
+    if(c->lane) return;
   }
   if(c->rec && c->rec->num_splats < MI_REC_MAX_SPLATS)
   {
@@ -514,11 +536,14 @@ static void o_sampler_pt(o_ctx *c, o_path *path)
       /* sampler_mis, pt.c:30-38: hero-wavelength weight, == 1 unless the pdf product leaves float range */
       double pdf = 1.0;
       for(int v=1;v<path->length;v++) pdf = pdf*(double)path->v[v].pdf;
-      const float w = (float)pdf/(float)pdf;
+      const float w = (float)pdf/o_g_hsum(c, (float)pdf);            /* mf_div(md_2f(pdf), mf_set1(mf_hsum(md_2f(pdf)))) */
       o_splat(c, path, w*o_path_throughput(path));
       if(path->length > 3)
-        if(o_path_russian_roulette(c, path, OMIN(1.0f, path->v[path->length-1].throughput/path->v[path->length-2].throughput)))
+      { /* pt.c:50: the hero's throughputs decide for all four (mf(throughput, 0)) */
+        const float t1 = o_g_hero(c, path->v[path->length-1].throughput), t2 = o_g_hero(c, path->v[path->length-2].throughput);
+        if(o_path_russian_roulette(c, path, OMIN(1.0f, t1/t2)))
           return;
+      }
     }
   }
 }
@@ -659,10 +684,10 @@ static int o_nee_sample(o_ctx *c, o_path *p)
       p->v[v].pdf = p->v[v].pdf*p_geo;
       edf = edf/p_geo;
     }
-    if(edf > 0.0f)
+    if(o_g_any(c, edf > 0.0f))                                          /* !mf_any(mf_gt(edf, 0)) -> fail, nee.h:188 */
     {
       bsdf = o_shader_brdf(c, p, v-1);
-      if(bsdf > 0.0f && !o_path_edge_init_volume(p, v) && o_path_visible(c, p, v))
+      if(o_g_any(c, bsdf > 0.0f) && !o_path_edge_init_volume(p, v) && o_path_visible(c, p, v))       /* nee.h:191 */
       {
         o_shader_prepare(c, p, v);
         const float G = o_path_G(p, v);
@@ -706,12 +731,12 @@ static void o_path_pop(o_path *path)
 }
 
 static float o_ptdl_mis(const o_path *p, float pdf, float pdf2)
-{ /* sampler_mis, src/sampler.d/ptdl.c:78-88 */
+{ /* sampler_mis, src/sampler.d/ptdl.c:78-88: the combined balance heuristic over wavelengths and techniques (hero: the sum runs over the four lanes) */
   double pdf_path = 1.0;
   for(int v=1;v<p->length-1;v++) pdf_path = pdf_path*(double)p->v[v].pdf;
   const double our = (double)pdf*pdf_path;
   const double other = (double)pdf2*pdf_path;
-  return (float)our/(float)(other + our);
+  return (float)our/o_g_hsum(O_CTX(p), (float)(other + our));
 }
 
 static void o_sampler_ptdl(o_ctx *c, o_path *path)
@@ -733,7 +758,7 @@ static void o_sampler_ptdl(o_ctx *c, o_path *path)
       if(o_nee_sample(c, path)) return;
       const int v2 = path->length-1;
       const float throughput = o_path_throughput(path)/rr;
-      if(throughput > 0.0f && (path->v[v2].mode & s_emit))
+      if(o_g_any(c, throughput > 0.0f) && (path->v[v2].mode & s_emit))            /* mf_any, ptdl.c:142 */
       {
         const float weight = o_ptdl_mis(path, rr*path->v[v2].pdf, o_path_pdf_extend(c, path, v2));
         o_splat(c, path, throughput*weight);
@@ -764,9 +789,11 @@ static void o_fill_record(const o_path *p, mi_path_record *r)
   }
 }
 
+static void o_hero_fill_ext(const o_path *p, int lane, oracle_hero_ext *x);
 static void o_trace(o_ctx *c, uint64_t index)
 { /* render_sample_path, src/render.d/gi.c:81-105 -> pointsampler_mutate -> path_init + sampler_create_path */
   o_path path;
+  path.ctx = c;
   path.lambda = 0.0f; path.throughput = 0.0f; path.length = 0; path.time = 0; path.index = index;
   path.scramble = 0.0f; path.pixel_i = path.pixel_j = 0.0f;
   memset(path.v, 0, 2*sizeof(o_vertex));
@@ -774,6 +801,7 @@ static void o_trace(o_ctx *c, uint64_t index)
   o_rand_seed(c, index, c->s->frame);
   if(c->s->sampler == MI_SAMPLER_PTDL) o_sampler_ptdl(c, &path);
   else o_sampler_pt(c, &path);
+  if(c->hero_ext) o_hero_fill_ext(&path, c->lane, c->hero_ext);
   c->cnt[4]++;
   c->cnt[6] += path.length;
   if(c->rec) o_fill_record(&path, c->rec);
@@ -806,6 +834,54 @@ void oracle_trace_records(const mi_scene_desc *s, uint64_t first, uint64_t count
 {
   o_prepare_points(s, first + count);
   for(uint64_t i=0;i<count;i++) o_trace_path(s, first + i, 0, out + i, 0);
+}
+
+/* ---------------------------------------------------------------- hero wavelengths: four lanes in lock step (o_core.h) */
+typedef struct o_hero_lane { o_ctx c; uint64_t first, count; mi_path_record *out; oracle_hero_ext *ext; } o_hero_lane;
+
+static void o_hero_fill_ext(const o_path *p, int lane, oracle_hero_ext *x)
+{
+  x->lambda[lane] = p->lambda;
+  for(int v=0;v<p->length && v<MI_REC_MAX_VERTS;v++)
+  {
+    x->throughput[v][lane] = p->v[v].throughput; x->pdf[v][lane] = p->v[v].pdf;
+    x->rd[v][lane] = p->v[v].shading.rd; x->rg[v][lane] = p->v[v].shading.rg; x->em[v][lane] = p->v[v].shading.em; x->eta[v][lane] = p->v[v].eta;
+  }
+}
+
+static void *o_hero_worker(void *arg)
+{
+  o_hero_lane *L = (o_hero_lane *)arg;
+  for(uint64_t i=0;i<L->count;i++)
+  {
+    L->c.rec = L->c.lane == 0 && L->out ? L->out + i : 0;
+    if(L->c.rec) { memset(L->c.rec, 0, sizeof(*L->c.rec)); L->c.rec->index = L->first + i; }
+    L->c.hero_ext = L->ext ? L->ext + i : 0;
+    L->c.hero_splats = 0;
+    o_trace(&L->c, L->first + i);
+  }
+  return 0;
+}
+
+/* paths [first, first + count) with MF_COUNT = 4 wavelengths each. out: the usual records with the HERO component of every spectral quantity
+   (what refharness/render_dump.c writes from a -DMF_COUNT=4 build); ext: all four components (may be NULL); fb: framebuffer or NULL */
+void oracle_hero_trace(const mi_scene_desc *s, uint64_t first, uint64_t count, mi_path_record *out, oracle_hero_ext *ext, float *fb, uint64_t *counters)
+{
+  o_prepare_points(s, first + count);
+  o_group grp;
+  memset(&grp, 0, sizeof(grp));
+  o_hero_lane lane[O_MF];
+  pthread_t th[O_MF];
+  if(ext) memset(ext, 0, sizeof(*ext)*count);
+  for(int l=0;l<O_MF;l++)
+  {
+    memset(lane + l, 0, sizeof(o_hero_lane));
+    lane[l].c.s = s; lane[l].c.grp = &grp; lane[l].c.lane = l; lane[l].c.fb = l == 0 ? fb : 0;
+    lane[l].first = first; lane[l].count = count; lane[l].out = out; lane[l].ext = ext;
+    pthread_create(th + l, 0, o_hero_worker, lane + l);
+  }
+  for(int l=0;l<O_MF;l++) pthread_join(th[l], 0);
+  if(counters) for(int i=0;i<8;i++) counters[i] += lane[0].c.cnt[i];
 }
 
 typedef struct o_job

@@ -202,14 +202,14 @@ float o_shader_prepare(o_ctx *c, o_path *p, int v)
   for(uint32_t k=0;k<m->num_ops;k++) o_prepare_op(s, m->op + k, p, v);      /* mult.c:154-167 */
   if(m->bsdf == MI_BSDF_DIFFUSE)
   { /* prepare_d, src/shader.c:157-162 */
-    if(p->v[v].shading.rd > 0.0f) p->v[v].material_modes = s_reflect | s_diffuse;
+    if(o_g_any(O_CTX(p), p->v[v].shading.rd > 0.0f)) p->v[v].material_modes = s_reflect | s_diffuse;      /* mf_any */
   }
   else if(m->bsdf == MI_BSDF_DIELECTRIC)
   { /* dielectric.c:67-81 */
     p->v[v].interior.ior = o_eta_from_abbe(m->param[0], m->param[1], p->lambda);
     p->v[v].material_modes = s_reflect | s_transmit;
     const float eta = o_path_eta_ratio(p, v);
-    if(fabsf(1.0f - eta) < 1e-3f) p->v[v].shading.roughness = 0.0f;
+    if(o_g_any(O_CTX(p), fabsf(1.0f - eta) < 1e-3f)) p->v[v].shading.roughness = 0.0f;        /* indexmatched: mf_any over the wavelengths, dielectric.c:61-65 */
     if(p->v[v].shading.roughness > 1e-3f) p->v[v].material_modes |= s_glossy;
     else p->v[v].material_modes |= s_specular;
   }
@@ -241,7 +241,7 @@ static float o_sample_diffuse(o_ctx *c, o_path *p)
   if(p->v[v-1].flags & s_inside) { if(cos_out_ng >= 0.0f) return 0.0f; }
   else if(cos_out_ng <= 0.0f) return 0.0f;
   const float throughput = p->v[v-1].shading.rd;
-  if(throughput > 0.0f) p->v[v-1].mode = s_diffuse | s_reflect;
+  if(o_g_any(c, throughput > 0.0f)) p->v[v-1].mode = s_diffuse | s_reflect;       /* mf_any, src/shader.c:202 */
   return throughput;
 }
 
@@ -374,8 +374,11 @@ static float o_sample_dielectric(o_ctx *c, o_path *p)
 { /* sample, dielectric.c:240-415 (MF_COUNT == 1 branches, culled_modes == 0) */
   const int v = p->length-1;
   const float eta_ratio = o_path_eta_ratio(p, v);
-  if(eta_ratio < 0.0f) return 0.0f;
-  if(o_indexmatched(eta_ratio, 1.0f))
+  /* hero wavelengths (c->grp, MF_COUNT = 4): the microfacet, the reflect / transmit choice and the outgoing direction are the HERO's (component 0:
+     mf(eta_ratio, 0), mf(R, 0), mf(cost2, 0), mf(cost, 0)); every lane then evaluates value and pdf of that direction for its own index of refraction */
+  const float eta_hero = o_g_hero(c, eta_ratio);
+  if(eta_hero < 0.0f) return 0.0f;
+  if(o_g_any(c, o_indexmatched(eta_ratio, 1.0f)))
   {
     for(int k=0;k<3;k++) p->e[v+1].omega[k] = p->e[v].omega[k];
     p->v[v].mode = s_specular | s_transmit;
@@ -393,8 +396,9 @@ static float o_sample_dielectric(o_ctx *c, o_path *p)
     const float wit[3] = { -dot3(p->v[v].hit.a, p->e[v].omega), -dot3(p->v[v].hit.b, p->e[v].omega), cos_in };
     /* the reference draws both numbers as call arguments (dielectric.c:266); gcc evaluates them
        right to left: first draw -> U2, second -> U1 */
-    const float U2 = o_point(c, p, v+1, o_dim_omega_y);
-    const float U1 = o_point(c, p, v+1, o_dim_omega_x);
+    float U1, U2;
+    if(c->grp) { U1 = o_point(c, p, v+1, o_dim_omega_x); U2 = o_point(c, p, v+1, o_dim_omega_y); }   /* the MF_COUNT=4 reference: this plugin only builds with clang, which evaluates left to right (oracle/Makefile mf4) */
+    else       { U2 = o_point(c, p, v+1, o_dim_omega_y); U1 = o_point(c, p, v+1, o_dim_omega_x); }
     o_ggx_sample_h(wit, r, r, U1, U2, ht);
     for(int k=0;k<3;k++) h[k] = ht[0]*p->v[v].hit.a[k] + ht[1]*p->v[v].hit.b[k] + ht[2]*n[k];
     pdf_h = o_ggx_pdf_h(p->e[v].omega, h, n, r);
@@ -408,8 +412,9 @@ static float o_sample_dielectric(o_ctx *c, o_path *p)
   const float cost2 = 1.0f - (nr*nr)*(1.0f - cosr*cosr);
   const float cost = cost2 <= 0.0f ? 0.0f : sqrtf(cost2);
   const float R = o_fresnel(n1, n2, cosr, cost);
+  const float R_hero = o_g_hero(c, R), cost2_hero = o_g_hero(c, cost2), cost_hero = o_g_hero(c, cost);
 
-  if(o_point(c, p, v+1, o_dim_scatter_mode) <= R)
+  if(o_point(c, p, v+1, o_dim_scatter_mode) <= R_hero)
   {
     p->v[v].mode = s_reflect;
     for(int k=0;k<3;k++) p->e[v+1].omega[k] = p->e[v].omega[k] + 2.0f*cosr*h[k];
@@ -428,16 +433,43 @@ static float o_sample_dielectric(o_ctx *c, o_path *p)
   }
   else
   {
-    if(cost2 <= 0.0f) return 0.0f;
-    const float f = eta_ratio*cosr - cost;
-    for(int k=0;k<3;k++) p->e[v+1].omega[k] = p->e[v].omega[k]*eta_ratio + f*h[k];
+    if(cost2_hero <= 0.0f) return 0.0f;                                     /* "can't sample hero, we're all dead" */
+    const float f = eta_hero*cosr - cost_hero;
+    for(int k=0;k<3;k++) p->e[v+1].omega[k] = p->e[v].omega[k]*eta_hero + f*h[k];
     o_normalise(p->e[v+1].omega);
     if(dot3(p->e[v+1].omega, n) >= 0.0f) return 0.0f;
     if(r <= GLOSSY_THR)
     {
-      p->v[v+1].pdf = 1.0f - R;
+      /* "specular transmit always selects single wavelength": mask = mf_hero = _mm_set_epi32(0u, ~0u, ~0u, ~0u) (include/mf.h:300) zeroes the components
+         whose mask bits are set -- _mm_set_epi32 lists the HIGHEST element first, so that is components 0, 1, 2: the one that survives is component 3 */
+      const int masked = c->grp && c->lane != O_MF - 1;
+      p->v[v+1].pdf = masked ? 0.0f : 1.0f - R;
       p->v[v].mode = s_specular | s_transmit;
-      return p->v[v].shading.rg;
+      return masked ? 0.0f : p->v[v].shading.rg;
+    }
+    if(c->grp)
+    { /* dielectric.c:353-411: "we sampled a half vector for the configuration of wi and wo. unfortunately it's only valid for the hero wavelength":
+         every component reconstructs the half vector ITS index of refraction needs to connect wi and wo, with its own Fresnel term */
+      const float *wi = p->e[v].omega, *wo = p->e[v+1].omega;
+      int mask = 0;
+      float h0 = n1*wi[0] - n2*wo[0], h1 = n1*wi[1] - n2*wo[1], h2 = n1*wi[2] - n2*wo[2];
+      const float hilen = 1.0f/sqrtf(h0*h0 + (h1*h1 + h2*h2));
+      h0 *= hilen; h1 *= hilen; h2 *= hilen;
+      if(n2 < n1) { h0 = -h0; h1 = -h1; h2 = -h2; }
+      const float cosh2 = h0*n[0] + (h1*n[1] + h2*n[2]);
+      mask |= cosh2 < 0.0f;
+      const float cosr2 = h0*-wi[0] + (h1*-wi[1] + h2*-wi[2]);
+      mask |= cosr2 <= 0.0f;
+      const float cost2b = 1.0f - (nr*nr)*(1.0f - cosr2*cosr2);
+      const float costb = cost2b <= 0.0f ? 0.0f : sqrtf(cost2b);
+      const float R2 = o_fresnel(n1, n2, cosr2, costb);
+      const float denom = n1*cosr2 - n2*costb;
+      float pdf2 = o_ggx_pdf_h_cos(cosh2, cos_in, cosr2, p->v[v].shading.roughness);
+      pdf2 = pdf2*(((n2*n2)*costb)/(denom*denom));
+      p->v[v+1].pdf = mask ? 0.0f : (pdf2*(1.0f - R2))/fabsf(dot3(p->e[v+1].omega, n));
+      p->v[v].mode = s_transmit | s_glossy;
+      const float G1 = o_ggx_G1(wo, n, p->v[v].shading.roughness);
+      return mask ? 0.0f : p->v[v].shading.rg*G1;
     }
     const float denom = n1*cosr - n2*cost;
     pdf *= n2*n2*cost/(denom*denom);
@@ -453,9 +485,9 @@ static float o_brdf_dielectric(o_path *p, int v)
   const float cos_in  = -dot3(p->v[v].hit.n, p->e[v].omega);
   const float cos_out =  dot3(p->v[v].hit.n, p->e[v+1].omega);
   const float eta_ratio = o_path_eta_ratio(p, v);
-  if(eta_ratio < 0.0f) return 0.0f;
+  if(o_g_hero(O_CTX(p), eta_ratio) < 0.0f) return 0.0f;                       /* mf(eta_ratio, 0) < 0, dielectric.c:423 */
   const float n1 = eta_ratio, n2 = 1.0f;
-  const int index_matched = o_indexmatched(n1, n2);
+  const int index_matched = o_g_any(O_CTX(p), o_indexmatched(n1, n2));       /* mf_any over the wavelengths */
   if(cos_out == 0.0f || cos_in == 0.0f) return 0.0f;
   if(!index_matched && (cos_in*cos_out > 0)) p->v[v].mode = s_reflect;
   else p->v[v].mode = s_transmit;
@@ -538,11 +570,11 @@ static float o_pdf_dielectric(o_path *p, int e1, int v, int e2)
   if(cos_out < 0.0f && !(p->v[v].mode & s_transmit)) return 0.0f;
   float h[3];
   const float eta = o_path_eta_ratio(p, v);
-  if(eta < 0.0f) return 0.0f;
+  if(o_g_all(O_CTX(p), eta < 0.0f)) return 0.0f;                              /* mf_all(mf_lt(eta, 0)), dielectric.c:133 */
   const float n1 = eta, n2 = 1.0f;
   int mask = 0;
   float cosr = 0.0f, cosh = 0.0f;
-  if(o_indexmatched(n1, n2))
+  if(o_g_any(O_CTX(p), o_indexmatched(n1, n2)))
   {
     const float dot_wo_n = dot3(wo, n);
     for(int k=0;k<3;k++) h[k] = -wi[k] + wo[k] - 2.0f*dot_wo_n*n[k];
@@ -675,8 +707,9 @@ static float o_sample_metal(o_ctx *c, o_path *p)
   {
     const float wit[3] = { -dot3(p->v[v].hit.a, p->e[v].omega), -dot3(p->v[v].hit.b, p->e[v].omega), -dot3(n, p->e[v].omega) };
     float ht[3];
-    const float U2 = o_point(c, p, v+1, o_dim_omega_y);
-    const float U1 = o_point(c, p, v+1, o_dim_omega_x);
+    float U1, U2;
+    if(c->grp) { U1 = o_point(c, p, v+1, o_dim_omega_x); U2 = o_point(c, p, v+1, o_dim_omega_y); }   /* the MF_COUNT=4 reference: this plugin only builds with clang, which evaluates left to right (oracle/Makefile mf4) */
+    else       { U2 = o_point(c, p, v+1, o_dim_omega_y); U1 = o_point(c, p, v+1, o_dim_omega_x); }
     o_ggx_sample_h(wit, r, r, U1, U2, ht);
     for(int k=0;k<3;k++) h[k] = ht[0]*p->v[v].hit.a[k] + ht[1]*p->v[v].hit.b[k] + ht[2]*n[k];
     pdf_h = o_ggx_pdf_h(p->e[v].omega, h, n, r);

@@ -97,6 +97,19 @@ typedef struct dump_rec_t
 }
 dump_rec_t;
 
+/* hero wavelengths (-DMF_COUNT=4, `make -C oracle mf4`): the record above takes the hero component (index 0) of every spectral quantity; the
+   extension behind it takes all MF_COUNT components. MF_COUNT = 1: no extension, the file format of rounds 1-4. */
+#if MF_COUNT > 1
+typedef struct dump_ext_t
+{
+  float lambda[MF_COUNT];
+  float throughput[DUMP_MAX_VERTS][MF_COUNT], pdf[DUMP_MAX_VERTS][MF_COUNT];
+  float rd[DUMP_MAX_VERTS][MF_COUNT], rg[DUMP_MAX_VERTS][MF_COUNT], em[DUMP_MAX_VERTS][MF_COUNT], eta[DUMP_MAX_VERTS][MF_COUNT];
+  float splat_value[DUMP_MAX_SPLATS][MF_COUNT];
+}
+dump_ext_t;
+#endif
+
 typedef struct render_t
 {
   atomic_int_fast32_t clear_tls;
@@ -110,6 +123,9 @@ typedef struct render_tls_t
   path_t path0, path1;
   path_t *curr_path, *tent_path;
   dump_rec_t rec;
+#if MF_COUNT > 1
+  dump_ext_t ext;
+#endif
 }
 render_tls_t;
 
@@ -131,7 +147,11 @@ render_t *render_init()
   r->dump_file = (fn && r->dump_n) ? fopen(fn, "wb") : 0;
   if(r->dump_file)
   {
+#if MF_COUNT > 1
+    uint32_t hdr[4] = { 0x70647263u /* 'crdp' */, (uint32_t)(sizeof(dump_rec_t) + sizeof(dump_ext_t)), DUMP_MAX_VERTS | (MF_COUNT << 16), PATHSPACE_MAX_VERTS };
+#else
     uint32_t hdr[4] = { 0x70647263u /* 'crdp' */, (uint32_t)sizeof(dump_rec_t), DUMP_MAX_VERTS, PATHSPACE_MAX_VERTS };
+#endif
     fwrite(hdr, sizeof(hdr), 1, r->dump_file);
   }
   return r;
@@ -177,6 +197,9 @@ void render_sample_path(uint64_t index)
   tent->index = index;
   if(index == 0 && getenv("CORONA_DUMP_TREE")) dump_tree(getenv("CORONA_DUMP_TREE"));
   if(dump) { memset(&tls->rec, 0, sizeof(tls->rec)); tls->rec.index = index; }
+#if MF_COUNT > 1
+  if(dump) memset(&tls->ext, 0, sizeof(tls->ext));
+#endif
   points_set_state(rt.points, common_get_threadid(), index, rt.anim_frame);
   pointsampler_mutate(tls->curr_path, tent);
   if(dump)
@@ -184,10 +207,10 @@ void render_sample_path(uint64_t index)
     dump_rec_t *r = &tls->rec;
     r->pixel_i = tent->sensor.pixel_i;
     r->pixel_j = tent->sensor.pixel_j;
-    r->lambda = tent->lambda;
+    r->lambda = mf(tent->lambda, 0);
     r->time = tent->time;
     r->scramble = tent->tangent_frame_scrambling;
-    r->throughput = tent->throughput;
+    r->throughput = mf(tent->throughput, 0);
     r->length = tent->length;
     for(int v=0;v<tent->length && v<DUMP_MAX_VERTS;v++)
     {
@@ -197,13 +220,25 @@ void render_sample_path(uint64_t index)
       d->dist = tent->e[v].dist;
       for(int k=0;k<3;k++) { d->x[k] = s->hit.x[k]; d->n[k] = s->hit.n[k]; d->gn[k] = s->hit.gn[k]; d->omega[k] = tent->e[v].omega[k]; }
       d->mode = s->mode; d->flags = s->flags;
-      d->throughput = s->throughput; d->pdf = s->pdf;
+      d->throughput = mf(s->throughput, 0); d->pdf = mf(s->pdf, 0);
       d->u = s->hit.u; d->v = s->hit.v;
-      d->rd = s->shading.rd; d->rg = s->shading.rg; d->em = s->shading.em; d->roughness = s->shading.roughness;
-      d->eta = s->diffgeo.eta;
+      d->rd = mf(s->shading.rd, 0); d->rg = mf(s->shading.rg, 0); d->em = mf(s->shading.em, 0); d->roughness = s->shading.roughness;
+      d->eta = mf(s->diffgeo.eta, 0);
+#if MF_COUNT > 1
+      for(int l=0;l<MF_COUNT;l++)
+      {
+        tls->ext.throughput[v][l] = mf(s->throughput, l); tls->ext.pdf[v][l] = mf(s->pdf, l);
+        tls->ext.rd[v][l] = mf(s->shading.rd, l); tls->ext.rg[v][l] = mf(s->shading.rg, l); tls->ext.em[v][l] = mf(s->shading.em, l);
+        tls->ext.eta[v][l] = mf(s->diffgeo.eta, l);
+      }
+#endif
       d->shader = s->hit.shader;
     }
     fwrite(r, sizeof(*r), 1, rt.render->dump_file);
+#if MF_COUNT > 1
+    for(int l=0;l<MF_COUNT;l++) tls->ext.lambda[l] = mf(tent->lambda, l);
+    fwrite(&tls->ext, sizeof(tls->ext), 1, rt.render->dump_file);
+#endif
   }
   /* plain MC: pointsampler_accept() == 0 for MOD_pointsampler=rand, nothing to swap */
 }
@@ -216,11 +251,18 @@ void render_splat(const path_t *p, const mf_t value)
     dump_splat_t *s = tls->rec.splat + tls->rec.num_splats++;
     s->length = p->length;
     s->tech = p->length ? p->v[p->length-1].tech : -1;
-    s->value = value;
+    s->value = mf(value, 0);
     s->col[0] = s->col[1] = s->col[2] = 0.0f;
+#if MF_COUNT > 1
+    for(int l=0;l<MF_COUNT;l++) tls->ext.splat_value[tls->rec.num_splats-1][l] = mf(value, l);
+    /* same filter as view_splat (src/view.c:455-463) */
+    if(mf_any(mf_gt(value, mf_set1(0.0f))) && mf_all(mf_lt(value, mf_set1(FLT_MAX))) && mf_all(mf_eq(value, value)))
+      spectrum_p_to_camera(p->lambda, value, s->col);
+#else
     /* same filter as view_splat (src/view.c:455-463) */
     if(value > 0.0f && value < FLT_MAX && value == value)
       spectrum_p_to_camera(p->lambda, value, s->col);
+#endif
   }
   view_splat(p, value);
 }

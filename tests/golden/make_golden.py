@@ -10,7 +10,7 @@ sources under /root/reference) and writes small data files that are committed:
   counters.json              -DACCEL_DEBUG work counters (rays, node visits, box hits, prim tests) for 1 spp
   tilemeans_<cfg>.npz        32x32 tile means + image means of high-spp reference renders (statistical oracle)
 
-Usage: python3 tests/golden/make_golden.py [quick|paths|mb|mbrl|images|all]
+Usage: python3 tests/golden/make_golden.py [quick|paths|mb|mbrl|smooth|images|all]
 """
 import json
 import os
@@ -191,6 +191,10 @@ def main():
         dump_paths("halton_fog_ptdl_mv8", "dump_ptdl_halton_mv8", 8, "0056_fog", 1280, 720, 6000)   # free-flight dimension from the Halton sampler
         dump_paths("halton_ptdl_rough_mv32", "dump_ptdl_halton_mv32", 32, "0052_rough", 1280, 720, 2000)
         counters()
+    if what in ("smooth", "paths", "all"):
+        # smooth glass (scenes/0066_smooth = 0010 with roughness 0): the specular branches of dielectric.c sample / brdf / pdf
+        dump_paths("smooth_pt_mv8", "dump_pt_xs_mv8", 8, "0066_smooth", 1280, 720, 3000)
+        dump_paths("smooth_ptdl_mv8", "dump_ptdl_xs_mv8", 8, "0066_smooth", 1280, 720, 3000)
     if what in ("mb", "quick", "paths", "all"):
         dump_mb_tree()
         if what == "mb":

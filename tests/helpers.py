@@ -17,6 +17,7 @@ REPO = Path(__file__).resolve().parent.parent
 GOLDEN = REPO / "tests" / "golden"
 SCENE_0010 = REPO / "scenes" / "0010_pt" / "test.nra2"
 SCENE_ROUGH = REPO / "scenes" / "0052_rough" / "test.nra2"
+SCENE_SMOOTH = REPO / "scenes" / "0066_smooth" / "test.nra2"     # 0010 with roughness 0: specular reflection / transmission
 SCENE_LARGE = REPO / "scenes" / "0064_large" / "test.nra2"     # 0010 with every backdrop quad split 8x8: 262 156 primitives, the top of the tree in LDS, the rest in HBM
 SCENE_FINE = REPO / "scenes" / "0054_fine" / "test.nra2"       # 0010 with every backdrop quad split 2x2 (tools/make_geo.py): 1711 nodes, too big for LDS
 SCENE_MEDIA = REPO / "scenes" / "0055_media" / "test.nra2"     # 0010 with a scattering medium inside the glass sphere (`interior`, `medium_rgb`)
@@ -61,6 +62,8 @@ def oracle_lib():
         o.oracle_rand_sequence.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
         o.oracle_rand_sequence.restype = C.c_float
         o.oracle_set_pixels_from_index.argtypes = [C.c_int]
+        o.oracle_hero_trace.argtypes = [C.POINTER(pkg.MiSceneDesc), C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        o.oracle_hero_trace.restype = None
         o.oracle_set_pixels_from_index.restype = None
         o.oracle_render_tiles.argtypes = [C.POINTER(pkg.MiSceneDesc), C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
         o.oracle_render_tiles.restype = C.c_double
@@ -73,6 +76,21 @@ def oracle_records(scene, first, count):
     out = np.zeros(count, dtype=pkg.record_dtype())
     oracle_lib().oracle_trace_records(scene.desc_ptr, first, count, out.ctypes.data)
     return out
+
+
+HERO_MF = 4
+# oracle_hero_ext (oracle/oracle.h) == dump_ext_t of the dump harness built with -DMF_COUNT=4 (oracle/refharness/render_dump.c)
+HERO_EXT = np.dtype([("lambda", "<f4", HERO_MF), ("throughput", "<f4", (8, HERO_MF)), ("pdf", "<f4", (8, HERO_MF)), ("rd", "<f4", (8, HERO_MF)),
+                     ("rg", "<f4", (8, HERO_MF)), ("em", "<f4", (8, HERO_MF)), ("eta", "<f4", (8, HERO_MF)), ("splat_value", "<f4", (8, HERO_MF))])
+
+
+def oracle_hero_records(scene, first, count, fb=None):
+    """hero wavelengths (MF_COUNT = 4): (records of the hero component, all four components of every spectral quantity)"""
+    pkg = load_pkg()
+    out = np.zeros(count, dtype=pkg.record_dtype())
+    ext = np.zeros(count, dtype=HERO_EXT)
+    oracle_lib().oracle_hero_trace(scene.desc_ptr, first, count, out.ctypes.data, ext.ctypes.data, None if fb is None else fb.ctypes.data, None)
+    return out, ext
 
 
 def oracle_intersect(scene, pos, direction, ignore_primid=None, max_dist=None):

@@ -343,7 +343,9 @@ def test_regression_report_pieces(tmp_path):
     spec.loader.exec_module(rr)
     for d in sorted((REPO / "scenes").iterdir()):
         if d.is_dir() and d.name[:4].isdigit():
-            assert (d / "args").exists() and (d / "maxerror").exists() and (d / "title").exists() and (d / "config.mk").read_text().startswith("MOD_sampler=")
+            assert (d / "title").exists() and (d / "config.mk").read_text().startswith("MOD_sampler=")
+            # a scene without `args` is not a regression test (scenes/0065_huge: bench and residency probe only; 0066_smooth: path fixtures only)
+            assert not (d / "args").exists() or (d / "maxerror").exists(), d.name
     img = np.random.default_rng(0).uniform(0, 1, size=(8, 16, 3)).astype(np.float32)
     rr.write_png(tmp_path / "a.png", img)
     raw = (tmp_path / "a.png").read_bytes()

@@ -18,7 +18,7 @@ import json
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, SCENE_0010, SCENE_ALL, SCENE_CAM_MB, SCENE_FINE, SCENE_FOG, SCENE_MB, SCENE_MB_LIGHT, SCENE_MB_ROUND, SCENE_MB_ROUND_LIGHT, SCENE_MEDIA, SCENE_NESTED, SCENE_METAL, SCENE_ROUGH, load_pkg, make_scene, oracle_lib, oracle_records, oracle_render
+from helpers import GOLDEN, SCENE_0010, SCENE_ALL, SCENE_CAM_MB, SCENE_FINE, SCENE_FOG, SCENE_MB, SCENE_MB_LIGHT, SCENE_MB_ROUND, SCENE_MB_ROUND_LIGHT, SCENE_MEDIA, SCENE_NESTED, SCENE_METAL, SCENE_ROUGH, SCENE_SMOOTH, load_pkg, make_scene, oracle_lib, oracle_records, oracle_render
 
 pkg = load_pkg()
 
@@ -27,6 +27,9 @@ CASES = [
     ("ptdl_mv8", pkg.MI_SAMPLER_PTDL, SCENE_0010, 1e-2),
     ("pt_mv4_256", pkg.MI_SAMPLER_PT, SCENE_0010, 1.5e-3),       # BASELINE config 1
     ("rough_mv32", pkg.MI_SAMPLER_PT, SCENE_ROUGH, 1.5e-3),      # BASELINE config 4 (0052 parameters)
+    # smooth glass (roughness 0 <= GLOSSY_THR): the specular branches of dielectric.c:303-343 (sample), :425-440 (brdf: zero), pdf
+    ("smooth_pt_mv8", pkg.MI_SAMPLER_PT, SCENE_SMOOTH, 1.5e-3),
+    ("smooth_ptdl_mv8", pkg.MI_SAMPLER_PTDL, SCENE_SMOOTH, 1e-2),
     ("fine_mv8", pkg.MI_SAMPLER_PT, SCENE_FINE, 1.5e-3),         # 16 384-quad backdrop: QBVH of 1711 nodes (host builder vs reference builder)
     ("metal_mv8", pkg.MI_SAMPLER_PT, SCENE_METAL, 1.5e-3),       # row a19: metal.c sample
     ("metal_ptdl_mv8", pkg.MI_SAMPLER_PTDL, SCENE_METAL, 1e-2),  # row a19: metal.c brdf / pdf through next event estimation
