@@ -312,6 +312,12 @@ def mi_lib():
             if "CORONA_MI_LIB" not in os.environ:
                 raise
         try:
+            m.mi_scene_set_wavelengths.argtypes = [C.c_void_p, C.c_int]
+            m.mi_trace_paths_hero.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
+        except AttributeError:
+            if "CORONA_MI_LIB" not in os.environ:
+                raise
+        try:
             m.mi_scene_kernel_name.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
             m.mi_scene_lds_nodes.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         except AttributeError:
@@ -342,9 +348,20 @@ def mi_lib():
 
 MI_SYMBOLS = ["mi_init", "mi_scene_create", "mi_scene_set_framebuffer", "mi_scene_set_stream", "mi_render",
               "mi_sync", "mi_fb_read", "mi_fb_clear", "mi_fb_device_ptr", "mi_counters", "mi_scene_set_counters", "mi_scene_set_traversal", "mi_scene_get_traversal", "mi_scene_set_metal_reference", "mi_trace_paths", "mi_intersect", "mi_plan_launches",
-              "mi_last_kernel_ms", "mi_last_kernel_launches", "mi_scene_stats", "mi_scene_lds_nodes", "mi_scene_kernel_name", "mi_scene_set_pixels", "mi_render_tiles", "mi_group_render_tiles", "mi_scene_destroy", "mi_shutdown", "mi_last_error", "mi_current_device", "mi_bsdf_test_run",
+              "mi_last_kernel_ms", "mi_last_kernel_launches", "mi_scene_stats", "mi_scene_lds_nodes", "mi_scene_kernel_name", "mi_scene_set_pixels", "mi_render_tiles", "mi_group_render_tiles", "mi_scene_set_wavelengths", "mi_trace_paths_hero", "mi_scene_destroy", "mi_shutdown", "mi_last_error", "mi_current_device", "mi_bsdf_test_run",
               "mi_group_create", "mi_group_size", "mi_group_scene", "mi_group_uses_rccl", "mi_group_render", "mi_group_fb_reduce", "mi_group_fb_read",
               "mi_group_fb_clear", "mi_group_sync", "mi_group_counters", "mi_group_destroy"]
+
+
+MI_WAVELENGTHS_HERO = 4
+
+
+def hero_ext_dtype():
+    """numpy dtype of mi_hero_ext (include/corona_mi.h)"""
+    import numpy as np
+    n = MI_WAVELENGTHS_HERO
+    return np.dtype([("lambda", "<f4", n), ("throughput", "<f4", (8, n)), ("pdf", "<f4", (8, n)), ("rd", "<f4", (8, n)), ("rg", "<f4", (8, n)),
+                     ("em", "<f4", (8, n)), ("eta", "<f4", (8, n)), ("splat_value", "<f4", (8, n))])
 
 
 def ray_dtypes():
@@ -446,6 +463,18 @@ class Backend:
         out = np.zeros(count, dtype=record_dtype())
         self._check(self.m.mi_trace_paths(self._ptr, first, count, out.ctypes.data), "mi_trace_paths")
         return out
+
+    def set_wavelengths(self, count):
+        """4 (MI_WAVELENGTHS_HERO): four wavelengths per path, the reference's MF_COUNT=4 build (mi_scene_set_wavelengths); 1: back to one"""
+        self._check(self.m.mi_scene_set_wavelengths(self._ptr, int(count)), "mi_scene_set_wavelengths")
+
+    def trace_paths_hero(self, first, count):
+        """(records with component 0 of every spectral quantity, mi_hero_ext with all four) of paths [first, first + count)"""
+        import numpy as np
+        out = np.zeros(count, dtype=record_dtype())
+        ext = np.zeros(count, dtype=hero_ext_dtype())
+        self._check(self.m.mi_trace_paths_hero(self._ptr, first, count, out.ctypes.data, ext.ctypes.data), "mi_trace_paths_hero")
+        return out, ext
 
     def intersect(self, pos, direction, ignore=None, max_dist=None):
         """closest hits of caller-supplied rays (test hook, mi_intersect): returns a structured array (primid, prim, dist, u, v)"""

@@ -122,6 +122,7 @@ struct mi_scene
   int fast;                         /* launch the FAST instantiations (mi_scene_set_traversal / CORONA_MI_TRAVERSAL): same hits, other work counters */
   bool media;                       /* some shape is filled with a homogeneous medium: MEDIA instantiations */
   bool norg;                        /* ... of those, the ones without the exchange between waves (scattering exterior medium) */
+  bool hero;                        /* launch the HERO instantiations: four wavelengths per path (mi_scene_set_wavelengths) */
   void *d_shape_medium, *d_prims_t1, *d_lights, *d_prim_cls;
   /* Halton point sampler */
   bool halton;
@@ -131,7 +132,7 @@ struct mi_scene
 };
 
 /* ---------------------------------------------------------------------------------------- kernel table
- * The megakernel's instantiations live in ten parts (mi_megakernel.h, mi_part.hip), one translation unit each. */
+ * The megakernel's instantiations live in sixteen parts (mi_megakernel.h, mi_part.hip), one translation unit each. */
 extern template const void *mi_path_part<false, false, false, false>(unsigned, const PathLaunch *);
 extern template const void *mi_path_part<true,  false, false, false>(unsigned, const PathLaunch *);
 extern template const void *mi_path_part<false, true,  false, false>(unsigned, const PathLaunch *);
@@ -146,12 +147,15 @@ extern template const void *mi_path_part<false, true,  false, false, true>(unsig
 extern template const void *mi_path_part<true,  true,  false, false, true>(unsigned, const PathLaunch *);
 extern template const void *mi_path_part<false, true,  false, true,  true>(unsigned, const PathLaunch *);
 extern template const void *mi_path_part<true,  true,  false, true,  true>(unsigned, const PathLaunch *);
+extern template const void *mi_path_part<false, false, false, false, false, true>(unsigned, const PathLaunch *);     /* HERO (mi_hero.h) */
+extern template const void *mi_path_part<true,  false, false, false, false, true>(unsigned, const PathLaunch *);
 
-static const void *path_kernel(bool ptdl, bool media, bool mb, bool fast, bool norg, unsigned which, const PathLaunch *L)
+static const void *path_kernel(bool ptdl, bool media, bool mb, bool fast, bool norg, unsigned which, const PathLaunch *L, bool hero = false)
 {
 #ifdef MI_DEV_FAST
-  if(media || mb) { fprintf(stderr, "[mi] internal: development build without the extended kernels\n"); abort(); }
+  if(media || mb || hero) { fprintf(stderr, "[mi] internal: development build without the extended kernels\n"); abort(); }
 #endif
+  if(hero) return ptdl ? mi_path_part<true, false, false, false, false, true>(which, L) : mi_path_part<false, false, false, false, false, true>(which, L);
   if(mb) return ptdl ? mi_path_part<true, true, true, false>(which, L) : mi_path_part<false, true, true, false>(which, L);   /* no FAST rounds with moving primitives */
   if(media)
   {
@@ -1046,7 +1050,7 @@ static void launch_path_kernel(mi_scene *s, bool record, int grid, uint64_t firs
                          ((s->counting || record) ? MI_WHICH_COUNT : 0u);
   PathLaunch L = { s->d, grid, s->lds_bytes, s->stream, (unsigned long long)first, (unsigned long long)n, (const uint32_t *)s->d_shape_material,
                    (const float *)s->d_shape_L, rec, (uint2 *)s->d_overflow };
-  (void)path_kernel(s->d.sampler == MI_SAMPLER_PTDL, s->media, s->d_prims_t1 != nullptr, s->fast != 0, s->norg, which, &L);
+  (void)path_kernel(s->d.sampler == MI_SAMPLER_PTDL, s->media, s->d_prims_t1 != nullptr, s->fast != 0, s->norg, which, &L, s->hero);
 }
 
 /* the share of [first, first + count) that member k of n takes: contiguous, remainder indices to the lowest members */
@@ -1114,6 +1118,24 @@ extern "C" int mi_scene_set_pixels(mi_scene *s, int mode)
   MI_ENTER(s, "null scene");
   if(mode != MI_PIXELS_SAMPLED && mode != MI_PIXELS_FROM_INDEX) return fail(MI_ERR_ARG, "mi_scene_set_pixels: unknown mode");
   s->d.pixels_from_index = mode == MI_PIXELS_FROM_INDEX ? 1u : 0u;
+  return MI_OK;
+}
+
+extern "C" int mi_scene_set_wavelengths(mi_scene *s, int count)
+{
+  MI_ENTER(s, "null scene");
+  if(count != 1 && count != MI_WAVELENGTHS_HERO) return fail(MI_ERR_ARG, "mi_scene_set_wavelengths: 1 or 4 wavelengths per path");
+  if(count == 1) { s->hero = false; return MI_OK; }
+  /* what the MF_COUNT = 4 restatement is pinned on (tests/test_oracle_hero.py); s->media also covers a moving camera and emitters without a one-burst record */
+  if(s->media || s->d_prims_t1 || s->halton)
+    return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_wavelengths: hero wavelengths need a scene without media, motion blur or emitters other than static triangles / quads, and the rand point sampler");
+  for(unsigned k=0;k<3;k++)
+  { /* the scene's three HERO kernels (production, counting, record) may use the LDS the scene was laid out for */
+    const unsigned which = (k == 2 ? MI_WHICH_RECORD | MI_WHICH_COUNT : k == 1 ? MI_WHICH_COUNT : 0u) | (s->nodes_lds ? MI_WHICH_NODES_LDS : 0u);
+    const void *kernel = path_kernel(s->d.sampler == MI_SAMPLER_PTDL, false, false, false, false, which, nullptr, true);
+    HIPCHK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
+  }
+  s->hero = true;
   return MI_OK;
 }
 
@@ -1245,6 +1267,36 @@ extern "C" int mi_trace_paths(mi_scene *s, uint64_t first_index, uint64_t count,
   return MI_OK;
 }
 
+extern "C" int mi_trace_paths_hero(mi_scene *s, uint64_t first_index, uint64_t count, mi_path_record *host_out, mi_hero_ext *host_ext)
+{
+  if(!s || !host_out) return fail(MI_ERR_ARG, "null argument");
+  MI_ENTER(s, "null scene");
+  if(!s->hero) return fail(MI_ERR_ARG, "mi_trace_paths_hero: the scene renders one wavelength per path (mi_scene_set_wavelengths(s, MI_WAVELENGTHS_HERO) first)");
+  if(!count) return MI_OK;
+  void *d_rec = nullptr, *d_ext = nullptr;
+  HIPCHK(hipMalloc(&d_rec, count*sizeof(mi_path_record)));
+  hipError_t e = hipMemsetAsync(d_rec, 0, count*sizeof(mi_path_record), s->stream);
+  if(e == hipSuccess && host_ext) e = hipMalloc(&d_ext, count*sizeof(mi_hero_ext));
+  if(e == hipSuccess && host_ext) e = hipMemsetAsync(d_ext, 0, count*sizeof(mi_hero_ext), s->stream);
+  if(e == hipSuccess)
+  {
+    int grid = s->grid;
+    const uint64_t need = (count + MI_BLOCK - 1)/MI_BLOCK;
+    if((uint64_t)grid > need) grid = (int)need;
+    s->d.hero_ext = (mi_hero_ext *)d_ext;
+    launch_path_kernel(s, true, grid, first_index, count, (mi_path_record *)d_rec);
+    s->d.hero_ext = nullptr;
+    e = hipGetLastError();
+  }
+  if(e == hipSuccess) e = hipStreamSynchronize(s->stream);
+  if(e == hipSuccess) e = hipMemcpy(host_out, d_rec, count*sizeof(mi_path_record), hipMemcpyDeviceToHost);
+  if(e == hipSuccess && host_ext) e = hipMemcpy(host_ext, d_ext, count*sizeof(mi_hero_ext), hipMemcpyDeviceToHost);
+  (void)hipFree(d_rec);
+  if(d_ext) (void)hipFree(d_ext);
+  if(e != hipSuccess) { snprintf(g_err, sizeof(g_err), "mi_trace_paths_hero: %s", hipGetErrorString(e)); fprintf(stderr, "[mi] %s\n", g_err); return MI_ERR_DEVICE; }
+  return MI_OK;
+}
+
 extern "C" int mi_intersect(mi_scene *s, const mi_ray *rays, uint64_t n, mi_hit *host_out)
 {
   if(!s || !rays || !host_out) return fail(MI_ERR_ARG, "null argument");
@@ -1311,8 +1363,8 @@ extern "C" int mi_scene_kernel_name(mi_scene *s, char *buf, size_t len)
   if(!s || !buf || len == 0) return fail(MI_ERR_ARG, "null argument");
   const bool mb = s->d_prims_t1 != nullptr;
   auto tf = [](bool b) { return b ? "true" : "false"; };
-  const int n = snprintf(buf, len, "mi_path_kernel<false, %s, %s, %s, %s, %s, %s, %s, %s>", tf(s->d.sampler == MI_SAMPLER_PTDL), tf(s->nodes_lds), tf(s->halton),
-                         tf(s->media), tf(mb), tf(s->counting != 0), tf(s->fast != 0 && !mb), tf(s->norg));
+  const int n = snprintf(buf, len, "mi_path_kernel<false, %s, %s, %s, %s, %s, %s, %s, %s, %s>", tf(s->d.sampler == MI_SAMPLER_PTDL), tf(s->nodes_lds), tf(s->halton),
+                         tf(s->media), tf(mb), tf(s->counting != 0), tf(s->fast != 0 && !mb && !s->hero), tf(s->norg), tf(s->hero));
   return (n < 0 || (size_t)n >= len) ? fail(MI_ERR_ARG, "mi_scene_kernel_name: buffer too small") : MI_OK;
 }
 

@@ -170,6 +170,7 @@ struct DScene
   uint32_t pixels_from_index;       /* 1: path i starts inside pixel (i mod W H) -- the hook of render_sample_path's tiled branch, src/render.d/gi.c:88-95 (mi_scene_set_pixels) */
   uint32_t tile_members;            /* > 0 during mi_render_tiles: the launch enumerates the pixels of the 32 x 32 tiles t = tile_member (mod tile_members) */
   uint32_t tile_member, tiles_local, tiles_x;
+  mi_hero_ext *hero_ext;            /* RECORD launches of the HERO kernels (mi_trace_paths_hero): all four components per path, or NULL */
 };
 
 #endif

@@ -1,0 +1,532 @@
+/* mi_hero.h -- hero wavelengths: the shading of the HERO instantiations of the megakernel (mi_megakernel.h), i.e. the reference built with
+ * -DMF_COUNT=4 (include/mf.h:280-423; mi_scene_set_wavelengths, include/corona_mi.h).
+ *
+ * A path carries FOUR wavelengths. The first (component 0, the hero) decides everything geometric -- which microfacet, reflect or transmit,
+ * Russian roulette --, all four weigh the path, and one splat adds the four colours (src/pathspace.c:189,218-221,253; src/sampler.d/pt.c:30-54,
+ * ptdl.c:78-148; include/pathspace/nee.h:188-191; src/shaders/dielectric.c:240-415; src/view.c:455-463 with include/spectrum.h:185-195).
+ *
+ * One LANE per path, as in every other kernel: the traversal is the scalar kernels' (a ray is a ray), and the spectral part of a vertex --
+ * colours, indices of refraction, Fresnel terms, pdfs, weights -- is evaluated for l = 0..3 by the SAME device functions the scalar kernels
+ * use (mi_kernels.h), called once per component from unrolled loops, component 0 first. What is common to the four calls (the surface, the
+ * sampled microfacet, the emitter sample) the compiler computes once. The places where the reference looks across the components (mf_any,
+ * mf_all, mf(x, 0), mf_hsum) are written out here or handed to the bsdf functions in a HeroCtx.
+ * Component 0 lives in the PathState the megakernel knows (ray, pdf product, throughput ...: what the traversal slices and the parking
+ * of path state touch), components 1..3 in the arrays of PathStateHero behind it: 21 registers more.
+ * Plain scenes only (no media, no moving primitives, `rand` point sampler): what the reference's MF_COUNT = 4 build was pinned on
+ * (tests/test_oracle_hero.py). No exchange between waves: a pool entry would have to carry the 21 words too. */
+#ifndef MI_HERO_H
+#define MI_HERO_H
+
+#include "mi_path.h"
+
+struct PathStateHero : PathState
+{
+  float lambda_x[3], throughput_x[3], pdf_x[3], cur_ior_x[3], sh_value_x[3];
+  double pdfprod_x[3];
+};
+
+__device__ __forceinline__ float hero_hsum(const float *a) { return (a[0] + a[1]) + (a[2] + a[3]); }   /* mf_hsum: two _mm_hadd_ps, include/mf.h:301-306 */
+
+/* view_splat for four components: mf_any(value > 0) && mf_all(value < FLT_MAX) && mf_all(value == value) (src/view.c:455-463), then
+   spectrum_p_to_xyz: xyz[k] += cmf_k(lambda_l) p[l] for l = 0..3 in that order (include/spectrum.h:185-195) */
+__device__ __forceinline__ bool hero_splat_colour(const DScene &sc, const float *lam, const float *value, float *col)
+{
+  const bool ok = (value[0] > 0.0f || value[1] > 0.0f || value[2] > 0.0f || value[3] > 0.0f) &&
+                  (value[0] < FLT_MAX && value[1] < FLT_MAX && value[2] < FLT_MAX && value[3] < FLT_MAX) &&
+                  (value[0] == value[0] && value[1] == value[1] && value[2] == value[2] && value[3] == value[3]);
+  col[0] = col[1] = col[2] = 0.0f;
+  if(ok)
+  {
+    float sum[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for(int l=0;l<MI_MF;l++)
+    {
+      float c[3];
+      spectrum_to_xyz(sc, lam[l], value[l], c);
+      sum[0] += c[0]; sum[1] += c[1]; sum[2] += c[2];
+    }
+    col[0] = sum[0]; col[1] = sum[1]; col[2] = sum[2];
+  }
+  return ok;
+}
+
+template<bool RECORD>
+__device__ __forceinline__ void hero_rec_vertex(const DScene &sc, unsigned long long slot, int v, const float *thr, const float *pdf, const Shading *sh, const float *eta)
+{
+  if(!RECORD || v >= MI_REC_MAX_VERTS || !sc.hero_ext) return;
+  mi_hero_ext &x = sc.hero_ext[slot];
+#pragma unroll
+  for(int l=0;l<MI_MF;l++)
+  {
+    x.throughput[v][l] = thr[l]; x.pdf[v][l] = pdf[l];
+    x.rd[v][l] = sh ? sh[l].rd : 0.0f; x.rg[v][l] = sh ? sh[l].rg : 0.0f; x.em[v][l] = sh ? sh[l].em : 0.0f; x.eta[v][l] = eta ? eta[l] : 0.0f;
+  }
+}
+
+template<bool RECORD, class CNT>
+__device__ __forceinline__ void path_generate_hero(const DScene &sc, PathStateHero &ps, unsigned long long index, mi_path_record *rec, unsigned long long slot, CNT &cnt,
+                                                   float px = -1.0f, float py = -1.0f)
+{
+  path_generate<RECORD, false, false, CNT, true>(sc, ps, index, rec, cnt, px, py, ps.lambda_x);
+#pragma unroll
+  for(int l=0;l<3;l++) { ps.throughput_x[l] = ps.throughput; ps.pdf_x[l] = ps.pdf; ps.cur_ior_x[l] = 1.0f; ps.pdfprod_x[l] = 1.0; ps.sh_value_x[l] = 0.0f; }
+  if(RECORD && sc.hero_ext)
+  {
+    mi_hero_ext &x = sc.hero_ext[slot];
+    x.lambda[0] = ps.lambda; x.lambda[1] = ps.lambda_x[0]; x.lambda[2] = ps.lambda_x[1]; x.lambda[3] = ps.lambda_x[2];
+    const float thr[4] = {ps.throughput, ps.throughput, ps.throughput, ps.throughput}, one[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+    hero_rec_vertex<RECORD>(sc, slot, 0, thr, one, nullptr, nullptr);
+  }
+}
+
+/* the splat of a next-event connection that path_visible has passed */
+template<bool RECORD, class CNT>
+__device__ __forceinline__ void shadow_splat_hero(const DScene &sc, PathStateHero &ps, mi_path_record *rec, unsigned long long slot, CNT &cnt, SplatReq &splat)
+{
+  ps.sh_pending = 0;
+  const float lam[4] = {ps.lambda, ps.lambda_x[0], ps.lambda_x[1], ps.lambda_x[2]};
+  const float value[4] = {ps.sh_value, ps.sh_value_x[0], ps.sh_value_x[1], ps.sh_value_x[2]};
+  float col[3];
+  const bool ok = hero_splat_colour(sc, lam, value, col);
+  if(RECORD)
+  {
+    if(rec->num_splats < MI_REC_MAX_SPLATS)
+    {
+      if(sc.hero_ext) for(int l=0;l<MI_MF;l++) sc.hero_ext[slot].splat_value[rec->num_splats][l] = value[l];
+      mi_path_splat &sp = rec->splat[rec->num_splats++];
+      sp.length = ps.sh_length; sp.tech = s_tech_nee; sp.value = value[0];
+      sp.col[0] = col[0]; sp.col[1] = col[1]; sp.col[2] = col[2];
+    }
+  }
+  if(ok)
+  {
+    MI_COUNT(cnt, 5, 1);
+    if(!RECORD) { splat.pending = true; splat.c0 = col[0]; splat.c1 = col[1]; splat.c2 = col[2]; }
+  }
+}
+
+template<bool RECORD, class CNT>
+__device__ __forceinline__ void shadow_resolve_hero(const DScene &sc, PathStateHero &ps, const Hit &hit, mi_path_record *rec, unsigned long long slot, CNT &cnt, SplatReq &splat)
+{ /* path_visible, src/pathspace.c:311-344 */
+  ps.sh_pending = 0;
+  const bool visible = (hit.dist >= ps.sh_dist) || (hit.prim == MI_NOPRIM) || (hit.prim == (ps.sh_light & ~MI_LIGHT_ANYHIT));
+  if(visible) shadow_splat_hero<RECORD>(sc, ps, rec, slot, cnt, splat);
+}
+
+/* path_shade (mi_path.h) for four components; the comments there name the reference lines of every step, here only what differs */
+template<bool RECORD, bool PTDL, class CNT>
+__device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero &ps, const Hit &hit, const uint32_t *shape_material, const float *shape_L,
+                                                mi_path_record *rec, unsigned long long slot, CNT &cnt, SplatReq &splat)
+{
+  const int v = ps.length;
+  bool alive = true;
+  const V3 omega = ps.dir;
+  const float lam[4] = {ps.lambda, ps.lambda_x[0], ps.lambda_x[1], ps.lambda_x[2]};
+  float thr[4] = {ps.throughput, ps.throughput_x[0], ps.throughput_x[1], ps.throughput_x[2]};
+  const float pdf_in[4] = {ps.pdf, ps.pdf_x[0], ps.pdf_x[1], ps.pdf_x[2]};
+  float ior[4] = {ps.cur_ior, ps.cur_ior_x[0], ps.cur_ior_x[1], ps.cur_ior_x[2]};
+  double pp[4] = {ps.pdfprod, ps.pdfprod_x[0], ps.pdfprod_x[1], ps.pdfprod_x[2]};
+  if(PTDL)
+  {
+    ps.sh_dir = mk3(0.0f, 0.0f, 0.0f); ps.sh_dist = 0.0f; ps.sh_value = 0.0f; ps.sh_light = 0u; ps.sh_length = 0;
+    ps.sh_value_x[0] = ps.sh_value_x[1] = ps.sh_value_x[2] = 0.0f;
+  }
+  if(hit.prim == MI_NOPRIM)
+  { /* environment vertex; black sky: the path ends */
+    const float G = ps.prev_cos;
+    float vpdf[4];
+#pragma unroll
+    for(int l=0;l<MI_MF;l++) { vpdf[l] = pdf_in[l]*G; pp[l] *= (double)vpdf[l]; }
+    ps.length++;
+    MI_COUNT(cnt, 6, 1);
+    if(RECORD)
+    {
+      const V3 x = mk3(ps.prev_x.x + sc.far_dist*omega.x, ps.prev_x.y + sc.far_dist*omega.y, ps.prev_x.z + sc.far_dist*omega.z);
+      Shading z; z.roughness = 1.0f; z.rs = z.rd = z.rg = z.em = 0.0f;
+      rec_vertex<RECORD>(rec, v, MI_PRIMID_INVALID, FLT_MAX, x, mk3(0, 0, 0), mk3(0, 0, 0), omega, s_absorb, s_environment, thr[0], vpdf[0], 0.0f, 0.0f, z, 0.0f, -1);
+      const Shading zz[4] = {z, z, z, z};
+      hero_rec_vertex<RECORD>(sc, slot, v, thr, vpdf, zz, nullptr);
+      rec->length = ps.length; rec->throughput = 0.0f;
+    }
+    alive = false;
+  }
+  else
+  {
+    Surf sf;
+    const V3 rorg = ray_origin<PTDL>(ps, false);
+    sf.x = mk3(rorg.x + hit.dist*ps.dir.x, rorg.y + hit.dist*ps.dir.y, rorg.z + hit.dist*ps.dir.z);
+    sf.u = hit.u; sf.v = hit.v;
+    const DPrimGeo &pshade = sc.primgeo[hit.prim];
+    const uint4 head = *(const uint4 *)&pshade;
+    const DMaterial &mat = sc.materials[head.y];
+    const uint4 mhead = *(const uint4 *)&mat;
+    const uint32_t mat_bsdf = mhead.x;
+    const float mat_p0 = __uint_as_float(mhead.z), mat_p1 = __uint_as_float(mhead.w);
+    surface_setup<false>(sc, hit.prim, head, omega, ps.scramble, sf, ps.time);
+    const uint32_t shape = (head.w >> 3) & 0x1fffffffu;
+    Shading sh[4];
+#pragma unroll
+    for(int l=0;l<MI_MF;l++) run_prepare_ops(sc, mat, mhead.y, sf, lam[l], sh[l]);
+    uint32_t material_modes = 0;
+    float eta[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+    HeroCtx hc;
+    hc.lane = 0; hc.any_im = false; hc.any_rd = false; hc.eta0 = 1.0f; hc.R0 = hc.cost20 = hc.cost0 = 0.0f; hc.u[0] = hc.u[1] = hc.u[2] = 0.0f; hc.k = 0;
+    if(RECORD || mat_bsdf != MI_BSDF_DIFFUSE)
+    {
+      Media hyp = ps.media;
+      media_apply(hyp, shape, (sf.flags & s_inside) != 0);
+      if(hyp.broken) { eta[0] = eta[1] = eta[2] = eta[3] = -1.0f; }
+      else
+      {
+        const int top = media_top_shape(hyp);
+#pragma unroll
+        for(int l=0;l<MI_MF;l++)
+        {
+          float interior_self = 1.0f;
+          if(mat_bsdf == MI_BSDF_DIELECTRIC) interior_self = eta_from_abbe(mat_p0, mat_p1, lam[l]);
+          const float ior2 = (top == (int)shape) ? interior_self : shape_interior_ior(sc, shape_material, top, lam[l]);
+          eta[l] = ior[l]/ior2;
+        }
+      }
+    }
+    hc.eta0 = eta[0];
+    hc.any_rd = sh[0].rd > 0.0f || sh[1].rd > 0.0f || sh[2].rd > 0.0f || sh[3].rd > 0.0f;
+    if(mat_bsdf == MI_BSDF_DIFFUSE) { if(hc.any_rd) material_modes = s_reflect | s_diffuse; }           /* mf_any(rd > 0), src/shader.c:161 */
+    else if(mat_bsdf == MI_BSDF_DIELECTRIC)
+    {
+      material_modes = s_reflect | s_transmit;
+      hc.any_im = fabsf(1.0f - eta[0]/1.0f) < 1e-3f || fabsf(1.0f - eta[1]/1.0f) < 1e-3f || fabsf(1.0f - eta[2]/1.0f) < 1e-3f || fabsf(1.0f - eta[3]/1.0f) < 1e-3f;
+      if(hc.any_im) sh[0].roughness = sh[1].roughness = sh[2].roughness = sh[3].roughness = 0.0f;       /* indexmatched() is an mf_any, dielectric.c:61-65 */
+      if(sh[0].roughness > GLOSSY_THR) material_modes |= s_glossy; else material_modes |= s_specular;
+    }
+    else if(mat_bsdf == MI_BSDF_METAL)
+    {
+      material_modes = s_reflect;
+      if(sh[0].roughness > 1e-4f) material_modes |= s_glossy; else material_modes |= s_specular;
+    }
+
+    const uint32_t type = head.x;
+    if((type > 2 || hit.dist < 1e-4f) && hit.prim == ps.ignore)
+    { /* self-intersection */
+      alive = false;
+      if(RECORD)
+      {
+        rec->length = ps.length; rec->throughput = 0.0f;
+        if(v >= 1 && v-1 < MI_REC_MAX_VERTS && !(ps.prev_mode & s_emit)) rec->v[v-1].mode = s_absorb;
+      }
+    }
+    else
+    {
+      uint32_t mode = s_absorb;
+      const bool any_em = sh[0].em > 0.0f || sh[1].em > 0.0f || sh[2].em > 0.0f || sh[3].em > 0.0f;     /* mf_any(em > 0), src/pathspace.c:876-877 */
+      if(any_em && !(sf.flags & s_inside)) { mode = s_emit; material_modes = s_emit; }
+      const float G = ps.prev_cos*fabsf(dot3(sf.n, omega))/(hit.dist*hit.dist);
+      float vpdf[4];
+      double pp_before[4];
+#pragma unroll
+      for(int l=0;l<MI_MF;l++) { vpdf[l] = pdf_in[l]*G; pp_before[l] = pp[l]; pp[l] *= (double)vpdf[l]; }
+      ps.length++;
+      MI_COUNT(cnt, 6, 1);
+      float path_throughput[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      if(mode & s_emit)
+      { /* lights_eval_vertex: mf_all(em <= 0) cannot hold here; one edf, the emission per component */
+        float edf = 0.0f;
+        const bool facing = !(dot3(sf.gn, omega) >= 0.0);
+        if(facing)
+        {
+          if(sh[0].roughness > 1.0f-1e-4f) edf = (float)(1.0f/MI_PI_D);
+          else
+          {
+            const float phongexp = 2.0f/(sh[0].roughness*sh[0].roughness) - 2.0f;
+            edf = (float)((double)(powf(fabsf(dot3(sf.gn, omega)), phongexp)*(phongexp+2.0f))/(2.0f*MI_PI_D));
+          }
+        }
+#pragma unroll
+        for(int l=0;l<MI_MF;l++) path_throughput[l] = 0.0f + thr[l]*(facing ? edf*sh[l].em : 0.0f);
+      }
+      float vthr[4] = {thr[0], thr[1], thr[2], thr[3]};
+      if(RECORD)
+      {
+        rec_vertex<RECORD>(rec, v, MI_GEO_PRIMID(pshade), hit.dist, sf.x, sf.n, sf.gn, omega, mode, sf.flags, vthr[0], vpdf[0], sf.u, sf.v, sh[0], eta[0], (int)head.y);
+        hero_rec_vertex<RECORD>(sc, slot, v, vthr, vpdf, sh, eta);
+        rec->length = ps.length; rec->throughput = path_throughput[0];
+      }
+      if(mode & s_emit)
+      {
+        float w[4], value[4];
+        if(PTDL)
+        { /* sampler_mis, ptdl.c:78-88: the balance heuristic over techniques AND wavelengths -- md_2f(our) / mf_hsum(md_2f(other + our)) */
+          float nee = 0.0f;
+          if(ps.length >= 3 && (ps.prev_material_modes & (s_diffuse | s_glossy)) && sc.p_geo > 0) nee = sc.p_geo*shape_L[shape];
+          float ours[4], sums[4];
+#pragma unroll
+          for(int l=0;l<MI_MF;l++)
+          {
+            const double our = (double)vpdf[l]*pp_before[l], other = (double)(1.0f*nee)*pp_before[l];
+            ours[l] = (float)our; sums[l] = (float)(other + our);
+          }
+          const float hs = hero_hsum(sums);
+#pragma unroll
+          for(int l=0;l<MI_MF;l++) w[l] = ours[l]/hs;
+        }
+        else
+        { /* sampler_mis, pt.c:30-38 */
+          float fp[4];
+#pragma unroll
+          for(int l=0;l<MI_MF;l++) fp[l] = (float)pp[l];
+          const float hs = hero_hsum(fp);
+#pragma unroll
+          for(int l=0;l<MI_MF;l++) w[l] = fp[l]/hs;
+        }
+#pragma unroll
+        for(int l=0;l<MI_MF;l++) value[l] = PTDL ? path_throughput[l]*w[l] : w[l]*path_throughput[l];
+        float col[3];
+        const bool ok = hero_splat_colour(sc, lam, value, col);
+        if(RECORD && rec->num_splats < MI_REC_MAX_SPLATS)
+        {
+          if(sc.hero_ext) for(int l=0;l<MI_MF;l++) sc.hero_ext[slot].splat_value[rec->num_splats][l] = value[l];
+          mi_path_splat &sp = rec->splat[rec->num_splats++];
+          sp.length = ps.length; sp.tech = s_tech_extend; sp.value = value[0];
+          sp.col[0] = col[0]; sp.col[1] = col[1]; sp.col[2] = col[2];
+        }
+        if(ok)
+        {
+          MI_COUNT(cnt, 5, 1);
+          if(!RECORD) { splat.pending = true; splat.c0 += col[0]; splat.c1 += col[1]; splat.c2 += col[2]; }
+        }
+        if(!PTDL && ps.length > 3)
+        { /* path_russian_roulette on the hero's throughputs (pt.c:50: mf(throughput, 0)); all four are scaled */
+          const float p_survival = DMIN(1.0f, vthr[0]/ps.prev_throughput);
+          PointSampler<false> pts(sc, ps.rng, ps.index, rand_beg_extend<PTDL>(v));
+          const float rr = pts(MI_DIM_RUSSIAN_R);
+          const float scale = rr >= p_survival ? mi_rcp(1.0f-p_survival) : mi_rcp(p_survival);
+          if(rr >= p_survival) alive = false;
+#pragma unroll
+          for(int l=0;l<MI_MF;l++) vthr[l] = vthr[l]*scale;
+          if(RECORD && v < MI_REC_MAX_VERTS)
+          {
+            float rp[4];
+#pragma unroll
+            for(int l=0;l<MI_MF;l++) rp[l] = alive ? vpdf[l]*p_survival : vpdf[l]*(1.0f-p_survival);
+            rec->v[v].throughput = vthr[0]; rec->v[v].pdf = rp[0];
+            hero_rec_vertex<RECORD>(sc, slot, v, vthr, rp, sh, eta);
+          }
+        }
+      }
+      {
+        const float eps0 = DMAX(DMAX(.5f, fabsf(sf.x.x)), DMAX(fabsf(sf.x.y), fabsf(sf.x.z)))*1e-4f;
+        ps.prev_x = sf.x; ps.org_eps = eps0; ps.ignore = hit.prim;
+        if(!PTDL) ps.org = sf.x;
+        ps.prev_cos = 0.0f; ps.throughput = 0.0f; ps.pdf = 0.0f;
+        ps.prev_material_modes = material_modes;
+      }
+      if(PTDL && ps.length >= (int)sc.max_verts) alive = false;
+      if(PTDL && alive)
+      { /* next event estimation */
+        (void)rng_next(ps.rng);
+        if(material_modes & (s_diffuse | s_glossy))
+        {
+          PointSampler<false> pts(sc, ps.rng, ps.index, rand_beg_nee(v + 1));
+          const float rnd = pts(MI_DIM_NEE_LIGHT1);
+          if(!(rnd < sc.p_sky) && rnd < sc.p_sky + sc.p_geo)
+          {
+            const float r3 = pts(MI_DIM_NEE_Y);
+            const float r2 = pts(MI_DIM_NEE_X);
+            const float r1 = pts(MI_DIM_NEE_LIGHT2);
+            uint32_t lpe;
+            Surf ls;
+            float lem[4], lrough;
+            float lpdf, ldist;
+            V3 ol;
+            { /* one-burst emitter records, as in the plain kernels (every scene the HERO kernels accept has them: mi_scene_set_wavelengths) */
+              const uint32_t t = sc.num_lights <= 4 ? sample_cdf4(sc.light_cdf4, (int)sc.num_lights, r1) : sample_cdf(sc.light_cdf, (int)sc.num_lights, r1);
+              float4 q0, q1, q2, q3, q4, q5, q6, q7, q8, q9;
+              if(MI_LIGHTS_LDS && sc.num_lights <= MI_LIGHTS_LDS)
+              {
+                const float4 *lq = lights_lds<false>() + t*(uint32_t)(sizeof(DLight)/16);
+                q0 = lq[0]; q1 = lq[1]; q2 = lq[2]; q3 = lq[3]; q4 = lq[4]; q5 = lq[5]; q6 = lq[6]; q7 = lq[7]; q8 = lq[8]; q9 = lq[9];
+              }
+              else
+              {
+                const float4 *lq = (const float4 *)(sc.lights + t);
+                q0 = lq[0]; q1 = lq[1]; q2 = lq[2]; q3 = lq[3]; q4 = lq[4]; q5 = lq[5]; q6 = lq[6]; q7 = lq[7]; q8 = lq[8]; q9 = lq[9];
+              }
+              lpe = __float_as_uint(q9.x);
+              const bool quad = __float_as_uint(q9.y) == MI_PRIM_QUAD;
+              const V3 v0 = mk3(q0.x, q0.y, q0.z), v1 = mk3(q0.w, q1.x, q1.y), v2 = mk3(q1.z, q1.w, q2.x), v3 = mk3(q2.y, q2.z, q2.w);
+              float hu, hv;
+              if(quad) { hu = r2; hv = r3; }
+              else { const float a = mi_sqrt(r2); hu = r3*a; hv = (1.0f-r3)*a; }
+              const bool second = quad && !(hv >= hu);
+              const float u = second ? hu - hv : hu;
+              const float vv = !quad ? hv : second ? hv : hv - hu;
+              ls.x = second ? tri_retime(v0, v2, v3, u, vv) : tri_retime(v0, v1, v2, u, vv);
+              ls.u = hu; ls.v = hv;
+              ol = sub3(ls.x, sf.x);
+              ldist = mi_sqrt(dot3(ol, ol));
+              const double il = 1./(double)ldist;
+              ol = mk3((float)((double)ol.x*il), (float)((double)ol.y*il), (float)((double)ol.z*il));
+              const V3 n0 = mk3(q3.x, q3.y, q3.z);
+              const V3 na = second ? mk3(q4.z, q4.w, q5.x) : mk3(q3.w, q4.x, q4.y);
+              const V3 nb = second ? mk3(q5.y, q5.z, q5.w) : mk3(q4.z, q4.w, q5.x);
+              ls.gn = second ? mk3(q6.w, q7.x, q7.y) : mk3(q6.x, q6.y, q6.z);
+              const float w = 1.0f - u - vv;
+              ls.n = normalise3(mk3(u*nb.x + vv*na.x + w*n0.x, u*nb.y + vv*na.y + w*n0.y, u*nb.z + vv*na.z + w*n0.z));
+              ls.flags = 0;
+              const float ec[3] = { q7.z, q7.w, q8.x };
+#pragma unroll
+              for(int l=0;l<MI_MF;l++) lem[l] = q8.y*spectrum_eval(ec, lam[l]);
+              lrough = q8.z;
+              lpdf = q8.w;
+            }
+            float edf[4];
+            {
+              double dir_term;
+              if(lrough > 1.0f-1e-4f) dir_term = (double)1.0f/MI_PI_D;
+              else
+              {
+                const float phongexp = 2.0f/(lrough*lrough) - 2.0f;
+                dir_term = (double)(powf(-dot3(ls.gn, ol), phongexp)*(phongexp + 2.0f))/(2.0f*MI_PI_D);
+              }
+#pragma unroll
+              for(int l=0;l<MI_MF;l++) edf[l] = (float)((double)(lem[l]/lpdf)*dir_term);
+            }
+            lpdf = lpdf*sc.p_geo;
+#pragma unroll
+            for(int l=0;l<MI_MF;l++) edf[l] = edf[l]/sc.p_geo;
+            if(edf[0] > 0.0f || edf[1] > 0.0f || edf[2] > 0.0f || edf[3] > 0.0f)                       /* mf_any(edf > 0), nee.h:188 */
+            {
+              BsdfEval be[4];
+#pragma unroll
+              for(int l=0;l<MI_MF;l++)
+              {
+                hc.lane = l;
+                if(mat_bsdf == MI_BSDF_DIFFUSE) be[l] = brdf_diffuse(sf, sh[l], ol);
+                else if(mat_bsdf == MI_BSDF_DIELECTRIC) be[l] = brdf_dielectric<true>(sf, sh[l], omega, ol, eta[l], &hc);
+                else be[l] = brdf_metal(sc, sf, sh[l], omega, ol, ior[l], (int)mat_p0, lam[l]);
+              }
+              bool okn = be[0].value > 0.0f || be[1].value > 0.0f || be[2].value > 0.0f || be[3].value > 0.0f;   /* mf_any(bsdf > 0), nee.h:191 */
+              if(okn && (be[0].mode & s_transmit))
+              {
+                Media hyp = ps.media;
+                media_apply(hyp, shape, (sf.flags & s_inside) != 0);
+                if(hyp.broken) okn = false;
+              }
+              if(okn)
+              {
+                const float eps = 1e-4f*DMAX(DMAX(.5f, fabsf(sf.x.x)), DMAX(fabsf(sf.x.y), fabsf(sf.x.z)));
+                V3 rd = sub3(ls.x, sf.x);
+                rd = scale3(rd, mi_rcp(mi_sqrt(dot3(rd, rd))));
+                const V3 ro = mk3(sf.x.x + eps*rd.x, sf.x.y + eps*rd.y, sf.x.z + eps*rd.z);
+                const V3 dv = mk3(ls.x.x - eps*rd.x - ro.x, ls.x.y - eps*rd.y - ro.y, ls.x.z - eps*rd.z - ro.z);
+                const float total_dist = mi_sqrt(dot3(dv, dv));
+                if(!(dot3(ls.gn, rd) >= 0) && total_dist > 0.0f)
+                {
+                  const float Gn = fabsf(dot3(sf.n, ol))*fabsf(dot3(ls.n, ol))/(ldist*ldist);
+                  float tn[4], ours[4], sums[4];
+                  const float wn = lpdf/(lpdf + 0.0f/1.0f);
+#pragma unroll
+                  for(int l=0;l<MI_MF;l++)
+                  {
+                    hc.lane = l;
+                    float t = ((vthr[l]*be[l].value)*(1.0f*edf[l]))*Gn;
+                    t = t + (vthr[l]*be[l].value)*((0.0f*Gn)/lpdf);
+                    tn[l] = t*wn;
+                    float pb;
+                    if(mat_bsdf == MI_BSDF_DIFFUSE) pb = (float)(1.0f/MI_PI_D);
+                    else if(mat_bsdf == MI_BSDF_DIELECTRIC) pb = pdf_dielectric<true>(sf, sh[l], omega, ol, eta[l], be[0].mode, &hc);
+                    else pb = pdf_metal(sf, sh[l], omega, ol, be[0].mode);
+                    const float pe = (1.0f*pb)*Gn;
+                    const double our = (double)(1.0f*lpdf)*pp[l], other = (double)pe*pp[l];
+                    ours[l] = (float)our; sums[l] = (float)(other + our);
+                  }
+                  const float hs = hero_hsum(sums);
+                  if(tn[0]/1.0f > 0.0f || tn[1]/1.0f > 0.0f || tn[2]/1.0f > 0.0f || tn[3]/1.0f > 0.0f)   /* mf_any(throughput > 0), ptdl.c:142 */
+                  {
+                    ps.sh_pending = 1;
+                    ps.prev_x = sf.x; ps.org_eps = eps;
+                    ps.sh_dir = rd; ps.sh_dist = total_dist;
+                    ps.sh_light = lpe; ps.ignore = hit.prim;
+                    ps.sh_value = (tn[0]/1.0f)*(ours[0]/hs);
+#pragma unroll
+                    for(int l=1;l<MI_MF;l++) ps.sh_value_x[l-1] = (tn[l]/1.0f)*(ours[l]/hs);
+                    ps.sh_length = ps.length + 1;
+                  }
+                }
+              }
+            }
+          }
+        }
+      }
+      if(alive && ps.length >= (int)sc.max_verts) alive = false;
+      if(alive && !(vthr[0] > 0.0f || vthr[1] > 0.0f || vthr[2] > 0.0f || vthr[3] > 0.0f))             /* !mf_any(throughput > 0), src/pathspace.c:189 */
+      {
+        alive = false;
+        if(RECORD && v < MI_REC_MAX_VERTS)
+        {
+          rec->v[v].throughput = 0.0f; rec->v[v].mode = s_absorb;
+          if(sc.hero_ext) for(int l=0;l<MI_MF;l++) sc.hero_ext[slot].throughput[v][l] = 0.0f;
+        }
+      }
+      if(alive)
+      {
+        BsdfSample bs[4];
+        get_scrambled_onb(ps.scramble, sf.n, sf.a, sf.b);
+        PointSampler<false> pts(sc, ps.rng, ps.index, rand_beg_extend<PTDL>(v + 1));
+        HeroPoints<PointSampler<false> > hp(pts, hc);
+#pragma unroll
+        for(int l=0;l<MI_MF;l++)
+        {
+          hc.lane = l; hc.k = 0;
+          if(mat_bsdf == MI_BSDF_DIFFUSE) sample_diffuse<HeroPoints<PointSampler<false> >, true>(hp, sf, sh[l], mode, bs[l], &hc);
+          else if(mat_bsdf == MI_BSDF_DIELECTRIC) sample_dielectric<HeroPoints<PointSampler<false> >, true>(hp, sf, sh[l], omega, eta[l], mode, bs[l], &hc);
+          else sample_metal<HeroPoints<PointSampler<false> >, true>(sc, hp, sf, sh[l], omega, ior[l], (int)mat_p0, lam[l], mode, bs[l]);
+        }
+        const V3 out = normalise3(bs[0].omega);
+        const float dts = ((sf.flags & s_inside) ? -1 : 1)*dot3(sf.gn, out);
+        const bool wrong_side = ((bs[0].mode & s_reflect) && (dts < 0.f)) || ((bs[0].mode & s_transmit) && (dts > 0.f));
+        float nthr[4];
+#pragma unroll
+        for(int l=0;l<MI_MF;l++) nthr[l] = vthr[l]*(wrong_side ? 0.0f : bs[l].weight);
+        uint32_t vmode = bs[0].mode;
+        bool ok = !(nthr[0] <= 0.0f && nthr[1] <= 0.0f && nthr[2] <= 0.0f && nthr[3] <= 0.0f);         /* mf_all(throughput <= 0), src/pathspace.c:253 */
+        if(ok && (vmode & s_transmit))
+        {
+          media_apply(ps.media, shape, (sf.flags & s_inside) != 0);
+          if(ps.media.broken) ok = false;
+          else
+          {
+            const int top = media_top_shape(ps.media);
+#pragma unroll
+            for(int l=0;l<MI_MF;l++) ior[l] = shape_interior_ior(sc, shape_material, top, lam[l]);
+          }
+        }
+        if(!ok)
+        {
+          alive = false;
+          if(!(vmode & s_emit)) vmode = s_absorb;
+        }
+        if(RECORD && v < MI_REC_MAX_VERTS) rec->v[v].mode = vmode;
+        if(alive)
+        {
+          const float eps = DMAX(DMAX(.5f, fabsf(sf.x.x)), DMAX(fabsf(sf.x.y), fabsf(sf.x.z)))*1e-4f;
+          ps.org = mk3(sf.x.x + eps*out.x, sf.x.y + eps*out.y, sf.x.z + eps*out.z);
+          ps.dir = out;
+          ps.ignore = hit.prim;
+          ps.prev_x = sf.x; ps.org_eps = eps;
+          ps.prev_cos = fabsf(dot3(sf.n, out));
+          ps.prev_throughput = vthr[0];
+          ps.prev_mode = vmode;
+          ps.prev_material_modes = material_modes;
+          ps.throughput = nthr[0]; ps.pdf = bs[0].pdf; ps.cur_ior = ior[0];
+#pragma unroll
+          for(int l=1;l<MI_MF;l++) { ps.throughput_x[l-1] = nthr[l]; ps.pdf_x[l-1] = bs[l].pdf; ps.cur_ior_x[l-1] = ior[l]; }
+        }
+      }
+    }
+  }
+  ps.pdfprod = pp[0]; ps.pdfprod_x[0] = pp[1]; ps.pdfprod_x[1] = pp[2]; ps.pdfprod_x[2] = pp[3];
+  if(!alive) { ps.active = 0; cnt.c[4]++; }
+}
+
+#endif

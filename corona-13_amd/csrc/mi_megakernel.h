@@ -10,7 +10,9 @@
 #define MI_MEGAKERNEL_H
 
 #include "mi_path.h"
+#include "mi_hero.h"
 #include "mi_regroup.h"
+#include <type_traits>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -117,7 +119,7 @@
 #endif
 
 /* ======================================================================================= persistent megakernel */
-template<bool RECORD, bool PTDL, bool NODES_LDS, bool HALTON = false, bool MEDIA = false, bool MB = false, bool COUNT = true, bool FAST = false, bool NORG = false>
+template<bool RECORD, bool PTDL, bool NODES_LDS, bool HALTON = false, bool MEDIA = false, bool MB = false, bool COUNT = true, bool FAST = false, bool NORG = false, bool HERO = false>
 __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned long long first, unsigned long long count,
                                                            const uint32_t *shape_material, const float *shape_L, mi_path_record *records,
                                                            uint2 *stack_overflow)
@@ -132,7 +134,9 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
   /* material queues (mi_regroup.h): the plain kernels trade surface vertices between the waves of the workgroup, by class of the material */
   /* NORG: the extended kernels once more WITHOUT the exchange, for scenes in a scattering exterior medium (a global fog): nearly every vertex
      is a volume vertex there, the exchange has nothing to sort, and its code costs that kernel 26 more spilled registers (fog ptdl 124 against 115 ms) */
-  constexpr bool REGROUP = MI_REGROUP && (!MB || MI_REGROUP_MB) && !NORG && (!MEDIA || MI_REGROUP_MEDIA);
+  /* HERO (mi_hero.h): four wavelengths per path, plain scenes. The LDS layout is the plain kernels' (the scene was laid out for them), the pools stay empty */
+  static_assert(!HERO || (!MEDIA && !MB && !HALTON && !FAST && !NORG), "hero wavelengths: plain scenes, rand point sampler, exact rounds");
+  constexpr bool REGROUP = MI_REGROUP && (!MB || MI_REGROUP_MB) && !NORG && (!MEDIA || MI_REGROUP_MEDIA) && !HERO;
   __shared__ PoolCtl pool_ctl;
   if(threadIdx.x == 0) blk_next = 0;
   Pool pool;
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
   static_assert(STACK >= MI_STACK_MIN, "the overflow area is sized for MI_STACK_MIN entries in LDS (mi_abi.hip)");
   static_assert(!(CHAIN && PARK_PS), "a chained lane draws the free-flight distance of its extension ray inside the slice: the generator must not be parked");
   Counters<COUNT || RECORD> cnt;        /* COUNT = false: only the path count (see Counters, mi_kernels.h) */
-  PathState ps;
+  typename std::conditional<HERO, PathStateHero, PathState>::type ps;
   ps.active = 0;
   ps.sh_pending = 0;
   bool exhausted = false;
@@ -218,8 +222,10 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
             { /* tile-owned sharding (mi_render_tiles): the launch's items are pixels of this member's tiles, tile_path() names their paths */
               float px, py;
               const unsigned long long index = tile_path(sc, first + i, px, py);
-              path_generate<RECORD, HALTON, MEDIA>(sc, ps, index, nullptr, cnt, px, py);
+              if constexpr(HERO) path_generate_hero<RECORD>(sc, ps, index, nullptr, 0ull, cnt, px, py);
+              else path_generate<RECORD, HALTON, MEDIA>(sc, ps, index, nullptr, cnt, px, py);
             }
+            else if constexpr(HERO) path_generate_hero<RECORD>(sc, ps, first + i, RECORD ? records + i : nullptr, i, cnt);
             else path_generate<RECORD, HALTON, MEDIA>(sc, ps, first + i, RECORD ? records + i : nullptr, cnt);
           }
           else exhausted = true;
@@ -375,7 +381,13 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
     {
       tracing = false;
       mi_path_record *rec = RECORD ? records + (ps.index - first) : nullptr;
-      if(tr_shadow) shadow_resolve<RECORD>(sc, ps, hit, rec, cnt, splat);
+      if constexpr(HERO)
+      {
+        const unsigned long long slot = RECORD ? ps.index - first : 0ull;
+        if(tr_shadow) shadow_resolve_hero<RECORD>(sc, ps, hit, rec, slot, cnt, splat);
+        else path_shade_hero<RECORD, PTDL>(sc, ps, hit, shape_material, shape_L, rec, slot, cnt, splat);
+      }
+      else if(tr_shadow) shadow_resolve<RECORD>(sc, ps, hit, rec, cnt, splat);
       else
       {
         if(CHAIN && ps.sh_pending == 2) shadow_splat<RECORD>(sc, ps, rec, cnt, splat);      /* the connection made at the vertex this ray left */
@@ -486,7 +498,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_intersect_kernel(DScene sc, const
 
 
 /* ---------------------------------------------------------------------------------------- kernel table
- * A part = one (PTDL, MEDIA, MB, FAST, NORG); inside it `which` selects bit 0 RECORD, 1 NODES_LDS, 2 HALTON, 3 COUNT. MB implies MEDIA and
+ * A part = one (PTDL, MEDIA, MB, FAST, NORG, HERO); inside it `which` selects bit 0 RECORD, 1 NODES_LDS, 2 HALTON, 3 COUNT. MB implies MEDIA and
  * has no FAST rounds (its leaf phase stays per lane); the RECORD kernels always count.
  * MI_DEV_FAST (development builds, tools/variants.sh): only the plain tree-in-LDS kernels (2: with the Halton ones) -- the other
  * parts compile to stubs. L = NULL: return the kernel's address without launching (hipFuncSetAttribute). */
@@ -507,7 +519,7 @@ struct PathLaunch
 #define MI_WHICH_HALTON 4u
 #define MI_WHICH_COUNT 8u
 
-template<bool PTDL, bool MEDIA, bool MB, bool FAST, bool NORG = false> const void *mi_path_part(unsigned which, const PathLaunch *L);
+template<bool PTDL, bool MEDIA, bool MB, bool FAST, bool NORG = false, bool HERO = false> const void *mi_path_part(unsigned which, const PathLaunch *L);
 
 static inline bool mi_path_which_valid(unsigned which)
 {
@@ -519,30 +531,30 @@ static inline bool mi_path_which_valid(unsigned which)
 }
 
 #ifdef MI_PART_DEFINE
-template<bool PTDL, bool MEDIA, bool MB, bool FAST, bool NORG, bool R, bool N, bool H, bool C> static const void *mi_path_go(const PathLaunch *L)
+template<bool PTDL, bool MEDIA, bool MB, bool FAST, bool NORG, bool HERO, bool R, bool N, bool H, bool C> static const void *mi_path_go(const PathLaunch *L)
 {
-  constexpr bool valid = !(MB && !MEDIA) && !(MB && FAST) && !(R && !C) && !(NORG && (!MEDIA || MB))
+  constexpr bool valid = !(MB && !MEDIA) && !(MB && FAST) && !(R && !C) && !(NORG && (!MEDIA || MB)) && !(HERO && (MEDIA || MB || FAST || NORG || H))
 #ifdef MI_DEV_FAST
                          && (!H || MI_DEV_FAST == 2) && !MEDIA && !MB && N
 #endif
                          ;
   if constexpr(valid)
   {
-    if(L) hipLaunchKernelGGL((mi_path_kernel<R, PTDL, N, H, MEDIA, MB, C, FAST, NORG>), dim3(L->grid), dim3(MI_BLOCK), L->lds_bytes, L->stream, L->d, L->first, L->n,
+    if(L) hipLaunchKernelGGL((mi_path_kernel<R, PTDL, N, H, MEDIA, MB, C, FAST, NORG, HERO>), dim3(L->grid), dim3(MI_BLOCK), L->lds_bytes, L->stream, L->d, L->first, L->n,
                              L->shape_material, L->shape_L, L->rec, L->overflow);
-    return (const void *)mi_path_kernel<R, PTDL, N, H, MEDIA, MB, C, FAST, NORG>;
+    return (const void *)mi_path_kernel<R, PTDL, N, H, MEDIA, MB, C, FAST, NORG, HERO>;
   }
   else { fprintf(stderr, "[mi] internal: kernel variant not built\n"); abort(); }
 }
-template<bool PTDL, bool MEDIA, bool MB, bool FAST, bool NORG, int LEFT, bool... B> static const void *mi_path_pick(unsigned which, const PathLaunch *L)
+template<bool PTDL, bool MEDIA, bool MB, bool FAST, bool NORG, bool HERO, int LEFT, bool... B> static const void *mi_path_pick(unsigned which, const PathLaunch *L)
 {
-  if constexpr(LEFT == 0) return mi_path_go<PTDL, MEDIA, MB, FAST, NORG, B...>(L);
-  else return (which & 1u) ? mi_path_pick<PTDL, MEDIA, MB, FAST, NORG, LEFT - 1, B..., true>(which >> 1, L)
-                           : mi_path_pick<PTDL, MEDIA, MB, FAST, NORG, LEFT - 1, B..., false>(which >> 1, L);
+  if constexpr(LEFT == 0) return mi_path_go<PTDL, MEDIA, MB, FAST, NORG, HERO, B...>(L);
+  else return (which & 1u) ? mi_path_pick<PTDL, MEDIA, MB, FAST, NORG, HERO, LEFT - 1, B..., true>(which >> 1, L)
+                           : mi_path_pick<PTDL, MEDIA, MB, FAST, NORG, HERO, LEFT - 1, B..., false>(which >> 1, L);
 }
-template<bool PTDL, bool MEDIA, bool MB, bool FAST, bool NORG> const void *mi_path_part(unsigned which, const PathLaunch *L)
+template<bool PTDL, bool MEDIA, bool MB, bool FAST, bool NORG, bool HERO> const void *mi_path_part(unsigned which, const PathLaunch *L)
 {
-  return mi_path_pick<PTDL, MEDIA, MB, FAST, NORG, 4>(which, L);
+  return mi_path_pick<PTDL, MEDIA, MB, FAST, NORG, HERO, 4>(which, L);
 }
 #endif
 

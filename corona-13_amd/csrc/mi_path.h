@@ -150,8 +150,9 @@ __device__ __forceinline__ unsigned long long tile_path(const DScene &sc, unsign
   return (f*sc.height + y)*sc.width + x;
 }
 
-template<bool RECORD, bool HALTON, bool MEDIA, class CNT>
-__device__ __forceinline__ void path_generate(const DScene &sc, PathState &ps, unsigned long long index, mi_path_record *rec, CNT &cnt, float px = -1.0f, float py = -1.0f)
+template<bool RECORD, bool HALTON, bool MEDIA, class CNT, bool HERO = false>
+__device__ __forceinline__ void path_generate(const DScene &sc, PathState &ps, unsigned long long index, mi_path_record *rec, CNT &cnt, float px = -1.0f, float py = -1.0f,
+                                              float *lambda_x = nullptr)
 {
   /* path_init + first half of path_extend (length == 0), src/pathspace.c:13-28,210-249 */
   MI_BLK(cnt, 0)
@@ -163,6 +164,11 @@ __device__ __forceinline__ void path_generate(const DScene &sc, PathState &ps, u
   const float lf0 = pts.template camera<MI_DIM_LAMBDA>() + 0/(float)1;
   const float lf = lf0 < 1.0f ? lf0 : fmodf(lf0, 1.0f);     /* fmodf(x, 1) == x for 0 <= x < 1; the libm loop only runs otherwise */
   ps.lambda = 360 + (830 - 360)*lf;
+  if(HERO)
+  { /* MF_COUNT = 4, src/pathspace.c:218-221: the point sampler is asked once PER COMPONENT, component l takes fmodf(number l + l/4, 1) */
+#pragma unroll
+    for(int l=1;l<4;l++) lambda_x[l-1] = 360 + (830 - 360)*fmodf(pts.template camera<MI_DIM_LAMBDA>() + l/(float)4, 1.0f);
+  }
   const float time = pts.template camera<MI_DIM_TIME>()*sc.cam.time_scale;
   if(!HALTON) { (void)rng_next(ps.rng); (void)rng_next(ps.rng); }   /* view_sample_camid twice (one camera): src/pathspace.c:226, src/view.c:846-847 */
   /* camera_sample, src/camera.d/thinlens.c:68-128; everything that does not depend on the random numbers is in sc.cc */

@@ -312,6 +312,31 @@ typedef struct mi_path_record
 } mi_path_record;
 int  mi_trace_paths(mi_scene *s, uint64_t first_index, uint64_t count, mi_path_record *host_out);
 
+/* Hero wavelengths: four wavelengths per path.
+ * replaces: the compile-time switch MF_COUNT of the reference (include/mf.h:280-423; `-DMF_COUNT=4` in a build's config): every spectral
+ * quantity of a path becomes a vector of four. path_init draws one wavelength per component (src/pathspace.c:218-221); component 0, the hero,
+ * decides sampling, Russian roulette and geometry (dielectric.c:293,326-328; pt.c:50); throughputs and pdfs are kept per component (a rough
+ * transmission re-derives its half vector per component, dielectric.c:353-411; a specular one keeps one component, :331-343); the MIS weight
+ * of a technique is its pdf over the SUM of all techniques' pdfs at all four wavelengths (pt.c:30-38, ptdl.c:78-88); view_splat adds the four
+ * colours (src/view.c:455-463, include/spectrum.h:185-195). Same expected image as one wavelength per path (measured on the reference:
+ * tests/golden/mf4_vs_mf1_measured.json), less colour noise per path.
+ *   mi_scene_set_wavelengths(s, MI_WAVELENGTHS_HERO): the renders and traces that follow run the HERO kernels; (s, 1) goes back.
+ * Only for what the reference's MF_COUNT = 4 build was pinned on (tests/test_oracle_hero.py): scenes without media, moving primitives or a
+ * moving camera, with the `rand` point sampler -- MI_ERR_UNSUPPORTED otherwise, nothing changes. Path i of a hero render is NOT path i of a
+ * scalar render: three more numbers are drawn before the camera sample.
+ *   mi_trace_paths_hero: mi_trace_paths, plus (ext != NULL) all four components of what the record holds for component 0 -- the layout of
+ * the reference-side dump harness' extension block (oracle/refharness/render_dump.c built with -DMF_COUNT=4). */
+#define MI_WAVELENGTHS_HERO 4
+typedef struct mi_hero_ext
+{
+  float lambda[MI_WAVELENGTHS_HERO];
+  float throughput[MI_REC_MAX_VERTS][MI_WAVELENGTHS_HERO], pdf[MI_REC_MAX_VERTS][MI_WAVELENGTHS_HERO];
+  float rd[MI_REC_MAX_VERTS][MI_WAVELENGTHS_HERO], rg[MI_REC_MAX_VERTS][MI_WAVELENGTHS_HERO], em[MI_REC_MAX_VERTS][MI_WAVELENGTHS_HERO], eta[MI_REC_MAX_VERTS][MI_WAVELENGTHS_HERO];
+  float splat_value[MI_REC_MAX_SPLATS][MI_WAVELENGTHS_HERO];
+} mi_hero_ext;
+int  mi_scene_set_wavelengths(mi_scene *s, int count);
+int  mi_trace_paths_hero(mi_scene *s, uint64_t first_index, uint64_t count, mi_path_record *host_out, mi_hero_ext *host_ext);
+
 /* Test hook: closest hit of n caller-supplied rays, i.e. accel_intersect (src/accel.d/qbvhmp.c:1262-1390)
  * + prims_intersect (src/prims.c:638-672) on their own. `ignore` is the builder-order index of the primitive
  * the ray starts on (ray_t.ignore, include/corona_common.h) or MI_RAY_NO_IGNORE; `max_dist` initialises hit.dist.
