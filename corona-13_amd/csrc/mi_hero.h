@@ -113,6 +113,475 @@ __device__ __forceinline__ void shadow_resolve_hero(const DScene &sc, PathStateH
   if(visible) shadow_splat_hero<RECORD>(sc, ps, rec, slot, cnt, splat);
 }
 
+/* ------------------------------------------------------------------------------------------ the bsdfs for four components
+ * The scalar kernels' functions (mi_kernels.h: sample_* / brdf_* / pdf_*) with the geometry -- the microfacet, the outgoing direction, the
+ * shadowing terms -- computed once and the wavelength-dependent part (index of refraction, Fresnel term, colour) in a loop over the
+ * components, expression for expression what the scalar function computes for that component. */
+struct HeroSample
+{
+  V3 omega;
+  uint32_t mode;
+  float pdf[MI_MF], weight[MI_MF];
+};
+struct HeroEval { float value[MI_MF]; uint32_t mode; };
+
+template<class PS>
+__device__ __forceinline__ void sample_diffuse_hero(PS &pts, const Surf &sf, const Shading *sh, bool any_rd, uint32_t mode_in, HeroSample &bs)
+{ /* sample_d, src/shader.c:165-205 */
+  const float x1 = pts(MI_DIM_OMEGA_X);
+  const float x2 = pts(MI_DIM_OMEGA_Y);
+  const float sq = mi_sqrt(x1);
+  const float c0 = mi_sqrt((float)(1.0 - (double)x1));
+  const float ang = (float)(2*MI_PI_D*(double)x2);
+  float sn, cs;
+  mi_sincosf(ang, &sn, &cs);
+  const float c1 = sq*cs, c2 = sq*sn;
+  bs.omega = mk3(c0*sf.n.x + c1*sf.a.x + c2*sf.b.x, c0*sf.n.y + c1*sf.a.y + c2*sf.b.y, c0*sf.n.z + c1*sf.a.z + c2*sf.b.z);
+  bs.mode = mode_in;
+#pragma unroll
+  for(int l=0;l<MI_MF;l++) { bs.pdf[l] = (float)(1.0f/MI_PI_D); bs.weight[l] = 0.0f; }
+  const float cos_out_ng = dot3(sf.gn, bs.omega);
+  if(sf.flags & s_inside) { if(cos_out_ng >= 0.0f) return; }
+  else if(cos_out_ng <= 0.0f) return;
+#pragma unroll
+  for(int l=0;l<MI_MF;l++) bs.weight[l] = sh[l].rd;
+  if(any_rd) bs.mode = s_diffuse | s_reflect;                      /* mf_any(mf_gt(throughput, 0)), src/shader.c:202 */
+}
+
+template<class PS>
+__device__ __forceinline__ void sample_dielectric_hero(PS &pts, const Surf &sf, const Shading *sh, const V3 wi, const float *eta, bool any_im,
+                                                       uint32_t mode_in, HeroSample &bs)
+{ /* sample, dielectric.c:240-415 with MF_COUNT = 4: the microfacet, the reflect / transmit choice and the outgoing direction are the hero's
+     (mf(eta_ratio, 0), mf(R, 0), mf(cost2, 0), mf(cost, 0)); every component weighs that direction with its own index of refraction */
+  bs.mode = mode_in; bs.omega = mk3(0, 0, 0);
+#pragma unroll
+  for(int l=0;l<MI_MF;l++) { bs.weight[l] = 0.0f; bs.pdf[l] = 1.0f; }
+  if(eta[0] < 0.0f) return;
+  if(any_im)
+  {
+    bs.omega = wi;
+    bs.mode = s_specular | s_transmit;
+#pragma unroll
+    for(int l=0;l<MI_MF;l++) bs.weight[l] = sh[l].rg;
+    return;
+  }
+  const V3 n = sf.n;
+  float pdf_h = 1.0f;
+  V3 h = n;
+  const float r = sh[0].roughness;
+  const float cos_in = -dot3(sf.n, wi);
+  if(r > GLOSSY_THR)
+  {
+    const V3 wit = mk3(-dot3(sf.a, wi), -dot3(sf.b, wi), cos_in);
+    /* the MF_COUNT = 4 reference: this plugin only builds with clang, which evaluates call arguments left to right (tests/test_oracle_hero.py);
+       the scalar build (gcc) draws them the other way round */
+    const float U1 = pts(MI_DIM_OMEGA_X);
+    const float U2 = pts(MI_DIM_OMEGA_Y);
+    const V3 ht = ggx_sample_h(wit, r, r, U1, U2);
+    h = mk3(ht.x*sf.a.x + ht.y*sf.b.x + ht.z*n.x, ht.x*sf.a.y + ht.y*sf.b.y + ht.z*n.y, ht.x*sf.a.z + ht.y*sf.b.z + ht.z*n.z);
+    pdf_h = ggx_pdf_h(wi, h, n, r);
+  }
+  float pdf = pdf_h;
+  const float cosr = -dot3(wi, h);
+  if(cosr <= 0.0f) return;
+  const float n2 = 1.0f;
+  float cost2[MI_MF], cost[MI_MF], R[MI_MF];
+#pragma unroll
+  for(int l=0;l<MI_MF;l++)
+  {
+    const float nr = eta[l]/n2;
+    cost2[l] = 1.0f - (nr*nr)*(1.0f - cosr*cosr);
+    cost[l] = cost2[l] <= 0.0f ? 0.0f : mi_sqrt(cost2[l]);
+    R[l] = fresnel_dielectric(eta[l], n2, cosr, cost[l]);
+  }
+  if(pts(MI_DIM_SCATTER_MODE) <= R[0])
+  {
+    bs.mode = s_reflect;
+    bs.omega = mk3(wi.x + 2.0f*cosr*h.x, wi.y + 2.0f*cosr*h.y, wi.z + 2.0f*cosr*h.z);
+    if(dot3(bs.omega, n) <= 0.0f) return;
+    pdf *= mi_rcp(4.0f*cosr);
+    if(r > GLOSSY_THR)
+    {
+      const float pdf_c = pdf/fabsf(dot3(bs.omega, n));
+#pragma unroll
+      for(int l=0;l<MI_MF;l++) bs.pdf[l] = R[l]*pdf_c;
+      bs.mode |= s_glossy;
+      if(dot3(bs.omega, n)*dot3(bs.omega, h) < 0.0f) return;
+      const float G1 = ggx_G1(bs.omega, n, r);
+#pragma unroll
+      for(int l=0;l<MI_MF;l++) bs.weight[l] = sh[l].rg*G1;
+      return;
+    }
+    bs.mode = s_reflect | s_specular;
+#pragma unroll
+    for(int l=0;l<MI_MF;l++) { bs.pdf[l] = R[l]; bs.weight[l] = sh[l].rg; }
+  }
+  else
+  {
+    if(cost2[0] <= 0.0f) return;                                     /* "can't sample hero, we're all dead" */
+    const float f = eta[0]*cosr - cost[0];
+    bs.omega = normalise3(mk3(wi.x*eta[0] + f*h.x, wi.y*eta[0] + f*h.y, wi.z*eta[0] + f*h.z));
+    if(dot3(bs.omega, n) >= 0.0f) return;
+    if(r <= GLOSSY_THR)
+    { /* "specular transmit always selects single wavelength": mask = mf_hero = _mm_set_epi32(0, ~0, ~0, ~0) (include/mf.h:300) zeroes the
+         components whose mask is set, and _mm_set_epi32 lists the highest element first -- components 0, 1, 2 die, component 3 carries on */
+      bs.mode = s_specular | s_transmit;
+#pragma unroll
+      for(int l=0;l<MI_MF;l++) { bs.pdf[l] = l == MI_MF - 1 ? 1.0f - R[l] : 0.0f; bs.weight[l] = l == MI_MF - 1 ? sh[l].rg : 0.0f; }
+      return;
+    }
+    /* dielectric.c:353-411: the sampled half vector connects wi and wo for the hero's index of refraction only; every component reconstructs
+       the one ITS index needs, with its own Fresnel term */
+    const V3 wo = bs.omega;
+    bs.mode = s_transmit | s_glossy;
+    const float G1 = ggx_G1(wo, n, r);
+    const float cos_on = fabsf(dot3(wo, n));
+#pragma unroll
+    for(int l=0;l<MI_MF;l++)
+    {
+      const float n1 = eta[l], nr = n1/n2;
+      bool mask = false;
+      float h0 = n1*wi.x - n2*wo.x, h1 = n1*wi.y - n2*wo.y, h2 = n1*wi.z - n2*wo.z;
+      const float hilen = 1.0f/mi_sqrt(h0*h0 + (h1*h1 + h2*h2));
+      h0 *= hilen; h1 *= hilen; h2 *= hilen;
+      if(n2 < n1) { h0 = -h0; h1 = -h1; h2 = -h2; }
+      const float cosh2 = h0*n.x + (h1*n.y + h2*n.z);
+      mask |= cosh2 < 0.0f;
+      const float cosr2 = h0*-wi.x + (h1*-wi.y + h2*-wi.z);
+      mask |= cosr2 <= 0.0f;
+      const float cost2b = 1.0f - (nr*nr)*(1.0f - cosr2*cosr2);
+      const float costb = cost2b <= 0.0f ? 0.0f : mi_sqrt(cost2b);
+      const float R2 = fresnel_dielectric(n1, n2, cosr2, costb);
+      const float denom = n1*cosr2 - n2*costb;
+      float pdf2 = ggx_pdf_h_cos(cosh2, cos_in, cosr2, r);
+      pdf2 = pdf2*(((n2*n2)*costb)/(denom*denom));
+      bs.pdf[l] = mask ? 0.0f : (pdf2*(1.0f - R2))/cos_on;
+      bs.weight[l] = mask ? 0.0f : sh[l].rg*G1;
+    }
+  }
+}
+
+template<class PS>
+__device__ __forceinline__ void sample_metal_hero(const DScene &sc, PS &pts, const Surf &sf, const Shading *sh, const V3 wi, const float *n1, int mat,
+                                                  const float *lam, uint32_t mode_in, HeroSample &bs)
+{ /* sample, metal.c:219-265: one microfacet, the conductor's n and k at each wavelength */
+  bs.mode = mode_in; bs.omega = mk3(0, 0, 0);
+#pragma unroll
+  for(int l=0;l<MI_MF;l++) { bs.weight[l] = 0.0f; bs.pdf[l] = 1.0f; }
+  const V3 n = sf.n;
+  V3 h = n;
+  float pdf_h = 1.0f;
+  const float r = sh[0].roughness;
+  if(r > 1e-4f)
+  {
+    const V3 wit = mk3(-dot3(sf.a, wi), -dot3(sf.b, wi), -dot3(n, wi));
+    const float U1 = pts(MI_DIM_OMEGA_X);           /* clang's order, see sample_dielectric_hero */
+    const float U2 = pts(MI_DIM_OMEGA_Y);
+    const V3 ht = ggx_sample_h(wit, r, r, U1, U2);
+    h = mk3(ht.x*sf.a.x + ht.y*sf.b.x + ht.z*n.x, ht.x*sf.a.y + ht.y*sf.b.y + ht.z*n.y, ht.x*sf.a.z + ht.y*sf.b.z + ht.z*n.z);
+    pdf_h = ggx_pdf_h(wi, h, n, r);
+  }
+  float pdf = pdf_h;
+  const float cosr = -dot3(wi, h);
+  if(!(cosr > 0.0f)) return;
+  float R[MI_MF];
+#pragma unroll
+  for(int l=0;l<MI_MF;l++)
+  {
+    const int i = (int)DCLAMP((lam[l] - 360.0f)/5.0f, 0, 94);
+    const float n2 = sc.metal_ior[(mat*95 + i)*2 + 0], k2 = -sc.metal_ior[(mat*95 + i)*2 + 1];
+    R[l] = (sc.metal_reference && metal_reference_kills(n1[l], n2, k2, cosr)) ? 0.0f : fresnel_metal(n1[l], n2, k2, cosr);
+  }
+  bs.mode = s_reflect;
+  bs.omega = mk3(wi.x + 2.0f*cosr*h.x, wi.y + 2.0f*cosr*h.y, wi.z + 2.0f*cosr*h.z);
+  if(dot3(bs.omega, n) <= 0.0f) return;
+  pdf *= mi_rcp(4.0f*cosr);
+  if(r > 1e-4f)
+  {
+    const float p = pdf/fabsf(dot3(bs.omega, n));
+#pragma unroll
+    for(int l=0;l<MI_MF;l++) bs.pdf[l] = p;
+    bs.mode |= s_glossy;
+    if(dot3(bs.omega, n)*dot3(bs.omega, h) < 0.0f) return;
+    const float G1 = ggx_G1(bs.omega, n, r);
+#pragma unroll
+    for(int l=0;l<MI_MF;l++) bs.weight[l] = R[l]*(sh[l].rg*G1);
+    return;
+  }
+  bs.mode |= s_specular;
+#pragma unroll
+  for(int l=0;l<MI_MF;l++) bs.weight[l] = R[l]*sh[l].rg;
+}
+
+__device__ __forceinline__ HeroEval brdf_diffuse_hero(const Surf &sf, const Shading *sh, const V3 wo)
+{ /* brdf_d, src/shader.c:207-252 */
+  HeroEval r; r.mode = s_diffuse | s_reflect;
+#pragma unroll
+  for(int l=0;l<MI_MF;l++) r.value[l] = 0.0f;
+  const float cos_out_ns = dot3(sf.n, wo);
+  if(cos_out_ns <= 0) return r;
+  const float cos_out_ng = dot3(sf.gn, wo);
+  if(sf.flags & s_inside) { if(cos_out_ng >= 0.0f) return r; }
+  else if(cos_out_ng <= 0.0f) return r;
+#pragma unroll
+  for(int l=0;l<MI_MF;l++) r.value[l] = (float)((double)sh[l].rd*((double)1.0f/MI_PI_D));
+  return r;
+}
+
+/* the transmission branches of brdf / pdf: the half vector depends on the component's index of refraction, so everything does */
+__device__ __forceinline__ float brdf_dielectric_transmit1(const V3 n, const V3 wi, const V3 wo, float cos_in, float cos_out, float n1, float rg, float r, bool glossy)
+{ /* brdf, dielectric.c:478-541, one component */
+  const float n2 = 1.0f;
+  bool mask = false;
+  float h0 = n1*wi.x - n2*wo.x, h1 = n1*wi.y - n2*wo.y, h2 = n1*wi.z - n2*wo.z;
+  const float hilen = mi_rcp(mi_sqrt(h0*h0 + (h1*h1 + h2*h2)));
+  h0 *= hilen; h1 *= hilen; h2 *= hilen;
+  float cosh2 = h0*n.x + (h1*n.y + h2*n.z);
+  const bool cosh_lt0 = cosh2 < 0.0f;
+  mask |= cosh_lt0 && (n1 < n2);
+  mask |= !cosh_lt0 && (n2 < n1);
+  if(cosh_lt0) { cosh2 = -cosh2; h0 = -h0; h1 = -h1; h2 = -h2; }
+  const float cosr2 = h0*-wi.x + (h1*-wi.y + h2*-wi.z);
+  mask |= cosr2 <= 0.0f;
+  const float nr = n1/n2;
+  const float cost2 = 1.0f - (nr*nr)*(1.0f - cosr2*cosr2);
+  const float cost = cost2 <= 0.0f ? 0.0f : mi_sqrt(cost2);
+  const float R2 = fresnel_dielectric(n1, n2, cosr2, cost);
+  const float DG1 = ggx_pdf_h_cos(cosh2, cos_in, cosr2, r);
+  const float G1 = ggx_G1_cos(cos_in, r);
+  const float cos_hwo = h0*wo.x + (h1*wo.y + h2*wo.z);
+  mask |= cos_hwo >= 0.0f;
+  float denom = n1*cosr2 - n2*cost;
+  denom = denom*denom;
+  if(glossy) return mask ? 0.0f : ((rg*(1.0f - R2))*((n2*n2)*(cost*(DG1*(G1*(1.0f/fabsf(cos_out)))))))/denom;
+  mask |= cosh2 < HALFVEC_COS_THR;
+  return mask ? 0.0f : rg*DCLAMP(1.0f - R2, 0.0f, 1.0f);
+}
+
+__device__ __forceinline__ HeroEval brdf_dielectric_hero(const Surf &sf, const Shading *sh, const V3 wi, const V3 wo, const float *eta, bool any_im)
+{ /* brdf, dielectric.c:418-541: mf(eta_ratio, 0) < 0 and mf_any(indexmatched) decide for all components */
+  HeroEval res; res.mode = s_absorb;
+#pragma unroll
+  for(int l=0;l<MI_MF;l++) res.value[l] = 0.0f;
+  const V3 n = sf.n;
+  const float cos_in  = -dot3(n, wi);
+  const float cos_out =  dot3(n, wo);
+  if(eta[0] < 0.0f) return res;
+  const float n2 = 1.0f;
+  const bool index_matched = any_im;
+  if(cos_out == 0.0f || cos_in == 0.0f) return res;
+  if(!index_matched && (cos_in*cos_out > 0)) res.mode = s_reflect;
+  else res.mode = s_transmit;
+  const float r = sh[0].roughness;
+  if((r > GLOSSY_THR) && !index_matched) res.mode |= s_glossy;
+  else res.mode |= s_specular;
+  if(index_matched)
+  {
+    const float dot_wo_n = dot3(wo, n);
+    const V3 h = normalise3(mk3(-wi.x + wo.x - 2.0f*dot_wo_n*n.x, -wi.y + wo.y - 2.0f*dot_wo_n*n.y, -wi.z + wo.z - 2.0f*dot_wo_n*n.z));
+    const float cosh = dot3(h, n);
+    if(cosh < 0.0f) return res;
+    if(cosh < HALFVEC_COS_THR) return res;
+#pragma unroll
+    for(int l=0;l<MI_MF;l++) res.value[l] = sh[l].rg;
+    return res;
+  }
+  else if(res.mode & s_reflect)
+  {
+    const V3 h = normalise3(mk3(-wi.x + wo.x, -wi.y + wo.y, -wi.z + wo.z));
+    const float cosh = dot3(h, n);
+    if(cosh < 0.0f) return res;
+    const float DG1 = (res.mode & s_specular) ? 1.0f : ggx_pdf_h(wi, h, n, r);
+    if(DG1 == 0) return res;
+    const float cosr = -dot3(h, wi);
+    if(cosr < 0.0f) return res;
+    const float G1 = ggx_G1(wo, n, r);
+    const bool glossy = (res.mode & s_glossy) != 0;
+    if(!glossy && cosh < HALFVEC_COS_THR) return res;
+    const float geo = DG1*G1/(4.0f*fabsf(cosr*cos_out));
+#pragma unroll
+    for(int l=0;l<MI_MF;l++)
+    {
+      const float nr = eta[l]/n2;
+      const float cost2 = 1.0f - (nr*nr)*(1.0f - cosr*cosr);
+      const float cost = cost2 <= 0.0f ? 0.0f : mi_sqrt(cost2);
+      const float R = fresnel_dielectric(eta[l], n2, cosr, cost);
+      res.value[l] = glossy ? (sh[l].rg*R)*geo : sh[l].rg*R;
+    }
+    return res;
+  }
+  else
+  {
+    if(cos_in == 0.0f) return res;
+    const bool glossy = (res.mode & s_glossy) != 0;
+#pragma unroll
+    for(int l=0;l<MI_MF;l++) res.value[l] = brdf_dielectric_transmit1(n, wi, wo, cos_in, cos_out, eta[l], sh[l].rg, r, glossy);
+    return res;
+  }
+}
+
+__device__ __forceinline__ void pdf_dielectric_hero(const Surf &sf, const Shading *sh, const V3 wi, const V3 wo, const float *eta, bool any_im, uint32_t mode, float *out)
+{ /* pdf, dielectric.c:96-237 */
+#pragma unroll
+  for(int l=0;l<MI_MF;l++) out[l] = 0.0f;
+  const V3 n = sf.n;
+  const float cos_in  = -dot3(n, wi);
+  const float cos_out =  dot3(n, wo);
+  if(cos_in*cos_out == 0.0f) return;
+  if(cos_out > 0.0f && !(mode & s_reflect))  return;
+  if(cos_out < 0.0f && !(mode & s_transmit)) return;
+  if(eta[0] < 0.0f) return;                              /* mf_all(eta < 0): the nesting breaks for all components or for none */
+  const float n2 = 1.0f;
+  const float r = sh[0].roughness;
+  if(any_im)
+  {
+    const float dot_wo_n = dot3(wo, n);
+    const V3 h = normalise3(mk3(-wi.x + wo.x - 2.0f*dot_wo_n*n.x, -wi.y + wo.y - 2.0f*dot_wo_n*n.y, -wi.z + wo.z - 2.0f*dot_wo_n*n.z));
+    const float cosh = dot3(h, n);
+    if(mode != (s_transmit | s_specular)) return;
+    if(cosh < HALFVEC_COS_THR) return;
+#pragma unroll
+    for(int l=0;l<MI_MF;l++) out[l] = 1.0f;
+    return;
+  }
+  if(mode & s_reflect)
+  {
+    const V3 h = normalise3(sub3(wi, wo));
+    const float cosh = fabsf(dot3(h, n));
+    const float cosr = fabsf(dot3(h, wi));
+    const bool spec = (mode & s_specular) != 0;
+    const float geo = spec ? 0.0f : ggx_pdf_h_cos(cosh, cos_in, cosr, r);
+    const float i4 = mi_rcp(4.0f*fabsf(dot3(wo, h)));
+#pragma unroll
+    for(int l=0;l<MI_MF;l++)
+    {
+      const float nr = eta[l]/n2;
+      const float cost2 = 1.0f - (nr*nr)*(1.0f - cosr*cosr);
+      const float cost = cost2 <= 0.0f ? 0.0f : mi_sqrt(cost2);
+      const float R = fresnel_dielectric(eta[l], n2, cosr, cost);
+      if(spec) { out[l] = cosh < HALFVEC_COS_THR ? 0.0f : R; continue; }
+      float pdf = 1.0f;
+      pdf = pdf*i4;
+      pdf = pdf*R;
+      pdf = pdf*geo;
+      pdf = pdf/fabsf(cos_out);
+      out[l] = !(pdf > 0.0f) ? 0.0f : pdf;
+    }
+    return;
+  }
+#pragma unroll
+  for(int l=0;l<MI_MF;l++)
+  {
+    const float n1 = eta[l];
+    bool mask = false;
+    float h0 = n1*wi.x - n2*wo.x, h1 = n1*wi.y - n2*wo.y, h2 = n1*wi.z - n2*wo.z;
+    const float hilen = mi_rcp(mi_sqrt(h0*h0 + (h1*h1 + h2*h2)));
+    h0 *= hilen; h1 *= hilen; h2 *= hilen;
+    if(n2 < n1) { h0 = -h0; h1 = -h1; h2 = -h2; }
+    const float cosh = h0*n.x + (h1*n.y + h2*n.z);
+    mask |= cosh < 0.0f;
+    const float cosr = h0*-wi.x + (h1*-wi.y + h2*-wi.z);
+    mask |= cosr <= 0.0f;
+    const float nr = n1/n2;
+    const float cost2 = 1.0f - (nr*nr)*(1.0f - cosr*cosr);
+    const float cost = cost2 <= 0.0f ? 0.0f : mi_sqrt(cost2);
+    const float R = fresnel_dielectric(n1, n2, cosr, cost);
+    if(mode & s_specular) { mask |= cosh < HALFVEC_COS_THR; out[l] = mask ? 0.0f : DCLAMP(1.0f - R, 0.0f, 1.0f); continue; }
+    float pdf = 1.0f;
+    const float denom = n1*cosr - n2*cost;
+    pdf = pdf*(((n2*n2)*cost)/(denom*denom));
+    pdf = pdf*DCLAMP(1.0f - R, 0.0f, 1.0f);
+    pdf = pdf*ggx_pdf_h_cos(cosh, cos_in, cosr, r);
+    pdf = pdf/fabsf(cos_out);
+    mask |= !(pdf > 0.0f);
+    out[l] = mask ? 0.0f : pdf;
+  }
+}
+
+__device__ __forceinline__ HeroEval brdf_metal_hero(const DScene &sc, const Surf &sf, const Shading *sh, const V3 wi, const V3 wo, const float *n1, int mat, const float *lam)
+{ /* brdf, metal.c:268-310 */
+  HeroEval res; res.mode = s_absorb;
+#pragma unroll
+  for(int l=0;l<MI_MF;l++) res.value[l] = 0.0f;
+  const V3 n = sf.n;
+  const float cos_in = -dot3(n, wi), cos_out = dot3(n, wo);
+  if(cos_out <= 0.0f || cos_in <= 0.0f) return res;
+  res.mode = s_reflect;
+  const float r = sh[0].roughness;
+  if(r > 1e-4f) res.mode |= s_glossy; else res.mode |= s_specular;
+  const V3 h = normalise3(mk3(-wi.x + wo.x, -wi.y + wo.y, -wi.z + wo.z));
+  const float cosh = dot3(h, n);
+  if(cosh < 0.0f) return res;
+  const float DG1 = ggx_pdf_h(wi, h, n, r);
+  if(DG1 == 0) return res;
+  const float cosr = -dot3(h, wi);
+  if(cosr < 0.0f) return res;
+  const float G1 = ggx_G1(wo, n, r);
+  const bool glossy = (res.mode & s_glossy) != 0;
+  if(!glossy && cosh < HALFVEC_COS_THR) return res;
+  const float geo = DG1*G1/(4.0f*fabsf(cosr*cos_out));
+#pragma unroll
+  for(int l=0;l<MI_MF;l++)
+  {
+    const int i = (int)DCLAMP((lam[l] - 360.0f)/5.0f, 0, 94);
+    const float n2 = sc.metal_ior[(mat*95 + i)*2 + 0], k2 = -sc.metal_ior[(mat*95 + i)*2 + 1];
+    const float R = fresnel_metal(n1[l], n2, k2, cosr);
+    res.value[l] = glossy ? (sh[l].rg*R)*geo : sh[l].rg*R;
+  }
+  return res;
+}
+
+/* run_prepare_ops (mi_kernels.h) for four wavelengths: every op is loaded once */
+__device__ __forceinline__ void run_prepare_ops_hero(const DScene &sc, const DMaterial &m, uint32_t num_ops, const Surf &sf, const float *lam, Shading *sh)
+{
+#pragma unroll
+  for(int l=0;l<MI_MF;l++) { sh[l].roughness = 1.0f; sh[l].rs = sh[l].rd = sh[l].rg = sh[l].em = 0.0f; }
+  for(uint32_t k=0;k<num_ops;k++)
+  {
+    const uint4 oa = *(const uint4 *)&m.op[k];
+    const float4 ob = *(const float4 *)((const char *)&m.op[k] + 16);
+    mi_shade_op op;
+    op.kind = oa.x; op.slot = oa.y; op.coeff[0] = __uint_as_float(oa.z); op.coeff[1] = __uint_as_float(oa.w);
+    op.coeff[2] = ob.x; op.mul = ob.y; op.roughness = ob.z;
+    if(op.kind == MI_OP_COLOR)
+    {
+#pragma unroll
+      for(int l=0;l<MI_MF;l++)
+      {
+        sh[l].roughness = op.roughness;
+        const float val = op.mul*spectrum_eval(op.coeff, lam[l]);
+        if(op.slot == MI_SLOT_EMISSION) set_slot(sh[l], op.slot, val);
+        else if(op.slot != MI_SLOT_UNUSED) set_slot(sh[l], op.slot, DCLAMP(val, 0.0f, 1.0f));
+      }
+    }
+    else
+    {
+      const float u = sf.s, t = sf.t;
+      const int i = (int)(14.0f*u) % 14, j = (int)(10.0f*t) % 10;
+      const float xu = 14.0f*u, xt = 10.0f*t;
+      const float fu = xu - truncf(xu), ft = xt - truncf(xt);
+      const bool border = fu < 0.1f || fu > 0.9f || ft < 0.1f || ft > 0.9f;
+#pragma unroll
+      for(int l=0;l<MI_MF;l++)
+      {
+        float val;
+        if(border) val = 0.3f;
+        else
+        {
+          const int b = (int)((lam[l] - 380.0f)/10.0f);
+          if(b < 0 || b >= 36) val = 0.0f;
+          else val = sc.checker[36*(14*j + i) + b];
+        }
+        set_slot(sh[l], op.slot, val);
+      }
+    }
+  }
+}
+
+#ifndef MI_HERO_FUSED
+#define MI_HERO_FUSED 1     /* 0: the first implementation -- the scalar functions called once per component with a HeroCtx (kept for A/B: same paths) */
+#endif
+
 /* path_shade (mi_path.h) for four components; the comments there name the reference lines of every step, here only what differs */
 template<bool RECORD, bool PTDL, class CNT>
 __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero &ps, const Hit &hit, const uint32_t *shape_material, const float *shape_L,
@@ -165,8 +634,12 @@ __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero 
     surface_setup<false>(sc, hit.prim, head, omega, ps.scramble, sf, ps.time);
     const uint32_t shape = (head.w >> 3) & 0x1fffffffu;
     Shading sh[4];
+#if MI_HERO_FUSED
+    run_prepare_ops_hero(sc, mat, mhead.y, sf, lam, sh);
+#else
 #pragma unroll
     for(int l=0;l<MI_MF;l++) run_prepare_ops(sc, mat, mhead.y, sf, lam[l], sh[l]);
+#endif
     uint32_t material_modes = 0;
     float eta[4] = {1.0f, 1.0f, 1.0f, 1.0f};
     HeroCtx hc;
@@ -396,6 +869,15 @@ __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero 
             for(int l=0;l<MI_MF;l++) edf[l] = edf[l]/sc.p_geo;
             if(edf[0] > 0.0f || edf[1] > 0.0f || edf[2] > 0.0f || edf[3] > 0.0f)                       /* mf_any(edf > 0), nee.h:188 */
             {
+#if MI_HERO_FUSED
+              HeroEval he;
+              if(mat_bsdf == MI_BSDF_DIFFUSE) he = brdf_diffuse_hero(sf, sh, ol);
+              else if(mat_bsdf == MI_BSDF_DIELECTRIC) he = brdf_dielectric_hero(sf, sh, omega, ol, eta, hc.any_im);
+              else he = brdf_metal_hero(sc, sf, sh, omega, ol, ior, (int)mat_p0, lam);
+              struct { float value; uint32_t mode; } be[4];
+#pragma unroll
+              for(int l=0;l<MI_MF;l++) { be[l].value = he.value[l]; be[l].mode = he.mode; }
+#else
               BsdfEval be[4];
 #pragma unroll
               for(int l=0;l<MI_MF;l++)
@@ -405,6 +887,7 @@ __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero 
                 else if(mat_bsdf == MI_BSDF_DIELECTRIC) be[l] = brdf_dielectric<true>(sf, sh[l], omega, ol, eta[l], &hc);
                 else be[l] = brdf_metal(sc, sf, sh[l], omega, ol, ior[l], (int)mat_p0, lam[l]);
               }
+#endif
               bool okn = be[0].value > 0.0f || be[1].value > 0.0f || be[2].value > 0.0f || be[3].value > 0.0f;   /* mf_any(bsdf > 0), nee.h:191 */
               if(okn && (be[0].mode & s_transmit))
               {
@@ -425,6 +908,12 @@ __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero 
                   const float Gn = fabsf(dot3(sf.n, ol))*fabsf(dot3(ls.n, ol))/(ldist*ldist);
                   float tn[4], ours[4], sums[4];
                   const float wn = lpdf/(lpdf + 0.0f/1.0f);
+#if MI_HERO_FUSED
+                  float pbs[4];
+                  if(mat_bsdf == MI_BSDF_DIFFUSE) pbs[0] = pbs[1] = pbs[2] = pbs[3] = (float)(1.0f/MI_PI_D);
+                  else if(mat_bsdf == MI_BSDF_DIELECTRIC) pdf_dielectric_hero(sf, sh, omega, ol, eta, hc.any_im, be[0].mode, pbs);
+                  else pbs[0] = pbs[1] = pbs[2] = pbs[3] = pdf_metal(sf, sh[0], omega, ol, be[0].mode);     /* no wavelength in it */
+#endif
 #pragma unroll
                   for(int l=0;l<MI_MF;l++)
                   {
@@ -433,9 +922,13 @@ __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero 
                     t = t + (vthr[l]*be[l].value)*((0.0f*Gn)/lpdf);
                     tn[l] = t*wn;
                     float pb;
+#if MI_HERO_FUSED
+                    pb = pbs[l];
+#else
                     if(mat_bsdf == MI_BSDF_DIFFUSE) pb = (float)(1.0f/MI_PI_D);
                     else if(mat_bsdf == MI_BSDF_DIELECTRIC) pb = pdf_dielectric<true>(sf, sh[l], omega, ol, eta[l], be[0].mode, &hc);
                     else pb = pdf_metal(sf, sh[l], omega, ol, be[0].mode);
+#endif
                     const float pe = (1.0f*pb)*Gn;
                     const double our = (double)(1.0f*lpdf)*pp[l], other = (double)pe*pp[l];
                     ours[l] = (float)our; sums[l] = (float)(other + our);
@@ -470,9 +963,18 @@ __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero 
       }
       if(alive)
       {
-        BsdfSample bs[4];
         get_scrambled_onb(ps.scramble, sf.n, sf.a, sf.b);
         PointSampler<false> pts(sc, ps.rng, ps.index, rand_beg_extend<PTDL>(v + 1));
+#if MI_HERO_FUSED
+        HeroSample hs;
+        if(mat_bsdf == MI_BSDF_DIFFUSE) sample_diffuse_hero(pts, sf, sh, hc.any_rd, mode, hs);
+        else if(mat_bsdf == MI_BSDF_DIELECTRIC) sample_dielectric_hero(pts, sf, sh, omega, eta, hc.any_im, mode, hs);
+        else sample_metal_hero(sc, pts, sf, sh, omega, ior, (int)mat_p0, lam, mode, hs);
+        struct { V3 omega; uint32_t mode; float pdf, weight; } bs[4];
+#pragma unroll
+        for(int l=0;l<MI_MF;l++) { bs[l].omega = hs.omega; bs[l].mode = hs.mode; bs[l].pdf = hs.pdf[l]; bs[l].weight = hs.weight[l]; }
+#else
+        BsdfSample bs[4];
         HeroPoints<PointSampler<false> > hp(pts, hc);
 #pragma unroll
         for(int l=0;l<MI_MF;l++)
@@ -482,6 +984,7 @@ __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero 
           else if(mat_bsdf == MI_BSDF_DIELECTRIC) sample_dielectric<HeroPoints<PointSampler<false> >, true>(hp, sf, sh[l], omega, eta[l], mode, bs[l], &hc);
           else sample_metal<HeroPoints<PointSampler<false> >, true>(sc, hp, sf, sh[l], omega, ior[l], (int)mat_p0, lam[l], mode, bs[l]);
         }
+#endif
         const V3 out = normalise3(bs[0].omega);
         const float dts = ((sf.flags & s_inside) ? -1 : 1)*dot3(sf.gn, out);
         const bool wrong_side = ((bs[0].mode & s_reflect) && (dts < 0.f)) || ((bs[0].mode & s_transmit) && (dts > 0.f));
