@@ -11,9 +11,9 @@
  * sampled microfacet, the emitter sample) the compiler computes once. The places where the reference looks across the components (mf_any,
  * mf_all, mf(x, 0), mf_hsum) are written out here or handed to the bsdf functions in a HeroCtx.
  * Component 0 lives in the PathState the megakernel knows (ray, pdf product, throughput ...: what the traversal slices and the parking
- * of path state touch), components 1..3 in the arrays of PathStateHero behind it: 21 registers more.
+ * of path state touch), components 1..3 in the arrays of PathStateHero behind it: 18 registers more.
  * Plain scenes only (no media, no moving primitives, `rand` point sampler): what the reference's MF_COUNT = 4 build was pinned on
- * (tests/test_oracle_hero.py). No exchange between waves: a pool entry would have to carry the 21 words too. */
+ * (tests/test_oracle_hero.py). No exchange between waves: a pool entry would have to carry the 18 words too. */
 #ifndef MI_HERO_H
 #define MI_HERO_H
 
@@ -21,8 +21,11 @@
 
 struct PathStateHero : PathState
 {
-  float lambda_x[3], throughput_x[3], pdf_x[3], cur_ior_x[3], sh_value_x[3];
+  float lambda_x[3], throughput_x[3], pdf_x[3], sh_value_x[3];
   double pdfprod_x[3];
+  /* (no cur_ior_x: the index of refraction of the volume a ray travels in is that of the innermost shape of the path's nesting stack, at the
+     component's wavelength -- shape_interior_ior(media_top_shape(ps.media), lambda_l), one 16-byte load and four divisions per vertex instead
+     of three registers through every traversal slice; component 0 keeps the PathState's cur_ior, which the scalar code maintains) */
 };
 
 __device__ __forceinline__ float hero_hsum(const float *a) { return (a[0] + a[1]) + (a[2] + a[3]); }   /* mf_hsum: two _mm_hadd_ps, include/mf.h:301-306 */
@@ -69,7 +72,7 @@ __device__ __forceinline__ void path_generate_hero(const DScene &sc, PathStateHe
 {
   path_generate<RECORD, false, false, CNT, true>(sc, ps, index, rec, cnt, px, py, ps.lambda_x);
 #pragma unroll
-  for(int l=0;l<3;l++) { ps.throughput_x[l] = ps.throughput; ps.pdf_x[l] = ps.pdf; ps.cur_ior_x[l] = 1.0f; ps.pdfprod_x[l] = 1.0; ps.sh_value_x[l] = 0.0f; }
+  for(int l=0;l<3;l++) { ps.throughput_x[l] = ps.throughput; ps.pdf_x[l] = ps.pdf; ps.pdfprod_x[l] = 1.0; ps.sh_value_x[l] = 0.0f; }
   if(RECORD && sc.hero_ext)
   {
     mi_hero_ext &x = sc.hero_ext[slot];
@@ -593,7 +596,7 @@ __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero 
   const float lam[4] = {ps.lambda, ps.lambda_x[0], ps.lambda_x[1], ps.lambda_x[2]};
   float thr[4] = {ps.throughput, ps.throughput_x[0], ps.throughput_x[1], ps.throughput_x[2]};
   const float pdf_in[4] = {ps.pdf, ps.pdf_x[0], ps.pdf_x[1], ps.pdf_x[2]};
-  float ior[4] = {ps.cur_ior, ps.cur_ior_x[0], ps.cur_ior_x[1], ps.cur_ior_x[2]};
+  float ior[4] = {ps.cur_ior, 1.0f, 1.0f, 1.0f};                /* e[v].vol.ior per component: see PathStateHero (filled in where a material asks for it) */
   double pp[4] = {ps.pdfprod, ps.pdfprod_x[0], ps.pdfprod_x[1], ps.pdfprod_x[2]};
   if(PTDL)
   {
@@ -646,6 +649,11 @@ __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero 
     hc.lane = 0; hc.any_im = false; hc.any_rd = false; hc.eta0 = 1.0f; hc.R0 = hc.cost20 = hc.cost0 = 0.0f; hc.u[0] = hc.u[1] = hc.u[2] = 0.0f; hc.k = 0;
     if(RECORD || mat_bsdf != MI_BSDF_DIFFUSE)
     {
+      {
+        const int top_in = media_top_shape(ps.media);
+#pragma unroll
+        for(int l=1;l<MI_MF;l++) ior[l] = shape_interior_ior(sc, shape_material, top_in, lam[l]);
+      }
       Media hyp = ps.media;
       media_apply(hyp, shape, (sf.flags & s_inside) != 0);
       if(hyp.broken) { eta[0] = eta[1] = eta[2] = eta[3] = -1.0f; }
@@ -999,9 +1007,7 @@ __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero 
           if(ps.media.broken) ok = false;
           else
           {
-            const int top = media_top_shape(ps.media);
-#pragma unroll
-            for(int l=0;l<MI_MF;l++) ior[l] = shape_interior_ior(sc, shape_material, top, lam[l]);
+            ior[0] = shape_interior_ior(sc, shape_material, media_top_shape(ps.media), lam[0]);
           }
         }
         if(!ok)
@@ -1023,7 +1029,7 @@ __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero 
           ps.prev_material_modes = material_modes;
           ps.throughput = nthr[0]; ps.pdf = bs[0].pdf; ps.cur_ior = ior[0];
 #pragma unroll
-          for(int l=1;l<MI_MF;l++) { ps.throughput_x[l-1] = nthr[l]; ps.pdf_x[l-1] = bs[l].pdf; ps.cur_ior_x[l-1] = ior[l]; }
+          for(int l=1;l<MI_MF;l++) { ps.throughput_x[l-1] = nthr[l]; ps.pdf_x[l-1] = bs[l].pdf; }
         }
       }
     }

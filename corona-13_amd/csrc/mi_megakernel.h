@@ -19,6 +19,9 @@
 #ifndef MI_BLOCK
 #define MI_BLOCK 1024    /* threads per workgroup: 16 waves/CU = 4 per SIMD (128 VGPRs each) */
 #endif
+#ifndef MI_BLOCK_HERO
+#define MI_BLOCK_HERO 1024   /* ... of the HERO kernels (mi_hero.h): their path state is 21 registers larger */
+#endif
 #ifndef MI_TAIL_LANES
 #define MI_TAIL_LANES 16       /* a traversal slice ends when fewer rays than this are still under way */
 #endif
@@ -78,6 +81,9 @@
 #ifndef MI_REGROUP_MEDIA
 #define MI_REGROUP_MEDIA 1   /* the exchange in the extended kernels too (media, moving camera): volume vertices are a class of their own */
 #endif
+#ifndef MI_REGROUP_HERO
+#define MI_REGROUP_HERO 1    /* the exchange in the HERO kernels (A/B: profiles/r05_hero.txt) */
+#endif
 #ifndef MI_REFILL_MIN
 #define MI_REFILL_MIN 12   /* with the exchange between waves (mi_regroup.h) the lanes of a wave become free in bursts (a wave that posts all its vertices) and in
                                   dribbles (one that pulled what the pool had): the dribbles wait. cfg 2 / cfg 3 with 1 / 8 / 16 / 24: 15.94 / 15.74 / 15.77 / 15.89 ms and
@@ -120,13 +126,14 @@
 
 /* ======================================================================================= persistent megakernel */
 template<bool RECORD, bool PTDL, bool NODES_LDS, bool HALTON = false, bool MEDIA = false, bool MB = false, bool COUNT = true, bool FAST = false, bool NORG = false, bool HERO = false>
-__global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned long long first, unsigned long long count,
+__global__ __launch_bounds__(HERO ? MI_BLOCK_HERO : MI_BLOCK) void mi_path_kernel(DScene sc, unsigned long long first, unsigned long long count,
                                                            const uint32_t *shape_material, const float *shape_L, mi_path_record *records,
                                                            uint2 *stack_overflow)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int BLK = HERO ? MI_BLOCK_HERO : MI_BLOCK;     /* threads of the workgroup */
   constexpr int COLUMN = MB ? MI_STACK_LDS_MB : (NORG || (MEDIA && !MI_REGROUP_MEDIA)) ? MI_STACK_LDS : MI_STACK_LDS_PLAIN;      /* stack entries per lane in LDS */
-  const Lds lds = lds_setup<MI_BLOCK, NODES_LDS, HALTON, PTDL && !MEDIA, COLUMN, MB>(sc, smem, stack_overflow);
+  const Lds lds = lds_setup<BLK, NODES_LDS, HALTON, PTDL && !MEDIA, COLUMN, MB>(sc, smem, stack_overflow);
 
   /* every workgroup owns a contiguous part of the path index range and hands it out through an LDS counter: the
      wave-level refill below then needs no global atomic at all (one shared counter costs ~11 ns per wave refill) */
@@ -134,16 +141,17 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
   /* material queues (mi_regroup.h): the plain kernels trade surface vertices between the waves of the workgroup, by class of the material */
   /* NORG: the extended kernels once more WITHOUT the exchange, for scenes in a scattering exterior medium (a global fog): nearly every vertex
      is a volume vertex there, the exchange has nothing to sort, and its code costs that kernel 26 more spilled registers (fog ptdl 124 against 115 ms) */
-  /* HERO (mi_hero.h): four wavelengths per path, plain scenes. The LDS layout is the plain kernels' (the scene was laid out for them), the pools stay empty */
+  /* HERO (mi_hero.h): four wavelengths per path, plain scenes. The LDS layout is the plain kernels' (the scene was laid out for them); a pool
+     entry is eight words longer, so the pools hold fewer */
   static_assert(!HERO || (!MEDIA && !MB && !HALTON && !FAST && !NORG), "hero wavelengths: plain scenes, rand point sampler, exact rounds");
-  constexpr bool REGROUP = MI_REGROUP && (!MB || MI_REGROUP_MB) && !NORG && (!MEDIA || MI_REGROUP_MEDIA) && !HERO;
+  constexpr bool REGROUP = MI_REGROUP && (!MB || MI_REGROUP_MB) && !NORG && (!MEDIA || MI_REGROUP_MEDIA) && (!HERO || MI_REGROUP_HERO);
   __shared__ PoolCtl pool_ctl;
   if(threadIdx.x == 0) blk_next = 0;
   Pool pool;
   pool.E = 0u;
   if(REGROUP)
   {
-    pool = pool_setup<RECORD, HALTON, MEDIA>(sc, lds.jobs - (threadIdx.x >> 6)*MI_JOBS_LDS + (MI_BLOCK/64)*MI_JOBS_LDS, &pool_ctl);
+    pool = pool_setup<RECORD, HALTON, MEDIA, HERO>(sc, lds.jobs - (threadIdx.x >> 6)*MI_JOBS_LDS + (BLK/64)*MI_JOBS_LDS, &pool_ctl);
     pool_init(pool, &pool_ctl);
     pool_stage_classes(pool, sc);
   }
@@ -257,19 +265,19 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
       V3 o = ray_origin<PTDL>(ps, tr_shadow), d = tr_shadow ? ps.sh_dir : ps.dir;
       const uint32_t ignore = ps.ignore;     /* the shadow ray of a vertex starts on the same primitive as its extension ray */
       const unsigned tail = exhausted_wave ? 1u : (unsigned)(PTDL ? MI_TAIL_LANES_PTDL : MI_TAIL_LANES);
-      lds_uint2 *parked = (lds_uint2 *)lds.stack + (STACK + RESULT_SLOTS)*MI_BLOCK;
+      lds_uint2 *parked = (lds_uint2 *)lds.stack + (STACK + RESULT_SLOTS)*BLK;
       if(MI_PRIO) __builtin_amdgcn_s_setprio(PTDL ? MI_PRIO_PTDL_TRACE : MI_PRIO_PT_TRACE);
       if(PARK_PS)
       {
         parked[0] = mi_u32x2{(uint32_t)ps.rng.s0, (uint32_t)(ps.rng.s0 >> 32)};
-        parked[MI_BLOCK] = mi_u32x2{(uint32_t)ps.rng.s1, (uint32_t)(ps.rng.s1 >> 32)};
+        parked[BLK] = mi_u32x2{(uint32_t)ps.rng.s1, (uint32_t)(ps.rng.s1 >> 32)};
         const unsigned long long pp = (unsigned long long)__double_as_longlong(ps.pdfprod);
-        if(PARK_N >= 3) parked[2*MI_BLOCK] = mi_u32x2{(uint32_t)pp, (uint32_t)(pp >> 32)};
-        if(PARK_N >= 4) parked[3*MI_BLOCK] = mi_u32x2{__float_as_uint(ps.pixel_i), __float_as_uint(ps.pixel_j)};
-        if(PARK_N >= 5) parked[4*MI_BLOCK] = mi_u32x2{__float_as_uint(ps.lambda), __float_as_uint(ps.scramble)};
-        if(PARK_N >= 6) parked[5*MI_BLOCK] = mi_u32x2{__float_as_uint(ps.throughput), __float_as_uint(ps.pdf)};
-        if(PARK_N >= 7) parked[6*MI_BLOCK] = mi_u32x2{__float_as_uint(ps.prev_cos), __float_as_uint(ps.cur_ior)};
-        if(PARK_N >= 8) parked[7*MI_BLOCK] = mi_u32x2{(uint32_t)ps.media.ids, (uint32_t)(ps.media.ids >> 32)};
+        if(PARK_N >= 3) parked[2*BLK] = mi_u32x2{(uint32_t)pp, (uint32_t)(pp >> 32)};
+        if(PARK_N >= 4) parked[3*BLK] = mi_u32x2{__float_as_uint(ps.pixel_i), __float_as_uint(ps.pixel_j)};
+        if(PARK_N >= 5) parked[4*BLK] = mi_u32x2{__float_as_uint(ps.lambda), __float_as_uint(ps.scramble)};
+        if(PARK_N >= 6) parked[5*BLK] = mi_u32x2{__float_as_uint(ps.throughput), __float_as_uint(ps.pdf)};
+        if(PARK_N >= 7) parked[6*BLK] = mi_u32x2{__float_as_uint(ps.prev_cos), __float_as_uint(ps.cur_ior)};
+        if(PARK_N >= 8) parked[7*BLK] = mi_u32x2{(uint32_t)ps.media.ids, (uint32_t)(ps.media.ids >> 32)};
       }
       while(true)
       {
@@ -297,21 +305,21 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
         const unsigned nbusy = __popcll(__ballot(busy));
         if(!nbusy) break;
         if(nbusy < tail && __any(tracing && ts.done)) break;
-        if(FAST) { trace_round_spec<MI_BLOCK, STACK, MB, PTDL && MI_ANYHIT, MI_SPEC_FMA == 2 || (MI_SPEC_FMA == 1 && PTDL)>(lds, sc.prims, o, d, ignore, hit, ts, busy, cnt); continue; }
-        if(busy) trace_round<MI_BLOCK, STACK, MB, PTDL && MI_ANYHIT, JOBS>(lds, sc.prims, o, d, ignore, hit, ts, cnt);
-        if(JOBS) leaf_jobs<MI_BLOCK, STACK, MB, PTDL && MI_ANYHIT>(lds, sc.prims, o, d, ignore, hit, ts, busy, cnt);   /* every lane of the wave takes part */
+        if(FAST) { trace_round_spec<BLK, STACK, MB, PTDL && MI_ANYHIT, MI_SPEC_FMA == 2 || (MI_SPEC_FMA == 1 && PTDL)>(lds, sc.prims, o, d, ignore, hit, ts, busy, cnt); continue; }
+        if(busy) trace_round<BLK, STACK, MB, PTDL && MI_ANYHIT, JOBS>(lds, sc.prims, o, d, ignore, hit, ts, cnt);
+        if(JOBS) leaf_jobs<BLK, STACK, MB, PTDL && MI_ANYHIT>(lds, sc.prims, o, d, ignore, hit, ts, busy, cnt);   /* every lane of the wave takes part */
       }
       if(PARK_PS)
       {
-        const mi_u32x2 a = parked[0], b = parked[MI_BLOCK];
+        const mi_u32x2 a = parked[0], b = parked[BLK];
         ps.rng.s0 = (unsigned long long)a.x | ((unsigned long long)a.y << 32);
         ps.rng.s1 = (unsigned long long)b.x | ((unsigned long long)b.y << 32);
-        if(PARK_N >= 3) { const mi_u32x2 c = parked[2*MI_BLOCK]; ps.pdfprod = __longlong_as_double((long long)((unsigned long long)c.x | ((unsigned long long)c.y << 32))); }
-        if(PARK_N >= 4) { const mi_u32x2 e = parked[3*MI_BLOCK]; ps.pixel_i = __uint_as_float(e.x); ps.pixel_j = __uint_as_float(e.y); }
-        if(PARK_N >= 5) { const mi_u32x2 f = parked[4*MI_BLOCK]; ps.lambda = __uint_as_float(f.x); ps.scramble = __uint_as_float(f.y); }
-        if(PARK_N >= 6) { const mi_u32x2 f = parked[5*MI_BLOCK]; ps.throughput = __uint_as_float(f.x); ps.pdf = __uint_as_float(f.y); }
-        if(PARK_N >= 7) { const mi_u32x2 f = parked[6*MI_BLOCK]; ps.prev_cos = __uint_as_float(f.x); ps.cur_ior = __uint_as_float(f.y); }
-        if(PARK_N >= 8) { const mi_u32x2 f = parked[7*MI_BLOCK]; ps.media.ids = (unsigned long long)f.x | ((unsigned long long)f.y << 32); }
+        if(PARK_N >= 3) { const mi_u32x2 c = parked[2*BLK]; ps.pdfprod = __longlong_as_double((long long)((unsigned long long)c.x | ((unsigned long long)c.y << 32))); }
+        if(PARK_N >= 4) { const mi_u32x2 e = parked[3*BLK]; ps.pixel_i = __uint_as_float(e.x); ps.pixel_j = __uint_as_float(e.y); }
+        if(PARK_N >= 5) { const mi_u32x2 f = parked[4*BLK]; ps.lambda = __uint_as_float(f.x); ps.scramble = __uint_as_float(f.y); }
+        if(PARK_N >= 6) { const mi_u32x2 f = parked[5*BLK]; ps.throughput = __uint_as_float(f.x); ps.pdf = __uint_as_float(f.y); }
+        if(PARK_N >= 7) { const mi_u32x2 f = parked[6*BLK]; ps.prev_cos = __uint_as_float(f.x); ps.cur_ior = __uint_as_float(f.y); }
+        if(PARK_N >= 8) { const mi_u32x2 f = parked[7*BLK]; ps.media.ids = (unsigned long long)f.x | ((unsigned long long)f.y << 32); }
       }
     }
     if(MI_PRIO) __builtin_amdgcn_s_setprio(PTDL ? MI_PRIO_PTDL_SHADE : MI_PRIO_PT_SHADE);
@@ -327,10 +335,10 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
     const bool keep = tracing && !ts.done;
     if(PARK && keep)
     {
-      lds_uint2 *col = (lds_uint2 *)lds.stack + STACK*MI_BLOCK;
+      lds_uint2 *col = (lds_uint2 *)lds.stack + STACK*BLK;
       col[0] = mi_u32x2{hit.prim, __float_as_uint(hit.dist)};
-      col[MI_BLOCK] = mi_u32x2{__float_as_uint(hit.u), __float_as_uint(hit.v)};
-      col[2*MI_BLOCK] = mi_u32x2{ts.current, (uint32_t)ts.sp | (ts.anyhit ? 0x10000u : 0u)};
+      col[BLK] = mi_u32x2{__float_as_uint(hit.u), __float_as_uint(hit.v)};
+      col[2*BLK] = mi_u32x2{ts.current, (uint32_t)ts.sp | (ts.anyhit ? 0x10000u : 0u)};
     }
     SplatReq splat;
     splat.pending = false; splat.c0 = splat.c1 = splat.c2 = 0.0f;
@@ -358,18 +366,29 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
       if(fin && !tr_shadow && hit.prim == MI_NOPRIM && !volume)
       {
         tracing = false;
-        path_escape<RECORD, MEDIA>(sc, ps, RECORD ? records + (ps.index - first) : nullptr, cnt);
+        if constexpr(HERO) path_shade_hero<RECORD, PTDL>(sc, ps, hit, shape_material, shape_L, RECORD ? records + (ps.index - first) : nullptr, RECORD ? ps.index - first : 0ull, cnt, splat);
+        else path_escape<RECORD, MEDIA>(sc, ps, RECORD ? records + (ps.index - first) : nullptr, cnt);
       }
 #endif
       /* a lane that still owes this iteration a splat keeps its pixel: it is free from the next iteration on */
       const bool freelane = !tracing && !ps.active && !ps.sh_pending && !splat.pending;
-      regroup_exchange<RECORD, PTDL, HALTON, MEDIA, MI_PRIO ? (PTDL ? MI_PRIO_PTDL_SHADE : MI_PRIO_PT_SHADE) : 0>(pool, ps, hit, ts, tracing, tr_shadow, surf0, cls, freelane, exhausted_wave, cnt);
+      regroup_exchange<RECORD, PTDL, HALTON, MEDIA, MI_PRIO ? (PTDL ? MI_PRIO_PTDL_SHADE : MI_PRIO_PT_SHADE) : 0, HERO>(pool, ps, hit, ts, tracing, tr_shadow, surf0, cls, freelane, exhausted_wave, cnt);
       MI_TT(cnt, 4)       /* (trav probe: part 4 = the end of the slice + the exchange between waves) */
       if(tracing && ts.done)
       {
         tracing = false;
         mi_path_record *rec = RECORD ? records + (ps.index - first) : nullptr;
-        if(PTDL && !MI_REGROUP_EARLY_SHADOW && tr_shadow) shadow_resolve<RECORD>(sc, ps, hit, rec, cnt, splat);
+        if constexpr(HERO)
+        {
+          const unsigned long long slot = RECORD ? ps.index - first : 0ull;
+          if(PTDL && tr_shadow) shadow_resolve_hero<RECORD>(sc, ps, hit, rec, slot, cnt, splat);
+          else
+          {
+            __builtin_assume(hit.prim != MI_NOPRIM);
+            path_shade_hero<RECORD, PTDL>(sc, ps, hit, shape_material, shape_L, rec, slot, cnt, splat);
+          }
+        }
+        else if(PTDL && !MI_REGROUP_EARLY_SHADOW && tr_shadow) shadow_resolve<RECORD>(sc, ps, hit, rec, cnt, splat);
         else
         {
           if(!MEDIA) __builtin_assume(hit.prim != MI_NOPRIM);     /* paths that left the scene have ended above */
@@ -399,8 +418,8 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_path_kernel(DScene sc, unsigned l
     {
       if(keep)
       {
-        const lds_uint2 *col = (const lds_uint2 *)lds.stack + STACK*MI_BLOCK;
-        const mi_u32x2 a = col[0], b = col[MI_BLOCK], c = col[2*MI_BLOCK];
+        const lds_uint2 *col = (const lds_uint2 *)lds.stack + STACK*BLK;
+        const mi_u32x2 a = col[0], b = col[BLK], c = col[2*BLK];
         hit.prim = a.x; hit.dist = __uint_as_float(a.y); hit.u = __uint_as_float(b.x); hit.v = __uint_as_float(b.y);
         ts.current = c.x; ts.sp = (int)(c.y & 0xffffu); ts.anyhit = (c.y & 0x10000u) != 0; ts.done = false;
         const V3 d = tr_shadow ? ps.sh_dir : ps.dir;
@@ -540,7 +559,7 @@ template<bool PTDL, bool MEDIA, bool MB, bool FAST, bool NORG, bool HERO, bool R
                          ;
   if constexpr(valid)
   {
-    if(L) hipLaunchKernelGGL((mi_path_kernel<R, PTDL, N, H, MEDIA, MB, C, FAST, NORG, HERO>), dim3(L->grid), dim3(MI_BLOCK), L->lds_bytes, L->stream, L->d, L->first, L->n,
+    if(L) hipLaunchKernelGGL((mi_path_kernel<R, PTDL, N, H, MEDIA, MB, C, FAST, NORG, HERO>), dim3(L->grid), dim3(HERO ? MI_BLOCK_HERO : MI_BLOCK), L->lds_bytes, L->stream, L->d, L->first, L->n,
                              L->shape_material, L->shape_L, L->rec, L->overflow);
     return (const void *)mi_path_kernel<R, PTDL, N, H, MEDIA, MB, C, FAST, NORG, HERO>;
   }

@@ -30,6 +30,7 @@
 #define MI_REGROUP_H
 
 #include "mi_path.h"
+#include "mi_hero.h"
 
 #ifndef MI_REGROUP
 #define MI_REGROUP 1
@@ -71,7 +72,9 @@ typedef __attribute__((address_space(3))) unsigned long long lds_u64_t;
 struct __attribute__((aligned(16))) PoolCtl { unsigned long long state, hint; };
 
 /* 8-byte words of a path vertex on its way through a pool */
-template<bool RECORD, bool HALTON, bool MEDIA = false> struct PoolLayout { static constexpr int BASE = RECORD ? 16 : HALTON ? 15 : 14, SLOTS = BASE + (MEDIA ? 3 : 0); };
+/* (HERO kernels, mi_hero.h: eight more for components 1..3 of wavelength, throughput, pdf and pdf product) */
+#define MI_POOL_HERO_SLOTS 8
+template<bool RECORD, bool HALTON, bool MEDIA = false, bool HERO = false> struct PoolLayout { static constexpr int BASE = RECORD ? 16 : HALTON ? 15 : 14, SLOTS = BASE + (MEDIA ? 3 : 0) + (HERO ? MI_POOL_HERO_SLOTS : 0); };
 
 /* The pools share their storage: E entries of SLOTS words ([slot][E], so that the lanes of a wave write neighbouring addresses), a list of
  * entry numbers per class, and the list of free entries. A vertex is written / read OUTSIDE the lock (its entry is then on no list); the
@@ -89,10 +92,10 @@ struct Pool
   uint32_t E;               /* entries; 0 = no exchange */
 };
 
-template<bool RECORD, bool HALTON, bool MEDIA>
+template<bool RECORD, bool HALTON, bool MEDIA, bool HERO = false>
 __device__ __forceinline__ Pool pool_setup(const DScene &sc, unsigned char *base, PoolCtl *ctl)
 {
-  constexpr uint32_t NS = PoolLayout<RECORD, HALTON, MEDIA>::SLOTS;
+  constexpr uint32_t NS = PoolLayout<RECORD, HALTON, MEDIA, HERO>::SLOTS;
   Pool p;
   p.ctl = (lds_u32_t *)ctl;
   uint32_t E = sc.pool_classes > 1u ? sc.pool_bytes/(NS*8u + 2u*(MI_POOL_CLASSES + 1u)) : 0u;
@@ -165,7 +168,7 @@ __device__ __forceinline__ void pool_leave(const Pool &pool, unsigned long long 
 
 
 /* a vertex into / out of an entry: the whole path state that is live between two rays (NS 8-byte words, [word][E]) */
-template<bool RECORD, bool PTDL, bool HALTON, bool MEDIA>
+template<bool RECORD, bool PTDL, bool HALTON, bool MEDIA, bool HERO = false>
 __device__ __forceinline__ void pool_write_vertex(lds_uint2 *e, uint32_t E, PathState &ps, const Hit &hit, bool &tracing)
 {
   constexpr int NB = PoolLayout<RECORD, HALTON, MEDIA>::BASE;
@@ -197,9 +200,21 @@ __device__ __forceinline__ void pool_write_vertex(lds_uint2 *e, uint32_t E, Path
       e[(NB + 1)*E] = mi_u32x2{__float_as_uint(ps.cur.g), (uint32_t)ps.cur.med};
       e[(NB + 2)*E] = mi_u32x2{__float_as_uint(ps.clip), __float_as_uint(ps.time)};
     }
+    if constexpr(HERO)
+    {
+      const PathStateHero &h = static_cast<const PathStateHero &>(ps);
+      constexpr int NH = PoolLayout<RECORD, HALTON, MEDIA>::SLOTS;
+      e[(NH + 0)*E] = mi_u32x2{__float_as_uint(h.lambda_x[0]), __float_as_uint(h.lambda_x[1])};
+      e[(NH + 1)*E] = mi_u32x2{__float_as_uint(h.lambda_x[2]), __float_as_uint(h.throughput_x[0])};
+      e[(NH + 2)*E] = mi_u32x2{__float_as_uint(h.throughput_x[1]), __float_as_uint(h.throughput_x[2])};
+      e[(NH + 3)*E] = mi_u32x2{__float_as_uint(h.pdf_x[0]), __float_as_uint(h.pdf_x[1])};
+      e[(NH + 4)*E] = mi_u32x2{__float_as_uint(h.pdf_x[2]), 0u};
+#pragma unroll
+      for(int l=0;l<3;l++) { const unsigned long long q = (unsigned long long)__double_as_longlong(h.pdfprod_x[l]); e[(NH + 5 + l)*E] = mi_u32x2{(uint32_t)q, (uint32_t)(q >> 32)}; }
+    }
     tracing = false; ps.active = 0; ps.sh_pending = 0;
 }
-template<bool RECORD, bool PTDL, bool HALTON, bool MEDIA>
+template<bool RECORD, bool PTDL, bool HALTON, bool MEDIA, bool HERO = false>
 __device__ __forceinline__ void pool_read_vertex(const lds_uint2 *e, uint32_t E, PathState &ps, Hit &hit, TraceState &ts, bool &tracing, bool &tr_shadow)
 {
   constexpr int NB = PoolLayout<RECORD, HALTON, MEDIA>::BASE;
@@ -233,6 +248,18 @@ __device__ __forceinline__ void pool_read_vertex(const lds_uint2 *e, uint32_t E,
       ps.cur.mu_s = __uint_as_float(a.x); ps.cur.mu_t = __uint_as_float(a.y); ps.cur.g = __uint_as_float(b.x); ps.cur.med = (int)b.y;
       ps.clip = __uint_as_float(c.x); ps.time = __uint_as_float(c.y);
     }
+    if constexpr(HERO)
+    {
+      PathStateHero &h = static_cast<PathStateHero &>(ps);
+      constexpr int NH = PoolLayout<RECORD, HALTON, MEDIA>::SLOTS;
+      const mi_u32x2 a = e[(NH + 0)*E], b = e[(NH + 1)*E], c = e[(NH + 2)*E], d = e[(NH + 3)*E], f = e[(NH + 4)*E];
+      h.lambda_x[0] = __uint_as_float(a.x); h.lambda_x[1] = __uint_as_float(a.y); h.lambda_x[2] = __uint_as_float(b.x);
+      h.throughput_x[0] = __uint_as_float(b.y); h.throughput_x[1] = __uint_as_float(c.x); h.throughput_x[2] = __uint_as_float(c.y);
+      h.pdf_x[0] = __uint_as_float(d.x); h.pdf_x[1] = __uint_as_float(d.y); h.pdf_x[2] = __uint_as_float(f.x);
+#pragma unroll
+      for(int l=0;l<3;l++) { const mi_u32x2 q = e[(NH + 5 + l)*E]; h.pdfprod_x[l] = __longlong_as_double((long long)((unsigned long long)q.x | ((unsigned long long)q.y << 32))); }
+      h.sh_value_x[0] = h.sh_value_x[1] = h.sh_value_x[2] = 0.0f;
+    }
     ps.active = 1; ps.sh_pending = 0;
     if(PTDL) { ps.sh_dir = mk3(0.0f, 0.0f, 0.0f); ps.sh_dist = 0.0f; ps.sh_value = 0.0f; ps.sh_light = 0u; ps.sh_length = 0; }
     tracing = true; tr_shadow = false;
@@ -248,7 +275,7 @@ __device__ __forceinline__ void pool_read_vertex(const lds_uint2 *e, uint32_t E,
  *             SIMD's other waves run their traversal slices at a higher priority keeps fifteen waves waiting)
  * Afterwards: lanes that posted are free (ps.active = 0, tracing = false); lanes that pulled hold a vertex to shade
  * (tracing = true, ts.done = true, tr_shadow = false). */
-template<bool RECORD, bool PTDL, bool HALTON, bool MEDIA, int PRIO, class CNT>
+template<bool RECORD, bool PTDL, bool HALTON, bool MEDIA, int PRIO, bool HERO = false, class CNT>
 __device__ __forceinline__ void regroup_exchange(const Pool &pool, PathState &ps, Hit &hit, TraceState &ts, bool &tracing, bool &tr_shadow,
                                                  bool surf, uint32_t cls, bool freelane, bool drain, CNT &cnt)
 {
@@ -404,8 +431,8 @@ __device__ __forceinline__ void regroup_exchange(const Pool &pool, PathState &ps
 #endif
   __builtin_amdgcn_s_setprio(PRIO);
   /* ---- the vertices themselves, outside the lock: the entries are on no list */
-  if(post) pool_write_vertex<RECORD, PTDL, HALTON, MEDIA>(pool.data + id_post, E, ps, hit, tracing);
-  if(pull) pool_read_vertex<RECORD, PTDL, HALTON, MEDIA>(pool.data + id_pull, E, ps, hit, ts, tracing, tr_shadow);
+  if(post) pool_write_vertex<RECORD, PTDL, HALTON, MEDIA, HERO>(pool.data + id_post, E, ps, hit, tracing);
+  if(pull) pool_read_vertex<RECORD, PTDL, HALTON, MEDIA, HERO>(pool.data + id_pull, E, ps, hit, ts, tracing, tr_shadow);
   /* ---- second critical section: the written entries onto their classes' lists, the read ones back onto the free list */
   __builtin_amdgcn_s_setprio(3);
   {
