@@ -182,6 +182,9 @@ class StubBackend:
     def set_pixels(self, on):
         self.pixels = on
 
+    def set_wavelengths(self, count):
+        self.wavelengths = count
+
     def render_tiles(self, first_frame, frames, member, members, tiles=None):
         local = (self.tiles - member + members - 1) // members if member < self.tiles else 0
         self.render(0, frames * local * 1024)
@@ -290,6 +293,9 @@ def main():
                          "indices, pixels are sampled (regression/0010_pt as the reference renders it: path for path the reference's paths). tiles: "
                          "rank r renders the 32 x 32 film tiles t = r (mod N) of every frame, pixels come from the path indices (the tiled branch of "
                          "the reference's render_sample_path, src/render.d/gi.c:88-95; mi_render_tiles) -- every rank splats into its own pixels")
+    ap.add_argument("--wavelengths", type=int, default=1, choices=[1, 4],
+                    help="4: hero wavelengths -- every path carries four wavelengths, the reference built with -DMF_COUNT=4 (mi_scene_set_wavelengths; "
+                         "plain scenes only). `value` stays PATHS per second; the roofline record is the scalar kernel's and is not reported")
     ap.add_argument("--reduce", default="torch", choices=["torch", "c"],
                     help="torch: one process per GPU, torch.distributed (RCCL) all-reduce of the framebuffer (what the driver launches); c: ONE process, "
                          "the N GPUs behind the C ABI (mi_group_*: index ranges split in the library, ncclReduce from the library)")
@@ -386,6 +392,8 @@ def main():
         my_tiles = (tiles - rank + world - 1) // world if rank < tiles else 0
         if args.shard == "tiles":
             be.set_pixels(True)
+        if args.wavelengths != 1:
+            be.set_wavelengths(args.wavelengths)
 
         def step(k):
             # rank r renders its own contiguous block of the step's path indices (or its own tiles of the step's frames): no data-path collective
@@ -640,14 +648,14 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic: regression/0010_pt scene (6 of 7 shapes, scenes/0010_pt), per-path xorshift128+ seeds",
-            "config": {"workload": cfg["name"], "tree": args.tree, "pointsampler": args.points, "traversal": main_r["traversal"],
+            "config": {"workload": cfg["name"], "tree": args.tree, "pointsampler": args.points, "traversal": main_r["traversal"], "wavelengths_per_path": args.wavelengths,
                        "paths_per_step": main_r["job"], "paths_per_step_per_gpu": main_r["launch_paths"],
                        "sharding": (f"32x32 film tiles t = rank (mod {world}), pixels from path indices (mi_render_tiles; {scaling})" if args.shard == "tiles"
                                     else f"path-index ranges x{world} ({scaling})") + ", framebuffer all-reduce + read-back of the last frame in the timed region"},
             # the timed kernel counts paths only; live_work_per_sample comes from one launch of the counting instantiation outside the timed region
             "counters_compiled_in": False,
-            "roofline": roofline_of(args.config, main_r),
-            "work_rate_vs_hbm": work_rate_of(args.config, main_r),
+            "roofline": roofline_of(args.config, main_r) if args.wavelengths == 1 else None,
+            "work_rate_vs_hbm": work_rate_of(args.config, main_r) if args.wavelengths == 1 else None,
         }
         if args.stub:
             out["stub"] = {"reduced_sum_last_frame": main_r["reduced_sum"], "expected": float(main_r["job"])}

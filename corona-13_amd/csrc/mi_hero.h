@@ -7,9 +7,11 @@
  *
  * One LANE per path, as in every other kernel: the traversal is the scalar kernels' (a ray is a ray), and the spectral part of a vertex --
  * colours, indices of refraction, Fresnel terms, pdfs, weights -- is evaluated for l = 0..3 by the SAME device functions the scalar kernels
- * use (mi_kernels.h), called once per component from unrolled loops, component 0 first. What is common to the four calls (the surface, the
- * sampled microfacet, the emitter sample) the compiler computes once. The places where the reference looks across the components (mf_any,
- * mf_all, mf(x, 0), mf_hsum) are written out here or handed to the bsdf functions in a HeroCtx.
+ * use (mi_kernels.h) where a quantity has one wavelength in it (colours, indices of refraction), and by four-component versions of the bsdf
+ * functions below: the geometry -- surface, sampled microfacet, emitter sample -- once, the Fresnel terms, pdfs and weights in loops over
+ * l = 0..3, expression for expression what the scalar function computes for one component (the first version called the scalar functions
+ * four times: same paths, 1.4 times the kernel time, profiles/r05_hero.txt). The places where the reference looks across the components
+ * (mf_any, mf_all, mf(x, 0), mf_hsum) are written out.
  * Component 0 lives in the PathState the megakernel knows (ray, pdf product, throughput ...: what the traversal slices and the parking
  * of path state touch), components 1..3 in the arrays of PathStateHero behind it: 18 registers more.
  * Plain scenes only (no media, no moving primitives, `rand` point sampler): what the reference's MF_COUNT = 4 build was pinned on
@@ -581,10 +583,6 @@ __device__ __forceinline__ void run_prepare_ops_hero(const DScene &sc, const DMa
   }
 }
 
-#ifndef MI_HERO_FUSED
-#define MI_HERO_FUSED 1     /* 0: the first implementation -- the scalar functions called once per component with a HeroCtx (kept for A/B: same paths) */
-#endif
-
 /* path_shade (mi_path.h) for four components; the comments there name the reference lines of every step, here only what differs */
 template<bool RECORD, bool PTDL, class CNT>
 __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero &ps, const Hit &hit, const uint32_t *shape_material, const float *shape_L,
@@ -637,16 +635,10 @@ __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero 
     surface_setup<false>(sc, hit.prim, head, omega, ps.scramble, sf, ps.time);
     const uint32_t shape = (head.w >> 3) & 0x1fffffffu;
     Shading sh[4];
-#if MI_HERO_FUSED
     run_prepare_ops_hero(sc, mat, mhead.y, sf, lam, sh);
-#else
-#pragma unroll
-    for(int l=0;l<MI_MF;l++) run_prepare_ops(sc, mat, mhead.y, sf, lam[l], sh[l]);
-#endif
     uint32_t material_modes = 0;
     float eta[4] = {1.0f, 1.0f, 1.0f, 1.0f};
-    HeroCtx hc;
-    hc.lane = 0; hc.any_im = false; hc.any_rd = false; hc.eta0 = 1.0f; hc.R0 = hc.cost20 = hc.cost0 = 0.0f; hc.u[0] = hc.u[1] = hc.u[2] = 0.0f; hc.k = 0;
+    bool any_im = false;         /* mf_any(indexmatched(eta_ratio, 1)), dielectric.c:61-65 */
     if(RECORD || mat_bsdf != MI_BSDF_DIFFUSE)
     {
       {
@@ -670,14 +662,13 @@ __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero 
         }
       }
     }
-    hc.eta0 = eta[0];
-    hc.any_rd = sh[0].rd > 0.0f || sh[1].rd > 0.0f || sh[2].rd > 0.0f || sh[3].rd > 0.0f;
-    if(mat_bsdf == MI_BSDF_DIFFUSE) { if(hc.any_rd) material_modes = s_reflect | s_diffuse; }           /* mf_any(rd > 0), src/shader.c:161 */
+    const bool any_rd = sh[0].rd > 0.0f || sh[1].rd > 0.0f || sh[2].rd > 0.0f || sh[3].rd > 0.0f;
+    if(mat_bsdf == MI_BSDF_DIFFUSE) { if(any_rd) material_modes = s_reflect | s_diffuse; }           /* mf_any(rd > 0), src/shader.c:161 */
     else if(mat_bsdf == MI_BSDF_DIELECTRIC)
     {
       material_modes = s_reflect | s_transmit;
-      hc.any_im = fabsf(1.0f - eta[0]/1.0f) < 1e-3f || fabsf(1.0f - eta[1]/1.0f) < 1e-3f || fabsf(1.0f - eta[2]/1.0f) < 1e-3f || fabsf(1.0f - eta[3]/1.0f) < 1e-3f;
-      if(hc.any_im) sh[0].roughness = sh[1].roughness = sh[2].roughness = sh[3].roughness = 0.0f;       /* indexmatched() is an mf_any, dielectric.c:61-65 */
+      any_im = fabsf(1.0f - eta[0]/1.0f) < 1e-3f || fabsf(1.0f - eta[1]/1.0f) < 1e-3f || fabsf(1.0f - eta[2]/1.0f) < 1e-3f || fabsf(1.0f - eta[3]/1.0f) < 1e-3f;
+      if(any_im) sh[0].roughness = sh[1].roughness = sh[2].roughness = sh[3].roughness = 0.0f;       /* indexmatched() is an mf_any, dielectric.c:61-65 */
       if(sh[0].roughness > GLOSSY_THR) material_modes |= s_glossy; else material_modes |= s_specular;
     }
     else if(mat_bsdf == MI_BSDF_METAL)
@@ -877,25 +868,13 @@ __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero 
             for(int l=0;l<MI_MF;l++) edf[l] = edf[l]/sc.p_geo;
             if(edf[0] > 0.0f || edf[1] > 0.0f || edf[2] > 0.0f || edf[3] > 0.0f)                       /* mf_any(edf > 0), nee.h:188 */
             {
-#if MI_HERO_FUSED
               HeroEval he;
               if(mat_bsdf == MI_BSDF_DIFFUSE) he = brdf_diffuse_hero(sf, sh, ol);
-              else if(mat_bsdf == MI_BSDF_DIELECTRIC) he = brdf_dielectric_hero(sf, sh, omega, ol, eta, hc.any_im);
+              else if(mat_bsdf == MI_BSDF_DIELECTRIC) he = brdf_dielectric_hero(sf, sh, omega, ol, eta, any_im);
               else he = brdf_metal_hero(sc, sf, sh, omega, ol, ior, (int)mat_p0, lam);
               struct { float value; uint32_t mode; } be[4];
 #pragma unroll
               for(int l=0;l<MI_MF;l++) { be[l].value = he.value[l]; be[l].mode = he.mode; }
-#else
-              BsdfEval be[4];
-#pragma unroll
-              for(int l=0;l<MI_MF;l++)
-              {
-                hc.lane = l;
-                if(mat_bsdf == MI_BSDF_DIFFUSE) be[l] = brdf_diffuse(sf, sh[l], ol);
-                else if(mat_bsdf == MI_BSDF_DIELECTRIC) be[l] = brdf_dielectric<true>(sf, sh[l], omega, ol, eta[l], &hc);
-                else be[l] = brdf_metal(sc, sf, sh[l], omega, ol, ior[l], (int)mat_p0, lam[l]);
-              }
-#endif
               bool okn = be[0].value > 0.0f || be[1].value > 0.0f || be[2].value > 0.0f || be[3].value > 0.0f;   /* mf_any(bsdf > 0), nee.h:191 */
               if(okn && (be[0].mode & s_transmit))
               {
@@ -916,27 +895,18 @@ __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero 
                   const float Gn = fabsf(dot3(sf.n, ol))*fabsf(dot3(ls.n, ol))/(ldist*ldist);
                   float tn[4], ours[4], sums[4];
                   const float wn = lpdf/(lpdf + 0.0f/1.0f);
-#if MI_HERO_FUSED
                   float pbs[4];
                   if(mat_bsdf == MI_BSDF_DIFFUSE) pbs[0] = pbs[1] = pbs[2] = pbs[3] = (float)(1.0f/MI_PI_D);
-                  else if(mat_bsdf == MI_BSDF_DIELECTRIC) pdf_dielectric_hero(sf, sh, omega, ol, eta, hc.any_im, be[0].mode, pbs);
+                  else if(mat_bsdf == MI_BSDF_DIELECTRIC) pdf_dielectric_hero(sf, sh, omega, ol, eta, any_im, be[0].mode, pbs);
                   else pbs[0] = pbs[1] = pbs[2] = pbs[3] = pdf_metal(sf, sh[0], omega, ol, be[0].mode);     /* no wavelength in it */
-#endif
 #pragma unroll
                   for(int l=0;l<MI_MF;l++)
                   {
-                    hc.lane = l;
                     float t = ((vthr[l]*be[l].value)*(1.0f*edf[l]))*Gn;
                     t = t + (vthr[l]*be[l].value)*((0.0f*Gn)/lpdf);
                     tn[l] = t*wn;
                     float pb;
-#if MI_HERO_FUSED
                     pb = pbs[l];
-#else
-                    if(mat_bsdf == MI_BSDF_DIFFUSE) pb = (float)(1.0f/MI_PI_D);
-                    else if(mat_bsdf == MI_BSDF_DIELECTRIC) pb = pdf_dielectric<true>(sf, sh[l], omega, ol, eta[l], be[0].mode, &hc);
-                    else pb = pdf_metal(sf, sh[l], omega, ol, be[0].mode);
-#endif
                     const float pe = (1.0f*pb)*Gn;
                     const double our = (double)(1.0f*lpdf)*pp[l], other = (double)pe*pp[l];
                     ours[l] = (float)our; sums[l] = (float)(other + our);
@@ -973,26 +943,13 @@ __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero 
       {
         get_scrambled_onb(ps.scramble, sf.n, sf.a, sf.b);
         PointSampler<false> pts(sc, ps.rng, ps.index, rand_beg_extend<PTDL>(v + 1));
-#if MI_HERO_FUSED
         HeroSample hs;
-        if(mat_bsdf == MI_BSDF_DIFFUSE) sample_diffuse_hero(pts, sf, sh, hc.any_rd, mode, hs);
-        else if(mat_bsdf == MI_BSDF_DIELECTRIC) sample_dielectric_hero(pts, sf, sh, omega, eta, hc.any_im, mode, hs);
+        if(mat_bsdf == MI_BSDF_DIFFUSE) sample_diffuse_hero(pts, sf, sh, any_rd, mode, hs);
+        else if(mat_bsdf == MI_BSDF_DIELECTRIC) sample_dielectric_hero(pts, sf, sh, omega, eta, any_im, mode, hs);
         else sample_metal_hero(sc, pts, sf, sh, omega, ior, (int)mat_p0, lam, mode, hs);
         struct { V3 omega; uint32_t mode; float pdf, weight; } bs[4];
 #pragma unroll
         for(int l=0;l<MI_MF;l++) { bs[l].omega = hs.omega; bs[l].mode = hs.mode; bs[l].pdf = hs.pdf[l]; bs[l].weight = hs.weight[l]; }
-#else
-        BsdfSample bs[4];
-        HeroPoints<PointSampler<false> > hp(pts, hc);
-#pragma unroll
-        for(int l=0;l<MI_MF;l++)
-        {
-          hc.lane = l; hc.k = 0;
-          if(mat_bsdf == MI_BSDF_DIFFUSE) sample_diffuse<HeroPoints<PointSampler<false> >, true>(hp, sf, sh[l], mode, bs[l], &hc);
-          else if(mat_bsdf == MI_BSDF_DIELECTRIC) sample_dielectric<HeroPoints<PointSampler<false> >, true>(hp, sf, sh[l], omega, eta[l], mode, bs[l], &hc);
-          else sample_metal<HeroPoints<PointSampler<false> >, true>(sc, hp, sf, sh[l], omega, ior[l], (int)mat_p0, lam[l], mode, bs[l]);
-        }
-#endif
         const V3 out = normalise3(bs[0].omega);
         const float dts = ((sf.flags & s_inside) ? -1 : 1)*dot3(sf.gn, out);
         const bool wrong_side = ((bs[0].mode & s_reflect) && (dts < 0.f)) || ((bs[0].mode & s_transmit) && (dts > 0.f));

@@ -2025,33 +2025,7 @@ __device__ __forceinline__ bool metal_reference_kills(float n1, float n2, float 
   return 0.5f*__builtin_fmaf(eta2r, sinr, len - 1.0f) < 0.0f;
 }
 
-/* ------------------------------------------------------------------------------------------ hero wavelengths (the reference built with
- * -DMF_COUNT=4, include/mf.h:280-423): a path carries four wavelengths; geometry and every decision follow component 0, the hero; the weights
- * carry all four. The HERO kernels (mi_hero.h) evaluate the bsdf functions below once per component, component 0 first, with this context:
- * the few places where the reference looks across the components (mf_any, mf_all, mf(x, 0)) read it instead of the component's own value.
- * HERO = false (every other kernel): the context is never touched and the functions compile to what they were. */
-#define MI_MF 4
-struct HeroCtx
-{
-  int lane;                  /* component being evaluated; 0 = hero */
-  bool any_im;               /* mf_any(indexmatched(eta_ratio, 1)), dielectric.c:61-65 */
-  bool any_rd;               /* mf_any(rd > 0): sample_d's mode, src/shader.c:202 */
-  float eta0;                /* mf(eta_ratio, 0) */
-  float R0, cost20, cost0;   /* the hero's Fresnel term / transmitted cosine for the sampled microfacet (left by component 0, dielectric.c:293,326-328) */
-  float u[3]; int k;         /* the numbers component 0 drew, replayed for 1..3 */
-};
-/* point sampler of a HERO bsdf sample: component 0 draws (and keeps) the numbers, the others get the same ones in the same order */
-template<class PS> struct HeroPoints
-{
-  PS &pts; HeroCtx &hc;
-  __device__ __forceinline__ HeroPoints(PS &p, HeroCtx &h) : pts(p), hc(h) {}
-  __device__ __forceinline__ float operator()(int dim)
-  {
-    const int k = hc.k++;
-    if(hc.lane == 0) { const float x = pts(dim); if(k == 0) hc.u[0] = x; else if(k == 1) hc.u[1] = x; else hc.u[2] = x; return x; }
-    return k == 0 ? hc.u[0] : k == 1 ? hc.u[1] : hc.u[2];
-  }
-};
+#define MI_MF 4      /* wavelengths per path in the HERO kernels (mi_hero.h) */
 
 /* ------------------------------------------------------------------------------------------ bsdf sampling */
 struct BsdfSample
@@ -2062,8 +2036,8 @@ struct BsdfSample
   uint32_t mode;     /* v[v].mode after sampling */
 };
 
-template<class PS, bool HERO = false>
-__device__ __forceinline__ void sample_diffuse(PS &pts, const Surf &sf, const Shading &sh, uint32_t mode_in, BsdfSample &bs, const HeroCtx *hc = nullptr)
+template<class PS>
+__device__ __forceinline__ void sample_diffuse(PS &pts, const Surf &sf, const Shading &sh, uint32_t mode_in, BsdfSample &bs)
 { /* sample_d, src/shader.c:165-205 */
   const float x1 = pts(MI_DIM_OMEGA_X);
   const float x2 = pts(MI_DIM_OMEGA_Y);
@@ -2081,17 +2055,16 @@ __device__ __forceinline__ void sample_diffuse(PS &pts, const Surf &sf, const Sh
   if(sf.flags & s_inside) { if(cos_out_ng >= 0.0f) return; }
   else if(cos_out_ng <= 0.0f) return;
   bs.weight = sh.rd;
-  if(HERO ? hc->any_rd : bs.weight > 0.0f) bs.mode = s_diffuse | s_reflect;      /* mf_any(mf_gt(throughput, 0)), src/shader.c:202 */
+  if(bs.weight > 0.0f) bs.mode = s_diffuse | s_reflect;
 }
 
-template<class PS, bool HERO = false>
+template<class PS>
 __device__ __forceinline__ void sample_dielectric(PS &pts, const Surf &sf, const Shading &sh, const V3 wi, float eta_ratio,
-                                                  uint32_t mode_in, BsdfSample &bs, HeroCtx *hc = nullptr)
-{ /* sample, dielectric.c:240-415 (MF_COUNT == 1; HERO: the MF_COUNT = 4 branches -- the microfacet, the reflect / transmit choice and the
-     outgoing direction are the hero's, every component then weighs that direction with its own index of refraction) */
+                                                  uint32_t mode_in, BsdfSample &bs)
+{ /* sample, dielectric.c:240-415 (MF_COUNT == 1) */
   bs.mode = mode_in; bs.weight = 0.0f; bs.pdf = 1.0f; bs.omega = mk3(0, 0, 0);
-  if((HERO ? hc->eta0 : eta_ratio) < 0.0f) return;
-  if(HERO ? hc->any_im : fabsf(1.0f - eta_ratio/1.0f) < 1e-3f)
+  if(eta_ratio < 0.0f) return;
+  if(fabsf(1.0f - eta_ratio/1.0f) < 1e-3f)
   {
     bs.omega = wi;
     bs.mode = s_specular | s_transmit;
@@ -2107,10 +2080,8 @@ __device__ __forceinline__ void sample_dielectric(PS &pts, const Surf &sf, const
   if(r > GLOSSY_THR)
   {
     const V3 wit = mk3(-dot3(sf.a, wi), -dot3(sf.b, wi), cos_in);
-    float U1, U2;
-    if(HERO) { U1 = pts(MI_DIM_OMEGA_X); U2 = pts(MI_DIM_OMEGA_Y); }   /* the MF_COUNT = 4 reference: this plugin only builds with clang, which evaluates
-                                                                          call arguments left to right (tests/test_oracle_hero.py) */
-    else { U2 = pts(MI_DIM_OMEGA_Y); U1 = pts(MI_DIM_OMEGA_X); }       /* argument evaluation order of the reference build (gcc), SURVEY app. B */
+    const float U2 = pts(MI_DIM_OMEGA_Y);          /* argument evaluation order of the reference build, SURVEY app. B */
+    const float U1 = pts(MI_DIM_OMEGA_X);
     const V3 ht = ggx_sample_h(wit, r, r, U1, U2);
     h = mk3(ht.x*sf.a.x + ht.y*sf.b.x + ht.z*n.x, ht.x*sf.a.y + ht.y*sf.b.y + ht.z*n.y, ht.x*sf.a.z + ht.y*sf.b.z + ht.z*n.z);
     pdf_h = ggx_pdf_h(wi, h, n, r);
@@ -2123,8 +2094,7 @@ __device__ __forceinline__ void sample_dielectric(PS &pts, const Surf &sf, const
   const float cost2 = 1.0f - (nr*nr)*(1.0f - cosr*cosr);
   const float cost = cost2 <= 0.0f ? 0.0f : mi_sqrt(cost2);
   const float R = fresnel_dielectric(n1, n2, cosr, cost);
-  if(HERO && hc->lane == 0) { hc->R0 = R; hc->cost20 = cost2; hc->cost0 = cost; }
-  if(pts(MI_DIM_SCATTER_MODE) <= (HERO ? hc->R0 : R))
+  if(pts(MI_DIM_SCATTER_MODE) <= R)
   {
     bs.mode = s_reflect;
     bs.omega = mk3(wi.x + 2.0f*cosr*h.x, wi.y + 2.0f*cosr*h.y, wi.z + 2.0f*cosr*h.z);
@@ -2144,43 +2114,15 @@ __device__ __forceinline__ void sample_dielectric(PS &pts, const Surf &sf, const
   }
   else
   {
-    if((HERO ? hc->cost20 : cost2) <= 0.0f) return;                      /* HERO: "can't sample hero, we're all dead" */
-    const float eta_h = HERO ? hc->eta0 : eta_ratio;
-    const float f = eta_h*cosr - (HERO ? hc->cost0 : cost);
-    bs.omega = normalise3(mk3(wi.x*eta_h + f*h.x, wi.y*eta_h + f*h.y, wi.z*eta_h + f*h.z));
+    if(cost2 <= 0.0f) return;
+    const float f = eta_ratio*cosr - cost;
+    bs.omega = normalise3(mk3(wi.x*eta_ratio + f*h.x, wi.y*eta_ratio + f*h.y, wi.z*eta_ratio + f*h.z));
     if(dot3(bs.omega, n) >= 0.0f) return;
     if(r <= GLOSSY_THR)
     {
-      /* HERO: "specular transmit always selects single wavelength": mask = mf_hero = _mm_set_epi32(0, ~0, ~0, ~0) (include/mf.h:300) zeroes the
-         components whose mask is set, and _mm_set_epi32 lists the highest element first -- components 0, 1, 2 die, component 3 carries on */
-      const bool masked = HERO && hc->lane != MI_MF - 1;
-      bs.pdf = masked ? 0.0f : 1.0f - R;
+      bs.pdf = 1.0f - R;
       bs.mode = s_specular | s_transmit;
-      bs.weight = masked ? 0.0f : sh.rg;
-      return;
-    }
-    if(HERO)
-    { /* dielectric.c:353-411: the sampled half vector connects wi and wo for the hero's index of refraction only; every component
-         reconstructs the one ITS index needs, with its own Fresnel term */
-      const V3 wo = bs.omega;
-      bool mask = false;
-      float h0 = n1*wi.x - n2*wo.x, h1 = n1*wi.y - n2*wo.y, h2 = n1*wi.z - n2*wo.z;
-      const float hilen = 1.0f/mi_sqrt(h0*h0 + (h1*h1 + h2*h2));
-      h0 *= hilen; h1 *= hilen; h2 *= hilen;
-      if(n2 < n1) { h0 = -h0; h1 = -h1; h2 = -h2; }
-      const float cosh2 = h0*n.x + (h1*n.y + h2*n.z);
-      mask |= cosh2 < 0.0f;
-      const float cosr2 = h0*-wi.x + (h1*-wi.y + h2*-wi.z);
-      mask |= cosr2 <= 0.0f;
-      const float cost2b = 1.0f - (nr*nr)*(1.0f - cosr2*cosr2);
-      const float costb = cost2b <= 0.0f ? 0.0f : mi_sqrt(cost2b);
-      const float R2 = fresnel_dielectric(n1, n2, cosr2, costb);
-      const float denom = n1*cosr2 - n2*costb;
-      float pdf2 = ggx_pdf_h_cos(cosh2, cos_in, cosr2, sh.roughness);
-      pdf2 = pdf2*(((n2*n2)*costb)/(denom*denom));
-      bs.pdf = mask ? 0.0f : (pdf2*(1.0f - R2))/fabsf(dot3(wo, n));
-      bs.mode = s_transmit | s_glossy;
-      bs.weight = mask ? 0.0f : sh.rg*ggx_G1(wo, n, sh.roughness);
+      bs.weight = sh.rg;
       return;
     }
     const float denom = n1*cosr - n2*cost;
@@ -2191,10 +2133,10 @@ __device__ __forceinline__ void sample_dielectric(PS &pts, const Surf &sf, const
   }
 }
 
-template<class PS, bool HERO = false>
+template<class PS>
 __device__ __forceinline__ void sample_metal(const DScene &sc, PS &pts, const Surf &sf, const Shading &sh, const V3 wi, float n1,
                                              int mat, float lambda, uint32_t mode_in, BsdfSample &bs)
-{ /* sample, metal.c:219-265 (HERO: the same code per component -- one microfacet, the conductor's n and k at each wavelength) */
+{ /* sample, metal.c:219-265 */
   bs.mode = mode_in; bs.weight = 0.0f; bs.pdf = 1.0f; bs.omega = mk3(0, 0, 0);
   const V3 n = sf.n;
   V3 h = n;
@@ -2203,9 +2145,8 @@ __device__ __forceinline__ void sample_metal(const DScene &sc, PS &pts, const Su
   if(r > 1e-4f)
   {
     const V3 wit = mk3(-dot3(sf.a, wi), -dot3(sf.b, wi), -dot3(n, wi));
-    float U1, U2;
-    if(HERO) { U1 = pts(MI_DIM_OMEGA_X); U2 = pts(MI_DIM_OMEGA_Y); }   /* clang's order, see sample_dielectric */
-    else { U2 = pts(MI_DIM_OMEGA_Y); U1 = pts(MI_DIM_OMEGA_X); }
+    const float U2 = pts(MI_DIM_OMEGA_Y);
+    const float U1 = pts(MI_DIM_OMEGA_X);
     const V3 ht = ggx_sample_h(wit, r, r, U1, U2);
     h = mk3(ht.x*sf.a.x + ht.y*sf.b.x + ht.z*n.x, ht.x*sf.a.y + ht.y*sf.b.y + ht.z*n.y, ht.x*sf.a.z + ht.y*sf.b.z + ht.z*n.z);
     pdf_h = ggx_pdf_h(wi, h, n, r);
@@ -2247,16 +2188,15 @@ __device__ __forceinline__ BsdfEval brdf_diffuse(const Surf &sf, const Shading &
   return r;
 }
 
-template<bool HERO = false>
-__device__ __forceinline__ BsdfEval brdf_dielectric(const Surf &sf, const Shading &sh, const V3 wi, const V3 wo, float eta_ratio, const HeroCtx *hc = nullptr)
-{ /* brdf, dielectric.c:418-541 (scalar; HERO: per component, with mf(eta_ratio, 0) < 0 and mf_any(indexmatched) from the context) */
+__device__ __forceinline__ BsdfEval brdf_dielectric(const Surf &sf, const Shading &sh, const V3 wi, const V3 wo, float eta_ratio)
+{ /* brdf, dielectric.c:418-541 (scalar) */
   BsdfEval res; res.value = 0.0f; res.mode = s_absorb;
   const V3 n = sf.n;
   const float cos_in  = -dot3(n, wi);
   const float cos_out =  dot3(n, wo);
-  if((HERO ? hc->eta0 : eta_ratio) < 0.0f) return res;
+  if(eta_ratio < 0.0f) return res;
   const float n1 = eta_ratio, n2 = 1.0f;
-  const bool index_matched = HERO ? hc->any_im : fabsf(1.0f - n1/n2) < 1e-3f;
+  const bool index_matched = fabsf(1.0f - n1/n2) < 1e-3f;
   if(cos_out == 0.0f || cos_in == 0.0f) return res;
   if(!index_matched && (cos_in*cos_out > 0)) res.mode = s_reflect;
   else res.mode = s_transmit;
@@ -2327,21 +2267,20 @@ __device__ __forceinline__ BsdfEval brdf_dielectric(const Surf &sf, const Shadin
   }
 }
 
-template<bool HERO = false>
-__device__ __forceinline__ float pdf_dielectric(const Surf &sf, const Shading &sh, const V3 wi, const V3 wo, float eta, uint32_t mode, const HeroCtx *hc = nullptr)
-{ /* pdf, dielectric.c:96-237 (forward direction; HERO: mf_all(eta < 0) -- the nesting breaks for all components or none -- and mf_any(indexmatched)) */
+__device__ __forceinline__ float pdf_dielectric(const Surf &sf, const Shading &sh, const V3 wi, const V3 wo, float eta, uint32_t mode)
+{ /* pdf, dielectric.c:96-237 (forward direction) */
   const V3 n = sf.n;
   const float cos_in  = -dot3(n, wi);
   const float cos_out =  dot3(n, wo);
   if(cos_in*cos_out == 0.0f) return 0.0f;
   if(cos_out > 0.0f && !(mode & s_reflect))  return 0.0f;
   if(cos_out < 0.0f && !(mode & s_transmit)) return 0.0f;
-  if((HERO ? hc->eta0 : eta) < 0.0f) return 0.0f;
+  if(eta < 0.0f) return 0.0f;
   const float n1 = eta, n2 = 1.0f;
   bool mask = false;
   float cosr = 0.0f, cosh = 0.0f;
   V3 h;
-  if(HERO ? hc->any_im : fabsf(1.0f - n1/n2) < 1e-3f)
+  if(fabsf(1.0f - n1/n2) < 1e-3f)
   {
     const float dot_wo_n = dot3(wo, n);
     h = normalise3(mk3(-wi.x + wo.x - 2.0f*dot_wo_n*n.x, -wi.y + wo.y - 2.0f*dot_wo_n*n.y, -wi.z + wo.z - 2.0f*dot_wo_n*n.z));

@@ -19,9 +19,19 @@
 #ifndef MI_BLOCK
 #define MI_BLOCK 1024    /* threads per workgroup: 16 waves/CU = 4 per SIMD (128 VGPRs each) */
 #endif
-#ifndef MI_BLOCK_HERO
-#define MI_BLOCK_HERO 1024   /* ... of the HERO kernels (mi_hero.h): their path state is 21 registers larger */
+/* ... per kind of kernel (the LDS layout scales with it: lds_setup<BLOCK>; the host lays the scene out for MI_BLOCK, a smaller workgroup uses less).
+   HERO kernels (mi_hero.h; 18 registers more path state), same box, 59 M paths: pt 1024 / 768 / 512 threads: 20.5 / 22.5 / - ms (without the exchange
+   26.4 / 29.6 / 40.1); ptdl 49.6 / 42.3 / - (64.2 / 60.9 / 79.8): the ptdl kernel spills 135 registers at 128, the pt kernel 55 */
+#ifndef MI_BLOCK_PTDL
+#define MI_BLOCK_PTDL MI_BLOCK
 #endif
+#ifndef MI_BLOCK_HERO
+#define MI_BLOCK_HERO 1024
+#endif
+#ifndef MI_BLOCK_HERO_PTDL
+#define MI_BLOCK_HERO_PTDL 768
+#endif
+#define MI_BLOCK_OF(HERO, PTDL) ((HERO) ? ((PTDL) ? MI_BLOCK_HERO_PTDL : MI_BLOCK_HERO) : ((PTDL) ? MI_BLOCK_PTDL : MI_BLOCK))
 #ifndef MI_TAIL_LANES
 #define MI_TAIL_LANES 16       /* a traversal slice ends when fewer rays than this are still under way */
 #endif
@@ -126,12 +136,12 @@
 
 /* ======================================================================================= persistent megakernel */
 template<bool RECORD, bool PTDL, bool NODES_LDS, bool HALTON = false, bool MEDIA = false, bool MB = false, bool COUNT = true, bool FAST = false, bool NORG = false, bool HERO = false>
-__global__ __launch_bounds__(HERO ? MI_BLOCK_HERO : MI_BLOCK) void mi_path_kernel(DScene sc, unsigned long long first, unsigned long long count,
+__global__ __launch_bounds__(MI_BLOCK_OF(HERO, PTDL)) void mi_path_kernel(DScene sc, unsigned long long first, unsigned long long count,
                                                            const uint32_t *shape_material, const float *shape_L, mi_path_record *records,
                                                            uint2 *stack_overflow)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int BLK = HERO ? MI_BLOCK_HERO : MI_BLOCK;     /* threads of the workgroup */
+  constexpr int BLK = MI_BLOCK_OF(HERO, PTDL);     /* threads of the workgroup */
   constexpr int COLUMN = MB ? MI_STACK_LDS_MB : (NORG || (MEDIA && !MI_REGROUP_MEDIA)) ? MI_STACK_LDS : MI_STACK_LDS_PLAIN;      /* stack entries per lane in LDS */
   const Lds lds = lds_setup<BLK, NODES_LDS, HALTON, PTDL && !MEDIA, COLUMN, MB>(sc, smem, stack_overflow);
 
@@ -559,7 +569,7 @@ template<bool PTDL, bool MEDIA, bool MB, bool FAST, bool NORG, bool HERO, bool R
                          ;
   if constexpr(valid)
   {
-    if(L) hipLaunchKernelGGL((mi_path_kernel<R, PTDL, N, H, MEDIA, MB, C, FAST, NORG, HERO>), dim3(L->grid), dim3(HERO ? MI_BLOCK_HERO : MI_BLOCK), L->lds_bytes, L->stream, L->d, L->first, L->n,
+    if(L) hipLaunchKernelGGL((mi_path_kernel<R, PTDL, N, H, MEDIA, MB, C, FAST, NORG, HERO>), dim3(L->grid), dim3(MI_BLOCK_OF(HERO, PTDL)), L->lds_bytes, L->stream, L->d, L->first, L->n,
                              L->shape_material, L->shape_L, L->rec, L->overflow);
     return (const void *)mi_path_kernel<R, PTDL, N, H, MEDIA, MB, C, FAST, NORG, HERO>;
   }
