@@ -231,6 +231,8 @@ def bench_group(args):
     per_frame = cfg["spp"] * scene.width * scene.height
     job = per_frame if scaling == "strong" else args.gpus * per_frame
     group = pkg.Group(scene, list(range(args.gpus)), traversal=None if args.traversal == "auto" else args.traversal)
+    if args.wavelengths != 1:
+        group.set_wavelengths(args.wavelengths)
     host = np.zeros((scene.height, scene.width, 3), dtype=np.float32)
     for k in range(args.warmup):
         group.render(k * job, job)

@@ -571,6 +571,11 @@ class Group:
     def uses_rccl(self):
         return bool(self.m.mi_group_uses_rccl(self._ptr))
 
+    def set_wavelengths(self, count):
+        """every member: mi_scene_set_wavelengths (4 = hero wavelengths)"""
+        for k in range(self.n):
+            self._check(self.m.mi_scene_set_wavelengths(C.c_void_p(self.m.mi_group_scene(self._ptr, k)), int(count)), "mi_scene_set_wavelengths")
+
     def render(self, first, count):
         self._check(self.m.mi_group_render(self._ptr, first, count), "mi_group_render")
 

@@ -153,3 +153,37 @@ def test_hero_is_refused_where_it_was_not_pinned():
     be.set_wavelengths(4)
     assert be.kernel_name().endswith("true>")
     be.close()
+
+
+def test_hero_sharding_by_tiles_and_by_group(monkeypatch):
+    """the two ways a job is shared between GPUs, with hero paths: tile-owned sharding (mi_render_tiles: two members' renders add up to the single
+    render, each splatting into its own pixels only up to the filter's reach) and index ranges behind the C ABI (mi_group of two members)"""
+    scene = make_scene(SCENE_0010, width=256, height=256, max_verts=8, sampler=pkg.MI_SAMPLER_PTDL)
+    frames = 4
+    be = pkg.Backend(scene, counters=False)
+    be.set_wavelengths(pkg.MI_WAVELENGTHS_HERO)
+    be.set_pixels(True)
+    be.render_tiles(0, frames)
+    whole = be.fb_read()
+    be.fb_clear()
+    be.render_tiles(0, frames, 0, 2)
+    be.render_tiles(0, frames, 1, 2)
+    parts = be.fb_read()
+    assert np.abs(parts - whole).max() <= 2e-4 * whole.max() and whole.max() > 0
+    # ... and it is the index-range render of the same frames in pixel mode
+    be.fb_clear()
+    be.render(0, frames * scene.width * scene.height)
+    assert np.abs(be.fb_read() - whole).max() <= 2e-4 * whole.max()
+    be.set_pixels(False)
+    be.fb_clear()
+    n = frames * scene.width * scene.height
+    be.render(0, n)
+    ref = be.fb_read()
+    be.close()
+    monkeypatch.setenv("CORONA_MI_GROUP_REDUCE", "peer")
+    two = pkg.Group(scene, [0, 0])
+    two.set_wavelengths(pkg.MI_WAVELENGTHS_HERO)
+    two.render(0, n)
+    got = two.fb_read()
+    assert np.abs(got - ref).max() <= 2e-4 * ref.max() and two.counters()[4] == n
+    two.close()
