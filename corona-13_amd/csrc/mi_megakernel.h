@@ -31,7 +31,15 @@
 #ifndef MI_BLOCK_HERO_PTDL
 #define MI_BLOCK_HERO_PTDL 768
 #endif
-#define MI_BLOCK_OF(HERO, PTDL) ((HERO) ? ((PTDL) ? MI_BLOCK_HERO_PTDL : MI_BLOCK_HERO) : ((PTDL) ? MI_BLOCK_PTDL : MI_BLOCK))
+#ifndef MI_BLOCK_PTDL_MEDIA
+#define MI_BLOCK_PTDL_MEDIA MI_BLOCK_PTDL     /* the extended ptdl kernels (media, moving camera, motion blur). 768 threads, same box (profiles/r05_hero.txt): media 17.2 -> 20.0 ms,
+                                                 media ptdl 32.2 -> 35.3, fog 37.5 -> 43.5, fog ptdl 115.1 -> 122.4, moving camera 16.6 -> 19.5, moving geometry 26.9 -> 32.1:
+                                                 every scalar kernel wants its sixteen waves, however much it spills (107 registers in the media ptdl kernel) */
+#endif
+#ifndef MI_BLOCK_MEDIA
+#define MI_BLOCK_MEDIA MI_BLOCK               /* the extended pt kernels */
+#endif
+#define MI_BLOCK_OF(HERO, PTDL, MEDIA) ((HERO) ? ((PTDL) ? MI_BLOCK_HERO_PTDL : MI_BLOCK_HERO) : (MEDIA) ? ((PTDL) ? MI_BLOCK_PTDL_MEDIA : MI_BLOCK_MEDIA) : ((PTDL) ? MI_BLOCK_PTDL : MI_BLOCK))
 #ifndef MI_TAIL_LANES
 #define MI_TAIL_LANES 16       /* a traversal slice ends when fewer rays than this are still under way */
 #endif
@@ -136,12 +144,12 @@
 
 /* ======================================================================================= persistent megakernel */
 template<bool RECORD, bool PTDL, bool NODES_LDS, bool HALTON = false, bool MEDIA = false, bool MB = false, bool COUNT = true, bool FAST = false, bool NORG = false, bool HERO = false>
-__global__ __launch_bounds__(MI_BLOCK_OF(HERO, PTDL)) void mi_path_kernel(DScene sc, unsigned long long first, unsigned long long count,
+__global__ __launch_bounds__(MI_BLOCK_OF(HERO, PTDL, MEDIA)) void mi_path_kernel(DScene sc, unsigned long long first, unsigned long long count,
                                                            const uint32_t *shape_material, const float *shape_L, mi_path_record *records,
                                                            uint2 *stack_overflow)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int BLK = MI_BLOCK_OF(HERO, PTDL);     /* threads of the workgroup */
+  constexpr int BLK = MI_BLOCK_OF(HERO, PTDL, MEDIA);     /* threads of the workgroup */
   constexpr int COLUMN = MB ? MI_STACK_LDS_MB : (NORG || (MEDIA && !MI_REGROUP_MEDIA)) ? MI_STACK_LDS : MI_STACK_LDS_PLAIN;      /* stack entries per lane in LDS */
   const Lds lds = lds_setup<BLK, NODES_LDS, HALTON, PTDL && !MEDIA, COLUMN, MB>(sc, smem, stack_overflow);
 
@@ -569,7 +577,7 @@ template<bool PTDL, bool MEDIA, bool MB, bool FAST, bool NORG, bool HERO, bool R
                          ;
   if constexpr(valid)
   {
-    if(L) hipLaunchKernelGGL((mi_path_kernel<R, PTDL, N, H, MEDIA, MB, C, FAST, NORG, HERO>), dim3(L->grid), dim3(MI_BLOCK_OF(HERO, PTDL)), L->lds_bytes, L->stream, L->d, L->first, L->n,
+    if(L) hipLaunchKernelGGL((mi_path_kernel<R, PTDL, N, H, MEDIA, MB, C, FAST, NORG, HERO>), dim3(L->grid), dim3(MI_BLOCK_OF(HERO, PTDL, MEDIA)), L->lds_bytes, L->stream, L->d, L->first, L->n,
                              L->shape_material, L->shape_L, L->rec, L->overflow);
     return (const void *)mi_path_kernel<R, PTDL, N, H, MEDIA, MB, C, FAST, NORG, HERO>;
   }
