@@ -1127,11 +1127,11 @@ extern "C" int mi_scene_set_wavelengths(mi_scene *s, int count)
   if(count != 1 && count != MI_WAVELENGTHS_HERO) return fail(MI_ERR_ARG, "mi_scene_set_wavelengths: 1 or 4 wavelengths per path");
   if(count == 1) { s->hero = false; return MI_OK; }
   /* what the MF_COUNT = 4 restatement is pinned on (tests/test_oracle_hero.py); s->media also covers a moving camera and emitters without a one-burst record */
-  if(s->media || s->d_prims_t1 || s->halton)
-    return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_wavelengths: hero wavelengths need a scene without media, motion blur or emitters other than static triangles / quads, and the rand point sampler");
+  if(s->media || s->d_prims_t1)
+    return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_wavelengths: hero wavelengths need a scene without media, motion blur or emitters other than static triangles / quads");
   for(unsigned k=0;k<3;k++)
   { /* the scene's three HERO kernels (production, counting, record) may use the LDS the scene was laid out for */
-    const unsigned which = (k == 2 ? MI_WHICH_RECORD | MI_WHICH_COUNT : k == 1 ? MI_WHICH_COUNT : 0u) | (s->nodes_lds ? MI_WHICH_NODES_LDS : 0u);
+    const unsigned which = (k == 2 ? MI_WHICH_RECORD | MI_WHICH_COUNT : k == 1 ? MI_WHICH_COUNT : 0u) | (s->nodes_lds ? MI_WHICH_NODES_LDS : 0u) | (s->halton ? MI_WHICH_HALTON : 0u);
     const void *kernel = path_kernel(s->d.sampler == MI_SAMPLER_PTDL, false, false, false, false, which, nullptr, true);
     HIPCHK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
   }
@@ -1273,6 +1273,7 @@ extern "C" int mi_trace_paths_hero(mi_scene *s, uint64_t first_index, uint64_t c
   MI_ENTER(s, "null scene");
   if(!s->hero) return fail(MI_ERR_ARG, "mi_trace_paths_hero: the scene renders one wavelength per path (mi_scene_set_wavelengths(s, MI_WAVELENGTHS_HERO) first)");
   if(!count) return MI_OK;
+  { const int eh = ensure_halton(s, first_index + count); if(eh) return eh; }
   void *d_rec = nullptr, *d_ext = nullptr;
   HIPCHK(hipMalloc(&d_rec, count*sizeof(mi_path_record)));
   hipError_t e = hipMemsetAsync(d_rec, 0, count*sizeof(mi_path_record), s->stream);

@@ -14,7 +14,7 @@
  * (mf_any, mf_all, mf(x, 0), mf_hsum) are written out.
  * Component 0 lives in the PathState the megakernel knows (ray, pdf product, throughput ...: what the traversal slices and the parking
  * of path state touch), components 1..3 in the arrays of PathStateHero behind it: 18 registers more.
- * Plain scenes only (no media, no moving primitives, `rand` point sampler): what the reference's MF_COUNT = 4 build was pinned on
+ * Plain scenes only (no media, no moving primitives; `rand` or `halton` point sampler): what the reference's MF_COUNT = 4 build was pinned on
  * (tests/test_oracle_hero.py). No exchange between waves: a pool entry would have to carry the 18 words too. */
 #ifndef MI_HERO_H
 #define MI_HERO_H
@@ -68,11 +68,11 @@ __device__ __forceinline__ void hero_rec_vertex(const DScene &sc, unsigned long 
   }
 }
 
-template<bool RECORD, class CNT>
+template<bool RECORD, bool HALTON, class CNT>
 __device__ __forceinline__ void path_generate_hero(const DScene &sc, PathStateHero &ps, unsigned long long index, mi_path_record *rec, unsigned long long slot, CNT &cnt,
                                                    float px = -1.0f, float py = -1.0f)
-{
-  path_generate<RECORD, false, false, CNT, true>(sc, ps, index, rec, cnt, px, py, ps.lambda_x);
+{ /* (HALTON: the four draws of path_init ask for the same dimension and get the same number -- the wavelengths are a quarter of the range apart) */
+  path_generate<RECORD, HALTON, false, CNT, true>(sc, ps, index, rec, cnt, px, py, ps.lambda_x);
 #pragma unroll
   for(int l=0;l<3;l++) { ps.throughput_x[l] = ps.throughput; ps.pdf_x[l] = ps.pdf; ps.pdfprod_x[l] = 1.0; ps.sh_value_x[l] = 0.0f; }
   if(RECORD && sc.hero_ext)
@@ -584,7 +584,7 @@ __device__ __forceinline__ void run_prepare_ops_hero(const DScene &sc, const DMa
 }
 
 /* path_shade (mi_path.h) for four components; the comments there name the reference lines of every step, here only what differs */
-template<bool RECORD, bool PTDL, class CNT>
+template<bool RECORD, bool PTDL, bool HALTON, class CNT>
 __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero &ps, const Hit &hit, const uint32_t *shape_material, const float *shape_L,
                                                 mi_path_record *rec, unsigned long long slot, CNT &cnt, SplatReq &splat)
 {
@@ -769,7 +769,7 @@ __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero 
         if(!PTDL && ps.length > 3)
         { /* path_russian_roulette on the hero's throughputs (pt.c:50: mf(throughput, 0)); all four are scaled */
           const float p_survival = DMIN(1.0f, vthr[0]/ps.prev_throughput);
-          PointSampler<false> pts(sc, ps.rng, ps.index, rand_beg_extend<PTDL>(v));
+          PointSampler<HALTON> pts(sc, ps.rng, ps.index, rand_beg_extend<PTDL>(v));
           const float rr = pts(MI_DIM_RUSSIAN_R);
           const float scale = rr >= p_survival ? mi_rcp(1.0f-p_survival) : mi_rcp(p_survival);
           if(rr >= p_survival) alive = false;
@@ -798,7 +798,7 @@ __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero 
         (void)rng_next(ps.rng);
         if(material_modes & (s_diffuse | s_glossy))
         {
-          PointSampler<false> pts(sc, ps.rng, ps.index, rand_beg_nee(v + 1));
+          PointSampler<HALTON> pts(sc, ps.rng, ps.index, rand_beg_nee(v + 1));
           const float rnd = pts(MI_DIM_NEE_LIGHT1);
           if(!(rnd < sc.p_sky) && rnd < sc.p_sky + sc.p_geo)
           {
@@ -815,7 +815,7 @@ __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero 
               float4 q0, q1, q2, q3, q4, q5, q6, q7, q8, q9;
               if(MI_LIGHTS_LDS && sc.num_lights <= MI_LIGHTS_LDS)
               {
-                const float4 *lq = lights_lds<false>() + t*(uint32_t)(sizeof(DLight)/16);
+                const float4 *lq = lights_lds<HALTON>() + t*(uint32_t)(sizeof(DLight)/16);
                 q0 = lq[0]; q1 = lq[1]; q2 = lq[2]; q3 = lq[3]; q4 = lq[4]; q5 = lq[5]; q6 = lq[6]; q7 = lq[7]; q8 = lq[8]; q9 = lq[9];
               }
               else
@@ -942,7 +942,7 @@ __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero 
       if(alive)
       {
         get_scrambled_onb(ps.scramble, sf.n, sf.a, sf.b);
-        PointSampler<false> pts(sc, ps.rng, ps.index, rand_beg_extend<PTDL>(v + 1));
+        PointSampler<HALTON> pts(sc, ps.rng, ps.index, rand_beg_extend<PTDL>(v + 1));
         HeroSample hs;
         if(mat_bsdf == MI_BSDF_DIFFUSE) sample_diffuse_hero(pts, sf, sh, any_rd, mode, hs);
         else if(mat_bsdf == MI_BSDF_DIELECTRIC) sample_dielectric_hero(pts, sf, sh, omega, eta, any_im, mode, hs);

@@ -43,6 +43,9 @@ def main():
     dump("mf4_rough_mv32", "mf4/dump_pt_xs_mv32", 32, "0052_rough", 1280, 720, 2000)
     dump("mf4_metal_mv8", "mf4/dump_pt_xs_mv8", 8, "0053_metal", 1280, 720, 2000)
     dump("mf4_smooth_ptdl_mv8", "mf4/dump_ptdl_xs_mv8", 8, "0066_smooth", 1280, 720, 3000)   # specular transmission: one component survives
+    # MOD_pointsampler = halton: the four draws of path_init ask for the SAME dimension, so the components are a quarter of the range apart
+    dump("mf4_halton_ptdl_mv8", "mf4/dump_ptdl_halton_mv8", 8, "0010_pt", 1280, 720, 3000)
+    dump("mf4_halton_rough_mv32", "mf4/dump_pt_halton_mv32", 32, "0052_rough", 1280, 720, 2000)
 
 
 if __name__ == "__main__":

@@ -24,12 +24,17 @@ HERO_GPU_CASES = [
     ("metal pt mv8", SCENE_METAL, pkg.MI_SAMPLER_PT, 8, 20000),
     ("metal ptdl mv8", SCENE_METAL, pkg.MI_SAMPLER_PTDL, 8, 20000),
     ("fine backdrop (tree in HBM) ptdl mv8", SCENE_FINE, pkg.MI_SAMPLER_PTDL, 8, 10000),
+    # MOD_pointsampler = halton: one number for the four wavelength draws (components a quarter of the range apart); depth 32 leaves the tables
+    ("halton ptdl mv8", SCENE_0010, pkg.MI_SAMPLER_PTDL, 8, 40000),
+    ("halton pt mv8", SCENE_0010, pkg.MI_SAMPLER_PT, 8, 30000),
+    ("halton rough dielectric ptdl mv32", SCENE_ROUGH, pkg.MI_SAMPLER_PTDL, 32, 10000),
 ]
 
 
 @pytest.mark.parametrize("name,scene_path,sampler,mv,n", HERO_GPU_CASES)
 def test_hero_paths_match_oracle(name, scene_path, sampler, mv, n):
-    scene = make_scene(scene_path, width=1280, height=720, max_verts=mv, sampler=sampler)
+    halton = name.startswith("halton")
+    scene = make_scene(scene_path, width=1280, height=720, max_verts=mv, sampler=sampler, pointsampler=pkg.MI_POINTS_HALTON if halton else pkg.MI_POINTS_RAND)
     be = pkg.Backend(scene)
     be.set_wavelengths(pkg.MI_WAVELENGTHS_HERO)
     first = 4321
@@ -39,6 +44,9 @@ def test_hero_paths_match_oracle(name, scene_path, sampler, mv, n):
     for f in ("pixel_i", "pixel_j", "lambda", "time", "scramble"):
         assert np.abs(gpu[f] - ora[f]).max() <= 1e-5, f
     assert np.abs(gext["lambda"] - oext["lambda"]).max() <= 1e-4             # fmodf + the range product, four draws
+    if halton:
+        d = (gext["lambda"][:, 1:] - gext["lambda"][:, :1]) % 470.0
+        assert np.abs(d - np.array([117.5, 235.0, 352.5], dtype=np.float32)).max() < 1e-2
     # the bounds of the scalar kernels' parity test (test_gpu_parity.py: test_paths_match_oracle)
     allowed = max(2, int(np.ceil(2e-5 * n)))
     same = gpu["length"] == ora["length"]
@@ -128,7 +136,7 @@ def test_hero_render_converges_to_the_scalar_render():
 
 
 def test_hero_is_refused_where_it_was_not_pinned():
-    for path, kw in ((SCENE_FOG, {}), (SCENE_MB, {}), (SCENE_0010, {"pointsampler": pkg.MI_POINTS_HALTON})):
+    for path, kw in ((SCENE_FOG, {}), (SCENE_MB, {})):
         scene = make_scene(path, width=256, height=256, max_verts=8, sampler=pkg.MI_SAMPLER_PT, **kw)
         be = pkg.Backend(scene)
         with pytest.raises(RuntimeError, match="hero wavelengths"):

@@ -30,7 +30,11 @@ HERO_CASES = [
     ("mf4_ptdl_mv8", pkg.MI_SAMPLER_PTDL, SCENE_0010, 0.998),
     ("mf4_rough_mv32", pkg.MI_SAMPLER_PT, SCENE_ROUGH, 0.998),
     ("mf4_smooth_ptdl_mv8", pkg.MI_SAMPLER_PTDL, SCENE_SMOOTH, 0.998),
-    ("mf4_metal_mv8", pkg.MI_SAMPLER_PT, SCENE_METAL, 0.99),     # the reference build's NaN at gold vertices, see test_oracle_golden.MIN_SAME_LENGTH
+    ("mf4_metal_mv8", pkg.MI_SAMPLER_PT, SCENE_METAL, 0.99),
+    # MOD_pointsampler = halton: the four draws of path_init ask the sampler for the same dimension and get the same number -- the components
+    # are exactly a quarter of the wavelength range apart (the method's stratification); depth 32 runs into the >= 256-dimension fall-back
+    ("mf4_halton_ptdl_mv8", pkg.MI_SAMPLER_PTDL, SCENE_0010, 0.998),
+    ("mf4_halton_rough_mv32", pkg.MI_SAMPLER_PT, SCENE_ROUGH, 0.998),     # the reference build's NaN at gold vertices, see test_oracle_golden.MIN_SAME_LENGTH
 ]
 
 
@@ -42,7 +46,8 @@ def hero_case(name, sampler, scene_path):
     g = np.load(GOLDEN / f"paths_{name}.npz")
     assert int(g["mf_count"]) == 4
     ref, rext = g["records"], g["ext"]
-    s = make_scene(scene_path, width=int(g["width"]), height=int(g["height"]), max_verts=int(g["max_verts"]), sampler=sampler)
+    s = make_scene(scene_path, width=int(g["width"]), height=int(g["height"]), max_verts=int(g["max_verts"]), sampler=sampler,
+                   pointsampler=pkg.MI_POINTS_HALTON if name.startswith("mf4_halton") else pkg.MI_POINTS_RAND)
     with reference_rsqrt() as emu:
         ora, oext = oracle_hero_records(s, 0, len(ref))
         exact = emu.exact
