@@ -3,11 +3,13 @@
  *
  *   corona-mi <scene.nra2> [-s spp] [-w width] [-h height] [-x postfix] [--frame n] [--batch n]
  *             [--sampler pt|ptdl] [--pointsampler rand|halton] [--max-verts n] [--rgb2spec lut]  [--iso v] [-c cam] [--info] [--device-build]
- *             [--gpus n | --devices i,j,...] [--traversal exact|fast]
+ *             [--gpus n | --devices i,j,...] [--traversal exact|fast] [--wavelengths 1|4]
  *
  * --gpus n renders on the first n GPUs of the node, --devices on the listed ones (a device may be named twice): every batch's path
  * indices are split over them (mi_group_render) and the framebuffers are added up on the first one (mi_group_fb_reduce: RCCL over
  * xGMI) before the image is read back -- the single host thread stands where the reference's worker pool stood.
+ *
+ * --wavelengths 4: hero wavelengths, four per path -- what a reference built with -DMF_COUNT=4 renders (mi_scene_set_wavelengths).
  *
  * --info validates the scene files (.nra2, .geo, .cam) on the host and prints what the backend would get, without
  * touching a GPU (validators for the on-disk formats).
@@ -41,7 +43,7 @@ int main(int argc, char *argv[])
   opt.verbose = 1;
   uint64_t spp = 10, batch = 1;              /* display_open default: 10 progressions */
   const char *postfix = "render";
-  int info_only = 0, device_build = 0, traversal = -1;
+  int info_only = 0, device_build = 0, traversal = -1, wavelengths = 1;
   int devices[64], num_devices = 0;
   for(int i=2;i<argc;i++)
   {
@@ -66,6 +68,12 @@ int main(int argc, char *argv[])
       else if(!strcmp(t, "fast")) traversal = MI_TRAVERSAL_FAST;
       else if(!strcmp(t, "auto")) traversal = -1;
       else { fprintf(stderr, "[corona-mi] --traversal %s: expected exact, fast or auto\n", t); return 1; }
+      continue;
+    }
+    if(!strcmp(argv[i], "--wavelengths") && i+1 < argc)
+    {
+      wavelengths = atoi(argv[++i]);
+      if(wavelengths != 1 && wavelengths != MI_WAVELENGTHS_HERO) { fprintf(stderr, "[corona-mi] --wavelengths %d: expected 1 or 4\n", wavelengths); return 1; }
       continue;
     }
     if(!strcmp(argv[i], "-s") && i+1 < argc) spp = strtoull(argv[++i], 0, 10);
@@ -124,6 +132,8 @@ int main(int argc, char *argv[])
   }
   if(mi_group_create(d, devices, num_devices, &group)) { fprintf(stderr, "[main] %s\n", mi_last_error()); return 2; }
   if(traversal >= 0) for(int k=0;k<num_devices;k++) mi_scene_set_traversal(mi_group_scene(group, k), traversal);
+  if(wavelengths != 1) for(int k=0;k<num_devices;k++)
+    if(mi_scene_set_wavelengths(mi_group_scene(group, k), wavelengths)) { fprintf(stderr, "[main] %s\n", mi_last_error()); return 2; }
   if(num_devices > 1) printf("[main] %d GPUs, framebuffer reduce: %s\n", num_devices, mi_group_uses_rccl(group) ? "RCCL (ncclReduce)" : "peer copies + add kernel");
 
   const uint64_t per = (uint64_t)d->width*d->height;

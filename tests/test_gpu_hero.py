@@ -195,3 +195,32 @@ def test_hero_sharding_by_tiles_and_by_group(monkeypatch):
     got = two.fb_read()
     assert np.abs(got - ref).max() <= 2e-4 * ref.max() and two.counters()[4] == n
     two.close()
+
+
+def test_command_line_renderer_with_hero_wavelengths(tmp_path):
+    """corona-mi --wavelengths 4 writes the image of the library's hero render of the same path indices (pfmdiff-mi, like the reference's regression
+    scripts); a scene the hero kernels do not take is an error with the library's message, not a scalar render"""
+    import shutil
+    import subprocess
+    from helpers import REPO
+    shutil.copytree(REPO / "scenes", tmp_path / "scenes")
+    cli = REPO / "corona-13_amd" / "host" / "corona-mi"
+    scene_file = tmp_path / "scenes" / "0010_pt" / "test.nra2"
+    out = subprocess.run([str(cli), str(scene_file), "-s", "16", "--batch", "16", "-w", "256", "-h", "256", "--max-verts", "8", "--sampler", "ptdl", "-x", "_hero",
+                          "--wavelengths", "4"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    scene = make_scene(SCENE_0010, inject=False, width=256, height=256, max_verts=8, sampler=pkg.MI_SAMPLER_PTDL)
+    be = pkg.Backend(scene, counters=False)
+    be.set_wavelengths(pkg.MI_WAVELENGTHS_HERO)
+    be.render(0, 16 * scene.width * scene.height)
+    img = be.fb_read() * scene.gain(16)
+    be.close()
+    with open(tmp_path / "lib.pfm", "wb") as f:
+        f.write(b"PF\n%d %d\n-1.0\n" % (img.shape[1], img.shape[0]))
+        f.write(np.ascontiguousarray(img, dtype=np.float32).tobytes())
+    d = subprocess.run([str(REPO / "corona-13_amd" / "host" / "pfmdiff-mi"), str(tmp_path / "scenes" / "0010_pt" / "test_hero_fb00.pfm"), str(tmp_path / "lib.pfm")],
+                       capture_output=True, text=True)
+    assert d.returncode == 0 and float(d.stdout.split("rmse:")[1]) < 1e-3, d.stdout + d.stderr
+    bad = subprocess.run([str(cli), str(tmp_path / "scenes" / "0056_fog" / "test.nra2"), "-s", "1", "-w", "64", "-h", "64", "--wavelengths", "4"], capture_output=True, text=True)
+    assert bad.returncode != 0 and "hero wavelengths" in bad.stderr
+    assert subprocess.run([str(cli), str(scene_file), "--wavelengths", "3"], capture_output=True, text=True).returncode == 1
