@@ -224,3 +224,27 @@ def test_command_line_renderer_with_hero_wavelengths(tmp_path):
     bad = subprocess.run([str(cli), str(tmp_path / "scenes" / "0056_fog" / "test.nra2"), "-s", "1", "-w", "64", "-h", "64", "--wavelengths", "4"], capture_output=True, text=True)
     assert bad.returncode != 0 and "hero wavelengths" in bad.stderr
     assert subprocess.run([str(cli), str(scene_file), "--wavelengths", "3"], capture_output=True, text=True).returncode == 1
+
+
+def test_hero_soak_half_a_million_paths():
+    """500 000 ptdl paths against the oracle, chunk by chunk: primitive sequence, vertex count and splat count of every path and the four
+    components of every vertex' throughput; the scalar kernels' bound (2 in 100 000 paths may differ)"""
+    scene = make_scene(SCENE_0010, width=1280, height=720, max_verts=8, sampler=pkg.MI_SAMPLER_PTDL)
+    be = pkg.Backend(scene)
+    be.set_wavelengths(pkg.MI_WAVELENGTHS_HERO)
+    total, chunk, bad, bad_splats = 500000, 125000, 0, 0
+    worst = 0.0
+    for first in range(999, 999 + total, chunk):
+        g, ge = be.trace_paths_hero(first, chunk)
+        o, oe = oracle_hero_records(scene, first, chunk)
+        k = np.arange(8)[None, :]
+        valid = k < np.minimum(o["length"], 8)[:, None]
+        ok = (g["length"] == o["length"]) & ((g["v"]["prim"] == o["v"]["prim"]) | ~valid).all(axis=1)
+        bad += int((~ok).sum())
+        bad_splats += int((ok & (g["num_splats"] != o["num_splats"])).sum())
+        m = ok[:, None] & valid & (k >= 1)
+        worst = max(worst, float(np.quantile(rel(ge["throughput"][m], oe["throughput"][m]), 0.9999)))
+    be.close()
+    assert bad <= 2e-5 * total, bad
+    assert bad_splats <= 2e-4 * total, bad_splats          # a grazing shadow ray or a weight at the underflow limit flips one connection (test_gpu_parity.py)
+    assert worst < 1e-3, worst
