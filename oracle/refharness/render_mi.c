@@ -361,6 +361,12 @@ static int setup(render_t *r)
   else if(count) { ndev = atoi(count); if(ndev < 1) ndev = 1; if(ndev > 64) ndev = 64; for(int k=0;k<ndev;k++) devices[k] = k; }
   if(!ndev) { if(mi_init(-1)) return 1; devices[0] = mi_current_device(); ndev = 1; }
   if(mi_group_create(&d, devices, ndev, &r->scene)) return 1;
+#if defined(MF_COUNT) && MF_COUNT == 4
+  /* this reference carries four wavelengths per path (include/mf.h): so must the device */
+  for(int k=0;k<ndev;k++)
+    if(mi_scene_set_wavelengths(mi_group_scene(r->scene, k), MI_WAVELENGTHS_HERO)) { fprintf(stderr, "[render_mi] %s\n", mi_last_error()); return 1; }
+  fprintf(stderr, "[render_mi] MF_COUNT = 4: hero wavelengths on the device\n");
+#endif
   if(ndev > 1) fprintf(stderr, "[render_mi] %d GPUs, framebuffer reduce: %s\n", ndev, mi_group_uses_rccl(r->scene) ? "RCCL (ncclReduce)" : "peer copies + add kernel");
   fprintf(stderr, "[render_mi] scene handed to the device: %u nodes, %lu primitives, %u shapes, %u shaders, %u emitter primitives, film %ux%u\n",
       d.num_nodes, (unsigned long)d.num_prims, d.num_shapes, d.num_materials, d.lights.num_prims, d.width, d.height);

@@ -184,3 +184,52 @@ def test_reference_host_image_equals_our_host(sampler, tmp_path):
     assert "2 GPUs, framebuffer reduce: peer copies + add kernel" in out.stderr and "1048576 paths on the device" in out.stderr, out.stderr
     ig = read_pfm(tmp_path / "scenes" / "0010_pt" / "test_refhost_g2_fb00.pfm")
     assert np.abs(ig - ia).max() <= 1e-4 * float(np.abs(ia).max())
+
+
+@pytest.mark.gpu
+def test_mf4_reference_host(tmp_path):
+    """The reference built with -DMF_COUNT=4 (hero wavelengths, include/mf.h) as host of the backend: oracle/_ref/mf4/corona_mi_ptdl_mv8 is that
+    build -- its loaders, tree builder, clang-built shader plugins, progression loop -- with refharness/render_mi.c as MOD_render, which asks the
+    device for four wavelengths per path when it is compiled that way (mi_scene_set_wavelengths). Its image is the image of our own host's
+    `--wavelengths 4` render of the same path indices; and the mean of a 256-sample pt render through the library is the mean of that reference's
+    OWN (CPU) render of the scene (tests/golden/mf4_vs_mf1_measured.json, measured with the same build), within the spread of its three frames."""
+    import json
+    binary = REF / "mf4" / "corona_mi_ptdl_mv8"
+    if not binary.exists() or not (REF / "data" / "ergb2spec.coeff").exists():
+        pytest.skip("oracle/_ref/mf4 was not built (make -C oracle mf4: needs /root/reference, build container only)")
+    shutil.copytree(REPO / "scenes", tmp_path / "scenes")
+    scene = tmp_path / "scenes" / "0010_pt" / "test.nra2"
+    env = dict(os.environ, LD_LIBRARY_PATH=str(REF / "mf4" / "shaders_mv8"), CORONA_MI_DATA=str(REPO / "corona-13_amd" / "data"))
+    out = subprocess.run([str(binary), str(scene), "-s", "16", "--batch", "16", "-w", "256", "-h", "256", "-t", "1", "-x", "_mf4host"],
+                         cwd=REF, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "MF_COUNT = 4: hero wavelengths on the device" in out.stderr and "1048576 paths on the device" in out.stderr, out.stderr
+    ours = subprocess.run([str(CLI), str(scene), "-s", "16", "--batch", "16", "-w", "256", "-h", "256", "--max-verts", "8", "--sampler", "ptdl", "--wavelengths", "4",
+                           "-x", "_ours4"], capture_output=True, text=True, timeout=600)
+    assert ours.returncode == 0, ours.stdout + ours.stderr
+    a = tmp_path / "scenes" / "0010_pt" / "test_mf4host_fb00.pfm"
+    b = tmp_path / "scenes" / "0010_pt" / "test_ours4_fb00.pfm"
+    d = subprocess.run([str(DIFF), str(a), str(b)], capture_output=True, text=True)
+    assert d.returncode == 0, d.stdout + d.stderr
+    assert float(d.stdout.split("rmse:")[1]) < 0.2, d.stdout                     # the scalar hosts' bound (camera frame's last bits differ between the hosts)
+    ia, ib = read_pfm(a), read_pfm(b)
+    assert ia.sum() > 0 and np.allclose(ia.sum(axis=(0, 1)), ib.sum(axis=(0, 1)), rtol=2e-3)
+    # and it is another image than the scalar render of the same indices
+    scalar = subprocess.run([str(CLI), str(scene), "-s", "16", "--batch", "16", "-w", "256", "-h", "256", "--max-verts", "8", "--sampler", "ptdl", "-x", "_ours1"],
+                            capture_output=True, text=True, timeout=600)
+    assert scalar.returncode == 0
+    i1 = read_pfm(tmp_path / "scenes" / "0010_pt" / "test_ours1_fb00.pfm")
+    assert np.sqrt(((i1 - ib) ** 2).mean()) > 10 * np.sqrt(((ia - ib) ** 2).mean())
+    # the reference's own MF_COUNT = 4 render (CPU, 256 x 256 x 256 spp, pt): same mean image
+    with open(REPO / "tests" / "golden" / "mf4_vs_mf1_measured.json") as f:
+        measured = json.load(f)
+    frames = np.array([measured["mf4"]["frames"][k] for k in sorted(measured["mf4"]["frames"])])
+    pkg = load_pkg()
+    scn = make_scene(SCENE_0010, width=256, height=256, max_verts=8, sampler=pkg.MI_SAMPLER_PT)
+    be = pkg.Backend(scn, counters=False)
+    be.set_wavelengths(pkg.MI_WAVELENGTHS_HERO)
+    be.render(0, 256 * 256 * 256)
+    mean = (be.fb_read() * scn.gain(256)).reshape(-1, 3).mean(axis=0)
+    be.close()
+    spread = frames.std(axis=0, ddof=1)
+    assert np.abs(mean - frames.mean(axis=0)).max() <= max(4.0 * float(spread.max()), 0.015 * float(frames.mean())), (mean, frames.mean(axis=0), spread)
