@@ -48,7 +48,7 @@ double oracle_render_tiles(const mi_scene_desc *s, uint64_t first_frame, uint64_
  * decisions by component 0; src/pathspace.c:215-221, src/sampler.d/pt.c:30-38, ptdl.c:78-88, src/shaders/dielectric.c:240-415). Pinned against per-path
  * dumps of that build (`make -C oracle mf4`, tests/golden/make_golden_mf4.py -> tests/golden/paths_mf4_*.npz, tests/test_oracle_golden.py).
  * out[i]: the record of path first + i with the HERO component of every spectral quantity; ext[i] (or NULL): all four components, the layout of the
- * dump harness' extension block; fb (or NULL): framebuffer to splat into; counters (or NULL): += the hero lane's. Plain scenes only (no media). */
+ * dump harness' extension block; fb (or NULL): framebuffer to splat into; counters (or NULL): += the hero lane's. */
 #define ORACLE_MF 4
 typedef struct oracle_hero_ext
 {
@@ -57,6 +57,7 @@ typedef struct oracle_hero_ext
   float rd[MI_REC_MAX_VERTS][ORACLE_MF], rg[MI_REC_MAX_VERTS][ORACLE_MF], em[MI_REC_MAX_VERTS][ORACLE_MF], eta[MI_REC_MAX_VERTS][ORACLE_MF];
   float splat_value[MI_REC_MAX_SPLATS][ORACLE_MF];
 } oracle_hero_ext;
+int  oracle_set_reference_ftz(int on);     /* hero lanes: flush denormals like the reference build (see oracle_path.c) */
 void oracle_hero_trace(const mi_scene_desc *s, uint64_t first, uint64_t count, mi_path_record *out, oracle_hero_ext *ext, float *fb, uint64_t *counters);
 
 /* fill records for [first, first+count) */

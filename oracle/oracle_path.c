@@ -256,10 +256,10 @@ static float o_vol_sample(o_ctx *c, o_path *p, int e)
   p->e[e].transmittance = 1.0f;
   if(p->e[e].vol.shader >= 0)
   {
-    if(p->e[e].vol.mu_s > 0.0f)
+    if(o_g_hero(c, p->e[e].vol.mu_s) > 0.0f)                 /* mf(mu_s, 0) > 0: the hero's medium decides whether a distance is sampled ... */
     {
       const float rf = o_point(c, p, e, 0);                /* s_dim_free_path */
-      dist = -logf(1.0f - rf)/p->e[e].vol.mu_t;
+      dist = -logf(1.0f - rf)/o_g_hero(c, p->e[e].vol.mu_t);   /* ... and samples it (mf(mu_t, 0), src/shader.c:95); transmittance and pdf per component */
       if(!(dist > 0.0)) dist = 1e-15;
       p->e[e].pdf = p->e[e].transmittance = expf(-dist*p->e[e].vol.mu_t);
       if(dist < p->e[e].dist) p->e[e].pdf = p->e[e].pdf*p->e[e].vol.mu_t;
@@ -272,7 +272,7 @@ static float o_vol_sample(o_ctx *c, o_path *p, int e)
 static float o_vol_pdf(const o_path *p, int e)
 { /* shader_vol_pdf, src/shader.c:108-131 */
   float pdf = 1.0f;
-  if(p->e[e].vol.shader >= 0 && p->e[e].vol.mu_s > 0.0f)
+  if(p->e[e].vol.shader >= 0 && o_g_hero(O_CTX(p), p->e[e].vol.mu_s) > 0.0f)      /* mf(mu_s, 0) > 0, src/shader.c:122 */
   {
     pdf = expf(-p->e[e].dist*p->e[e].vol.mu_t);
     if(!(p->v[e].flags & s_environment) && p->v[e].hit.prim == MI_PRIMID_INVALID) pdf = pdf*p->e[e].vol.mu_t;
@@ -288,7 +288,7 @@ static int o_path_propagate(o_ctx *c, o_path *path, int v)
   path->v[v].mode = s_absorb;
   path->v[v].flags = s_none;
   /* homogeneous + scattering: sample the clip distance first, then trace up to it (src/pathspace.c:717-751) */
-  const int sample_vol_first = path->e[v].vol.mu_s > 0.0;
+  const int sample_vol_first = o_g_hero(c, path->e[v].vol.mu_s) > 0.0;          /* mf(mu_s, 0) > 0, src/pathspace.c:720 */
   int vshader = -1;
   float clipdist = FLT_MAX;
   if(sample_vol_first)
@@ -849,9 +849,24 @@ static void o_hero_fill_ext(const o_path *p, int lane, oracle_hero_ext *x)
   }
 }
 
+/* test switch: the hero lanes flush denormal floats to zero like the reference BUILD does (-ffast-math links crtfastmath: FTZ | DAZ in MXCSR). It
+ * matters where a component's pdf or throughput underflows -- deep paths through a medium: the reference's MIS weight of such a connection is
+ * 0 / 0 = NaN in all four components (view_splat drops it), with denormals kept it is a finite weight on a contribution of 1e-14. Off by default
+ * (the device keeps denormals); tests/test_oracle_hero.py turns it on for the comparison with the reference's dumps. */
+static int o_reference_ftz = 0;
+#if defined(__x86_64__)
+#include <xmmintrin.h>
+int oracle_set_reference_ftz(int on) { o_reference_ftz = on; return 1; }
+#else
+int oracle_set_reference_ftz(int on) { (void)on; return 0; }
+#endif
+
 static void *o_hero_worker(void *arg)
 {
   o_hero_lane *L = (o_hero_lane *)arg;
+#if defined(__x86_64__)
+  if(o_reference_ftz) _mm_setcsr(_mm_getcsr() | 0x8040u);        /* this thread only: it ends with the call */
+#endif
   for(uint64_t i=0;i<L->count;i++)
   {
     L->c.rec = L->c.lane == 0 && L->out ? L->out + i : 0;

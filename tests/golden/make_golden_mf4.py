@@ -46,6 +46,14 @@ def main():
     # MOD_pointsampler = halton: the four draws of path_init ask for the SAME dimension, so the components are a quarter of the range apart
     dump("mf4_halton_ptdl_mv8", "mf4/dump_ptdl_halton_mv8", 8, "0010_pt", 1280, 720, 3000)
     dump("mf4_halton_rough_mv32", "mf4/dump_pt_halton_mv32", 32, "0052_rough", 1280, 720, 2000)
+    # the extended scenes: media (mu_t per component, the free-flight distance from the hero's), moving camera, moving geometry and emitters
+    dump("mf4_media_ptdl_mv8", "mf4/dump_ptdl_xs_mv8", 8, "0055_media", 1280, 720, 4000)
+    dump("mf4_media_pt_mv32", "mf4/dump_pt_xs_mv32", 32, "0055_media", 1280, 720, 3000)
+    dump("mf4_fog_ptdl_mv8", "mf4/dump_ptdl_xs_mv8", 8, "0056_fog", 1280, 720, 3000)
+    dump("mf4_nested_pt_mv8", "mf4/dump_pt_xs_mv8", 8, "0057_nested", 1280, 720, 3000)
+    dump("mf4_cam_mb_ptdl_mv8", "mf4/dump_ptdl_xs_mv8", 8, "0058_cam_mb", 1280, 720, 3000)
+    dump("mf4_mb_ptdl_mv8", "mf4/dump_ptdl_xs_mv8", 8, "0059_mb", 1280, 720, 3000)
+    dump("mf4_all_ptdl_mv8", "mf4/dump_ptdl_xs_mv8", 8, "0061_all", 1280, 720, 2500)
 
 
 if __name__ == "__main__":
