@@ -132,7 +132,7 @@ struct mi_scene
 };
 
 /* ---------------------------------------------------------------------------------------- kernel table
- * The megakernel's instantiations live in sixteen parts (mi_megakernel.h, mi_part.hip), one translation unit each. */
+ * The megakernel's instantiations live in twenty-two parts (mi_megakernel.h, mi_part.hip), one translation unit each. */
 extern template const void *mi_path_part<false, false, false, false>(unsigned, const PathLaunch *);
 extern template const void *mi_path_part<true,  false, false, false>(unsigned, const PathLaunch *);
 extern template const void *mi_path_part<false, true,  false, false>(unsigned, const PathLaunch *);
@@ -147,15 +147,27 @@ extern template const void *mi_path_part<false, true,  false, false, true>(unsig
 extern template const void *mi_path_part<true,  true,  false, false, true>(unsigned, const PathLaunch *);
 extern template const void *mi_path_part<false, true,  false, true,  true>(unsigned, const PathLaunch *);
 extern template const void *mi_path_part<true,  true,  false, true,  true>(unsigned, const PathLaunch *);
-extern template const void *mi_path_part<false, false, false, false, false, true>(unsigned, const PathLaunch *);     /* HERO (mi_hero.h) */
+extern template const void *mi_path_part<false, false, false, false, false, true>(unsigned, const PathLaunch *);     /* HERO (mi_hero.h): plain, media, motion blur, no exchange */
 extern template const void *mi_path_part<true,  false, false, false, false, true>(unsigned, const PathLaunch *);
+extern template const void *mi_path_part<false, true,  false, false, false, true>(unsigned, const PathLaunch *);
+extern template const void *mi_path_part<true,  true,  false, false, false, true>(unsigned, const PathLaunch *);
+extern template const void *mi_path_part<false, true,  true,  false, false, true>(unsigned, const PathLaunch *);
+extern template const void *mi_path_part<true,  true,  true,  false, false, true>(unsigned, const PathLaunch *);
+extern template const void *mi_path_part<false, true,  false, false, true,  true>(unsigned, const PathLaunch *);
+extern template const void *mi_path_part<true,  true,  false, false, true,  true>(unsigned, const PathLaunch *);
 
 static const void *path_kernel(bool ptdl, bool media, bool mb, bool fast, bool norg, unsigned which, const PathLaunch *L, bool hero = false)
 {
 #ifdef MI_DEV_FAST
   if(media || mb || hero) { fprintf(stderr, "[mi] internal: development build without the extended kernels\n"); abort(); }
 #endif
-  if(hero) return ptdl ? mi_path_part<true, false, false, false, false, true>(which, L) : mi_path_part<false, false, false, false, false, true>(which, L);
+  if(hero)
+  { /* four wavelengths per path: the exact rounds of the scene's variant */
+    if(mb) return ptdl ? mi_path_part<true, true, true, false, false, true>(which, L) : mi_path_part<false, true, true, false, false, true>(which, L);
+    if(media && norg) return ptdl ? mi_path_part<true, true, false, false, true, true>(which, L) : mi_path_part<false, true, false, false, true, true>(which, L);
+    if(media) return ptdl ? mi_path_part<true, true, false, false, false, true>(which, L) : mi_path_part<false, true, false, false, false, true>(which, L);
+    return ptdl ? mi_path_part<true, false, false, false, false, true>(which, L) : mi_path_part<false, false, false, false, false, true>(which, L);
+  }
   if(mb) return ptdl ? mi_path_part<true, true, true, false>(which, L) : mi_path_part<false, true, true, false>(which, L);   /* no FAST rounds with moving primitives */
   if(media)
   {
@@ -1126,13 +1138,10 @@ extern "C" int mi_scene_set_wavelengths(mi_scene *s, int count)
   MI_ENTER(s, "null scene");
   if(count != 1 && count != MI_WAVELENGTHS_HERO) return fail(MI_ERR_ARG, "mi_scene_set_wavelengths: 1 or 4 wavelengths per path");
   if(count == 1) { s->hero = false; return MI_OK; }
-  /* what the MF_COUNT = 4 restatement is pinned on (tests/test_oracle_hero.py); s->media also covers a moving camera and emitters without a one-burst record */
-  if(s->media || s->d_prims_t1)
-    return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_wavelengths: hero wavelengths need a scene without media, motion blur or emitters other than static triangles / quads");
   for(unsigned k=0;k<3;k++)
   { /* the scene's three HERO kernels (production, counting, record) may use the LDS the scene was laid out for */
     const unsigned which = (k == 2 ? MI_WHICH_RECORD | MI_WHICH_COUNT : k == 1 ? MI_WHICH_COUNT : 0u) | (s->nodes_lds ? MI_WHICH_NODES_LDS : 0u) | (s->halton ? MI_WHICH_HALTON : 0u);
-    const void *kernel = path_kernel(s->d.sampler == MI_SAMPLER_PTDL, false, false, false, false, which, nullptr, true);
+    const void *kernel = path_kernel(s->d.sampler == MI_SAMPLER_PTDL, s->media, s->d_prims_t1 != nullptr, false, s->norg, which, nullptr, true);
     HIPCHK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
   }
   s->hero = true;

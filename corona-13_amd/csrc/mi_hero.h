@@ -14,8 +14,8 @@
  * (mf_any, mf_all, mf(x, 0), mf_hsum) are written out.
  * Component 0 lives in the PathState the megakernel knows (ray, pdf product, throughput ...: what the traversal slices and the parking
  * of path state touch), components 1..3 in the arrays of PathStateHero behind it: 18 registers more.
- * Plain scenes only (no media, no moving primitives; `rand` or `halton` point sampler): what the reference's MF_COUNT = 4 build was pinned on
- * (tests/test_oracle_hero.py). No exchange between waves: a pool entry would have to carry the 18 words too. */
+ * Every kind of scene the scalar kernels take (MEDIA / MB switches as there), `rand` or `halton` point sampler: what the reference's MF_COUNT = 4
+ * build was pinned on (tests/test_oracle_hero.py). No exchange between waves: a pool entry would have to carry the 18 words too. */
 #ifndef MI_HERO_H
 #define MI_HERO_H
 
@@ -68,11 +68,11 @@ __device__ __forceinline__ void hero_rec_vertex(const DScene &sc, unsigned long 
   }
 }
 
-template<bool RECORD, bool HALTON, class CNT>
+template<bool RECORD, bool HALTON, bool MEDIA = false, class CNT>
 __device__ __forceinline__ void path_generate_hero(const DScene &sc, PathStateHero &ps, unsigned long long index, mi_path_record *rec, unsigned long long slot, CNT &cnt,
                                                    float px = -1.0f, float py = -1.0f)
 { /* (HALTON: the four draws of path_init ask for the same dimension and get the same number -- the wavelengths are a quarter of the range apart) */
-  path_generate<RECORD, HALTON, false, CNT, true>(sc, ps, index, rec, cnt, px, py, ps.lambda_x);
+  path_generate<RECORD, HALTON, MEDIA, CNT, true>(sc, ps, index, rec, cnt, px, py, ps.lambda_x);
 #pragma unroll
   for(int l=0;l<3;l++) { ps.throughput_x[l] = ps.throughput; ps.pdf_x[l] = ps.pdf; ps.pdfprod_x[l] = 1.0; ps.sh_value_x[l] = 0.0f; }
   if(RECORD && sc.hero_ext)
@@ -583,11 +583,298 @@ __device__ __forceinline__ void run_prepare_ops_hero(const DScene &sc, const DMa
   }
 }
 
+/* ------------------------------------------------------------------------------------------ media and emitters for four components */
+/* the medium of the edge under way per component: component 0 is the PathState's (the scalar code maintains it), 1..3 are looked up where the
+   path is -- the innermost shape of its nesting stack, or the exterior -- at their wavelengths (like the index of refraction: PathStateHero) */
+__device__ __forceinline__ void hero_media(const DScene &sc, const PathStateHero &ps, const float *lam, Medium *med)
+{
+  med[0] = ps.cur;
+  const int top = media_top_shape(ps.media);
+#pragma unroll
+  for(int l=1;l<MI_MF;l++) med[l] = shape_interior_medium(sc, top, lam[l]);
+}
+/* shader_vol_pdf towards a surface, src/shader.c:108-131: whether the edge has a pdf other than 1 is the HERO's question (mf(mu_s, 0) > 0), the
+   value is the component's */
+__device__ __forceinline__ float hero_pdf_to_surface(const Medium &hero, const Medium &m, float dist) { return (hero.med >= 0 && hero.mu_s > 0.0f) ? expf(-dist*m.mu_t) : 1.0f; }
+
+/* lights_sample_next_event + the emitter's shader_prepare for four wavelengths: the point on the emitter once, its emission per component.
+   Plain kernels: one-burst records from LDS or L2; extended kernels: records where the scene has them (light_record_sample, mi_path.h),
+   else the generic chain emitter list -> primitive -> shading record -> material (moving or analytic emitters) */
+template<bool HALTON, bool MEDIA, bool MB>
+__device__ __forceinline__ void hero_sample_emitter(const DScene &sc, float r1, float r2, float r3, const float *lam, const V3 from, float scramble, float time,
+                                                    uint32_t &lpe, Surf &ls, float *lem, float &lrough, float &lpdf, float &ldist, V3 &ol)
+{
+  if(!MB && (!MEDIA || sc.lights != nullptr))
+  {
+    const uint32_t t = (!MEDIA && sc.num_lights <= 4) ? sample_cdf4(sc.light_cdf4, (int)sc.num_lights, r1) : sample_cdf(sc.light_cdf, (int)sc.num_lights, r1);
+    float4 q0, q1, q2, q3, q4, q5, q6, q7, q8, q9;
+    if(!MEDIA && MI_LIGHTS_LDS && sc.num_lights <= MI_LIGHTS_LDS)
+    {
+      const float4 *lq = lights_lds<HALTON>() + t*(uint32_t)(sizeof(DLight)/16);
+      q0 = lq[0]; q1 = lq[1]; q2 = lq[2]; q3 = lq[3]; q4 = lq[4]; q5 = lq[5]; q6 = lq[6]; q7 = lq[7]; q8 = lq[8]; q9 = lq[9];
+    }
+    else
+    {
+      const float4 *lq = (const float4 *)(sc.lights + t);
+      q0 = lq[0]; q1 = lq[1]; q2 = lq[2]; q3 = lq[3]; q4 = lq[4]; q5 = lq[5]; q6 = lq[6]; q7 = lq[7]; q8 = lq[8]; q9 = lq[9];
+    }
+    lpe = __float_as_uint(q9.x);
+    const bool quad = __float_as_uint(q9.y) == MI_PRIM_QUAD;
+    const V3 v0 = mk3(q0.x, q0.y, q0.z), v1 = mk3(q0.w, q1.x, q1.y), v2 = mk3(q1.z, q1.w, q2.x), v3 = mk3(q2.y, q2.z, q2.w);
+    float hu, hv;
+    if(quad) { hu = r2; hv = r3; }
+    else { const float a = mi_sqrt(r2); hu = r3*a; hv = (1.0f-r3)*a; }
+    const bool second = quad && !(hv >= hu);
+    const float u = second ? hu - hv : hu;
+    const float vv = !quad ? hv : second ? hv : hv - hu;
+    ls.x = second ? tri_retime(v0, v2, v3, u, vv) : tri_retime(v0, v1, v2, u, vv);
+    ls.u = hu; ls.v = hv;
+    ol = sub3(ls.x, from);
+    ldist = mi_sqrt(dot3(ol, ol));
+    const double il = 1./(double)ldist;
+    ol = mk3((float)((double)ol.x*il), (float)((double)ol.y*il), (float)((double)ol.z*il));
+    const V3 n0 = mk3(q3.x, q3.y, q3.z);
+    const V3 na = second ? mk3(q4.z, q4.w, q5.x) : mk3(q3.w, q4.x, q4.y);
+    const V3 nb = second ? mk3(q5.y, q5.z, q5.w) : mk3(q4.z, q4.w, q5.x);
+    ls.gn = second ? mk3(q6.w, q7.x, q7.y) : mk3(q6.x, q6.y, q6.z);
+    const float w = 1.0f - u - vv;
+    ls.n = normalise3(mk3(u*nb.x + vv*na.x + w*n0.x, u*nb.y + vv*na.y + w*n0.y, u*nb.z + vv*na.z + w*n0.z));
+    ls.flags = 0;
+    const float ec[3] = { q7.z, q7.w, q8.x };
+#pragma unroll
+    for(int l=0;l<MI_MF;l++) lem[l] = q8.y*spectrum_eval(ec, lam[l]);
+    lrough = q8.z;
+    lpdf = q8.w;
+  }
+  else
+  {
+    const uint32_t t = sample_cdf(sc.light_cdf, (int)sc.num_lights, r1);
+    lpe = sc.light_prim[t];
+    const uint32_t lp = lpe & ~MI_LIGHT_ANYHIT;
+    ls.x = prim_sample<MB>(sc.prims[lp], sc.primgeo[lp], r2, r3, ls.u, ls.v, MB ? sc.prims_t1 + lp : nullptr, time);
+    ol = sub3(ls.x, from);
+    ldist = mi_sqrt(dot3(ol, ol));
+    const double il = 1./(double)ldist;
+    ol = mk3((float)((double)ol.x*il), (float)((double)ol.y*il), (float)((double)ol.z*il));
+    const uint4 lhead = *(const uint4 *)&sc.primgeo[lp];
+    surface_setup<MB>(sc, lp, lhead, ol, scramble, ls, time);
+    Shading lsh[4];
+    run_prepare_ops_hero(sc, sc.materials[lhead.y], sc.materials[lhead.y].num_ops, ls, lam, lsh);
+#pragma unroll
+    for(int l=0;l<MI_MF;l++) lem[l] = lsh[l].em;
+    lrough = lsh[0].roughness;
+    lpdf = sc.light_L[t];
+  }
+}
+/* the emitter's edf towards -ol over the sampling pdf, per component (nee.h:92-130 with lights_sample_next_event's tail); lpdf becomes the vertex pdf */
+__device__ __forceinline__ void hero_emitter_edf(const DScene &sc, const Surf &ls, const V3 ol, const float *lem, float lrough, float &lpdf, float *edf)
+{
+  double dir_term;
+  if(lrough > 1.0f-1e-4f) dir_term = (double)1.0f/MI_PI_D;
+  else
+  {
+    const float phongexp = 2.0f/(lrough*lrough) - 2.0f;
+    dir_term = (double)(powf(-dot3(ls.gn, ol), phongexp)*(phongexp + 2.0f))/(2.0f*MI_PI_D);
+  }
+#pragma unroll
+  for(int l=0;l<MI_MF;l++) edf[l] = (float)((double)(lem[l]/lpdf)*dir_term);
+  lpdf = lpdf*sc.p_geo;
+#pragma unroll
+  for(int l=0;l<MI_MF;l++) edf[l] = edf[l]/sc.p_geo;
+}
+
+/* path_shade_volume (mi_path.h) for four components: the extension ray ended at the free-flight distance the HERO's medium sampled */
+template<bool RECORD, bool PTDL, bool HALTON, bool MB, class CNT>
+__device__ __forceinline__ void path_shade_volume_hero(const DScene &sc, PathStateHero &ps, mi_path_record *rec, unsigned long long slot, CNT &cnt)
+{
+  const int v = ps.length;
+  bool alive = true;
+  const V3 omega = ps.dir;
+  const float dist = ps.clip;
+  const float lam[4] = {ps.lambda, ps.lambda_x[0], ps.lambda_x[1], ps.lambda_x[2]};
+  const float thr[4] = {ps.throughput, ps.throughput_x[0], ps.throughput_x[1], ps.throughput_x[2]};
+  const float pdf_in[4] = {ps.pdf, ps.pdf_x[0], ps.pdf_x[1], ps.pdf_x[2]};
+  double pp[4] = {ps.pdfprod, ps.pdfprod_x[0], ps.pdfprod_x[1], ps.pdfprod_x[2]};
+  Medium med[4];
+  hero_media(sc, ps, lam, med);
+  Surf sf;
+  const V3 rorg = ray_origin<PTDL>(ps, false);
+  sf.x = mk3(rorg.x + dist*ps.dir.x, rorg.y + dist*ps.dir.y, rorg.z + dist*ps.dir.z);
+  sf.n = omega; sf.gn = omega;
+  get_scrambled_onb(ps.scramble, sf.n, sf.a, sf.b);
+  sf.u = sf.v = sf.s = sf.t = 0.0f; sf.flags = 0;
+  const uint32_t material_modes = s_volume | s_glossy;
+  const float G = ps.prev_cos*1.0f/(dist*dist);
+  float vpdf[4], vthr[4], epdf[4];
+#pragma unroll
+  for(int l=0;l<MI_MF;l++)
+  { /* per component: transmittance exp(-d mu_t), pdf = transmittance * mu_t at the distance the hero sampled (src/shader.c:95-97) */
+    const float eT = expf(-dist*med[l].mu_t);
+    epdf[l] = eT*med[l].mu_t;
+    vpdf[l] = (pdf_in[l]*epdf[l])*G;
+    pp[l] *= (double)vpdf[l];
+    vthr[l] = thr[l]*(eT/epdf[l]);
+  }
+  ps.length++;
+  MI_COUNT(cnt, 6, 1);
+  if(RECORD)
+  {
+    Shading z; z.roughness = z.rs = z.rd = z.rg = z.em = 0.0f;
+    rec_vertex<RECORD>(rec, v, MI_PRIMID_INVALID, dist, sf.x, sf.n, sf.gn, omega, s_absorb, 0, vthr[0], vpdf[0], 0.0f, 0.0f, z, 0.0f, med[0].med);
+    const Shading zz[4] = {z, z, z, z};
+    hero_rec_vertex<RECORD>(sc, slot, v, vthr, vpdf, zz, nullptr);
+    rec->length = ps.length; rec->throughput = (thr[0]*0.0f)/epdf[0];
+  }
+  {
+    ps.prev_x = sf.x; ps.org_eps = 0.0f; ps.ignore = MI_NOPRIM;
+    if(!PTDL) ps.org = sf.x;
+    ps.prev_cos = 0.0f; ps.throughput = 0.0f; ps.pdf = 0.0f;
+    ps.prev_material_modes = material_modes;
+    if(PTDL)
+    {
+      ps.sh_dir = mk3(0.0f, 0.0f, 0.0f); ps.sh_dist = 0.0f; ps.sh_value = 0.0f; ps.sh_light = 0u; ps.sh_length = 0;
+      ps.sh_value_x[0] = ps.sh_value_x[1] = ps.sh_value_x[2] = 0.0f;
+    }
+  }
+  if(PTDL && ps.length >= (int)sc.max_verts) alive = false;
+  if(PTDL && alive)
+  { /* next event estimation from the volume vertex */
+    (void)rng_next(ps.rng);
+    PointSampler<HALTON> pts(sc, ps.rng, ps.index, rand_beg_nee(v + 1));
+    const float rnd = pts(MI_DIM_NEE_LIGHT1);
+    if(!(rnd < sc.p_sky) && rnd < sc.p_sky + sc.p_geo)
+    {
+      const float r3 = pts(MI_DIM_NEE_Y);
+      const float r2 = pts(MI_DIM_NEE_X);
+      const float r1 = pts(MI_DIM_NEE_LIGHT2);
+      uint32_t lpe;
+      Surf ls;
+      V3 ol;
+      float ldist, lpdf, lem[4], lrough, edf[4];
+      hero_sample_emitter<HALTON, true, MB>(sc, r1, r2, r3, lam, sf.x, ps.scramble, ps.time, lpe, ls, lem, lrough, lpdf, ldist, ol);
+      hero_emitter_edf(sc, ls, ol, lem, lrough, lpdf, edf);
+      if(edf[0] > 0.0f || edf[1] > 0.0f || edf[2] > 0.0f || edf[3] > 0.0f)
+      {
+        const float hg = eval_hg(med[0].g, omega, ol);
+        float bsdf[4];
+#pragma unroll
+        for(int l=0;l<MI_MF;l++) bsdf[l] = med[l].mu_s*hg;               /* medium_rgb.c:98-102 */
+        if(bsdf[0] > 0.0f || bsdf[1] > 0.0f || bsdf[2] > 0.0f || bsdf[3] > 0.0f)
+        {
+          const float eps = 1e-4f*DMAX(DMAX(.5f, fabsf(sf.x.x)), DMAX(fabsf(sf.x.y), fabsf(sf.x.z)));
+          V3 rd = sub3(ls.x, sf.x);
+          rd = scale3(rd, mi_rcp(mi_sqrt(dot3(rd, rd))));
+          const V3 ro = sf.x;
+          const V3 dv = mk3(ls.x.x - eps*rd.x - ro.x, ls.x.y - eps*rd.y - ro.y, ls.x.z - eps*rd.z - ro.z);
+          const float total_dist = mi_sqrt(dot3(dv, dv));
+          if(!(dot3(ls.gn, rd) >= 0) && total_dist > 0.0f)
+          {
+            const float Gn = 1.0f*fabsf(dot3(ls.n, ol))/(ldist*ldist);
+            float tn[4], ours[4], sums[4];
+#pragma unroll
+            for(int l=0;l<MI_MF;l++)
+            {
+              const float T = media_transmittance(med[l], ldist);
+              float t = ((vthr[l]*bsdf[l])*(T*edf[l]))*Gn;
+              t = t + (vthr[l]*bsdf[l])*((0.0f*Gn)/lpdf);
+              const float wn = lpdf/(lpdf + 0.0f/T);
+              tn[l] = t*wn;
+              const float pe = (hero_pdf_to_surface(med[0], med[l], ldist)*hg)*Gn;
+              const double our = (double)(1.0f*lpdf)*pp[l], other = (double)pe*pp[l];
+              ours[l] = (float)our; sums[l] = (float)(other + our);
+            }
+            const float hs = hero_hsum(sums);
+            if(tn[0]/1.0f > 0.0f || tn[1]/1.0f > 0.0f || tn[2]/1.0f > 0.0f || tn[3]/1.0f > 0.0f)
+            {
+              ps.sh_pending = 1;
+              ps.prev_x = sf.x; ps.org_eps = 0.0f;
+              ps.sh_dir = rd; ps.sh_dist = total_dist;
+              ps.sh_light = lpe; ps.ignore = MI_NOPRIM;
+              ps.sh_value = (tn[0]/1.0f)*(ours[0]/hs);
+#pragma unroll
+              for(int l=1;l<MI_MF;l++) ps.sh_value_x[l-1] = (tn[l]/1.0f)*(ours[l]/hs);
+              ps.sh_length = ps.length + 1;
+            }
+          }
+        }
+      }
+    }
+  }
+  if(alive && ps.length >= (int)sc.max_verts) alive = false;
+  if(alive && !(vthr[0] > 0.0f || vthr[1] > 0.0f || vthr[2] > 0.0f || vthr[3] > 0.0f))
+  {
+    alive = false;
+    if(RECORD && v < MI_REC_MAX_VERTS)
+    {
+      rec->v[v].throughput = 0.0f; rec->v[v].mode = s_absorb;
+      if(sc.hero_ext) for(int l=0;l<MI_MF;l++) sc.hero_ext[slot].throughput[v][l] = 0.0f;
+    }
+  }
+  if(alive)
+  { /* the phase function has no wavelength in it: one direction, one pdf; the weight mu_s per component */
+    PointSampler<HALTON> pts(sc, ps.rng, ps.index, rand_beg_extend<PTDL>(v + 1));
+    const float r2 = pts(MI_DIM_OMEGA_Y);          /* (medium_rgb.c compiles with gcc in the MF_COUNT = 4 build too: its order) */
+    const float r1 = pts(MI_DIM_OMEGA_X);
+    const float g = med[0].g;
+    float o0, o1, o2, pdf;
+    if(g == 0.0f)
+    {
+      const float z = 1.f - 2.f*r1;
+      const float r = mi_sqrt(1.f - z*z);
+      const float phi = (float)(2.f*MI_PI_D*(double)r2);
+      float sn, cs;
+      mi_sincosf(phi, &sn, &cs);
+      o0 = r*cs; o1 = r*sn; o2 = z;
+      pdf = (float)(1.0/(4.0*MI_PI_D));
+    }
+    else
+    {
+      const float sqr = (1.0f-g*g)/(1.0f+g*(2.0f*r1-1.0f));
+      const float cos_theta = 1.0f/(2.0f*g)*(1.0f + g*g - sqr*sqr);
+      const float phi = (float)(2.0f*MI_PI_D*(double)r2);
+      const float l = mi_sqrt(fmaxf(0.0f, 1.0f-cos_theta*cos_theta));
+      float sn, cs;
+      mi_sincosf(phi, &sn, &cs);
+      o0 = cos_theta; o1 = cs*l; o2 = sn*l;
+      pdf = (float)(1.0/(4.0*MI_PI_D)*(double)(1.0f-g*g)/(double)powf(1.0f + g*g - 2.0f*g*cos_theta, 3.0f/2.0f));
+    }
+    V3 wo = mk3(sf.n.x*o0 + sf.a.x*o1 + sf.b.x*o2, sf.n.y*o0 + sf.a.y*o1 + sf.b.y*o2, sf.n.z*o0 + sf.a.z*o1 + sf.b.z*o2);
+    wo = normalise3(wo);
+    float nthr[4];
+#pragma unroll
+    for(int l=0;l<MI_MF;l++) nthr[l] = vthr[l]*med[l].mu_s;
+    const uint32_t vmode = s_glossy | s_volume;
+    if(nthr[0] <= 0.0f && nthr[1] <= 0.0f && nthr[2] <= 0.0f && nthr[3] <= 0.0f) alive = false;       /* mf_all(throughput <= 0), src/pathspace.c:253 */
+    if(RECORD && v < MI_REC_MAX_VERTS) rec->v[v].mode = alive ? vmode : (uint32_t)s_absorb;
+    if(alive)
+    {
+      ps.org = sf.x;
+      ps.dir = wo;
+      ps.ignore = MI_NOPRIM;
+      ps.prev_x = sf.x; ps.org_eps = 0.0f;
+      ps.prev_cos = 1.0f;
+      ps.prev_throughput = vthr[0];
+      ps.prev_mode = vmode;
+      ps.prev_material_modes = material_modes;
+      ps.throughput = nthr[0]; ps.pdf = pdf;
+#pragma unroll
+      for(int l=1;l<MI_MF;l++) { ps.throughput_x[l-1] = nthr[l]; ps.pdf_x[l-1] = pdf; }
+    }
+  }
+  ps.pdfprod = pp[0]; ps.pdfprod_x[0] = pp[1]; ps.pdfprod_x[1] = pp[2]; ps.pdfprod_x[2] = pp[3];
+  if(!alive) { ps.active = 0; cnt.c[4]++; }
+}
+
 /* path_shade (mi_path.h) for four components; the comments there name the reference lines of every step, here only what differs */
-template<bool RECORD, bool PTDL, bool HALTON, class CNT>
+template<bool RECORD, bool PTDL, bool HALTON, bool MEDIA = false, bool MB = false, class CNT>
 __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero &ps, const Hit &hit, const uint32_t *shape_material, const float *shape_L,
                                                 mi_path_record *rec, unsigned long long slot, CNT &cnt, SplatReq &splat)
 {
+  if(MEDIA && hit.prim == MI_NOPRIM && ps.clip < FLT_MAX)
+  {
+    path_shade_volume_hero<RECORD, PTDL, HALTON, MB>(sc, ps, rec, slot, cnt);
+    return;
+  }
   const int v = ps.length;
   bool alive = true;
   const V3 omega = ps.dir;
@@ -596,6 +883,8 @@ __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero 
   const float pdf_in[4] = {ps.pdf, ps.pdf_x[0], ps.pdf_x[1], ps.pdf_x[2]};
   float ior[4] = {ps.cur_ior, 1.0f, 1.0f, 1.0f};                /* e[v].vol.ior per component: see PathStateHero (filled in where a material asks for it) */
   double pp[4] = {ps.pdfprod, ps.pdfprod_x[0], ps.pdfprod_x[1], ps.pdfprod_x[2]};
+  Medium med[4];                                                 /* the medium of the edge that ends here (extended kernels) */
+  if(MEDIA) hero_media(sc, ps, lam, med);
   if(PTDL)
   {
     ps.sh_dir = mk3(0.0f, 0.0f, 0.0f); ps.sh_dist = 0.0f; ps.sh_value = 0.0f; ps.sh_light = 0u; ps.sh_length = 0;
@@ -606,16 +895,19 @@ __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero 
     const float G = ps.prev_cos;
     float vpdf[4];
 #pragma unroll
-    for(int l=0;l<MI_MF;l++) { vpdf[l] = pdf_in[l]*G; pp[l] *= (double)vpdf[l]; }
+    for(int l=0;l<MI_MF;l++) { vpdf[l] = MEDIA ? (pdf_in[l]*1.0f)*G : pdf_in[l]*G; pp[l] *= (double)vpdf[l]; }
     ps.length++;
     MI_COUNT(cnt, 6, 1);
     if(RECORD)
     {
       const V3 x = mk3(ps.prev_x.x + sc.far_dist*omega.x, ps.prev_x.y + sc.far_dist*omega.y, ps.prev_x.z + sc.far_dist*omega.z);
       Shading z; z.roughness = 1.0f; z.rs = z.rd = z.rg = z.em = 0.0f;
-      rec_vertex<RECORD>(rec, v, MI_PRIMID_INVALID, FLT_MAX, x, mk3(0, 0, 0), mk3(0, 0, 0), omega, s_absorb, s_environment, thr[0], vpdf[0], 0.0f, 0.0f, z, 0.0f, -1);
+      float ethr[4];
+#pragma unroll
+      for(int l=0;l<MI_MF;l++) ethr[l] = MEDIA ? thr[l]*(media_transmittance(med[l], FLT_MAX)/1.0f) : thr[l];
+      rec_vertex<RECORD>(rec, v, MI_PRIMID_INVALID, FLT_MAX, x, mk3(0, 0, 0), mk3(0, 0, 0), omega, s_absorb, s_environment, ethr[0], vpdf[0], 0.0f, 0.0f, z, 0.0f, -1);
       const Shading zz[4] = {z, z, z, z};
-      hero_rec_vertex<RECORD>(sc, slot, v, thr, vpdf, zz, nullptr);
+      hero_rec_vertex<RECORD>(sc, slot, v, ethr, vpdf, zz, nullptr);
       rec->length = ps.length; rec->throughput = 0.0f;
     }
     alive = false;
@@ -632,7 +924,7 @@ __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero 
     const uint4 mhead = *(const uint4 *)&mat;
     const uint32_t mat_bsdf = mhead.x;
     const float mat_p0 = __uint_as_float(mhead.z), mat_p1 = __uint_as_float(mhead.w);
-    surface_setup<false>(sc, hit.prim, head, omega, ps.scramble, sf, ps.time);
+    surface_setup<MB>(sc, hit.prim, head, omega, ps.scramble, sf, ps.time);
     const uint32_t shape = (head.w >> 3) & 0x1fffffffu;
     Shading sh[4];
     run_prepare_ops_hero(sc, mat, mhead.y, sf, lam, sh);
@@ -677,7 +969,7 @@ __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero 
       if(sh[0].roughness > 1e-4f) material_modes |= s_glossy; else material_modes |= s_specular;
     }
 
-    const uint32_t type = head.x;
+    const uint32_t type = MB ? head.x & 7u : head.x;                /* the motion-blur kernels flag moving primitives in bit 3 (MI_GEO_MB) */
     if((type > 2 || hit.dist < 1e-4f) && hit.prim == ps.ignore)
     { /* self-intersection */
       alive = false;
@@ -693,10 +985,16 @@ __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero 
       const bool any_em = sh[0].em > 0.0f || sh[1].em > 0.0f || sh[2].em > 0.0f || sh[3].em > 0.0f;     /* mf_any(em > 0), src/pathspace.c:876-877 */
       if(any_em && !(sf.flags & s_inside)) { mode = s_emit; material_modes = s_emit; }
       const float G = ps.prev_cos*fabsf(dot3(sf.n, omega))/(hit.dist*hit.dist);
-      float vpdf[4];
+      float vpdf[4], eT[4], epdf[4];
       double pp_before[4];
 #pragma unroll
-      for(int l=0;l<MI_MF;l++) { vpdf[l] = pdf_in[l]*G; pp_before[l] = pp[l]; pp[l] *= (double)vpdf[l]; }
+      for(int l=0;l<MI_MF;l++)
+      { /* edge in a medium: transmittance per component; whether the edge has a pdf is the hero's question (hero_pdf_to_surface) */
+        eT[l] = MEDIA ? media_transmittance(med[l], hit.dist) : 1.0f;
+        epdf[l] = MEDIA ? hero_pdf_to_surface(med[0], med[l], hit.dist) : 1.0f;
+        vpdf[l] = MEDIA ? (pdf_in[l]*epdf[l])*G : pdf_in[l]*G;
+        pp_before[l] = pp[l]; pp[l] *= (double)vpdf[l];
+      }
       ps.length++;
       MI_COUNT(cnt, 6, 1);
       float path_throughput[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -714,9 +1012,15 @@ __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero 
           }
         }
 #pragma unroll
-        for(int l=0;l<MI_MF;l++) path_throughput[l] = 0.0f + thr[l]*(facing ? edf*sh[l].em : 0.0f);
+        for(int l=0;l<MI_MF;l++)
+        {
+          const float Le = facing ? edf*sh[l].em : 0.0f;
+          path_throughput[l] = MEDIA ? (thr[l]*0.0f)/epdf[l] + (thr[l]*(eT[l]/epdf[l]))*Le : 0.0f + thr[l]*Le;
+        }
       }
-      float vthr[4] = {thr[0], thr[1], thr[2], thr[3]};
+      float vthr[4];
+#pragma unroll
+      for(int l=0;l<MI_MF;l++) vthr[l] = MEDIA ? thr[l]*(eT[l]/epdf[l]) : thr[l];
       if(RECORD)
       {
         rec_vertex<RECORD>(rec, v, MI_GEO_PRIMID(pshade), hit.dist, sf.x, sf.n, sf.gn, omega, mode, sf.flags, vthr[0], vpdf[0], sf.u, sf.v, sh[0], eta[0], (int)head.y);
@@ -810,62 +1114,9 @@ __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero 
             float lem[4], lrough;
             float lpdf, ldist;
             V3 ol;
-            { /* one-burst emitter records, as in the plain kernels (every scene the HERO kernels accept has them: mi_scene_set_wavelengths) */
-              const uint32_t t = sc.num_lights <= 4 ? sample_cdf4(sc.light_cdf4, (int)sc.num_lights, r1) : sample_cdf(sc.light_cdf, (int)sc.num_lights, r1);
-              float4 q0, q1, q2, q3, q4, q5, q6, q7, q8, q9;
-              if(MI_LIGHTS_LDS && sc.num_lights <= MI_LIGHTS_LDS)
-              {
-                const float4 *lq = lights_lds<HALTON>() + t*(uint32_t)(sizeof(DLight)/16);
-                q0 = lq[0]; q1 = lq[1]; q2 = lq[2]; q3 = lq[3]; q4 = lq[4]; q5 = lq[5]; q6 = lq[6]; q7 = lq[7]; q8 = lq[8]; q9 = lq[9];
-              }
-              else
-              {
-                const float4 *lq = (const float4 *)(sc.lights + t);
-                q0 = lq[0]; q1 = lq[1]; q2 = lq[2]; q3 = lq[3]; q4 = lq[4]; q5 = lq[5]; q6 = lq[6]; q7 = lq[7]; q8 = lq[8]; q9 = lq[9];
-              }
-              lpe = __float_as_uint(q9.x);
-              const bool quad = __float_as_uint(q9.y) == MI_PRIM_QUAD;
-              const V3 v0 = mk3(q0.x, q0.y, q0.z), v1 = mk3(q0.w, q1.x, q1.y), v2 = mk3(q1.z, q1.w, q2.x), v3 = mk3(q2.y, q2.z, q2.w);
-              float hu, hv;
-              if(quad) { hu = r2; hv = r3; }
-              else { const float a = mi_sqrt(r2); hu = r3*a; hv = (1.0f-r3)*a; }
-              const bool second = quad && !(hv >= hu);
-              const float u = second ? hu - hv : hu;
-              const float vv = !quad ? hv : second ? hv : hv - hu;
-              ls.x = second ? tri_retime(v0, v2, v3, u, vv) : tri_retime(v0, v1, v2, u, vv);
-              ls.u = hu; ls.v = hv;
-              ol = sub3(ls.x, sf.x);
-              ldist = mi_sqrt(dot3(ol, ol));
-              const double il = 1./(double)ldist;
-              ol = mk3((float)((double)ol.x*il), (float)((double)ol.y*il), (float)((double)ol.z*il));
-              const V3 n0 = mk3(q3.x, q3.y, q3.z);
-              const V3 na = second ? mk3(q4.z, q4.w, q5.x) : mk3(q3.w, q4.x, q4.y);
-              const V3 nb = second ? mk3(q5.y, q5.z, q5.w) : mk3(q4.z, q4.w, q5.x);
-              ls.gn = second ? mk3(q6.w, q7.x, q7.y) : mk3(q6.x, q6.y, q6.z);
-              const float w = 1.0f - u - vv;
-              ls.n = normalise3(mk3(u*nb.x + vv*na.x + w*n0.x, u*nb.y + vv*na.y + w*n0.y, u*nb.z + vv*na.z + w*n0.z));
-              ls.flags = 0;
-              const float ec[3] = { q7.z, q7.w, q8.x };
-#pragma unroll
-              for(int l=0;l<MI_MF;l++) lem[l] = q8.y*spectrum_eval(ec, lam[l]);
-              lrough = q8.z;
-              lpdf = q8.w;
-            }
+            hero_sample_emitter<HALTON, MEDIA, MB>(sc, r1, r2, r3, lam, sf.x, ps.scramble, ps.time, lpe, ls, lem, lrough, lpdf, ldist, ol);
             float edf[4];
-            {
-              double dir_term;
-              if(lrough > 1.0f-1e-4f) dir_term = (double)1.0f/MI_PI_D;
-              else
-              {
-                const float phongexp = 2.0f/(lrough*lrough) - 2.0f;
-                dir_term = (double)(powf(-dot3(ls.gn, ol), phongexp)*(phongexp + 2.0f))/(2.0f*MI_PI_D);
-              }
-#pragma unroll
-              for(int l=0;l<MI_MF;l++) edf[l] = (float)((double)(lem[l]/lpdf)*dir_term);
-            }
-            lpdf = lpdf*sc.p_geo;
-#pragma unroll
-            for(int l=0;l<MI_MF;l++) edf[l] = edf[l]/sc.p_geo;
+            hero_emitter_edf(sc, ls, ol, lem, lrough, lpdf, edf);
             if(edf[0] > 0.0f || edf[1] > 0.0f || edf[2] > 0.0f || edf[3] > 0.0f)                       /* mf_any(edf > 0), nee.h:188 */
             {
               HeroEval he;
@@ -876,11 +1127,19 @@ __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero 
 #pragma unroll
               for(int l=0;l<MI_MF;l++) { be[l].value = he.value[l]; be[l].mode = he.mode; }
               bool okn = be[0].value > 0.0f || be[1].value > 0.0f || be[2].value > 0.0f || be[3].value > 0.0f;   /* mf_any(bsdf > 0), nee.h:191 */
+              Medium nmed[4];                                              /* volume of the connection edge, per component */
+              if(MEDIA) { nmed[0] = med[0]; nmed[1] = med[1]; nmed[2] = med[2]; nmed[3] = med[3]; }
               if(okn && (be[0].mode & s_transmit))
               {
                 Media hyp = ps.media;
                 media_apply(hyp, shape, (sf.flags & s_inside) != 0);
                 if(hyp.broken) okn = false;
+                else if(MEDIA)
+                {
+                  const int ctop = media_top_shape(hyp);
+#pragma unroll
+                  for(int l=0;l<MI_MF;l++) nmed[l] = shape_interior_medium(sc, ctop, lam[l]);
+                }
               }
               if(okn)
               {
@@ -894,7 +1153,6 @@ __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero 
                 {
                   const float Gn = fabsf(dot3(sf.n, ol))*fabsf(dot3(ls.n, ol))/(ldist*ldist);
                   float tn[4], ours[4], sums[4];
-                  const float wn = lpdf/(lpdf + 0.0f/1.0f);
                   float pbs[4];
                   if(mat_bsdf == MI_BSDF_DIFFUSE) pbs[0] = pbs[1] = pbs[2] = pbs[3] = (float)(1.0f/MI_PI_D);
                   else if(mat_bsdf == MI_BSDF_DIELECTRIC) pdf_dielectric_hero(sf, sh, omega, ol, eta, any_im, be[0].mode, pbs);
@@ -902,12 +1160,13 @@ __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero 
 #pragma unroll
                   for(int l=0;l<MI_MF;l++)
                   {
-                    float t = ((vthr[l]*be[l].value)*(1.0f*edf[l]))*Gn;
+                    const float nT = MEDIA ? media_transmittance(nmed[l], ldist) : 1.0f;
+                    float t = ((vthr[l]*be[l].value)*(nT*edf[l]))*Gn;
                     t = t + (vthr[l]*be[l].value)*((0.0f*Gn)/lpdf);
+                    const float wn = lpdf/(lpdf + 0.0f/nT);
                     tn[l] = t*wn;
-                    float pb;
-                    pb = pbs[l];
-                    const float pe = (1.0f*pb)*Gn;
+                    const float pb = pbs[l];
+                    const float pe = ((MEDIA ? hero_pdf_to_surface(nmed[0], nmed[l], ldist) : 1.0f)*pb)*Gn;
                     const double our = (double)(1.0f*lpdf)*pp[l], other = (double)pe*pp[l];
                     ours[l] = (float)our; sums[l] = (float)(other + our);
                   }
@@ -964,7 +1223,9 @@ __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero 
           if(ps.media.broken) ok = false;
           else
           {
-            ior[0] = shape_interior_ior(sc, shape_material, media_top_shape(ps.media), lam[0]);
+            const int top = media_top_shape(ps.media);
+            ior[0] = shape_interior_ior(sc, shape_material, top, lam[0]);
+            if(MEDIA) ps.cur = shape_interior_medium(sc, top, lam[0]);
           }
         }
         if(!ok)

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(MI_BLOCK_OF(HERO, PTDL, MEDIA)) void mi_path_kernel
      is a volume vertex there, the exchange has nothing to sort, and its code costs that kernel 26 more spilled registers (fog ptdl 124 against 115 ms) */
   /* HERO (mi_hero.h): four wavelengths per path, plain scenes. The LDS layout is the plain kernels' (the scene was laid out for them); a pool
      entry is eight words longer, so the pools hold fewer */
-  static_assert(!HERO || (!MEDIA && !MB && !FAST && !NORG), "hero wavelengths: plain scenes, exact rounds");
+  static_assert(!HERO || !FAST, "hero wavelengths: exact rounds");
   constexpr bool REGROUP = MI_REGROUP && (!MB || MI_REGROUP_MB) && !NORG && (!MEDIA || MI_REGROUP_MEDIA) && (!HERO || MI_REGROUP_HERO);
   __shared__ PoolCtl pool_ctl;
   if(threadIdx.x == 0) blk_next = 0;
@@ -248,10 +248,10 @@ __global__ __launch_bounds__(MI_BLOCK_OF(HERO, PTDL, MEDIA)) void mi_path_kernel
             { /* tile-owned sharding (mi_render_tiles): the launch's items are pixels of this member's tiles, tile_path() names their paths */
               float px, py;
               const unsigned long long index = tile_path(sc, first + i, px, py);
-              if constexpr(HERO) path_generate_hero<RECORD, HALTON>(sc, ps, index, nullptr, 0ull, cnt, px, py);
+              if constexpr(HERO) path_generate_hero<RECORD, HALTON, MEDIA>(sc, ps, index, nullptr, 0ull, cnt, px, py);
               else path_generate<RECORD, HALTON, MEDIA>(sc, ps, index, nullptr, cnt, px, py);
             }
-            else if constexpr(HERO) path_generate_hero<RECORD, HALTON>(sc, ps, first + i, RECORD ? records + i : nullptr, i, cnt);
+            else if constexpr(HERO) path_generate_hero<RECORD, HALTON, MEDIA>(sc, ps, first + i, RECORD ? records + i : nullptr, i, cnt);
             else path_generate<RECORD, HALTON, MEDIA>(sc, ps, first + i, RECORD ? records + i : nullptr, cnt);
           }
           else exhausted = true;
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(MI_BLOCK_OF(HERO, PTDL, MEDIA)) void mi_path_kernel
       if(fin && !tr_shadow && hit.prim == MI_NOPRIM && !volume)
       {
         tracing = false;
-        if constexpr(HERO) path_shade_hero<RECORD, PTDL, HALTON>(sc, ps, hit, shape_material, shape_L, RECORD ? records + (ps.index - first) : nullptr, RECORD ? ps.index - first : 0ull, cnt, splat);
+        if constexpr(HERO) path_shade_hero<RECORD, PTDL, HALTON, MEDIA, MB>(sc, ps, hit, shape_material, shape_L, RECORD ? records + (ps.index - first) : nullptr, RECORD ? ps.index - first : 0ull, cnt, splat);
         else path_escape<RECORD, MEDIA>(sc, ps, RECORD ? records + (ps.index - first) : nullptr, cnt);
       }
 #endif
@@ -402,8 +402,8 @@ __global__ __launch_bounds__(MI_BLOCK_OF(HERO, PTDL, MEDIA)) void mi_path_kernel
           if(PTDL && tr_shadow) shadow_resolve_hero<RECORD>(sc, ps, hit, rec, slot, cnt, splat);
           else
           {
-            __builtin_assume(hit.prim != MI_NOPRIM);
-            path_shade_hero<RECORD, PTDL, HALTON>(sc, ps, hit, shape_material, shape_L, rec, slot, cnt, splat);
+            if(!MEDIA) __builtin_assume(hit.prim != MI_NOPRIM);
+            path_shade_hero<RECORD, PTDL, HALTON, MEDIA, MB>(sc, ps, hit, shape_material, shape_L, rec, slot, cnt, splat);
           }
         }
         else if(PTDL && !MI_REGROUP_EARLY_SHADOW && tr_shadow) shadow_resolve<RECORD>(sc, ps, hit, rec, cnt, splat);
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(MI_BLOCK_OF(HERO, PTDL, MEDIA)) void mi_path_kernel
       {
         const unsigned long long slot = RECORD ? ps.index - first : 0ull;
         if(tr_shadow) shadow_resolve_hero<RECORD>(sc, ps, hit, rec, slot, cnt, splat);
-        else path_shade_hero<RECORD, PTDL, HALTON>(sc, ps, hit, shape_material, shape_L, rec, slot, cnt, splat);
+        else path_shade_hero<RECORD, PTDL, HALTON, MEDIA, MB>(sc, ps, hit, shape_material, shape_L, rec, slot, cnt, splat);
       }
       else if(tr_shadow) shadow_resolve<RECORD>(sc, ps, hit, rec, cnt, splat);
       else
@@ -570,7 +570,7 @@ static inline bool mi_path_which_valid(unsigned which)
 #ifdef MI_PART_DEFINE
 template<bool PTDL, bool MEDIA, bool MB, bool FAST, bool NORG, bool HERO, bool R, bool N, bool H, bool C> static const void *mi_path_go(const PathLaunch *L)
 {
-  constexpr bool valid = !(MB && !MEDIA) && !(MB && FAST) && !(R && !C) && !(NORG && (!MEDIA || MB)) && !(HERO && (MEDIA || MB || FAST || NORG))
+  constexpr bool valid = !(MB && !MEDIA) && !(MB && FAST) && !(R && !C) && !(NORG && (!MEDIA || MB)) && !(HERO && FAST)
 #ifdef MI_DEV_FAST
                          && (!H || MI_DEV_FAST == 2) && !MEDIA && !MB && N
 #endif

@@ -321,8 +321,9 @@ int  mi_trace_paths(mi_scene *s, uint64_t first_index, uint64_t count, mi_path_r
  * colours (src/view.c:455-463, include/spectrum.h:185-195). Same expected image as one wavelength per path (measured on the reference:
  * tests/golden/mf4_vs_mf1_measured.json), less colour noise per path.
  *   mi_scene_set_wavelengths(s, MI_WAVELENGTHS_HERO): the renders and traces that follow run the HERO kernels; (s, 1) goes back.
- * Only for what the reference's MF_COUNT = 4 build was pinned on (tests/test_oracle_hero.py): scenes without media, moving primitives or a
- * moving camera (either point sampler) -- MI_ERR_UNSUPPORTED otherwise, nothing changes. Path i of a hero render is NOT path i of a
+ * Every scene the backend takes, with either point sampler: the extended kernels (media: the free-flight distance is the hero medium's, transmittance
+ * and pdf per component, src/shader.c:76-131; moving camera, moving geometry and emitters) have HERO instantiations too; all of it pinned to per-path dumps
+ * of the reference built that way (tests/test_oracle_hero.py). Path i of a hero render is NOT path i of a
  * scalar render: three more numbers are drawn before the camera sample.
  *   mi_trace_paths_hero: mi_trace_paths, plus (ext != NULL) all four components of what the record holds for component 0 -- the layout of
  * the reference-side dump harness' extension block (oracle/refharness/render_dump.c built with -DMF_COUNT=4). */
