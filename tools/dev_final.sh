@@ -10,7 +10,7 @@ for c in cfg2 cfg3; do
   (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/hero_trace_$c -- python3 $GRAFT_REPO_ROOT/bench.py --config $c --wavelengths 4 --steps 5 --no-cpu-baseline --no-secondary > /dev/null 2>&1)
   cp gpurun_out/$TAG/hero_trace_$c/*/*_kernel_stats.csv gpurun_out/$TAG/hero_kernel_stats_$c.csv; rm -rf gpurun_out/$TAG/hero_trace_$c
 done
-python3 tools/hero_time.py 64 > gpurun_out/$TAG/hero_time.txt 2>&1
+python3 tools/hero_time.py --extended 64 > gpurun_out/$TAG/hero_time.txt 2>&1
 python3 tests/regression_report.py --out gpurun_out/$TAG/regression > gpurun_out/$TAG/regression.txt 2>&1
 rm -rf gpurun_out/$TAG/regression/*/*.png gpurun_out/$TAG/regression/report.html
 tail -2 gpurun_out/$TAG/profile.out | cut -c1-3000; cat gpurun_out/$TAG/all_configs.txt gpurun_out/$TAG/regression.txt
