@@ -521,7 +521,7 @@ def main():
             return None
         fl = json.load(open(f))
         ptdl = config == "cfg3"
-        if ptdl and "vertex_valu_ptdl" not in fl:
+        if (ptdl and "vertex_valu_ptdl" not in fl) or config not in fl.get("mix", {}):
             return None
         b, vv, mix = fl["blocks"], fl["vertex_valu_ptdl" if ptdl else "vertex_valu"], fl["mix"][config]
         dc, paths = r["dc"], max(r["dc"][4], 1)

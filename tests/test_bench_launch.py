@@ -109,3 +109,21 @@ def test_gpus_4_default_is_strong_scaling_of_the_headline_frame():
     assert out["n_gpus"] == 4 and out["scaling"] == "strong"
     assert out["config"]["paths_per_step"] == per_frame and out["config"]["paths_per_step_per_gpu"] == per_frame // 4
     assert out["stub"]["reduced_sum_last_frame"] == per_frame
+
+
+def test_committed_profile_files_have_what_bench_reads():
+    """bench.py's roofline record reads the newest committed PMC summaries and the floor file; a missing key there used to surface only on the GPU box, in the
+    one run whose library matches the profile (round 5: the regenerated floor file had lost its `mix` block and bench.py raised KeyError)"""
+    import json
+    prof = REPO / "profiles"
+    floor = json.load(open(sorted(prof.glob("r*_valu_floor.json"))[-1]))
+    for key in ("blocks", "vertex_valu", "vertex_valu_ptdl", "mix"):
+        assert key in floor, key
+    for cfg, k in (("cfg2", "surface_vertices_per_ray"), ("cfg3", "surface_vertices_per_extension_ray")):
+        assert {k, "diffuse_share", "dielectric_share"} <= set(floor["mix"][cfg])
+    for b in ("node_visit", "prim_test", "generate", "shadow_resolve", "splat_pass_of_four"):
+        assert "valu" in floor["blocks"][b], b
+    for name in ("pmc_summary.json", "pmc_summary_ptdl.json"):
+        s = json.load(open(sorted(prof.glob("r*_" + name))[-1]))
+        for key in ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "gpu_cycles_per_launch", "build_id", "kernel", "kernel_ms"):
+            assert key in s, (name, key)

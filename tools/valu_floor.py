@@ -4,6 +4,7 @@ read from the code of tools/micro/floor_blocks.hip (the product's own functions 
 difference has no prologue, epilogue or loop control in it).  python3 tools/valu_floor.py > profiles/r05_valu_floor.json
 bench.py prices the live work counters with these numbers (roofline.valu_floor_per_path)."""
 import json
+import os
 import re
 import subprocess
 import sys
@@ -56,6 +57,14 @@ def main():
            "note": "vertex = path_shade of the pt sampler between two rays (surface set-up, material ops, emitter hit, Russian roulette, bsdf sample, next ray) "
                    "with the bsdf blocks and the set-up of the primitive kinds it does not run taken out; the emitter / roulette / nested-media branches a given "
                    "vertex skips are still counted, so the vertex figures are upper estimates and the floor errs on the high side"}
+    # the scene's vertex mix (classes of the surface vertices of regression/0010_pt, tools/block_probe.py of the build without the exchange) is a property of
+    # the paths, not of the kernels: carried over from the newest committed floor file that has it (bench.py needs it for the floor of the bench line)
+    import glob
+    for prev in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "r*_valu_floor.json")), reverse=True):
+        mix = json.load(open(prev)).get("mix")
+        if mix:
+            out["mix"] = mix
+            break
     json.dump(out, sys.stdout, indent=1)
     print()
 
