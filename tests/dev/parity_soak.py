@@ -1,5 +1,6 @@
 """development helper (GPU box): GPU path records against the oracle on millions of paths, in chunks
-(python3 tests/dev/parity_soak.py [paths per configuration] [base|ext] [auto|exact|fast])"""
+(python3 tests/dev/parity_soak.py [paths per configuration] [base|ext] [auto|exact|fast|hero]); hero: four wavelengths per path
+(mi_scene_set_wavelengths) against oracle_hero_trace, the throughput deviation over all four components"""
 import sys, time
 sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parent.parent))
 import numpy as np
@@ -20,14 +21,21 @@ for name, path, sampler, mv in CASES[sys.argv[2] if len(sys.argv) > 2 else "base
     scene = make_scene(path, width=1280, height=720, max_verts=mv, sampler=sampler,
                        pointsampler=pkg.MI_POINTS_HALTON if name.startswith("halton") else pkg.MI_POINTS_RAND)
     mode = sys.argv[3] if len(sys.argv) > 3 else "auto"
-    be = pkg.Backend(scene) if mode == "auto" else pkg.Backend(scene, traversal=mode)
-    name = f"{name} [{be.traversal()}]"
+    hero = mode == "hero"
+    be = pkg.Backend(scene) if mode in ("auto", "hero") else pkg.Backend(scene, traversal=mode)
+    if hero:
+        be.set_wavelengths(pkg.MI_WAVELENGTHS_HERO)
+    name = f"{name} [{'hero' if hero else be.traversal()}]"
     n = same_len = same_prims = same_splats = 0
     worst_thr = 0.0
     t0 = time.time()
     for first in range(777, 777 + total, chunk):
-        g = be.trace_paths(first, chunk)
-        o = oracle_records(scene, first, chunk)
+        if hero:
+            g, ge = be.trace_paths_hero(first, chunk)
+            o, oe = oracle_hero_records(scene, first, chunk)
+        else:
+            g = be.trace_paths(first, chunk)
+            o = oracle_records(scene, first, chunk)
         sl = g["length"] == o["length"]
         k = np.arange(8)[None, :]
         valid = k < np.minimum(o["length"], 8)[:, None]
@@ -35,7 +43,7 @@ for name, path, sampler, mv in CASES[sys.argv[2] if len(sys.argv) > 2 else "base
         ss = sp & (g["num_splats"] == o["num_splats"])
         n += chunk; same_len += int(sl.sum()); same_prims += int(sp.sum()); same_splats += int(ss.sum())
         m = sp[:, None] & valid & (k >= 1)
-        thr_g, thr_o = g["v"]["throughput"][m], o["v"]["throughput"][m]
+        thr_g, thr_o = (ge["throughput"][m], oe["throughput"][m]) if hero else (g["v"]["throughput"][m], o["v"]["throughput"][m])
         rel = np.abs(thr_g - thr_o) / np.maximum(1e-20, np.maximum(np.abs(thr_g), np.abs(thr_o)))
         worst_thr = max(worst_thr, float(np.quantile(rel, 0.9999)) if len(rel) else 0.0)
     be.close()
