@@ -127,3 +127,14 @@ def test_committed_profile_files_have_what_bench_reads():
         s = json.load(open(sorted(prof.glob("r*_" + name))[-1]))
         for key in ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "gpu_cycles_per_launch", "build_id", "kernel", "kernel_ms"):
             assert key in s, (name, key)
+
+
+def test_gpus_2_hero_wavelengths():
+    """--wavelengths 4 reaches every rank's backend; the line says so, reports no scalar-kernel roofline, and the job's paths are shared as usual"""
+    r = run_bench("--gpus", "2", "--stub", "--steps", "2", "--warmup", "0", "--config", "cfg1", "--wavelengths", "4")
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json_line(r.stdout)
+    per_frame = 4 * 256 * 256
+    assert out["n_gpus"] == 2 and out["config"]["wavelengths_per_path"] == 4 and out["roofline"] is None and out["work_rate_vs_hbm"] is None
+    assert out["stub"]["reduced_sum_last_frame"] == out["stub"]["expected"] == out["config"]["paths_per_step"]
+    assert run_bench("--stub", "--wavelengths", "3").returncode != 0
