@@ -132,9 +132,10 @@ static inline void o_g_meet(o_ctx *c)
 {
   o_group *g = c->grp;
   const int s = c->sense ^= 1;
-  if(__sync_add_and_fetch(&g->arrived, 1) == O_MF) { g->arrived = 0; __sync_synchronize(); g->sense = s; }
-  else { int spins = 0; while(g->sense != s) { if(++spins > 4000) sched_yield(); else __builtin_ia32_pause(); } }
-  __sync_synchronize();
+  /* what a lane wrote into the group before it arrives is visible to every lane that has seen the new sense (release / acquire on `sense`,
+     acquire-release on the arrival count: the last lane has seen the others' writes and publishes them with its own) */
+  if(__atomic_add_fetch(&g->arrived, 1, __ATOMIC_ACQ_REL) == O_MF) { __atomic_store_n(&g->arrived, 0, __ATOMIC_RELAXED); __atomic_store_n(&g->sense, s, __ATOMIC_RELEASE); }
+  else { int spins = 0; while(__atomic_load_n(&g->sense, __ATOMIC_ACQUIRE) != s) { if(++spins > 4000) sched_yield(); else __builtin_ia32_pause(); } }
 }
 static inline int o_g_any(o_ctx *c, int cond)       /* mf_any */
 {
