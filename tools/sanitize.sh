@@ -1,0 +1,21 @@
+#!/bin/bash
+# build container (CPU only): the oracle and the host library under AddressSanitizer + UndefinedBehaviorSanitizer, and the hero lanes of the oracle
+# (four threads meeting at a spin barrier, oracle/o_core.h) under ThreadSanitizer. GPU sanitizers are not available on the pool.
+#   tools/sanitize.sh        -> runs tests/test_oracle_golden.py, test_oracle_hero.py, test_host.py against the instrumented libraries
+set -e
+cd "$(dirname "$0")/.."
+SAN="-fsanitize=address,undefined -fno-sanitize-recover=undefined"
+OSRC="oracle/oracle_geo.c oracle/oracle_halton.c oracle/oracle_path.c oracle/oracle_shade.c"
+gcc -O1 -g -fPIC -std=c11 -fno-strict-aliasing -D_GNU_SOURCE -Iinclude -pthread $SAN -shared $OSRC -o /tmp/liboracle_asan.so -lm -pthread
+gcc -O1 -g -fPIC -std=c11 -fno-strict-aliasing -D_GNU_SOURCE -Iinclude -pthread -fsanitize=thread -shared $OSRC -o /tmp/liboracle_tsan.so -lm -pthread
+# the tree builder and the coefficient fetch keep their float contract (corona-13_amd/Makefile: QBVH_CFLAGS), or the tree is another one
+Q="-O3 -ffast-math -fno-finite-math-only -march=x86-64-v3 -fPIC -std=c11 -D_GNU_SOURCE -Iinclude -Icorona-13_amd/host"
+gcc $Q $SAN -g -c corona-13_amd/host/ch_qbvh.c -o /tmp/ch_qbvh_asan.o
+gcc $Q $SAN -g -c corona-13_amd/host/ch_rgb2spec_lut.c -o /tmp/ch_lut_asan.o
+gcc -O1 -g -fPIC -std=c11 -D_GNU_SOURCE -Iinclude -Icorona-13_amd/host $SAN -shared corona-13_amd/host/ch_scene.c corona-13_amd/host/ch_rgb2spec.c corona-13_amd/host/ch_pfm.c \
+    /tmp/ch_qbvh_asan.o /tmp/ch_lut_asan.o -o /tmp/libcorona_host_asan.so -lm -ldl
+PRE="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)"
+CORONA_ORACLE_LIB=/tmp/liboracle_asan.so CORONA_HOST_LIB=/tmp/libcorona_host_asan.so LD_PRELOAD="$PRE" ASAN_OPTIONS=detect_leaks=0 \
+  python3 -m pytest tests/test_oracle_golden.py tests/test_oracle_hero.py tests/test_host.py -q -p no:cacheprovider
+CORONA_ORACLE_LIB=/tmp/liboracle_tsan.so LD_PRELOAD="$(gcc -print-file-name=libtsan.so)" TSAN_OPTIONS="report_signal_unsafe=0" \
+  python3 -m pytest tests/test_oracle_hero.py -q -p no:cacheprovider -k "mf4_pt_mv8 or mf4_fog or untouched"
