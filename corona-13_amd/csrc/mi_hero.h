@@ -15,7 +15,8 @@
  * Component 0 lives in the PathState the megakernel knows (ray, pdf product, throughput ...: what the traversal slices and the parking
  * of path state touch), components 1..3 in the arrays of PathStateHero behind it: 18 registers more.
  * Every kind of scene the scalar kernels take (MEDIA / MB switches as there), `rand` or `halton` point sampler: what the reference's MF_COUNT = 4
- * build was pinned on (tests/test_oracle_hero.py). No exchange between waves: a pool entry would have to carry the 18 words too. */
+ * build was pinned on (tests/test_oracle_hero.py). The exchange between waves (mi_regroup.h) carries the fifteen words of components 1..3 that are live
+ * between two rays in eight more slots of a pool entry. */
 #ifndef MI_HERO_H
 #define MI_HERO_H
 
@@ -1123,13 +1124,10 @@ __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero 
               if(mat_bsdf == MI_BSDF_DIFFUSE) he = brdf_diffuse_hero(sf, sh, ol);
               else if(mat_bsdf == MI_BSDF_DIELECTRIC) he = brdf_dielectric_hero(sf, sh, omega, ol, eta, any_im);
               else he = brdf_metal_hero(sc, sf, sh, omega, ol, ior, (int)mat_p0, lam);
-              struct { float value; uint32_t mode; } be[4];
-#pragma unroll
-              for(int l=0;l<MI_MF;l++) { be[l].value = he.value[l]; be[l].mode = he.mode; }
-              bool okn = be[0].value > 0.0f || be[1].value > 0.0f || be[2].value > 0.0f || be[3].value > 0.0f;   /* mf_any(bsdf > 0), nee.h:191 */
+              bool okn = he.value[0] > 0.0f || he.value[1] > 0.0f || he.value[2] > 0.0f || he.value[3] > 0.0f;   /* mf_any(bsdf > 0), nee.h:191 */
               Medium nmed[4];                                              /* volume of the connection edge, per component */
               if(MEDIA) { nmed[0] = med[0]; nmed[1] = med[1]; nmed[2] = med[2]; nmed[3] = med[3]; }
-              if(okn && (be[0].mode & s_transmit))
+              if(okn && (he.mode & s_transmit))
               {
                 Media hyp = ps.media;
                 media_apply(hyp, shape, (sf.flags & s_inside) != 0);
@@ -1155,14 +1153,14 @@ __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero 
                   float tn[4], ours[4], sums[4];
                   float pbs[4];
                   if(mat_bsdf == MI_BSDF_DIFFUSE) pbs[0] = pbs[1] = pbs[2] = pbs[3] = (float)(1.0f/MI_PI_D);
-                  else if(mat_bsdf == MI_BSDF_DIELECTRIC) pdf_dielectric_hero(sf, sh, omega, ol, eta, any_im, be[0].mode, pbs);
-                  else pbs[0] = pbs[1] = pbs[2] = pbs[3] = pdf_metal(sf, sh[0], omega, ol, be[0].mode);     /* no wavelength in it */
+                  else if(mat_bsdf == MI_BSDF_DIELECTRIC) pdf_dielectric_hero(sf, sh, omega, ol, eta, any_im, he.mode, pbs);
+                  else pbs[0] = pbs[1] = pbs[2] = pbs[3] = pdf_metal(sf, sh[0], omega, ol, he.mode);     /* no wavelength in it */
 #pragma unroll
                   for(int l=0;l<MI_MF;l++)
                   {
                     const float nT = MEDIA ? media_transmittance(nmed[l], ldist) : 1.0f;
-                    float t = ((vthr[l]*be[l].value)*(nT*edf[l]))*Gn;
-                    t = t + (vthr[l]*be[l].value)*((0.0f*Gn)/lpdf);
+                    float t = ((vthr[l]*he.value[l])*(nT*edf[l]))*Gn;
+                    t = t + (vthr[l]*he.value[l])*((0.0f*Gn)/lpdf);
                     const float wn = lpdf/(lpdf + 0.0f/nT);
                     tn[l] = t*wn;
                     const float pb = pbs[l];
@@ -1206,16 +1204,13 @@ __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero 
         if(mat_bsdf == MI_BSDF_DIFFUSE) sample_diffuse_hero(pts, sf, sh, any_rd, mode, hs);
         else if(mat_bsdf == MI_BSDF_DIELECTRIC) sample_dielectric_hero(pts, sf, sh, omega, eta, any_im, mode, hs);
         else sample_metal_hero(sc, pts, sf, sh, omega, ior, (int)mat_p0, lam, mode, hs);
-        struct { V3 omega; uint32_t mode; float pdf, weight; } bs[4];
-#pragma unroll
-        for(int l=0;l<MI_MF;l++) { bs[l].omega = hs.omega; bs[l].mode = hs.mode; bs[l].pdf = hs.pdf[l]; bs[l].weight = hs.weight[l]; }
-        const V3 out = normalise3(bs[0].omega);
+        const V3 out = normalise3(hs.omega);
         const float dts = ((sf.flags & s_inside) ? -1 : 1)*dot3(sf.gn, out);
-        const bool wrong_side = ((bs[0].mode & s_reflect) && (dts < 0.f)) || ((bs[0].mode & s_transmit) && (dts > 0.f));
+        const bool wrong_side = ((hs.mode & s_reflect) && (dts < 0.f)) || ((hs.mode & s_transmit) && (dts > 0.f));
         float nthr[4];
 #pragma unroll
-        for(int l=0;l<MI_MF;l++) nthr[l] = vthr[l]*(wrong_side ? 0.0f : bs[l].weight);
-        uint32_t vmode = bs[0].mode;
+        for(int l=0;l<MI_MF;l++) nthr[l] = vthr[l]*(wrong_side ? 0.0f : hs.weight[l]);
+        uint32_t vmode = hs.mode;
         bool ok = !(nthr[0] <= 0.0f && nthr[1] <= 0.0f && nthr[2] <= 0.0f && nthr[3] <= 0.0f);         /* mf_all(throughput <= 0), src/pathspace.c:253 */
         if(ok && (vmode & s_transmit))
         {
@@ -1245,9 +1240,9 @@ __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero 
           ps.prev_throughput = vthr[0];
           ps.prev_mode = vmode;
           ps.prev_material_modes = material_modes;
-          ps.throughput = nthr[0]; ps.pdf = bs[0].pdf; ps.cur_ior = ior[0];
+          ps.throughput = nthr[0]; ps.pdf = hs.pdf[0]; ps.cur_ior = ior[0];
 #pragma unroll
-          for(int l=1;l<MI_MF;l++) { ps.throughput_x[l-1] = nthr[l]; ps.pdf_x[l-1] = bs[l].pdf; }
+          for(int l=1;l<MI_MF;l++) { ps.throughput_x[l-1] = nthr[l]; ps.pdf_x[l-1] = hs.pdf[l]; }
         }
       }
     }
