@@ -280,3 +280,27 @@ def test_hero_soak_half_a_million_paths():
     assert bad <= 2e-5 * total, bad
     assert bad_splats <= 2e-4 * total, bad_splats          # a grazing shadow ray or a weight at the underflow limit flips one connection (test_gpu_parity.py)
     assert worst < 1e-3, worst
+
+
+@pytest.mark.parametrize("scene_dir", ["0055_media", "0056_fog", "0057_nested", "0058_cam_mb", "0059_mb", "0066_smooth"])
+def test_hero_image_mean_against_the_mf4_reference_render(scene_dir):
+    """End to end against the reference built with -DMF_COUNT=4 itself: its own CPU renders of the extended scenes (pt, 256 x 256, 128 spp, three frames:
+    tests/golden/mf4_scene_means.json, written by tests/golden/measure_mf4_scenes.py in the build container) and the device's hero render of the same
+    scene have the same mean image -- media (free flight from the hero's medium), fog, nested media, moving camera, moving geometry, smooth glass (one
+    component survives a specular transmission)."""
+    import json
+    from helpers import REPO
+    with open(GOLDEN / "mf4_scene_means.json") as f:
+        measured = json.load(f)
+    ref = measured["scenes"][scene_dir]
+    scene = make_scene(REPO / "scenes" / scene_dir / "test.nra2", width=measured["size"], height=measured["size"], max_verts=8, sampler=pkg.MI_SAMPLER_PT)
+    spp = 4 * measured["spp"]
+    be = pkg.Backend(scene, counters=False)
+    be.set_wavelengths(pkg.MI_WAVELENGTHS_HERO)
+    be.render(0, spp * scene.width * scene.height)
+    mean = (be.fb_read() * scene.gain(spp)).reshape(-1, 3).mean(axis=0)
+    be.close()
+    rmean, sd = np.array(ref["mean"]), np.array(ref["sd_between_frames"])
+    # the reference's mean of three frames has sd / sqrt(3); the device's 512 spp a quarter of a frame's variance; 4 sigma of the difference, at least 1 %
+    tol = np.maximum(4.0 * sd * np.sqrt(1.0 / 3.0 + 0.25), 0.01 * rmean)
+    assert (np.abs(mean - rmean) <= tol).all(), (mean, rmean, tol)
