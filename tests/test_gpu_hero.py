@@ -304,3 +304,38 @@ def test_hero_image_mean_against_the_mf4_reference_render(scene_dir):
     # the reference's mean of three frames has sd / sqrt(3); the device's 512 spp a quarter of a frame's variance; 4 sigma of the difference, at least 1 %
     tol = np.maximum(4.0 * sd * np.sqrt(1.0 / 3.0 + 0.25), 0.01 * rmean)
     assert (np.abs(mean - rmean) <= tol).all(), (mean, rmean, tol)
+
+
+def test_hero_on_a_device_built_tree_and_a_tree_beyond_lds():
+    """the traversal is the scalar kernels': hero paths do not depend on where the tree comes from (built on the device: same hits, so the same
+    paths as on the host-built tree) nor on where it lives (262 144-quad backdrop: the top of the tree in LDS, the rest from HBM) -- against the oracle"""
+    from helpers import SCENE_LARGE
+    scene = make_scene(SCENE_0010, width=1280, height=720, max_verts=8, sampler=pkg.MI_SAMPLER_PTDL)
+    n = 20000
+    host = pkg.Backend(scene)
+    host.set_wavelengths(pkg.MI_WAVELENGTHS_HERO)
+    a, ae = host.trace_paths_hero(0, n)
+    host.close()
+    dev = pkg.Backend(scene, device_build=True)
+    dev.set_wavelengths(pkg.MI_WAVELENGTHS_HERO)
+    b, be_ = dev.trace_paths_hero(0, n)
+    dev.close()
+    same = (a["length"] == b["length"]) & (a["num_splats"] == b["num_splats"])
+    assert (~same).sum() <= 2
+    k = np.arange(8)[None, :]
+    valid = k < np.minimum(a["length"], 8)[:, None]
+    assert (((a["v"]["prim"] != b["v"]["prim"]) & valid).any(axis=1) & same).sum() <= 2
+    assert np.array_equal(ae["throughput"][same], be_["throughput"][same], equal_nan=True) or (rel(ae["throughput"][same], be_["throughput"][same]) > 1e-5).mean() < 1e-4
+    big = make_scene(SCENE_LARGE, width=1280, height=720, max_verts=8, sampler=pkg.MI_SAMPLER_PT)
+    be = pkg.Backend(big)
+    be.set_wavelengths(pkg.MI_WAVELENGTHS_HERO)
+    assert 0 < be.lds_nodes() < big.desc.num_nodes
+    g, ge = be.trace_paths_hero(100, 8000)
+    be.close()
+    o, oe = oracle_hero_records(big, 100, 8000)
+    ok = g["length"] == o["length"]
+    assert (~ok).sum() <= 2
+    valid = k < np.minimum(o["length"], 8)[:, None]
+    assert (((g["v"]["prim"] != o["v"]["prim"]) & valid).any(axis=1) & ok).sum() <= 2
+    m = ok[:, None] & valid & (k >= 1)
+    assert np.quantile(rel(ge["throughput"][m], oe["throughput"][m]), 0.999) < 1e-3
