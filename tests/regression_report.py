@@ -51,7 +51,7 @@ def write_png(fn, xyz):
     Path(fn).write_bytes(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
 
 
-def run_test(scene_dir, out, keep_pfm=False):
+def run_test(scene_dir, out, keep_pfm=False, wavelengths=1):
     name = scene_dir.name
     args = (scene_dir / "args").read_text().split()
     maxerror = float((scene_dir / "maxerror").read_text()) if (scene_dir / "maxerror").exists() else 0.11
@@ -68,8 +68,8 @@ def run_test(scene_dir, out, keep_pfm=False):
     tmp = Path(tempfile.mkdtemp(prefix="corona_reg_"))
     shutil.copytree(REPO / "scenes", tmp / "scenes")
     t0 = time.time()
-    p = subprocess.run([str(CLI), str(tmp / "scenes" / name / "test.nra2")] + args + ["--sampler", sampler, "--max-verts", "8", "-x", "_mi"],
-                       capture_output=True, text=True)
+    p = subprocess.run([str(CLI), str(tmp / "scenes" / name / "test.nra2")] + args + ["--sampler", sampler, "--max-verts", "8", "-x", "_mi"] +
+                       (["--wavelengths", str(wavelengths)] if wavelengths != 1 else []), capture_output=True, text=True)
     res["seconds"] = time.time() - t0
     res["log"] = (p.stdout + p.stderr)[-2000:]
     render = work / "testrender_fb00.pfm"
@@ -136,12 +136,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=str(REPO / "gpurun_out" / "regression"))
     ap.add_argument("--keep-pfm", action="store_true", help="keep the float images next to the previews (7 MB each)")
+    ap.add_argument("--wavelengths", type=int, default=1, choices=[1, 4],
+                    help="4: the test renders carry four wavelengths per path (corona-mi --wavelengths 4, the reference's MF_COUNT = 4); the references stay the "
+                         "MF_COUNT = 1 reference's renders -- same expected image, the thresholds are the scalar tests' noise floors")
     ap.add_argument("scenes", nargs="*")
     a = ap.parse_args()
     out = Path(a.out)
     out.mkdir(parents=True, exist_ok=True)
     dirs = sorted(d for d in (REPO / "scenes").iterdir() if d.is_dir() and (d / "args").exists() and (not a.scenes or d.name in a.scenes))
-    results = [run_test(d, out, a.keep_pfm) for d in dirs]
+    results = [run_test(d, out, a.keep_pfm, a.wavelengths) for d in dirs]
     write_report(out, results)
     for r in results:
         print("%-14s %-11s rmse %-10s max %-5g %s" % (r["name"], r["status"], "-" if r["rmse"] is None else "%.4g" % r["rmse"], r["maxerror"], r["title"]))
