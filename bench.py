@@ -302,6 +302,9 @@ def main():
                     help="torch: one process per GPU, torch.distributed (RCCL) all-reduce of the framebuffer (what the driver launches); c: ONE process, "
                          "the N GPUs behind the C ABI (mi_group_*: index ranges split in the library, ncclReduce from the library)")
     ap.add_argument("--stub", action="store_true", help="TEST ONLY: no GPU, gloo, a stub instead of the HIP backend (launch / sharding / reduce logic)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="TEST ONLY: all ranks render on device 0 and reduce over gloo (RCCL refuses two ranks on one device): the multi-rank path -- sharding, "
+                         "double-buffered reduce, read-back -- with the real kernels on a one-GPU box. The rate it prints is not a measurement")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -323,6 +326,8 @@ def main():
     if not args.stub:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+        if args.share_gpu:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
     device = "cpu" if args.stub else f"cuda:{local_rank}"
     # under torch.distributed.run (RANK/WORLD_SIZE/MASTER_* in the environment) a process group is always formed, also
@@ -336,7 +341,7 @@ def main():
         saved = os.dup(1)
         os.dup2(2, 1)
         try:
-            if args.stub:
+            if args.stub or args.share_gpu:
                 dist.init_process_group("gloo", rank=rank, world_size=world)
             else:
                 dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
@@ -637,7 +642,8 @@ def main():
         total = args.steps * main_r["job"]
         out = {
             "metric": ("Msamples/sec (and ms/frame) at 1280x720, 64 spp, regression/0010_pt" if args.config == "cfg2" else "Msamples/sec (and ms/frame), " + args.config)
-                      if not args.stub else "STUB (no rendering: launch/sharding/reduce logic only)",
+                      if not (args.stub or args.share_gpu) else "STUB (no rendering: launch/sharding/reduce logic only)" if args.stub
+                      else "SHARED GPU (all ranks on device 0, gloo reduce: a test of the multi-rank path, not a measurement)",
             "value": total / main_r["elapsed"] / 1e6,
             "unit": "Msamples/s",
             "n_gpus": world,
