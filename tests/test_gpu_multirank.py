@@ -35,3 +35,13 @@ def test_ranks_sharing_one_gpu_render_the_single_rank_frame(extra):
         # bench.py itself exits non-zero on a wrong path count or an image mean off the reference's; the reduced frame is the single-rank frame
         for a, b in zip(many["image"]["mean_xyz"], one["image"]["mean_xyz"]):
             assert abs(a - b) <= 2e-5 * abs(b), (many["image"], one["image"])
+
+
+def test_weak_scaling_ranks_sharing_one_gpu():
+    """weak scaling (every rank a whole frame of its own indices): twice the paths, the reduced frame = the sum of two frames -- bench.py's own image and
+    path-count checks pass, and the mean per frame is the single-frame mean within the two frames' noise"""
+    one = run_bench("--gpus", "1", "--config", "cfg2", "--scaling", "weak")
+    two = run_bench("--gpus", "2", "--share-gpu", "--config", "cfg2", "--scaling", "weak")
+    assert two["scaling"] == "weak" and two["config"]["paths_per_step"] == 2 * one["config"]["paths_per_step"]
+    for a, b in zip(two["image"]["mean_xyz"], one["image"]["mean_xyz"]):
+        assert abs(a - b) <= 0.01 * abs(b), (two["image"], one["image"])
