@@ -339,3 +339,23 @@ def test_hero_on_a_device_built_tree_and_a_tree_beyond_lds():
     assert (((g["v"]["prim"] != o["v"]["prim"]) & valid).any(axis=1) & ok).sum() <= 2
     m = ok[:, None] & valid & (k >= 1)
     assert np.quantile(rel(ge["throughput"][m], oe["throughput"][m]), 0.999) < 1e-3
+
+
+def test_hero_entry_points_at_the_c_abi():
+    """the two entry points as a C host calls them: null arguments and a wrong count are errors with a message, the extension block is optional, an empty
+    range is no work, and the records of a call without the extension block are the records of a call with it"""
+    import ctypes as C
+    m = pkg.mi_lib()
+    assert m.mi_scene_set_wavelengths(None, 4) < 0 and m.mi_last_error()
+    assert m.mi_trace_paths_hero(None, 0, 1, None, None) < 0
+    scene = make_scene(SCENE_0010, width=256, height=256, max_verts=8, sampler=pkg.MI_SAMPLER_PTDL)
+    be = pkg.Backend(scene)
+    assert m.mi_scene_set_wavelengths(be._ptr, 0) < 0 and m.mi_scene_set_wavelengths(be._ptr, 8) < 0 and b"1 or 4" in m.mi_last_error()
+    be.set_wavelengths(pkg.MI_WAVELENGTHS_HERO)
+    rec = np.zeros(3000, dtype=pkg.record_dtype())
+    assert m.mi_trace_paths_hero(be._ptr, 0, 3000, None, None) < 0                  # records are not optional
+    assert m.mi_trace_paths_hero(be._ptr, 77, 3000, rec.ctypes.data, None) == 0     # the extension block is
+    assert m.mi_trace_paths_hero(be._ptr, 77, 0, rec.ctypes.data, None) == 0
+    both, ext = be.trace_paths_hero(77, 3000)
+    assert rec.tobytes() == both.tobytes() and np.array_equal(ext["lambda"][:, 0], rec["lambda"])
+    be.close()
