@@ -926,6 +926,7 @@ __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero 
     const uint32_t mat_bsdf = mhead.x;
     const float mat_p0 = __uint_as_float(mhead.z), mat_p1 = __uint_as_float(mhead.w);
     surface_setup<MB>(sc, hit.prim, head, omega, ps.scramble, sf, ps.time);
+    MI_PHASE(cnt, 2)
     const uint32_t shape = (head.w >> 3) & 0x1fffffffu;
     Shading sh[4];
     run_prepare_ops_hero(sc, mat, mhead.y, sf, lam, sh);
@@ -970,6 +971,7 @@ __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero 
       if(sh[0].roughness > 1e-4f) material_modes |= s_glossy; else material_modes |= s_specular;
     }
 
+    MI_PHASE(cnt, 3)
     const uint32_t type = MB ? head.x & 7u : head.x;                /* the motion-blur kernels flag moving primitives in bit 3 (MI_GEO_MB) */
     if((type > 2 || hit.dist < 1e-4f) && hit.prim == ps.ignore)
     { /* self-intersection */
@@ -1186,6 +1188,7 @@ __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero 
           }
         }
       }
+      MI_PHASE(cnt, 4)
       if(alive && ps.length >= (int)sc.max_verts) alive = false;
       if(alive && !(vthr[0] > 0.0f || vthr[1] > 0.0f || vthr[2] > 0.0f || vthr[3] > 0.0f))             /* !mf_any(throughput > 0), src/pathspace.c:189 */
       {
@@ -1204,6 +1207,7 @@ __device__ __forceinline__ void path_shade_hero(const DScene &sc, PathStateHero 
         if(mat_bsdf == MI_BSDF_DIFFUSE) sample_diffuse_hero(pts, sf, sh, any_rd, mode, hs);
         else if(mat_bsdf == MI_BSDF_DIELECTRIC) sample_dielectric_hero(pts, sf, sh, omega, eta, any_im, mode, hs);
         else sample_metal_hero(sc, pts, sf, sh, omega, ior, (int)mat_p0, lam, mode, hs);
+        MI_PHASE(cnt, 7)
         const V3 out = normalise3(hs.omega);
         const float dts = ((sf.flags & s_inside) ? -1 : 1)*dot3(sf.gn, out);
         const bool wrong_side = ((hs.mode & s_reflect) && (dts < 0.f)) || ((hs.mode & s_transmit) && (dts > 0.f));

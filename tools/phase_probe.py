@@ -4,11 +4,14 @@ import sys, os
 sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parent.parent / "tests"))
 from helpers import *
 pkg = load_pkg()
-which = sys.argv[1] if len(sys.argv) > 1 else "0010"        # python3 tools/phase_probe.py [0010|fog|media|mb]
+which = sys.argv[1] if len(sys.argv) > 1 else "0010"        # python3 tools/phase_probe.py [0010|fog|media|mb] [hero]
+hero = len(sys.argv) > 2 and sys.argv[2] == "hero"
 path = {"0010": SCENE_0010, "fog": SCENE_FOG, "media": SCENE_MEDIA, "mb": SCENE_MB}[which]
 for name, mv, sampler in (("pt mv8", 8, 0), ("ptdl mv8", 8, 1)):
     scene = make_scene(path, width=1280, height=720, max_verts=mv, sampler=sampler)
     be = pkg.Backend(scene)
+    if hero:
+        be.set_wavelengths(4)
     per = scene.width * scene.height
     be.render(0, per); be.sync()
     c0 = be.counters(); be.render(per, 8 * per); be.sync(); c1 = be.counters()
