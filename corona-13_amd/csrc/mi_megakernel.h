@@ -99,6 +99,10 @@
 #ifndef MI_REGROUP_MEDIA
 #define MI_REGROUP_MEDIA 1   /* the exchange in the extended kernels too (media, moving camera): volume vertices are a class of their own */
 #endif
+#ifndef MI_PARK_HERO_PT
+#define MI_PARK_HERO_PT 0    /* entries of path state the HERO pt kernel parks in the lane's stack column during a slice (its 55 spilled registers against a shallower LDS
+                                stack). Same box, cfg 2 / cfg 4, 0 / 3 / 4 entries: 20.43 / 20.36 / 20.64 ms and 22.18 / 22.07 / 22.41: nothing to gain, off */
+#endif
 #ifndef MI_REGROUP_HERO
 #define MI_REGROUP_HERO 1    /* the exchange in the HERO kernels (A/B: profiles/r05_hero.txt) */
 #endif
@@ -186,8 +190,8 @@ __global__ __launch_bounds__(MI_BLOCK_OF(HERO, PTDL, MEDIA)) void mi_path_kernel
      column for the length of a slice, so that the rounds' registers (a job pass holds a whole primitive record and a second ray) do
      not push path state into scratch, from where the shading blocks would fetch it back word by word. Costs four stack entries. */
   constexpr bool CHAIN = MI_CHAIN && PTDL && !FAST;    /* shadow ray and extension ray of a vertex in one slice (below) */
-  constexpr bool PARK_PS = MI_PARK_PATH && !MB && (FAST ? (PTDL || MI_PARK_PATH == 2) : (JOBS && PTDL && MI_PARK_ENTRIES_EXACT > 0));
-  constexpr int PARK_N = !PARK_PS ? 0 : !FAST ? MI_PARK_ENTRIES_EXACT : PTDL ? MI_PARK_ENTRIES : MI_PARK_ENTRIES_PT;   /* 8-byte entries of the column that hold parked path state */
+  constexpr bool PARK_PS = MI_PARK_PATH && !MB && (FAST ? (PTDL || MI_PARK_PATH == 2) : (JOBS && (PTDL || (HERO && MI_PARK_HERO_PT > 0)) && MI_PARK_ENTRIES_EXACT > 0));
+  constexpr int PARK_N = !PARK_PS ? 0 : !FAST ? ((HERO && !PTDL) ? MI_PARK_HERO_PT : MI_PARK_ENTRIES_EXACT) : PTDL ? MI_PARK_ENTRIES : MI_PARK_ENTRIES_PT;   /* 8-byte entries of the column that hold parked path state */
   constexpr int RESULT_SLOTS = (JOBS || FAST) ? 3 : 0;                       /* FAST: the rounds of trace_round_spec (mi_kernels.h), same result slots */
   constexpr int STACK = COLUMN - RESULT_SLOTS - PARK_N;
   static_assert(STACK >= MI_STACK_MIN, "the overflow area is sized for MI_STACK_MIN entries in LDS (mi_abi.hip)");
