@@ -502,7 +502,7 @@ def main():
         return res
 
     def kernel_name(r):
-        return r["kernel"] + " (RECORD, PTDL, NODES_LDS, HALTON, MEDIA, MB, COUNT, FAST, NORG)"
+        return r["kernel"] + " (RECORD, PTDL, NODES_LDS, HALTON, MEDIA, MB, COUNT, FAST, NORG, HERO)"
 
     def work_rate_of(config, r):
         """SURVEY 8(d)'s figure under its own name: algorithmic bytes per launch / launch duration, beside the HBM peak. The 0.5 MB scene
@@ -637,6 +637,18 @@ def main():
                      "ms_per_step": 1e3 * sec["elapsed"] / 3, "scaling": "weak", "roofline": roofline_of("cfg3", sec),
                      "work_rate_vs_hbm": work_rate_of("cfg3", sec), "image": check_image("cfg3", sec) if rank == 0 else None}
 
+    hero = None
+    if args.config == "cfg2" and not args.no_secondary and not args.stub and args.wavelengths == 1:
+        # the same frame with four wavelengths per path (mi_scene_set_wavelengths, the reference's MF_COUNT = 4), timed like `secondary`: PATHS per second
+        args.wavelengths = 4
+        try:
+            h = measure("cfg2", 3, 1, scaling)
+        finally:
+            args.wavelengths = 1
+        hero = {"workload": h["cfg"]["name"] + ", four wavelengths per path (hero wavelengths)", "value": 3 * h["job"] / h["elapsed"] / 1e6, "unit": "Mpaths/s",
+                "wavelength_samples_per_s": 4 * 3 * h["job"] / h["elapsed"] / 1e6, "steps": 3, "warmup": 1, "ms_per_step": 1e3 * h["elapsed"] / 3, "scaling": scaling,
+                "kernel": kernel_name(h), "kernel_ms": h["kms"], "image": check_image("cfg2", h) if rank == 0 else None}
+
     if rank == 0:
         cfg = main_r["cfg"]
         total = args.steps * main_r["job"]
@@ -671,6 +683,8 @@ def main():
             out["image"] = check_image(args.config, main_r)
             if secondary:
                 out["secondary"] = secondary
+            if hero:
+                out["hero_wavelengths"] = hero
             if not args.no_cpu_baseline and world == 1 and args.config == "cfg2":
                 cb = cpu_baseline(*main_r["scene_wh"])
                 if cb:
