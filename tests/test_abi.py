@@ -31,6 +31,11 @@ def test_struct_sizes_match_header():
     assert C.sizeof(pkg.MiPathRecord) == 40 + 8 * 24 + 8 * 112
     ray, hit = pkg.ray_dtypes()
     assert ray.itemsize == 32 and hit.itemsize == 32          # mi_ray, mi_hit
+    # mi_hero_ext: lambda[4] + six per-vertex quantities [8][4] + splat_value[8][4], floats; = oracle_hero_ext = the dump harness' extension block
+    assert pkg.hero_ext_dtype().itemsize == 4 * (4 + 6 * 8 * 4 + 8 * 4) == 912
+    import re
+    hdr = (REPO / "include" / "corona_mi.h").read_text()
+    assert re.search(r"#define MI_WAVELENGTHS_HERO 4\b", hdr) and "mi_scene_set_wavelengths" in hdr and "mi_trace_paths_hero" in hdr
 
 
 def test_product_never_imports_oracle():
