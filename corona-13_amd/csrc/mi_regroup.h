@@ -108,7 +108,8 @@ __device__ __forceinline__ Pool pool_setup(const DScene &sc, unsigned char *base
   p.cls = (E && sc.pool_cls_bytes) ? (lds_u32_t *)(base + sc.pool_bytes) : nullptr;
   return p;
 }
-/* call from all threads of the workgroup before the barrier that starts the kernel */
+/* call from all threads of the workgroup before the barrier that starts the kernel. (One thread per entry: E <= 1024 = the scalar kernels' workgroup; the HERO
+   ptdl kernels run 768 threads and their 22- to 27-word entries cap E at MI_POOL_BYTES_MAX / 186 = 264.) */
 __device__ __forceinline__ void pool_init(const Pool &p, PoolCtl *ctl)
 {
   if(threadIdx.x == 0) { ctl->state = (unsigned long long)p.E << 48; ctl->hint = ctl->state; }
