@@ -359,3 +359,20 @@ def test_hero_entry_points_at_the_c_abi():
     both, ext = be.trace_paths_hero(77, 3000)
     assert rec.tobytes() == both.tobytes() and np.array_equal(ext["lambda"][:, 0], rec["lambda"])
     be.close()
+
+
+def test_hero_ignores_the_traversal_switch():
+    """the HERO kernels have the exact rounds only: a scene switched to the FAST rounds renders its hero paths with them all the same (and says so in the
+    kernel's name), its scalar paths with the FAST rounds"""
+    scene = make_scene(SCENE_0010, width=1280, height=720, max_verts=8, sampler=pkg.MI_SAMPLER_PT)
+    a = pkg.Backend(scene, traversal="exact")
+    a.set_wavelengths(pkg.MI_WAVELENGTHS_HERO)
+    ra, ea = a.trace_paths_hero(0, 5000)
+    a.close()
+    b = pkg.Backend(scene, traversal="fast", counters=False)
+    assert b.kernel_name().split(", ")[7] == "true"           # scalar: the FAST instantiation
+    b.set_wavelengths(pkg.MI_WAVELENGTHS_HERO)
+    assert b.kernel_name().split(", ")[7] == "false" and b.kernel_name().endswith("true>")
+    rb, eb = b.trace_paths_hero(0, 5000)
+    b.close()
+    assert ra.tobytes() == rb.tobytes() and ea.tobytes() == eb.tobytes()
