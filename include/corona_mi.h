@@ -264,7 +264,8 @@ int  mi_scene_set_counters(mi_scene *s, int enable);
  * 219-265; csrc/mi_kernels.h: metal_reference_kills). Off (default): the formula as written, sampling and evaluation consistent
  * (the BSDF battle test passes). On (or CORONA_MI_METAL=reference when the scene is created): the same samples are ended as the
  * reference build ends them -- images of metal scenes then carry the reference's energy, the battle test fails where the
- * reference's own does. */
+ * reference's own does. (With four wavelengths per path, mi_scene_set_wavelengths, the predicate is applied per component; the MF_COUNT = 4
+ * reference's metal plugin is a clang build whose compiled Fresnel term was not examined for the artefact: leave the switch off there.) */
 int  mi_scene_set_metal_reference(mi_scene *s, int enable);
 
 /* How a ray walks the tree. Both modes return the same closest hit, bit for bit (distance, primitive, u, v), hence the same paths
