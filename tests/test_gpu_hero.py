@@ -376,3 +376,31 @@ def test_hero_ignores_the_traversal_switch():
     rb, eb = b.trace_paths_hero(0, 5000)
     b.close()
     assert ra.tobytes() == rb.tobytes() and ea.tobytes() == eb.tobytes()
+
+
+def test_hero_pixels_from_path_indices():
+    """MI_PIXELS_FROM_INDEX with four wavelengths per path: path i starts inside pixel (i mod W H) with its generator seeded through the hash of its index
+    (the mode tile-owned sharding renders in) -- path for path against the oracle's hero lanes in that mode"""
+    from helpers import oracle_pixels
+    scene = make_scene(SCENE_0010, width=640, height=352, max_verts=8, sampler=pkg.MI_SAMPLER_PTDL)
+    W, H = scene.width, scene.height
+    be = pkg.Backend(scene)
+    be.set_wavelengths(pkg.MI_WAVELENGTHS_HERO)
+    be.set_pixels(True)
+    first, n = 2 * W * H - 5000, 20000
+    gpu, gext = be.trace_paths_hero(first, n)
+    be.close()
+    with oracle_pixels():
+        ora, oext = oracle_hero_records(scene, first, n)
+    idx = (first + np.arange(n)) % (W * H)
+    # inside the pixel its index names (pixel + a number in [0, 1): in float the sum may come out as the next pixel's edge, one path in 20 000 here)
+    di, dj = gpu["pixel_i"] - (idx % W), gpu["pixel_j"] - (idx // W)
+    assert (di >= 0).all() and (di <= 1).all() and (dj >= 0).all() and (dj <= 1).all() and (di == 1).sum() + (dj == 1).sum() <= 3
+    assert np.abs(gpu["pixel_i"] - ora["pixel_i"]).max() <= 1e-4 and np.abs(gpu["pixel_j"] - ora["pixel_j"]).max() <= 1e-4 and np.abs(gext["lambda"] - oext["lambda"]).max() <= 1e-4
+    same = gpu["length"] == ora["length"]
+    assert (~same).sum() <= 2 and (gpu["num_splats"] != ora["num_splats"]).sum() <= 8
+    for k in range(1, 8):
+        m = same & (ora["length"] > k)
+        if m.sum():
+            assert (gpu["v"]["prim"][m, k] != ora["v"]["prim"][m, k]).sum() <= 2
+            assert (rel(gext["throughput"][m, k], oext["throughput"][m, k]).max(axis=1) >= 1e-3).sum() <= max(3, int(1e-3 * m.sum()))
