@@ -404,3 +404,28 @@ def test_hero_pixels_from_path_indices():
         if m.sum():
             assert (gpu["v"]["prim"][m, k] != ora["v"]["prim"][m, k]).sum() <= 2
             assert (rel(gext["throughput"][m, k], oext["throughput"][m, k]).max(axis=1) >= 1e-3).sum() <= max(3, int(1e-3 * m.sum()))
+
+
+def test_hero_other_frame_seed_large_indices_and_edge_cases():
+    """another frame number, path indices beyond 2^32, a range of one path, a range that does not fill a workgroup, max depth 2 (no bounce) and 32"""
+    scene = make_scene(SCENE_0010, width=640, height=352, max_verts=8, frame=7, sampler=pkg.MI_SAMPLER_PTDL)
+    be = pkg.Backend(scene)
+    be.set_wavelengths(pkg.MI_WAVELENGTHS_HERO)
+    for first, n in ((0, 4000), ((1 << 33) + 12345, 4000), (5, 1), (99, 777)):
+        gpu, gext = be.trace_paths_hero(first, n)
+        ora, oext = oracle_hero_records(scene, first, n)
+        assert np.array_equal(gpu["index"], ora["index"]) and len(gpu) == n
+        assert np.abs(gpu["pixel_i"] - ora["pixel_i"]).max() <= 1e-5 and np.abs(gext["lambda"] - oext["lambda"]).max() <= 1e-4
+        assert (gpu["length"] != ora["length"]).sum() <= max(1, int(1e-3 * n))
+        m = (gpu["length"] == ora["length"]) & (ora["length"] > 2)
+        if m.sum():
+            assert (gpu["v"]["prim"][m, 2] != ora["v"]["prim"][m, 2]).sum() <= max(1, int(1e-3 * n))
+    be.close()
+    for mv in (2, 32):
+        s2 = make_scene(SCENE_0010, width=640, height=352, max_verts=mv, sampler=pkg.MI_SAMPLER_PTDL)
+        b2 = pkg.Backend(s2)
+        b2.set_wavelengths(pkg.MI_WAVELENGTHS_HERO)
+        gpu, gext = b2.trace_paths_hero(1000, 6000)
+        b2.close()
+        ora, oext = oracle_hero_records(s2, 1000, 6000)
+        assert gpu["length"].max() <= mv and (gpu["length"] != ora["length"]).sum() <= 6 and (gpu["num_splats"] != ora["num_splats"]).sum() <= 12
