@@ -434,3 +434,41 @@ def test_hero_other_frame_seed_large_indices_and_edge_cases():
         b2.close()
         ora, oext = oracle_hero_records(s2, 1000, 6000)
         assert gpu["length"].max() <= mv and (gpu["length"] != ora["length"]).sum() <= 6 and (gpu["num_splats"] != ora["num_splats"]).sum() <= 12
+
+
+def test_hero_exchange_between_waves_changes_no_path(monkeypatch):
+    """The pools of the exchange between waves carry components 1..3 of a hero path in eight more words per vertex (csrc/mi_regroup.h): which lane finishes a
+    path must not matter to the path. Records and extension blocks with the exchange (the default) and without it (CORONA_MI_REGROUP=0) are the same BYTES --
+    plain pt / ptdl, the extended kernels (volume vertices as a class), Halton, a tree in HBM, launches smaller than a wave and than a workgroup; rendered
+    frames agree to the order of the float atomics and count every path."""
+    from helpers import SCENE_CAM_MB
+    cases = [(SCENE_0010, pkg.MI_SAMPLER_PT, "rand", 8, 300000), (SCENE_0010, pkg.MI_SAMPLER_PTDL, "rand", 8, 200000), (SCENE_METAL, pkg.MI_SAMPLER_PTDL, "rand", 8, 150000),
+             (SCENE_MEDIA, pkg.MI_SAMPLER_PTDL, "rand", 32, 100000), (SCENE_CAM_MB, pkg.MI_SAMPLER_PT, "rand", 8, 100000),
+             (SCENE_0010, pkg.MI_SAMPLER_PTDL, "halton", 8, 100000), (SCENE_FINE, pkg.MI_SAMPLER_PT, "rand", 8, 100000)]
+    for path, sampler, points, mv, n in cases:
+        scene = make_scene(path, width=1280, height=720, max_verts=mv, sampler=sampler, pointsampler=pkg.MI_POINTS_HALTON if points == "halton" else pkg.MI_POINTS_RAND)
+        monkeypatch.setenv("CORONA_MI_REGROUP", "0")
+        off = pkg.Backend(scene)
+        monkeypatch.delenv("CORONA_MI_REGROUP")
+        on = pkg.Backend(scene)
+        off.set_wavelengths(pkg.MI_WAVELENGTHS_HERO); on.set_wavelengths(pkg.MI_WAVELENGTHS_HERO)
+        for first, count in ((5, n), (123456789, 1), (77, 63), (1000, 1000), (2 ** 33 + 9, 50000)):
+            (a, ae), (b, be_) = off.trace_paths_hero(first, count), on.trace_paths_hero(first, count)
+            assert a.tobytes() == b.tobytes() and ae.tobytes() == be_.tobytes(), (str(path), sampler, points, first, count)
+        off.close(); on.close()
+        per = 2 * scene.width * scene.height
+        frames = []
+        for env in ("0", None):
+            if env is None:
+                monkeypatch.delenv("CORONA_MI_REGROUP", raising=False)
+            else:
+                monkeypatch.setenv("CORONA_MI_REGROUP", env)
+            be = pkg.Backend(scene, counters=False)
+            be.set_wavelengths(pkg.MI_WAVELENGTHS_HERO)
+            c0 = be.counters()
+            be.render(9 * per, per)
+            frames.append(be.fb_read())
+            assert be.counters()[4] - c0[4] == per
+            be.close()
+        monkeypatch.delenv("CORONA_MI_REGROUP", raising=False)
+        assert np.abs(frames[0] - frames[1]).max() <= 2e-4 * np.abs(frames[0]).max(), (str(path), sampler)
