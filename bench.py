@@ -606,8 +606,12 @@ def main():
                       "frac": lds_bytes / (r["kms"] * 1e-3) / 1e12 / LDS_PEAK_TBS, "per_sample": lds_bytes / paths}
         return out
 
-    def check_image(config, r):
+    def check_image(config, r, hero=False):
         """a bench line is only printed for a frame that is the reference's image: exits non-zero on an empty or wrong one"""
+        hero = hero or args.wavelengths == 4
+        # four wavelengths per path: the MF_COUNT = 4 reference's own mean image lies up to 0.7 % from the MF_COUNT = 1 reference's (tests/golden/mf4_vs_mf1_measured.json:
+        # ratio 0.999 / 1.005 / 1.007, Z 1.0627 against 1.0554), and the device renders that build's paths: twice the tolerance against the scalar converged mean
+        conv_tol = CONVERGED_MEAN_TOL * (2.0 if hero else 1.0)
         ref = REFERENCE_IMAGE_MEAN.get(config)
         if args.stub or r["image_mean"] is None:
             return None
@@ -622,9 +626,9 @@ def main():
         if conv and r.get("image_mean_many") and args.tree == "reference":
             worst = max(abs(a - b) for a, b in zip(r["image_mean_many"], conv))
             out.update({"mean_xyz_many": r["image_mean_many"], "many_spp": r["image_mean_many_spp"], "converged_reference_mean_xyz": list(conv),
-                        "converged_tolerance": CONVERGED_MEAN_TOL, "converged_off_by": worst})
-            if worst > CONVERGED_MEAN_TOL:
-                raise SystemExit(f"bench.py: the mean of {r['image_mean_many_spp']} spp of {config} {r['image_mean_many']} is {worst:.4f} off the converged reference's {conv} (tolerance {CONVERGED_MEAN_TOL})")
+                        "converged_tolerance": conv_tol, "converged_off_by": worst})
+            if worst > conv_tol:
+                raise SystemExit(f"bench.py: the mean of {r['image_mean_many_spp']} spp of {config} {r['image_mean_many']} is {worst:.4f} off the converged reference's {conv} (tolerance {conv_tol})")
         return out
 
     scaling = args.scaling or CONFIGS[args.config].get("scaling", "weak")
@@ -647,7 +651,7 @@ def main():
             args.wavelengths = 1
         hero = {"workload": h["cfg"]["name"] + ", four wavelengths per path (hero wavelengths)", "value": 3 * h["job"] / h["elapsed"] / 1e6, "unit": "Mpaths/s",
                 "wavelength_samples_per_s": 4 * 3 * h["job"] / h["elapsed"] / 1e6, "steps": 3, "warmup": 1, "ms_per_step": 1e3 * h["elapsed"] / 3, "scaling": scaling,
-                "kernel": kernel_name(h), "kernel_ms": h["kms"], "image": check_image("cfg2", h) if rank == 0 else None}
+                "kernel": kernel_name(h), "kernel_ms": h["kms"], "image": check_image("cfg2", h, hero=True) if rank == 0 else None}
 
     if rank == 0:
         cfg = main_r["cfg"]
