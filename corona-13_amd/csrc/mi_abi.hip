@@ -5,6 +5,7 @@
  * traces path indices [first, first+count) and splats them into the device framebuffer.
  */
 #include "mi_megakernel.h"
+#include "mi_wavefront.h"
 #include "mi_build.h"
 #include "mi_halton.h"
 #include <cstring>
@@ -124,6 +125,10 @@ struct mi_scene
   bool norg;                        /* ... of those, the ones without the exchange between waves (scattering exterior medium) */
   bool hero;                        /* launch the HERO instantiations: four wavelengths per path (mi_scene_set_wavelengths) */
   void *d_shape_medium, *d_prims_t1, *d_lights, *d_prim_cls;
+  /* wavefront kernel (mi_wavefront.h): plain pt scenes; the workgroups' path tables */
+  bool wavefront;
+  void *d_wf_table;
+  uint32_t wf_entries;
   /* Halton point sampler */
   bool halton;
   HaltonTables *halton_tables;
@@ -155,6 +160,8 @@ extern template const void *mi_path_part<false, true,  true,  false, false, true
 extern template const void *mi_path_part<true,  true,  true,  false, false, true>(unsigned, const PathLaunch *);
 extern template const void *mi_path_part<false, true,  false, false, true,  true>(unsigned, const PathLaunch *);
 extern template const void *mi_path_part<true,  true,  false, false, true,  true>(unsigned, const PathLaunch *);
+
+extern template const void *mi_wave_part<false>(unsigned, const PathLaunch *);       /* the wavefront kernel (mi_wavefront.h, part 24) */
 
 static const void *path_kernel(bool ptdl, bool media, bool mb, bool fast, bool norg, unsigned which, const PathLaunch *L, bool hero = false)
 {
@@ -502,7 +509,8 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
         }
         link = MI_LEAF32 | (uint32_t)(first << 5) | (uint32_t)cntp;
       }
-      else link = newid[(uint32_t)nd.child[c]];
+      else if(nd.child[c] < (uint64_t)N) link = newid[(uint32_t)nd.child[c]];
+      else link = MI_LEAF32;          /* a node no ray reaches (tree_depth has checked every reachable link) may hold anything: an empty leaf instead of an index beyond the table */
       memcpy(&rec[6*4 + c], &link, 4);
     }
     axes[nn] = (uint32_t)(nd.axis0 & 3) | ((uint32_t)(nd.axis00 & 3) << 2) | ((uint32_t)(nd.axis01 & 3) << 4);
@@ -926,13 +934,35 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
     /* the exchange runs only if EVERY kernel the scene can launch gets its 32 entries: the same formula as pool_setup (mi_regroup.h) with the
        widest entry among them (the RECORD kernels', three more words in the extended kernels). A scene in the gap -- room for the pools of
        some kernels but not of others -- used to pay for pools (shorter stack columns, no FAST rounds) that traded nothing. */
-    const uint32_t ns_max = (uint32_t)PoolLayout<true, true, false>::SLOTS + (s->media ? 3u : 0u);
+    const uint32_t ns_max = (uint32_t)PoolLayout<true, true, false>::SLOTS + (s->media ? 3u : 0u) + (uint32_t)MI_POOL_HERO_SLOTS;     /* (the HERO kernels' entries are the widest: mi_scene_set_wavelengths may come later) */
     const uint32_t e_min = (uint32_t)((room - cls_lds)/(ns_max*8u + 2u*(MI_POOL_CLASSES + 1u))) & ~7u;
     const bool on = MI_REGROUP && classes > 1 && !s->norg && (!mb_kernels || MI_REGROUP_MB) && e_min >= 32u;
     d.pool_classes = on ? classes : 0u;
     d.pool_cls_bytes = on ? (uint32_t)cls_lds : 0u;
     if(on) room -= d.pool_cls_bytes;
     d.pool_bytes = on ? (uint32_t)room : 0u;
+    { /* the wavefront kernel (mi_wavefront.h): plain pt scenes, no media, no moving primitives. It lays the LDS out for itself -- shorter stack
+         columns (MI_WF_COLUMN), and everything behind the job lists but the class table belongs to its five lists of entry numbers -- next to the
+         megakernel's layout of the same scene (records of hero paths, mi_scene_set_wavelengths: those kernels keep their own). CORONA_MI_WAVEFRONT=0 / 1
+         switches it off / on (default: MI_WAVEFRONT_DEFAULT); it needs room for 256 entries. */
+      const char *we = getenv("CORONA_MI_WAVEFRONT");
+      const bool wanted = (we && we[0]) ? atoi(we) != 0 : MI_WAVEFRONT_DEFAULT != 0;
+      const size_t wf_fixed = halton_bytes + lights_bytes + (size_t)SL*K*16 + (size_t)MI_WF_COLUMN*MI_BLOCK*sizeof(uint2) + (size_t)(MI_BLOCK/64)*MI_JOBS_LDS + static_bytes;
+      size_t wroom = wf_fixed < lds_total ? lds_total - wf_fixed : 0;
+      wroom &= ~(size_t)15;
+      const size_t wcls = cls_bytes*5 <= wroom ? ((cls_bytes + 15) & ~(size_t)15) : 0;
+      wroom -= wcls;
+      s->wavefront = wanted && h->sampler == MI_SAMPLER_PT && !s->media && !mb_kernels && wroom/(2u*(MI_POOL_CLASSES + 1u)) >= 256u &&
+                     (on ? wcls == cls_lds : true);            /* (one DScene.pool_cls_bytes for both kernels) */
+      if(s->wavefront)
+      {
+        if(!on) { d.pool_classes = classes; d.pool_cls_bytes = (uint32_t)wcls; }
+        d.wf_list_bytes = (uint32_t)wroom;
+        if(s->lds_bytes + d.pool_bytes + d.pool_cls_bytes < wf_fixed - static_bytes + wroom + wcls) s->lds_bytes = wf_fixed - static_bytes + wroom + wcls - d.pool_bytes - d.pool_cls_bytes;
+      }
+      const char *ee = getenv("CORONA_MI_WAVEFRONT_ENTRIES");
+      s->wf_entries = (ee && atoi(ee) >= 256 && atoi(ee) <= 4032) ? (uint32_t)atoi(ee) & ~63u : (uint32_t)MI_WF_ENTRIES;
+    }
     s->lds_bytes += d.pool_bytes + d.pool_cls_bytes;
     /* one launch size for every kernel of the scene: mi_intersect_kernel keeps full stack columns */
     const size_t isect_bytes = mb_kernels ? 0 : (size_t)SL*K*16 + isect_stack_bytes;
@@ -962,6 +992,13 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
       if(mi_path_which_valid(which))
         kernels.push_back(path_kernel(h->sampler == MI_SAMPLER_PTDL, s->media, s->d_prims_t1 != nullptr, (k & 4u) != 0, s->norg, which, nullptr));
     }
+    if(s->wavefront)
+      for(unsigned k=0;k<4;k++)
+      {
+        const unsigned which = ((k & 1u) ? MI_WHICH_RECORD | MI_WHICH_COUNT : 0u) | ((k & 2u) ? MI_WHICH_COUNT : 0u) | (s->nodes_lds ? MI_WHICH_NODES_LDS : 0u) |
+                               (h->pointsampler == MI_POINTS_HALTON ? MI_WHICH_HALTON : 0u);
+        if(mi_path_which_valid(which)) kernels.push_back(mi_wave_part<false>(which, nullptr));
+      }
     for(const void *k : kernels)
       if(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes) != hipSuccess)
       { mi_scene_destroy(s); return fail(MI_ERR_DEVICE, "cannot raise the dynamic LDS limit"); }
@@ -991,6 +1028,8 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
     if(hipMalloc(&s->d_overflow, extra*(size_t)s->grid*MI_BLOCK*sizeof(uint2)) != hipSuccess)
     { mi_scene_destroy(s); return fail(MI_ERR_NOMEM, "cannot allocate the traversal stack overflow area"); }
   }
+  if(s->wavefront && hipMalloc(&s->d_wf_table, (size_t)s->grid*MI_WF_QUADS_MAX*s->wf_entries*sizeof(uint4)) != hipSuccess)
+  { mi_scene_destroy(s); return fail(MI_ERR_NOMEM, "cannot allocate the wavefront kernel's path tables"); }
   /* uploads and clears above ran on the null stream, rendering runs on a non-blocking one: everything is in place before the first launch */
   if(hipDeviceSynchronize() != hipSuccess) { mi_scene_destroy(s); return fail(MI_ERR_DEVICE, "device synchronisation failed after the scene upload"); }
   *out = s;
@@ -1061,7 +1100,8 @@ static void launch_path_kernel(mi_scene *s, bool record, int grid, uint64_t firs
   const unsigned which = (record ? MI_WHICH_RECORD : 0u) | (s->nodes_lds ? MI_WHICH_NODES_LDS : 0u) | (s->halton ? MI_WHICH_HALTON : 0u) |
                          ((s->counting || record) ? MI_WHICH_COUNT : 0u);
   PathLaunch L = { s->d, grid, s->lds_bytes, s->stream, (unsigned long long)first, (unsigned long long)n, (const uint32_t *)s->d_shape_material,
-                   (const float *)s->d_shape_L, rec, (uint2 *)s->d_overflow };
+                   (const float *)s->d_shape_L, rec, (uint2 *)s->d_overflow, (uint2 *)s->d_wf_table, s->wf_entries };
+  if(s->wavefront && !s->hero) { (void)mi_wave_part<false>(which, &L); return; }
   (void)path_kernel(s->d.sampler == MI_SAMPLER_PTDL, s->media, s->d_prims_t1 != nullptr, s->fast != 0, s->norg, which, &L, s->hero);
 }
 
@@ -1373,6 +1413,11 @@ extern "C" int mi_scene_kernel_name(mi_scene *s, char *buf, size_t len)
   if(!s || !buf || len == 0) return fail(MI_ERR_ARG, "null argument");
   const bool mb = s->d_prims_t1 != nullptr;
   auto tf = [](bool b) { return b ? "true" : "false"; };
+  if(s->wavefront && !s->hero)
+  {
+    const int n = snprintf(buf, len, "mi_wave_kernel<false, false, %s, %s, %s>", tf(s->nodes_lds), tf(s->halton), tf(s->counting != 0));
+    return (n < 0 || (size_t)n >= len) ? fail(MI_ERR_ARG, "mi_scene_kernel_name: buffer too small") : MI_OK;
+  }
   const int n = snprintf(buf, len, "mi_path_kernel<false, %s, %s, %s, %s, %s, %s, %s, %s, %s>", tf(s->d.sampler == MI_SAMPLER_PTDL), tf(s->nodes_lds), tf(s->halton),
                          tf(s->media), tf(mb), tf(s->counting != 0), tf(s->fast != 0 && !mb && !s->hero), tf(s->norg), tf(s->hero));
   return (n < 0 || (size_t)n >= len) ? fail(MI_ERR_ARG, "mi_scene_kernel_name: buffer too small") : MI_OK;
@@ -1384,7 +1429,7 @@ extern "C" void mi_scene_destroy(mi_scene *s)
   (void)hipSetDevice(s->device);
   void *bufs[] = { s->d_nodes, s->d_axes, s->d_prims, s->d_primgeo, s->d_materials, s->d_light_prim, s->d_light_cdf, s->d_light_L,
                    s->d_cie, s->d_checker, s->d_metal, s->d_counters, s->d_shape_material, s->d_shape_L, s->d_overflow, s->d_fb_own,
-                   s->d_halton_dim, s->d_halton_perm, s->d_shape_medium, s->d_prims_t1, s->d_lights, s->d_prim_cls };
+                   s->d_halton_dim, s->d_halton_perm, s->d_shape_medium, s->d_prims_t1, s->d_lights, s->d_prim_cls, s->d_wf_table };
   delete s->halton_tables;
   if(s->h_stage) { (void)hipHostFree(s->h_stage); (void)hipEventDestroy(s->ev_stage[0]); (void)hipEventDestroy(s->ev_stage[1]); }
   for(void *b : bufs) if(b) (void)hipFree(b);

@@ -554,6 +554,8 @@ struct PathLaunch
   const float *shape_L;
   mi_path_record *rec;
   uint2 *overflow;
+  uint2 *table;               /* the wavefront kernel's path tables (mi_wavefront.h), one per workgroup */
+  uint32_t table_entries;
 };
 #define MI_WHICH_RECORD 1u
 #define MI_WHICH_NODES_LDS 2u

@@ -30,7 +30,7 @@ def test_ranks_sharing_one_gpu_render_the_single_rank_frame(extra):
     assert one["n_gpus"] == 1 and one["image"]["mean_xyz"]
     for n in (2, 3):
         many = run_bench("--gpus", str(n), "--share-gpu", "--config", "cfg2", "--scaling", "strong", *extra)
-        assert many["n_gpus"] == n and many["rccl_ranks"] == n and many["metric"].startswith("SHARED GPU")
+        assert many["n_gpus"] == n and many["rccl_ranks"] == 0 and many["metric"].startswith("SHARED GPU")
         assert many["config"]["paths_per_step"] == one["config"]["paths_per_step"]
         # bench.py itself exits non-zero on a wrong path count or an image mean off the reference's; the reduced frame is the single-rank frame
         for a, b in zip(many["image"]["mean_xyz"], one["image"]["mean_xyz"]):
@@ -45,3 +45,17 @@ def test_weak_scaling_ranks_sharing_one_gpu():
     assert two["scaling"] == "weak" and two["config"]["paths_per_step"] == 2 * one["config"]["paths_per_step"]
     for a, b in zip(two["image"]["mean_xyz"], one["image"]["mean_xyz"]):
         assert abs(a - b) <= 0.01 * abs(b), (two["image"], one["image"])
+
+
+@pytest.mark.parametrize("shard", ["indices", "tiles"])
+def test_cfg5_eight_rank_rehearsal(shard):
+    """configs[4] as the driver would launch it on an 8-GPU node -- 3840 x 2160 (film 3840 x 2176: eight ranks x two 100 MB framebuffers of the double-buffered
+    reduce), strong scaling, index ranges and tile ownership -- with eight ranks on the one GPU there is, at 2 spp instead of 1024: the reduced frame is the
+    single-rank frame, every path is counted (bench.py exits non-zero otherwise)"""
+    one = run_bench("--gpus", "1", "--config", "cfg5", "--spp", "2", "--shard", shard)
+    many = run_bench("--gpus", "8", "--share-gpu", "--config", "cfg5", "--spp", "2", "--shard", shard)
+    assert many["n_gpus"] == 8 and many["scaling"] == "strong" and "REHEARSAL" in many["config"]["workload"]
+    assert many["config"]["paths_per_step"] == one["config"]["paths_per_step"] == 2 * 3840 * 2176
+    assert 8 * many["config"]["paths_per_step_per_gpu"] >= many["config"]["paths_per_step"] > 7 * many["config"]["paths_per_step_per_gpu"]
+    for a, b in zip(many["image"]["mean_xyz"], one["image"]["mean_xyz"]):
+        assert abs(a - b) <= 2e-5 * abs(b), (many["image"], one["image"])
