@@ -49,6 +49,13 @@
 #ifndef MI_ANYHIT
 #define MI_ANYHIT 1      /* shadow rays towards flagged emitters stop at the first occluder (MI_LIGHT_ANYHIT, mi_device.h) */
 #endif
+#ifndef MI_SHADOW_CACHE
+#define MI_SHADOW_CACHE 0   /* 1: the production ptdl kernels test an any-hit shadow ray against the lane's LAST OCCLUDER before they traverse (the reference's cache in
+                               front of accel_visible, src/accel.d/qbvhmp.c:1392-1490: one primitive per thread, :186-187, :1405). The verdict cannot change -- any
+                               occluder inside the connection is an occluder. Measured (profiles/r06_levers.txt) and switched off: a lane's consecutive shadow rays
+                               belong to unrelated vertices (the exchange moves paths between lanes), the test costs every wave that starts one shadow ray a
+                               primitive test, and the cache hits too rarely to pay for it */
+#endif
 #ifndef MI_LEAF_JOBS
 #define MI_LEAF_JOBS 1
 #endif
@@ -207,6 +214,8 @@ __global__ __launch_bounds__(MI_BLOCK_OF(HERO, PTDL, MEDIA)) void mi_path_kernel
   Hit hit;
   hit.prim = MI_NOPRIM; hit.dist = FLT_MAX; hit.u = hit.v = 0.0f;
   bool tracing = false, tr_shadow = false;
+  constexpr bool SCACHE = MI_SHADOW_CACHE && PTDL && MI_ANYHIT && (!COUNT || MI_SHADOW_CACHE == 2) && !RECORD && !MB && !HERO;
+  uint32_t occluder = MI_NOPRIM;         /* SCACHE: the primitive that ended this lane's last occluded shadow ray */
 
   MI_PHASE_INIT(cnt)
 #ifdef MI_PROFILE_TRAV
@@ -278,6 +287,14 @@ __global__ __launch_bounds__(MI_BLOCK_OF(HERO, PTDL, MEDIA)) void mi_path_kernel
       if(PTDL && MI_ANYHIT) ts.anyhit = tr_shadow && (ps.sh_light & MI_LIGHT_ANYHIT);
       if(MB) { ts.time = ps.time; ts.prims_t1 = sc.prims_t1; }      /* motion-blurred primitives are tested at the path's time */
       tracing = true;
+      if(SCACHE && ts.anyhit && occluder != MI_NOPRIM && occluder != ps.ignore)
+      { /* the last occluder first: a triangle or quad that cuts this connection too ends the ray before it starts */
+        const PrimRegs rec = prim_load(sc.prims, occluder);
+        Hit h;
+        h.prim = MI_NOPRIM; h.dist = ps.sh_dist; h.u = h.v = 0.0f;
+        if(__float_as_uint(rec.q3.x) >= MI_PRIM_TRI) triquad_intersect(rec, __float_as_uint(rec.q3.x), ray_origin<PTDL>(ps, true), ps.sh_dir, h, occluder);
+        if(h.prim != MI_NOPRIM && h.dist < ps.sh_dist) { hit = h; ts.done = true; ts.sp = 0; ts.current = MI_LEAF32; }
+      }
     }
     MI_TT(cnt, 5)
     /* ------------------------------------------------------------ a slice of traversal: while-while rounds until only a tail of
@@ -379,7 +396,7 @@ __global__ __launch_bounds__(MI_BLOCK_OF(HERO, PTDL, MEDIA)) void mi_path_kernel
       {
         tracing = false;
         mi_path_record *rec = RECORD ? records + (ps.index - first) : nullptr;
-        if(tr_shadow) shadow_resolve<RECORD>(sc, ps, hit, rec, cnt, splat);
+        if(tr_shadow) { if(SCACHE && hit.prim != MI_NOPRIM && hit.dist < ps.sh_dist && hit.prim != (ps.sh_light & ~MI_LIGHT_ANYHIT)) occluder = hit.prim; shadow_resolve<RECORD>(sc, ps, hit, rec, cnt, splat); }
         else path_escape<RECORD, MEDIA>(sc, ps, rec, cnt);
       }
 #else
@@ -410,7 +427,7 @@ __global__ __launch_bounds__(MI_BLOCK_OF(HERO, PTDL, MEDIA)) void mi_path_kernel
             path_shade_hero<RECORD, PTDL, HALTON, MEDIA, MB>(sc, ps, hit, shape_material, shape_L, rec, slot, cnt, splat);
           }
         }
-        else if(PTDL && !MI_REGROUP_EARLY_SHADOW && tr_shadow) shadow_resolve<RECORD>(sc, ps, hit, rec, cnt, splat);
+        else if(PTDL && !MI_REGROUP_EARLY_SHADOW && tr_shadow) { if(SCACHE && hit.prim != MI_NOPRIM && hit.dist < ps.sh_dist && hit.prim != (ps.sh_light & ~MI_LIGHT_ANYHIT)) occluder = hit.prim; shadow_resolve<RECORD>(sc, ps, hit, rec, cnt, splat); }
         else
         {
           if(!MEDIA) __builtin_assume(hit.prim != MI_NOPRIM);     /* paths that left the scene have ended above */
@@ -428,7 +445,7 @@ __global__ __launch_bounds__(MI_BLOCK_OF(HERO, PTDL, MEDIA)) void mi_path_kernel
         if(tr_shadow) shadow_resolve_hero<RECORD>(sc, ps, hit, rec, slot, cnt, splat);
         else path_shade_hero<RECORD, PTDL, HALTON, MEDIA, MB>(sc, ps, hit, shape_material, shape_L, rec, slot, cnt, splat);
       }
-      else if(tr_shadow) shadow_resolve<RECORD>(sc, ps, hit, rec, cnt, splat);
+      else if(tr_shadow) { if(SCACHE && hit.prim != MI_NOPRIM && hit.dist < ps.sh_dist && hit.prim != (ps.sh_light & ~MI_LIGHT_ANYHIT)) occluder = hit.prim; shadow_resolve<RECORD>(sc, ps, hit, rec, cnt, splat); }
       else
       {
         if(CHAIN && ps.sh_pending == 2) shadow_splat<RECORD>(sc, ps, rec, cnt, splat);      /* the connection made at the vertex this ray left */

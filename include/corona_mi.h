@@ -319,8 +319,9 @@ int  mi_trace_paths(mi_scene *s, uint64_t first_index, uint64_t count, mi_path_r
  * decides sampling, Russian roulette and geometry (dielectric.c:293,326-328; pt.c:50); throughputs and pdfs are kept per component (a rough
  * transmission re-derives its half vector per component, dielectric.c:353-411; a specular one keeps one component, :331-343); the MIS weight
  * of a technique is its pdf over the SUM of all techniques' pdfs at all four wavelengths (pt.c:30-38, ptdl.c:78-88); view_splat adds the four
- * colours (src/view.c:455-463, include/spectrum.h:185-195). Same expected image as one wavelength per path (measured on the reference:
- * tests/golden/mf4_vs_mf1_measured.json), less colour noise per path.
+ * colours (src/view.c:455-463, include/spectrum.h:185-195). The same estimator in expectation, less colour noise per path; measured on the reference: the
+ * MF_COUNT = 4 build's 512-spp mean of the bench film lies within 0.06 % (pt) / 0.25 % (ptdl) of the scalar build's converged mean
+ * (tests/golden/mf4_film_means.json) -- renders with four wavelengths are held against THAT build's mean (bench.py).
  *   mi_scene_set_wavelengths(s, MI_WAVELENGTHS_HERO): the renders and traces that follow run the HERO kernels; (s, 1) goes back.
  * Every scene the backend takes, with either point sampler: the extended kernels (media: the free-flight distance is the hero medium's, transmittance
  * and pdf per component, src/shader.c:76-131; moving camera, moving geometry and emitters) have HERO instantiations too; all of it pinned to per-path dumps
