@@ -967,8 +967,35 @@ __device__ __forceinline__ void leaf_jobs(const Lds &lds, const DPrim *prims, co
     h.dist = __shfl(hit.dist, src);
     const uint32_t sign = (uint32_t)__shfl((int)ignore, src);
     const int off = src - (int)lane;
-    const uint32_t type = __float_as_uint(rec.q3.x);
-    const bool both = triquad_intersect<true>(rec, type, so, sd, h, prim);
+    uint32_t type = __float_as_uint(rec.q3.x);
+    PrimRegs use = rec;
+#ifndef MI_MB_MOVING_JOBS
+#define MI_MB_MOVING_JOBS 1
+#endif
+    if(MB && MI_MB_MOVING_JOBS)
+    { /* motion-blur kernels: a moving triangle / quad (type 0, pad[0] = vertex count; the record holds the shutter-open VERTICES, prims_t1 the shutter-close
+         ones) is a job like a static one -- its vertices at the OWNER's time (geo_get_vertex_time, include/geo.h:120-138: (1-t) v(open) + t v(close) per
+         component), then the edges and the usual test, the arithmetic of analytic_intersect. So is a static triangle / quad that mi_mark_ordered_kernel put
+         off behind it (pad[1] = MI_PRIM_ORDERED, plain record): what the order of the tests can change -- a quad crossed in both halves -- poisons the
+         owner's slot below and the owner works through its leaf in the reference's order; every other result is the minimum over the leaf, later wins a tie. */
+      const uint32_t pad0 = __float_as_uint(rec.q3.y), pad1 = __float_as_uint(rec.q3.z);
+      const bool put_off = type == 0u && pad0 >= MI_PRIM_TRI;
+      const float stime = __shfl(ts.time, src);          /* (outside the branch: ds_bpermute only reads lanes that execute it) */
+      if(put_off && pad1 != MI_PRIM_ORDERED)
+      {
+        const float4 *q1p = (const float4 *)(ts.prims_t1 + prim);
+        const float4 c0 = q1p[0], c1 = q1p[1], c2 = q1p[2];
+        const float w0 = 1.0f - stime, w1 = stime;
+        const V3 v0 = mk3(w0*rec.q0.x + w1*c0.x, w0*rec.q0.y + w1*c0.y, w0*rec.q0.z + w1*c0.z);
+        const V3 v1 = mk3(w0*rec.q0.w + w1*c0.w, w0*rec.q1.x + w1*c1.x, w0*rec.q1.y + w1*c1.y);
+        const V3 v2 = mk3(w0*rec.q1.z + w1*c1.z, w0*rec.q1.w + w1*c1.w, w0*rec.q2.x + w1*c2.x);
+        const V3 v3 = mk3(w0*rec.q2.y + w1*c2.y, w0*rec.q2.z + w1*c2.z, w0*rec.q2.w + w1*c2.w);
+        const V3 e1 = sub3(v1, v0), e2 = sub3(v2, v0), e3 = sub3(v3, v0);
+        use.q0 = make_float4(v0.x, v0.y, v0.z, e1.x); use.q1 = make_float4(e1.y, e1.z, e2.x, e2.y); use.q2 = make_float4(e2.z, e3.x, e3.y, e3.z);
+      }
+      if(put_off) type = pad0;
+    }
+    const bool both = triquad_intersect<true>(use, type, so, sd, h, prim);
     const bool tq = valid && type >= MI_PRIM_TRI && prim != sign;       /* triangle.h:271 */
     const bool cand = tq && !both && h.prim != MI_NOPRIM;
     const mi_u64 key = ((mi_u64)__float_as_uint(h.dist) << 32) | (mi_u64)(31u - k);

@@ -71,7 +71,9 @@
 #define MI_LEAF_JOBS_MEDIA 1  /* ... in the extended (media / moving camera) pt kernels: +7 % (0055_media, 0056_fog, 0058_cam_mb) */
 #endif
 #ifndef MI_LEAF_JOBS_MB
-#define MI_LEAF_JOBS_MB 0     /* ... in the motion-blur pt kernels: parity green, but 1748 against 1923 Msamples/s on 0059_mb (every moving primitive is a put-off test) */
+#define MI_LEAF_JOBS_MB 1     /* ... in the motion-blur kernels. Rounds 2-5: off (1748 against 1923 Msamples/s on 0059_mb: every moving primitive was a put-off test, the
+                                 job passes found nothing to do and cost three stack entries). Round 6: a moving triangle / quad IS a job -- the worker interpolates its
+                                 vertices at the owner's time (leaf_jobs, mi_kernels.h): 0059_mb 26.7 -> 22.7 ms (profiles/r06_levers.txt) */
 #endif
 #ifndef MI_PARK_TRACE
 #define MI_PARK_TRACE 1   /* the tail lanes' traversal state waits in LDS while the others shade: 1 = in the ptdl FAST kernel (38.6 against 40.4 ms),
@@ -211,6 +213,7 @@ __global__ __launch_bounds__(MI_BLOCK_OF(HERO, PTDL, MEDIA)) void mi_path_kernel
   const unsigned lane = __lane_id();
   TraceState ts;
   ts.done = true;
+  ts.time = 0.0f; ts.prims_t1 = MB ? sc.prims_t1 : nullptr;      /* (every lane of a wave works on the leaf jobs of a motion-blur round, also one that has not started a ray yet) */
   Hit hit;
   hit.prim = MI_NOPRIM; hit.dist = FLT_MAX; hit.u = hit.v = 0.0f;
   bool tracing = false, tr_shadow = false;

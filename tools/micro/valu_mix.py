@@ -29,9 +29,14 @@ DEFAULT_SPLIT = {
     "int64": {"v_lshrrev_b64": 112, "v_mad_u64_u32": 107, "v_lshl_add_u64": 91, "v_lshlrev_b64": 61},
     "cvt": {"v_cvt_f32_u32": 1},
     "f64": {"v_mul_f64": 35, "v_fma_f64": 15, "v_add_f64": 10},
-    # what no class counter counts: selects, moves, compares, min / max, the division helpers
+    # what no class counter counts: selects, moves, compares, min / max, the division helpers. Its DYNAMIC composition is not measurable (no counter, no PC
+    # sampling on this pool), so the class is generated twice and the peak is reported as a bracket:
+    #   "other"       the whole kernel's static histogram (over-weights cold shading code: IEEE division helpers)
+    #   "other_hot"   what the hottest loop -- the node visit, a third of all executed vector instructions -- is made of besides f32 math:
+    #                 21 selects, 4 compares, 8 min / max + 8 three-operand min3 / max3, a few moves (csrc/mi_kernels.h: node_visit)
     "other": {"v_cndmask_b32": 607, "v_mov_b32": 554, "v_cmp_lt_f32": 520, "v_cmp_eq_u32": 250, "v_div_scale_f32": 163, "v_div_fixup_f32": 123,
               "v_div_fmas_f32": 82, "v_max_f32": 71, "v_readlane_b32": 64},
+    "other_hot": {"v_cndmask_b32": 21, "v_cmp_lt_f32": 4, "v_max_f32": 8, "v_max3_f32": 8, "v_mov_b32": 6},
 }
 
 # one instance of an opcode on chain k: F = float accumulators f0..f15, I = ints, D = doubles (4), S = scalar pairs for compare results
@@ -48,7 +53,7 @@ TEMPLATES = {
     "v_mul_f64": "v_mul_f64 {D}, {D}, {cd}", "v_fma_f64": "v_fma_f64 {D}, {D}, {cd}, {cd}", "v_add_f64": "v_add_f64 {D}, {D}, {cd}",
     "v_cndmask_b32": "v_cndmask_b32 {F}, {F}, {c0}, {S}", "v_mov_b32": "v_mov_b32 {F}, {c0}", "v_cmp_lt_f32": "v_cmp_lt_f32 {S}, {F}, {c1}",
     "v_cmp_eq_u32": "v_cmp_eq_u32 {S}, {I}, {ci}", "v_div_scale_f32": "v_div_scale_f32 {F}, {S}, {F}, {c0}, {c1}", "v_div_fixup_f32": "v_div_fixup_f32 {F}, {F}, {c0}, {c1}",
-    "v_div_fmas_f32": "v_div_fmas_f32 {F}, {F}, {c0}, {c1}", "v_max_f32": "v_max_f32 {F}, {F}, {c1}", "v_readlane_b32": "v_readlane_b32 s38, {I}, 3",
+    "v_div_fmas_f32": "v_div_fmas_f32 {F}, {F}, {c0}, {c1}", "v_max_f32": "v_max_f32 {F}, {F}, {c1}", "v_max3_f32": "v_max3_f32 {F}, {F}, {c0}, {c1}", "v_readlane_b32": "v_readlane_b32 s38, {I}, 3",
 }
 CHAINS = 16
 BLOCK = 480          # vector instructions of the generated block
@@ -78,11 +83,11 @@ def split_from_asm(path):
     return {cls: (ops if ops else DEFAULT_SPLIT[cls]) for cls, ops in out.items()}
 
 
-def generate(frac, split):
+def generate(frac, split, hot=False):
     """BLOCK instructions with the classes' shares, each class split by its opcodes, interleaved so that no class clusters"""
     want = []
     for cls, f in frac.items():
-        ops = split[cls]
+        ops = split[cls if not (cls == "other" and hot) else "other_hot"]
         tot = float(sum(ops.values()))
         for op, n in ops.items():
             want.append((op, f * n / tot * BLOCK))
@@ -108,6 +113,8 @@ SRC = r"""
 #include <cstdio>
 __global__ void __launch_bounds__(1024) k_mix(float *out, int iters, unsigned long long *clk)
 {
+  extern __shared__ float lds_pad[];          /* 100 KB per workgroup: ONE workgroup per CU, i.e. 4 waves per SIMD on all 256 CUs -- the path kernel's geometry */
+  if(iters < 0) lds_pad[threadIdx.x] = 0.0f;
   const unsigned long long t0 = clock64(), w0 = wall_clock64();
   float f[16]; unsigned int n[8]; double d[4];
   for(int k=0;k<16;k++) f[k] = 1.0f + threadIdx.x*1e-3f + k;
@@ -133,20 +140,19 @@ int main()
   unsigned long long *dclk, hclk[512]; if(hipMalloc(&dclk, sizeof(hclk)) != hipSuccess) return 1;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int iters = 4000, block = %d;
-  k_mix<<<256, 1024>>>(dout, 50, nullptr);
+  if(hipFuncSetAttribute((const void *)k_mix, hipFuncAttributeMaxDynamicSharedMemorySize, 100*1024) != hipSuccess) return 2;
+  k_mix<<<256, 1024, 100*1024>>>(dout, 50, nullptr);
   double best = 1e30;
   for(int r=0;r<5;r++)
   {
-    hipEventRecord(e0); k_mix<<<256, 1024>>>(dout, iters, dclk); hipEventRecord(e1); hipEventSynchronize(e1);
+    hipEventRecord(e0); k_mix<<<256, 1024, 100*1024>>>(dout, iters, dclk); hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); if(ms < best) best = ms;
   }
   const double waves = 256.0*16.0, instr = waves*(double)iters*block;
   hipMemcpy(hclk, dclk, sizeof(hclk), hipMemcpyDeviceToHost);
   double ticks = 0, wall = 0; for(int b=0;b<256;b++) { ticks += (double)hclk[2*b]; wall += (double)hclk[2*b + 1]; }
-  const double ghz = ticks/wall*0.1;       /* shader clock during the run: clock64 ticks per 100 MHz wall tick */
-  printf("{\"ms\": %%.4f, \"wave_instructions\": %%.0f, \"ginstr_per_s\": %%.2f, \"cycles_per_instruction_per_simd_at_2p4GHz\": %%.3f, \"shader_clock_GHz\": %%.3f, "
-         "\"cycles_per_instruction_per_simd\": %%.3f}\n", best, instr, instr/(best*1e-3)/1e9,
-         best*1e-3*2.4e9/(16.0/4.0*(double)iters*block), ghz, (ticks/256.0)/(16.0/4.0*(double)iters*block));
+  printf("{\"ms\": %%.4f, \"wave_instructions\": %%.0f, \"ginstr_per_s\": %%.2f, \"cycles_per_instruction_per_simd_at_2p4GHz\": %%.3f, \"clock64_over_wall_clock64\": %%.3f}\n",
+         best, instr, instr/(best*1e-3)/1e9, best*1e-3*2.4e9/(16.0/4.0*(double)iters*block), ticks/wall);
   return 0;
 }
 """
@@ -161,18 +167,20 @@ def main():
     for path in args:
         summary = json.load(open(path))
         frac = classes_of(summary)
-        lines, counts = generate(frac, split)
-        body = "\n".join('      "%s\\n"' % l for l in lines)
-        with tempfile.TemporaryDirectory() as td:
-            src = os.path.join(td, "valu_mix_gen.hip")
-            open(src, "w").write(SRC % (body, len(lines)))
-            exe = os.path.join(td, "valu_mix_gen")
-            subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", src, "-o", exe], stderr=subprocess.DEVNULL)
-            if "--build-only" in sys.argv:
-                res = {"built": True}
-            else:
-                res = json.loads(subprocess.check_output([exe], text=True).strip().splitlines()[-1])
-        res.update({"kernel": summary.get("kernel"), "class_shares": frac, "block_instructions": len(lines), "block_opcodes": counts})
+        res = {"kernel": summary.get("kernel"), "class_shares": frac}
+        for tag, hot in (("uncounted_class_as_whole_kernel", False), ("uncounted_class_as_node_visit", True)):
+            lines, counts = generate(frac, split, hot)
+            body = "\n".join('      "%s\\n"' % l for l in lines)
+            with tempfile.TemporaryDirectory() as td:
+                src = os.path.join(td, "valu_mix_gen.hip")
+                open(src, "w").write(SRC % (body, len(lines)))
+                exe = os.path.join(td, "valu_mix_gen")
+                subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", src, "-o", exe], stderr=subprocess.DEVNULL)
+                r = {"built": True} if "--build-only" in sys.argv else json.loads(subprocess.check_output([exe], text=True).strip().splitlines()[-1])
+            r.update({"block_instructions": len(lines), "block_opcodes": counts})
+            res[tag] = r
+        if "--build-only" not in sys.argv:
+            res["peak_ginstr_per_s"] = sorted(res[t]["ginstr_per_s"] for t in ("uncounted_class_as_whole_kernel", "uncounted_class_as_node_visit"))
         out[os.path.basename(path)] = res
     json.dump(out, sys.stdout, indent=1)
     print()
