@@ -102,14 +102,16 @@ typedef struct o_path
  * All four lanes draw the same random numbers and take the same branches (every wavelength-dependent branch goes through a hook), so they meet
  * at the same hooks in the same order. Scalar mode (grp == NULL, everything before round 5): a hook is the identity on the lane's own value. */
 #include <pthread.h>
-#define O_MF 4
+#define O_MF_MAX 8                /* MF_COUNT = 4 (SSE, include/mf.h:280-423) or 8 (AVX, include/mf.h:22-279): o_group.n lanes */
+#define O_MF(c) ((c)->grp->n)
 typedef struct o_group
 {
   volatile int arrived, sense;   /* sense-reversing spin barrier: the lanes meet twice per hook, a futex sleep each time cost 2 ms per path */
-  volatile float f[O_MF];
-  volatile double d[O_MF];
-  volatile int b[O_MF];
-  volatile float col[O_MF][3];
+  int n;                         /* lanes = wavelengths per path */
+  volatile float f[O_MF_MAX];
+  volatile double d[O_MF_MAX];
+  volatile int b[O_MF_MAX];
+  volatile float col[O_MF_MAX][3];
 } o_group;
 
 typedef struct o_ctx
@@ -122,7 +124,7 @@ typedef struct o_ctx
   float *fb;
   int atomic_fb;
   mi_path_record *rec;
-  oracle_hero_ext *hero_ext;     /* hero wavelengths: all components of the finished path (every lane writes its own column) */
+  float *hero_ext;               /* hero wavelengths: all components of the finished path (every lane writes its own column): oracle_hero_ext with n columns */
   int hero_splats;
   uint64_t cnt[8];
 } o_ctx;
@@ -134,14 +136,15 @@ static inline void o_g_meet(o_ctx *c)
   const int s = c->sense ^= 1;
   /* what a lane wrote into the group before it arrives is visible to every lane that has seen the new sense (release / acquire on `sense`,
      acquire-release on the arrival count: the last lane has seen the others' writes and publishes them with its own) */
-  if(__atomic_add_fetch(&g->arrived, 1, __ATOMIC_ACQ_REL) == O_MF) { __atomic_store_n(&g->arrived, 0, __ATOMIC_RELAXED); __atomic_store_n(&g->sense, s, __ATOMIC_RELEASE); }
+  if(__atomic_add_fetch(&g->arrived, 1, __ATOMIC_ACQ_REL) == g->n) { __atomic_store_n(&g->arrived, 0, __ATOMIC_RELAXED); __atomic_store_n(&g->sense, s, __ATOMIC_RELEASE); }
   else { int spins = 0; while(__atomic_load_n(&g->sense, __ATOMIC_ACQUIRE) != s) { if(++spins > 4000) sched_yield(); else __builtin_ia32_pause(); } }
 }
 static inline int o_g_any(o_ctx *c, int cond)       /* mf_any */
 {
   if(!c || !c->grp) return cond;
   c->grp->b[c->lane] = cond; o_g_meet(c);
-  const int r = c->grp->b[0] | c->grp->b[1] | c->grp->b[2] | c->grp->b[3];
+  int r = 0;
+  for(int l=0;l<c->grp->n;l++) r |= c->grp->b[l];
   o_g_meet(c);
   return r;
 }
@@ -149,7 +152,8 @@ static inline int o_g_all(o_ctx *c, int cond)       /* mf_all */
 {
   if(!c || !c->grp) return cond;
   c->grp->b[c->lane] = cond; o_g_meet(c);
-  const int r = c->grp->b[0] & c->grp->b[1] & c->grp->b[2] & c->grp->b[3];
+  int r = 1;
+  for(int l=0;l<c->grp->n;l++) r &= c->grp->b[l];
   o_g_meet(c);
   return r;
 }
@@ -161,15 +165,22 @@ static inline float o_g_hero(o_ctx *c, float x)     /* mf(x, 0) */
   o_g_meet(c);
   return r;
 }
-static inline float o_g_hsum(o_ctx *c, float x)     /* mf_hsum: _mm_hadd_ps twice = (a0 + a1) + (a2 + a3), include/mf.h:301-306 */
+static inline float o_g_hsum(o_ctx *c, float x)     /* mf_hsum: _mm_hadd_ps twice = (a0 + a1) + (a2 + a3), include/mf.h:301-306; eight components: _mm256_hadd_ps twice,
+                                                       then the upper half is added to the lower, include/mf.h:44-51 = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7)) */
 {
   if(!c || !c->grp) return x;
   c->grp->f[c->lane] = x; o_g_meet(c);
-  const float r = (c->grp->f[0] + c->grp->f[1]) + (c->grp->f[2] + c->grp->f[3]);
+  float r = (c->grp->f[0] + c->grp->f[1]) + (c->grp->f[2] + c->grp->f[3]);
+  if(c->grp->n == 8) r = r + ((c->grp->f[4] + c->grp->f[5]) + (c->grp->f[6] + c->grp->f[7]));
   o_g_meet(c);
   return r;
 }
 #define O_CTX(p) ((p)->ctx)
+/* the n-column layout of oracle_hero_ext (oracle.h) = dump_ext_t of the dump harness built with -DMF_COUNT=n: lambda[n], then six per-vertex fields [V][n], then splat_value[S][n] */
+#define O_EXT_LAMBDA(c)        ((c)->hero_ext + (c)->lane)
+#define O_EXT_VERTEX(c, F, v)  ((c)->hero_ext + (c)->grp->n*(1 + (F)*MI_REC_MAX_VERTS + (v)) + (c)->lane)      /* F: 0 throughput, 1 pdf, 2 rd, 3 rg, 4 em, 5 eta */
+#define O_EXT_SPLAT(c, k)      ((c)->hero_ext + (c)->grp->n*(1 + 6*MI_REC_MAX_VERTS + (k)) + (c)->lane)
+#define O_EXT_FLOATS(n)        ((n)*(1 + 6*MI_REC_MAX_VERTS + MI_REC_MAX_SPLATS))
 
 /* oracle_rng: src/points.d/xorshift128p.c */
 float o_rand(o_ctx *c);

@@ -59,6 +59,9 @@ typedef struct oracle_hero_ext
 } oracle_hero_ext;
 int  oracle_set_reference_ftz(int on);     /* hero lanes: flush denormals like the reference build (see oracle_path.c) */
 void oracle_hero_trace(const mi_scene_desc *s, uint64_t first, uint64_t count, mi_path_record *out, oracle_hero_ext *ext, float *fb, uint64_t *counters);
+/* the same with n = 4 or 8 wavelengths per path (MF_COUNT = 8: the AVX branch, include/mf.h:22-279; pinned to dumps of that build, tests/test_oracle_hero.py);
+ * ext (or NULL): per path the layout of oracle_hero_ext with n columns instead of four = n (1 + 6 MI_REC_MAX_VERTS + MI_REC_MAX_SPLATS) floats */
+void oracle_hero_trace_n(const mi_scene_desc *s, int n, uint64_t first, uint64_t count, mi_path_record *out, float *ext, float *fb, uint64_t *counters);
 
 /* fill records for [first, first+count) */
 void oracle_trace_records(const mi_scene_desc *s, uint64_t first, uint64_t count, mi_path_record *out);

@@ -375,9 +375,9 @@ static int o_path_extend(o_ctx *c, o_path *path)
     if(c->grp)
     { /* MF_COUNT = 4, src/pathspace.c:218-221: the point sampler is asked once PER COMPONENT -- with the `rand` sampler four numbers --, component l
          takes fmodf(number l + l / 4, 1). Every lane draws all four (the lanes' generators stay in step) and keeps its own. */
-      float lfs[O_MF];
+      float lfs[O_MF_MAX];
       lfs[0] = lf;
-      for(int l=1;l<O_MF;l++) lfs[l] = fmodf(o_point(c, path, 0, o_dim_lambda) + l/(float)O_MF, 1.0f);
+      for(int l=1;l<O_MF(c);l++) lfs[l] = fmodf(o_point(c, path, 0, o_dim_lambda) + l/(float)O_MF(c), 1.0f);
       lf = lfs[c->lane];
     }
     path->lambda = 360 + (830 - 360)*lf;                          /* spectrum_sample_lambda, include/spectrum.h:206-210 */
@@ -486,9 +486,9 @@ static void o_splat(o_ctx *c, const o_path *path, float value)
   { /* spectrum_p_to_xyz, include/spectrum.h:185-195: xyz[k] += b[k] * p[l] for l = 0 .. 3 in that order; the hero lane splats the sum */
     for(int k=0;k<3;k++) c->grp->col[c->lane][k] = col[k];
     o_g_meet(c);
-    for(int k=0;k<3;k++) { col[k] = 0.0f; for(int l=0;l<O_MF;l++) col[k] += c->grp->col[l][k]; }
+    for(int k=0;k<3;k++) { col[k] = 0.0f; for(int l=0;l<O_MF(c);l++) col[k] += c->grp->col[l][k]; }
     o_g_meet(c);
-    if(c->hero_ext && c->hero_splats < MI_REC_MAX_SPLATS) c->hero_ext->splat_value[c->hero_splats][c->lane] = value;
+    if(c->hero_ext && c->hero_splats < MI_REC_MAX_SPLATS) *O_EXT_SPLAT(c, c->hero_splats) = value;
     c->hero_splats++;
     if(c->lane) return;
   }
@@ -789,7 +789,7 @@ static void o_fill_record(const o_path *p, mi_path_record *r)
   }
 }
 
-static void o_hero_fill_ext(const o_path *p, int lane, oracle_hero_ext *x);
+static void o_hero_fill_ext(const o_path *p, o_ctx *c);
 static void o_trace(o_ctx *c, uint64_t index)
 { /* render_sample_path, src/render.d/gi.c:81-105 -> pointsampler_mutate -> path_init + sampler_create_path */
   o_path path;
@@ -801,7 +801,7 @@ static void o_trace(o_ctx *c, uint64_t index)
   o_rand_seed(c, index, c->s->frame);
   if(c->s->sampler == MI_SAMPLER_PTDL) o_sampler_ptdl(c, &path);
   else o_sampler_pt(c, &path);
-  if(c->hero_ext) o_hero_fill_ext(&path, c->lane, c->hero_ext);
+  if(c->hero_ext) o_hero_fill_ext(&path, c);
   c->cnt[4]++;
   c->cnt[6] += path.length;
   if(c->rec) o_fill_record(&path, c->rec);
@@ -837,15 +837,15 @@ void oracle_trace_records(const mi_scene_desc *s, uint64_t first, uint64_t count
 }
 
 /* ---------------------------------------------------------------- hero wavelengths: four lanes in lock step (o_core.h) */
-typedef struct o_hero_lane { o_ctx c; uint64_t first, count; mi_path_record *out; oracle_hero_ext *ext; } o_hero_lane;
+typedef struct o_hero_lane { o_ctx c; uint64_t first, count; mi_path_record *out; float *ext; } o_hero_lane;
 
-static void o_hero_fill_ext(const o_path *p, int lane, oracle_hero_ext *x)
+static void o_hero_fill_ext(const o_path *p, o_ctx *c)
 {
-  x->lambda[lane] = p->lambda;
+  *O_EXT_LAMBDA(c) = p->lambda;
   for(int v=0;v<p->length && v<MI_REC_MAX_VERTS;v++)
   {
-    x->throughput[v][lane] = p->v[v].throughput; x->pdf[v][lane] = p->v[v].pdf;
-    x->rd[v][lane] = p->v[v].shading.rd; x->rg[v][lane] = p->v[v].shading.rg; x->em[v][lane] = p->v[v].shading.em; x->eta[v][lane] = p->v[v].eta;
+    *O_EXT_VERTEX(c, 0, v) = p->v[v].throughput; *O_EXT_VERTEX(c, 1, v) = p->v[v].pdf;
+    *O_EXT_VERTEX(c, 2, v) = p->v[v].shading.rd; *O_EXT_VERTEX(c, 3, v) = p->v[v].shading.rg; *O_EXT_VERTEX(c, 4, v) = p->v[v].shading.em; *O_EXT_VERTEX(c, 5, v) = p->v[v].eta;
   }
 }
 
@@ -871,7 +871,7 @@ static void *o_hero_worker(void *arg)
   {
     L->c.rec = L->c.lane == 0 && L->out ? L->out + i : 0;
     if(L->c.rec) { memset(L->c.rec, 0, sizeof(*L->c.rec)); L->c.rec->index = L->first + i; }
-    L->c.hero_ext = L->ext ? L->ext + i : 0;
+    L->c.hero_ext = L->ext ? L->ext + i*O_EXT_FLOATS(L->c.grp->n) : 0;
     L->c.hero_splats = 0;
     o_trace(&L->c, L->first + i);
   }
@@ -882,20 +882,27 @@ static void *o_hero_worker(void *arg)
    (what refharness/render_dump.c writes from a -DMF_COUNT=4 build); ext: all four components (may be NULL); fb: framebuffer or NULL */
 void oracle_hero_trace(const mi_scene_desc *s, uint64_t first, uint64_t count, mi_path_record *out, oracle_hero_ext *ext, float *fb, uint64_t *counters)
 {
+  oracle_hero_trace_n(s, 4, first, count, out, (float *)ext, fb, counters);
+}
+/* ... with n = 4 (MF_COUNT = 4, SSE) or 8 (MF_COUNT = 8, AVX: include/mf.h:22-279) wavelengths; ext: O_EXT_FLOATS(n) floats per path, the n-column layout of oracle_hero_ext */
+void oracle_hero_trace_n(const mi_scene_desc *s, int n, uint64_t first, uint64_t count, mi_path_record *out, float *ext, float *fb, uint64_t *counters)
+{
+  if(n != 4 && n != 8) return;
   o_prepare_points(s, first + count);
   o_group grp;
   memset(&grp, 0, sizeof(grp));
-  o_hero_lane lane[O_MF];
-  pthread_t th[O_MF];
-  if(ext) memset(ext, 0, sizeof(*ext)*count);
-  for(int l=0;l<O_MF;l++)
+  grp.n = n;
+  o_hero_lane lane[O_MF_MAX];
+  pthread_t th[O_MF_MAX];
+  if(ext) memset(ext, 0, sizeof(float)*O_EXT_FLOATS(n)*count);
+  for(int l=0;l<n;l++)
   {
     memset(lane + l, 0, sizeof(o_hero_lane));
     lane[l].c.s = s; lane[l].c.grp = &grp; lane[l].c.lane = l; lane[l].c.fb = l == 0 ? fb : 0;
     lane[l].first = first; lane[l].count = count; lane[l].out = out; lane[l].ext = ext;
     pthread_create(th + l, 0, o_hero_worker, lane + l);
   }
-  for(int l=0;l<O_MF;l++) pthread_join(th[l], 0);
+  for(int l=0;l<n;l++) pthread_join(th[l], 0);
   if(counters) for(int i=0;i<8;i++) counters[i] += lane[0].c.cnt[i];
 }
 

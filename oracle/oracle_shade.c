@@ -442,7 +442,7 @@ static float o_sample_dielectric(o_ctx *c, o_path *p)
     {
       /* "specular transmit always selects single wavelength": mask = mf_hero = _mm_set_epi32(0u, ~0u, ~0u, ~0u) (include/mf.h:300) zeroes the components
          whose mask bits are set -- _mm_set_epi32 lists the HIGHEST element first, so that is components 0, 1, 2: the one that survives is component 3 */
-      const int masked = c->grp && c->lane != O_MF - 1;
+      const int masked = c->grp && c->lane != O_MF(c) - 1;       /* (eight components: _mm256_set_epi32(0u, ~0u x 7), include/mf.h:42 -- the eighth survives) */
       p->v[v+1].pdf = masked ? 0.0f : 1.0f - R;
       p->v[v].mode = s_specular | s_transmit;
       return masked ? 0.0f : p->v[v].shading.rg;

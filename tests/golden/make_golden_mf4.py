@@ -13,7 +13,8 @@ import numpy as np
 sys.path.insert(0, str(Path(__file__).resolve().parent))
 from make_golden import GOLD, REF, REPO, run_ref      # noqa: E402
 
-MV_DUMP, NS_DUMP, MF = 8, 8, 4
+MV_DUMP, NS_DUMP = 8, 8
+MF = 8 if "--mf=8" in sys.argv or ("--mf" in sys.argv and sys.argv[sys.argv.index("--mf") + 1] == "8") else 4       # --mf 8: the AVX build (`make -C oracle mf8`)
 EXT = np.dtype([("lambda", "<f4", MF), ("throughput", "<f4", (MV_DUMP, MF)), ("pdf", "<f4", (MV_DUMP, MF)), ("rd", "<f4", (MV_DUMP, MF)), ("rg", "<f4", (MV_DUMP, MF)),
                 ("em", "<f4", (MV_DUMP, MF)), ("eta", "<f4", (MV_DUMP, MF)), ("splat_value", "<f4", (NS_DUMP, MF))])
 
@@ -24,7 +25,7 @@ def dump(name, binary, mv, scene, w, h, n):
     work = Path(tempfile.mkdtemp(prefix="corona_mf4_"))
     fn = work / "paths.bin"
     run_ref(binary, mv, scene, ["-s", "1", "-w", str(w), "-h", str(h), "-t", "1", "-x", "_dump"],
-            env={"CORONA_DUMP_N": str(n), "CORONA_DUMP_FILE": str(fn), "LD_LIBRARY_PATH": str(REF / "mf4" / f"shaders_mv{mv}")}, work=work)
+            env={"CORONA_DUMP_N": str(n), "CORONA_DUMP_FILE": str(fn), "LD_LIBRARY_PATH": str(REF / f"mf{MF}" / f"shaders_mv{mv}")}, work=work)
     raw = fn.read_bytes()
     hdr = np.frombuffer(raw, dtype="<u4", count=4)
     rdt = pkg.record_dtype()
@@ -37,6 +38,14 @@ def dump(name, binary, mv, scene, w, h, n):
 
 
 def main():
+    if MF == 8:
+        # eight wavelengths per path (include/mf.h:22-279): pt, ptdl and smooth glass (one component survives a specular transmission: the eighth)
+        subprocess.check_call(["make", "-C", str(REPO / "oracle"), "mf8"], stdout=subprocess.DEVNULL)
+        dump("mf8_pt_mv8", "mf8/dump_pt_xs_mv8", 8, "0010_pt", 1280, 720, 3000)
+        dump("mf8_ptdl_mv8", "mf8/dump_ptdl_xs_mv8", 8, "0010_pt", 1280, 720, 3000)
+        dump("mf8_smooth_ptdl_mv8", "mf8/dump_ptdl_xs_mv8", 8, "0066_smooth", 1280, 720, 3000)
+        dump("mf8_media_ptdl_mv8", "mf8/dump_ptdl_xs_mv8", 8, "0055_media", 1280, 720, 3000)      # mf_exp = exp256_ps in this build
+        return
     subprocess.check_call(["make", "-C", str(REPO / "oracle"), "mf4"], stdout=subprocess.DEVNULL)
     dump("mf4_pt_mv8", "mf4/dump_pt_xs_mv8", 8, "0010_pt", 1280, 720, 3000)
     dump("mf4_ptdl_mv8", "mf4/dump_ptdl_xs_mv8", 8, "0010_pt", 1280, 720, 3000)

@@ -64,6 +64,8 @@ def oracle_lib():
         o.oracle_set_pixels_from_index.argtypes = [C.c_int]
         o.oracle_hero_trace.argtypes = [C.POINTER(pkg.MiSceneDesc), C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         o.oracle_hero_trace.restype = None
+        o.oracle_hero_trace_n.argtypes = [C.POINTER(pkg.MiSceneDesc), C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        o.oracle_hero_trace_n.restype = None
         o.oracle_set_pixels_from_index.restype = None
         o.oracle_render_tiles.argtypes = [C.POINTER(pkg.MiSceneDesc), C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
         o.oracle_render_tiles.restype = C.c_double
@@ -84,12 +86,21 @@ HERO_EXT = np.dtype([("lambda", "<f4", HERO_MF), ("throughput", "<f4", (8, HERO_
                      ("rg", "<f4", (8, HERO_MF)), ("em", "<f4", (8, HERO_MF)), ("eta", "<f4", (8, HERO_MF)), ("splat_value", "<f4", (8, HERO_MF))])
 
 
-def oracle_hero_records(scene, first, count, fb=None):
-    """hero wavelengths (MF_COUNT = 4): (records of the hero component, all four components of every spectral quantity)"""
+def hero_ext_dtype(mf):
+    """dump_ext_t of the dump harness built with -DMF_COUNT=mf"""
+    return np.dtype([("lambda", "<f4", mf), ("throughput", "<f4", (8, mf)), ("pdf", "<f4", (8, mf)), ("rd", "<f4", (8, mf)),
+                     ("rg", "<f4", (8, mf)), ("em", "<f4", (8, mf)), ("eta", "<f4", (8, mf)), ("splat_value", "<f4", (8, mf))])
+
+
+def oracle_hero_records(scene, first, count, fb=None, mf=4):
+    """hero wavelengths (MF_COUNT = 4, or 8: the AVX build): (records of the hero component, all mf components of every spectral quantity)"""
     pkg = load_pkg()
     out = np.zeros(count, dtype=pkg.record_dtype())
-    ext = np.zeros(count, dtype=HERO_EXT)
-    oracle_lib().oracle_hero_trace(scene.desc_ptr, first, count, out.ctypes.data, ext.ctypes.data, None if fb is None else fb.ctypes.data, None)
+    ext = np.zeros(count, dtype=HERO_EXT if mf == 4 else hero_ext_dtype(mf))
+    if mf == 4:
+        oracle_lib().oracle_hero_trace(scene.desc_ptr, first, count, out.ctypes.data, ext.ctypes.data, None if fb is None else fb.ctypes.data, None)
+    else:
+        oracle_lib().oracle_hero_trace_n(scene.desc_ptr, mf, first, count, out.ctypes.data, ext.ctypes.data, None if fb is None else fb.ctypes.data, None)
     return out, ext
 
 

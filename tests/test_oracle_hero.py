@@ -44,6 +44,13 @@ HERO_CASES = [
     ("mf4_cam_mb_ptdl_mv8", pkg.MI_SAMPLER_PTDL, SCENE_CAM_MB, 0.998),
     ("mf4_mb_ptdl_mv8", pkg.MI_SAMPLER_PTDL, SCENE_MB, 0.998),
     ("mf4_all_ptdl_mv8", pkg.MI_SAMPLER_PTDL, SCENE_ALL, 0.998),     # the reference build's NaN at gold vertices, see test_oracle_golden.MIN_SAME_LENGTH
+    # MF_COUNT = 8 (round 6): the AVX branch of include/mf.h (22-279), eight lanes of the oracle. `make -C oracle mf8` + make_golden_mf4.py --mf 8:
+    # wavelengths an eighth of the range apart, mf_hsum = ((a0+a1)+(a2+a3)) + ((a4+a5)+(a6+a7)) (mf.h:44-51), a specular transmission keeps the EIGHTH
+    # component (mf.h:42), exp256_ps in the media code
+    ("mf8_pt_mv8", pkg.MI_SAMPLER_PT, SCENE_0010, 0.998),
+    ("mf8_ptdl_mv8", pkg.MI_SAMPLER_PTDL, SCENE_0010, 0.998),
+    ("mf8_smooth_ptdl_mv8", pkg.MI_SAMPLER_PTDL, SCENE_SMOOTH, 0.998),
+    ("mf8_media_ptdl_mv8", pkg.MI_SAMPLER_PTDL, SCENE_MEDIA, 0.998),
 ]
 
 
@@ -53,17 +60,18 @@ def rel(a, b):
 
 def hero_case(name, sampler, scene_path):
     g = np.load(GOLDEN / f"paths_{name}.npz")
-    assert int(g["mf_count"]) == 4
+    mf = int(g["mf_count"])
+    assert mf == (8 if name.startswith("mf8") else 4)
     ref, rext = g["records"], g["ext"]
     s = make_scene(scene_path, width=int(g["width"]), height=int(g["height"]), max_verts=int(g["max_verts"]), sampler=sampler,
-                   pointsampler=pkg.MI_POINTS_HALTON if name.startswith("mf4_halton") else pkg.MI_POINTS_RAND)
+                   pointsampler=pkg.MI_POINTS_HALTON if "_halton" in name else pkg.MI_POINTS_RAND)
     oracle_lib().oracle_set_reference_ftz(1)         # the reference build flushes denormals (-ffast-math): deep paths through media, see oracle_path.c
     try:
         with reference_rsqrt() as emu:
-            ora, oext = oracle_hero_records(s, 0, len(ref))
+            ora, oext = oracle_hero_records(s, 0, len(ref), mf=mf)
             exact = emu.exact
         if not exact:
-            ora, oext = oracle_hero_records(s, 0, len(ref))
+            ora, oext = oracle_hero_records(s, 0, len(ref), mf=mf)
     finally:
         oracle_lib().oracle_set_reference_ftz(0)
     return ref, rext, ora, oext, exact, s
@@ -91,8 +99,17 @@ def test_hero_oracle_matches_mf4_reference_paths(name, sampler, scene_path, min_
         # (p99 where a few hundred paths reach the depth; the median where a handful do -- the pdf of a GGX lobe of roughness 0.04 moves
         #  by per cent when the direction moves in the sixth digit)
         q = 0.99 if ok.sum() >= 100 else 0.5
-        assert np.quantile(rel(oext["throughput"][ok, k], rext["throughput"][ok, k]), q) <= tol_thr, k
-        assert np.quantile(rel(oext["pdf"][ok, k], rext["pdf"][ok, k]), q) <= tol_pdf, k
+        # (a path whose pdf is NaN in the reference's dump -- 0 / 0 at a vertex that transmits nothing, one in 3000 of the MF_COUNT = 8 fixture -- is NaN in the oracle too)
+        for f, tol in (("throughput", tol_thr), ("pdf", tol_pdf)):
+            a, b = oext[f][ok, k], rext[f][ok, k]
+            assert np.array_equal(np.isnan(a), np.isnan(b)), (f, k)
+            dev = np.where(np.isnan(a), 0.0, rel(a, b))
+            if q == 0.5:
+                assert np.quantile(dev, q) <= tol, (f, k)
+            else:
+                # the 99th percentile, counted in PATHS (all components of a chaotic path deviate together: with eight of them three paths of 263 are
+                # 1.1 % of the entries): at most 1 % of the paths, three where fewer than 300 reach the depth, may lie outside
+                assert (dev.max(axis=1) > tol).sum() <= max(3, int(np.ceil(0.01 * ok.sum()))), (f, k, int((dev.max(axis=1) > tol).sum()), int(ok.sum()))
         assert np.quantile(rel(oext["eta"][ok, k], rext["eta"][ok, k]), 0.999) <= 1e-6, k
         # which components a vertex zeroes is a decision, not arithmetic: specular transmission keeps component 3 only
         # (the reference build flushes denormals -- -ffast-math links crtfastmath --, the oracle keeps them: a throughput below FLT_MIN counts as zero)
@@ -126,21 +143,23 @@ def test_hero_oracle_matches_mf4_reference_paths(name, sampler, scene_path, min_
     assert np.abs(e_ref - e_ora).max() / np.abs(e_ref).max() <= (2e-3 if exact else 1e-2)
 
 
-def test_hero_specular_transmission_keeps_the_last_component():
+@pytest.mark.parametrize("fixture", ["mf4_smooth_ptdl_mv8", "mf8_smooth_ptdl_mv8"])
+def test_hero_specular_transmission_keeps_the_last_component(fixture):
     """dielectric.c:331-343 with mf_hero = _mm_set_epi32(0, ~0, ~0, ~0) (include/mf.h:300): `mf_select(0, x, mask)` zeroes the components whose
     mask is set and _mm_set_epi32 lists the highest element first -- the hero and components 1, 2 die, component 3 carries the path on. The glass
     of scenes/0066_smooth has roughness 0: in the reference's dump every path through it has exactly that pattern, and so has the oracle's."""
-    ref, rext, ora, oext, _, _ = hero_case("mf4_smooth_ptdl_mv8", pkg.MI_SAMPLER_PTDL, SCENE_SMOOTH)
+    ref, rext, ora, oext, _, _ = hero_case(fixture, pkg.MI_SAMPLER_PTDL, SCENE_SMOOTH)
+    last = rext["lambda"].shape[1] - 1            # eight components: _mm256_set_epi32(0u, ~0u x 7), include/mf.h:42 -- the eighth survives
     S_SPECULAR, S_TRANSMIT = 256, 2
     seen = 0
     for k in range(1, 7):
         for rec, ext in ((ref, rext), (ora, oext)):
-            m = (rec["length"] > k + 1) & (rec["v"]["mode"][:, k] == (S_SPECULAR | S_TRANSMIT)) & (ext["eta"][:, k, 0] != 1.0) & (ext["throughput"][:, k, 3] > 0)
+            m = (rec["length"] > k + 1) & (rec["v"]["mode"][:, k] == (S_SPECULAR | S_TRANSMIT)) & (ext["eta"][:, k, 0] != 1.0) & (ext["throughput"][:, k, last] > 0)
             # (index-matched transitions are specular|transmit too but keep all four: excluded by comparing the etas of the components)
-            m &= np.abs(ext["eta"][:, k, 0] - ext["eta"][:, k, 3]) > 0
+            m &= np.abs(ext["eta"][:, k, 0] - ext["eta"][:, k, last]) > 0
             if m.sum():
                 seen += int(m.sum())
-                assert (ext["throughput"][m, k + 1, :3] == 0).all()
+                assert (ext["throughput"][m, k + 1, :last] == 0).all()
     assert seen > 20
 
 
