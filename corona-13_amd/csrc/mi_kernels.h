@@ -2577,7 +2577,15 @@ __device__ __forceinline__ void splat_wave(const DScene &sc, bool pending, float
     if(inside && weight > 0)
     {
       const float g = mi_rcp(weight)*f;
+#if defined(MI_EXP_SPLAT) && MI_EXP_SPLAT == 1     /* experiment (profiles/r06_levers.txt block 4): the filter is evaluated, nothing is written */
+      if(g != g) sc.fb[0] = g;
+      continue;
+#endif
+#if defined(MI_EXP_SPLAT) && MI_EXP_SPLAT == 2     /* experiment: every tap goes to one 32 x 32 tile of the film (what a tile buffer on chip would absorb: no traffic behind L2) */
+      float *px = sc.fb + 3*((size_t)((x0+u) & 31) + (size_t)wd*((y0+v) & 31));
+#else
       float *px = sc.fb + 3*((size_t)(x0+u) + (size_t)wd*(y0+v));
+#endif
       atomicAdd(px+0, s0*g);
       atomicAdd(px+1, s1*g);
       atomicAdd(px+2, s2*g);
