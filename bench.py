@@ -171,6 +171,18 @@ def committed_profile(kernel="pt"):
     return json.loads(files[-1].read_text()), files[-1].name
 
 
+def committed_mix_peak(summary_name):
+    """the measured vector-issue peak for the instruction mix of a committed PMC summary (tools/micro/valu_mix.py -> profiles/rNN_valu_mix_peak.json), or None"""
+    for f in sorted((REPO / "profiles").glob("r*_valu_mix_peak.json"), reverse=True):
+        try:
+            d = json.loads(f.read_text()).get(summary_name)
+        except ValueError:
+            continue
+        if d and "peak_ginstr_per_s" in d:
+            return {"peak_ginstr_per_s": d["peak_ginstr_per_s"], "source": f.name}
+    return None
+
+
 class StubBackend:
     """TEST ONLY (--stub, tests/test_bench_launch.py): stands in for the HIP backend where there is no GPU so that the launch,
     sharding, reduce and JSON logic of this file can run under gloo. It renders nothing: it adds the number of path indices it
@@ -586,17 +598,20 @@ def main():
                         "valu_instr_per_path": instr_per_path, "clock_ghz": clock_ghz, "source": prof_name,
                         # the instruction count belongs to the build the profile was taken from
                         "profile_build_id": prof.get("build_id"), "library_build_id": build, "profile_matches_library": fresh})
-            if "valu_pipe_cycles_model" in prof:
-                # the same instructions priced with what gfx950 charges for them (tools/micro/valu_cost.hip: a wave64 f32 add / mul / fma occupies a SIMD for
-                # 2 cycles, min / max / compare / select / integer / conversion ops for 4, transcendentals and f64 for 8; mix from the SQ_INSTS_VALU_* counters of
-                # the same committed passes): the share of the vector pipes' cycles this launch fills. `frac` counts every instruction as 2 cycles.
-                cyc = prof["valu_pipe_cycles_model"] / prof_paths * r["launch_paths"]
-                out["frac_cycle_weighted"] = cyc / (CUS * SIMDS_PER_CU) / (r["kms"] * 1e-3 * clock_ghz * 1e9)
-                out["valu_mix"] = prof.get("valu_mix")
+            # the same rate against what the machine SUSTAINS for this kernel's instruction mix (round 6; VERDICT r5 item 4 iii): tools/micro/valu_mix.py generates a
+            # memory-free kernel with the mix of the committed SQ_INSTS_VALU_* passes (the class no counter covers -- selects, compares, min / max, moves -- once as
+            # the whole kernel's ISA has it, once as the node visit has it: a bracket) and measures its vector instructions per second at this kernel's geometry
+            # (1024-thread workgroups, one per CU). frac_of_mix_peak = achieved / that peak, [low, high]; `frac` above prices every instruction at 2 cycles.
+            mix_peak = committed_mix_peak(prof_name)
+            if mix_peak:
+                lo, hi = mix_peak["peak_ginstr_per_s"]
+                out["frac_of_mix_peak"] = [achieved / hi, achieved / lo]
+                out["mix_peak"] = {"unit": "G wave64-instr/s", "peak": [lo, hi], "source": mix_peak["source"]}
+            out["valu_mix"] = prof.get("valu_mix")
             if not fresh:
                 # never a stale fraction: the committed counters are of another build (or of another instantiation than the
                 # one this run launched) -- the live fields (kernel_ms, traffic-free LDS line, algorithmic_hbm_frac) stay, the counter-derived ones go
-                for k in ("achieved", "frac", "useful_lane_frac", "valu_instr_per_path", "lane_utilisation", "frac_cycle_weighted", "valu_mix"):
+                for k in ("achieved", "frac", "useful_lane_frac", "valu_instr_per_path", "lane_utilisation", "frac_of_mix_peak", "valu_mix"):
                     out[k] = None
                 out["stale_profile"] = (f"{prof_name} was taken from library build {prof.get('build_id')} / kernel {prof.get('kernel')}; this run loaded build {build} and launched "
                                         f"{r['kernel']}: re-run tools/profile.sh and commit its summary")
@@ -697,6 +712,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic: regression/0010_pt scene (6 of 7 shapes, scenes/0010_pt), per-path xorshift128+ seeds",
             "config": {"workload": cfg["name"], "tree": args.tree, "pointsampler": args.points, "traversal": main_r["traversal"], "wavelengths_per_path": args.wavelengths,
+                       "kernel": kernel_name(main_r),
                        "paths_per_step": main_r["job"], "paths_per_step_per_gpu": main_r["launch_paths"],
                        "sharding": (f"32x32 film tiles t = rank (mod {world}), pixels from path indices (mi_render_tiles; {scaling})" if args.shard == "tiles"
                                     else f"path-index ranges x{world} ({scaling})") + ", framebuffer all-reduce + read-back of the last frame in the timed region"},

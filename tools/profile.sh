@@ -18,8 +18,7 @@ pmc sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU 
 pmc mem SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS
 pmc l2 TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum
 pmc grbm GRBM_GUI_ACTIVE
-# instruction classes (round 5): gfx950 issues the plain f32 add / mul / fma of a wave64 in 2 cycles, most other vector ops in 4, transcendentals in 8
-# (tools/micro/valu_cost.hip) -- the mix says how busy the vector pipes are, which SQ_INSTS_VALU x 2 cycles underestimates
+# instruction classes: what tools/micro/valu_mix.py builds its calibration kernel from
 pmc mix SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_SMEM
 pmc mix2 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_BRANCH SQ_INSTS_FLAT SQ_WAIT_INST_LDS
 python3 $R/tools/hbm_copy.py > $OUT/hbm_copy.json 2>/dev/null
@@ -62,16 +61,15 @@ for tag, kname in KERNELS.items():
         res["valu_instr_per_path"] = res["SQ_INSTS_VALU"] / res["paths_per_launch"]
         res["salu_instr_per_path"] = res.get("SQ_INSTS_SALU", 0.0) / res["paths_per_launch"]
         if "SQ_INSTS_VALU_FMA_F32" in res:
-            # vector pipe occupancy from the instruction mix: plain f32 add / mul / fma 2 cycles per wave64 instruction, transcendentals 8, f64 8 (quarter
-            # rate), everything else 4 (min / max / compare / select / integer / conversions: tools/micro/valu_cost.hip measured 4.4 against 2.5)
+            # the instruction mix (round 5 priced it with a 2 / 4 / 8-cycle model; round 6 measures the rate a kernel of this mix sustains: tools/micro/valu_mix.py below)
             f32 = res.get("SQ_INSTS_VALU_ADD_F32", 0.0) + res.get("SQ_INSTS_VALU_MUL_F32", 0.0) + res["SQ_INSTS_VALU_FMA_F32"]
             trans = res.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
             f64 = res.get("SQ_INSTS_VALU_ADD_F64", 0.0) + res.get("SQ_INSTS_VALU_MUL_F64", 0.0) + res.get("SQ_INSTS_VALU_FMA_F64", 0.0)
             other = res["SQ_INSTS_VALU"] - f32 - trans - f64
             res["valu_mix"] = {"f32_add_mul_fma": f32 / res["SQ_INSTS_VALU"], "transcendental": trans / res["SQ_INSTS_VALU"], "f64": f64 / res["SQ_INSTS_VALU"], "other": other / res["SQ_INSTS_VALU"]}
-            res["valu_pipe_cycles_model"] = 2.0 * f32 + 8.0 * trans + 8.0 * f64 + 4.0 * other
-            res["valu_pipe_busy_model"] = res["valu_pipe_cycles_model"] / simds / cycles
     json.dump(res, open(out + ("/pmc_summary.json" if tag == "pt" else "/pmc_summary_ptdl.json"), "w"), indent=1)
     print(json.dumps(res))
 PY
+# the vector-issue peak for the two kernels' instruction mixes (round 6): a generated memory-free kernel per summary, tools/micro/valu_mix.py
+python3 $R/tools/micro/valu_mix.py $OUT/pmc_summary.json $OUT/pmc_summary_ptdl.json > $OUT/valu_mix_peak.json 2> $OUT/valu_mix.err || echo "valu_mix.py failed: see $OUT/valu_mix.err"
 cat $OUT/bench.json; head -3 $OUT/kernel_stats.csv

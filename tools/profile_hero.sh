@@ -9,6 +9,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for CFG in cfg2 cfg3; do
   CMD="$R/bench.py --config $CFG --wavelengths 4 --steps 3 --warmup 1 --no-cpu-baseline --no-secondary"
+  python3 $CMD > $OUT/hero_bench_$CFG.json 2> $OUT/hero_bench_$CFG.err          # un-profiled: the line names the kernel the library launches (config.kernel)
   pmc() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_hero_${CFG}_$name -- python3 $CMD > $OUT/pmc_hero_${CFG}_$name.log 2>&1; cp $OUT/pmc_hero_${CFG}_$name/*/*_counter_collection.csv $OUT/pmc_hero_${CFG}_$name.csv; }
   pmc sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_ANY
   pmc mem SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS
@@ -24,7 +25,8 @@ import csv, glob, json, collections, hashlib
 out = "$OUT"
 res = {"build_id": hashlib.sha256(open("$R/corona-13_amd/csrc/libcorona_mi.so", "rb").read()).hexdigest()[:16], "paths_per_launch": 64 * 1280 * 736}
 for cfg, ptdl in (("cfg2", "false"), ("cfg3", "true")):
-    kname = "mi_path_kernel<false, %s, true, false, false, false, false, false, false, true>" % ptdl      # the production HERO kernel of the scene
+    # the instantiation the library launched for this configuration, by its own name (bench.py: config.kernel from mi_scene_kernel_name) -- not re-derived here
+    kname = json.load(open(out + "/hero_bench_%s.json" % cfg))["config"]["kernel"].split(" (")[0]
     r = {"kernel": kname}
     for f in glob.glob(out + "/pmc_hero_%s_*.csv" % cfg):
         agg = collections.defaultdict(list)
@@ -34,6 +36,8 @@ for cfg, ptdl in (("cfg2", "false"), ("cfg3", "true")):
                 r["VGPR_Count"] = row.get("VGPR_Count"); r["Scratch_Size"] = row.get("Scratch_Size"); r["Workgroup_Size"] = row.get("Workgroup_Size"); r["LDS_Block_Size"] = row.get("LDS_Block_Size")
         for k, v in agg.items():
             r[k] = sum(v) / len(v)
+    if "SQ_INSTS_VALU" not in r:
+        raise SystemExit("profile_hero.sh: no counter row matches kernel %s of %s" % (kname, cfg))
     n = res["paths_per_launch"]
     if "SQ_INSTS_VALU" in r:
         r["valu_instr_per_path"] = r["SQ_INSTS_VALU"] / n
@@ -47,8 +51,7 @@ for cfg, ptdl in (("cfg2", "false"), ("cfg3", "true")):
         if "GRBM_GUI_ACTIVE" in r:
             cycles = r["GRBM_GUI_ACTIVE"] / 8
             r["gpu_cycles_per_launch"] = cycles
-            r["valu_pipe_busy_model"] = (2 * plain + 4 * other + 8 * (trans + f64)) / 1024 / cycles
     res[cfg] = r
 json.dump(res, open(out + "/pmc_summary_hero.json", "w"), indent=1)
-print(json.dumps({c: {k: res[c].get(k) for k in ("valu_instr_per_path", "lane_utilisation", "salu_instr_per_path", "valu_pipe_busy_model", "Scratch_Size", "Workgroup_Size", "valu_mix")} for c in ("cfg2", "cfg3")}, indent=1))
+print(json.dumps({c: {k: res[c].get(k) for k in ("valu_instr_per_path", "lane_utilisation", "salu_instr_per_path", "Scratch_Size", "Workgroup_Size", "valu_mix")} for c in ("cfg2", "cfg3")}, indent=1))
 PY
