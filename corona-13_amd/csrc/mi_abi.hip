@@ -125,6 +125,7 @@ struct mi_scene
   bool norg;                        /* ... of those, the ones without the exchange between waves (scattering exterior medium) */
   bool hero;                        /* launch the HERO instantiations: four wavelengths per path (mi_scene_set_wavelengths) */
   void *d_shape_medium, *d_prims_t1, *d_lights, *d_prim_cls;
+  void *d_rng_jump;                 /* the generator's jump tables (rng_seed_jump, mi_kernels.h) */
   /* wavefront kernel (mi_wavefront.h): plain pt scenes; the workgroups' path tables */
   bool wavefront;
   void *d_wf_table;
@@ -135,6 +136,8 @@ struct mi_scene
   uint64_t halton_epoch;            /* end index >> 32 the device tables were drawn for */
   void *d_halton_dim, *d_halton_perm;
 };
+
+static int upload_rng_jump(mi_scene *s);      /* (below, next to the launch that forms the constant) */
 
 /* ---------------------------------------------------------------------------------------- kernel table
  * The megakernel's instantiations live in twenty-two parts (mi_megakernel.h, mi_part.hip), one translation unit each. */
@@ -1028,6 +1031,7 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
     if(hipMalloc(&s->d_overflow, extra*(size_t)s->grid*MI_BLOCK*sizeof(uint2)) != hipSuccess)
     { mi_scene_destroy(s); return fail(MI_ERR_NOMEM, "cannot allocate the traversal stack overflow area"); }
   }
+  if(upload_rng_jump(s) != MI_OK) { mi_scene_destroy(s); return fail(MI_ERR_NOMEM, "cannot allocate the generator's jump tables"); }
   if(s->wavefront && hipMalloc(&s->d_wf_table, (size_t)s->grid*MI_WF_QUADS_MAX*s->wf_entries*sizeof(uint4)) != hipSuccess)
   { mi_scene_destroy(s); return fail(MI_ERR_NOMEM, "cannot allocate the wavefront kernel's path tables"); }
   /* uploads and clears above ran on the null stream, rendering runs on a non-blocking one: everything is in place before the first launch */
@@ -1093,8 +1097,42 @@ static int ensure_halton(mi_scene *s, uint64_t end_index)
   return MI_OK;
 }
 
+/* ten rounds of xorshift128+ on the host (points_set_state's warm-up, src/points.d/xorshift128p.c:53-74): rng_seed_jump's tables and launch constants */
+static void rng_ten_rounds(uint64_t &a0, uint64_t &a1)
+{
+  for(int k=0;k<10;k++)
+  {
+    uint64_t s1 = a0;
+    const uint64_t s0 = a1;
+    a0 = s0;
+    s1 ^= s1 << 23; s1 ^= s1 >> 17; s1 ^= s0; s1 ^= s0 >> 26;
+    a1 = s1;
+  }
+}
+static int upload_rng_jump(mi_scene *s)
+{ /* [4][256]: the ten rounds of the seed whose only set bits are byte b of s0 = value v */
+  std::vector<uint32_t> t(4*256*4);
+  for(int b=0;b<4;b++) for(int v=0;v<256;v++)
+  {
+    uint64_t a0 = (uint64_t)v << (8*b), a1 = 0;
+    rng_ten_rounds(a0, a1);
+    uint32_t *e = &t[(size_t)(b*256 + v)*4];
+    e[0] = (uint32_t)a0; e[1] = (uint32_t)(a0 >> 32); e[2] = (uint32_t)a1; e[3] = (uint32_t)(a1 >> 32);
+  }
+  if(hipMalloc(&s->d_rng_jump, t.size()*4) != hipSuccess || hipMemcpy(s->d_rng_jump, t.data(), t.size()*4, hipMemcpyHostToDevice) != hipSuccess) return MI_ERR_NOMEM;
+  s->d.rng_jump = (const uint4 *)s->d_rng_jump;
+  return MI_OK;
+}
+
 static void launch_path_kernel(mi_scene *s, bool record, int grid, uint64_t first, uint64_t n, mi_path_record *rec)
-{ /* pick the instantiation: the part by PTDL (sampler) x MEDIA ("extended": media, moving camera, emitters without a one-burst
+{
+  { /* the launch constant of rng_seed_jump: the rounds of (high word of 1 + index, 2 + frame) for the launch's first index; lanes of a launch that crosses a
+       multiple of 2^32 see another high word and run the rounds themselves */
+    uint64_t a0 = (1ull + first) & 0xffffffff00000000ull, a1 = 2ull + s->d.frame;
+    s->d.rng_jump_hi = (uint32_t)(a0 >> 32);
+    rng_ten_rounds(a0, a1);
+    s->d.rng_jump_c[0] = (uint32_t)a0; s->d.rng_jump_c[1] = (uint32_t)(a0 >> 32); s->d.rng_jump_c[2] = (uint32_t)a1; s->d.rng_jump_c[3] = (uint32_t)(a1 >> 32);
+  } /* pick the instantiation: the part by PTDL (sampler) x MEDIA ("extended": media, moving camera, emitters without a one-burst
      record) x MB (moving primitives) x FAST (traversal rounds), inside it RECORD (test hook) x NODES_LDS (tree fits LDS) x HALTON
      (point sampler) x COUNT (debug counters) */
   const unsigned which = (record ? MI_WHICH_RECORD : 0u) | (s->nodes_lds ? MI_WHICH_NODES_LDS : 0u) | (s->halton ? MI_WHICH_HALTON : 0u) |
@@ -1429,7 +1467,7 @@ extern "C" void mi_scene_destroy(mi_scene *s)
   (void)hipSetDevice(s->device);
   void *bufs[] = { s->d_nodes, s->d_axes, s->d_prims, s->d_primgeo, s->d_materials, s->d_light_prim, s->d_light_cdf, s->d_light_L,
                    s->d_cie, s->d_checker, s->d_metal, s->d_counters, s->d_shape_material, s->d_shape_L, s->d_overflow, s->d_fb_own,
-                   s->d_halton_dim, s->d_halton_perm, s->d_shape_medium, s->d_prims_t1, s->d_lights, s->d_prim_cls, s->d_wf_table };
+                   s->d_halton_dim, s->d_halton_perm, s->d_shape_medium, s->d_prims_t1, s->d_lights, s->d_prim_cls, s->d_wf_table, s->d_rng_jump };
   delete s->halton_tables;
   if(s->h_stage) { (void)hipHostFree(s->h_stage); (void)hipEventDestroy(s->ev_stage[0]); (void)hipEventDestroy(s->ev_stage[1]); }
   for(void *b : bufs) if(b) (void)hipFree(b);

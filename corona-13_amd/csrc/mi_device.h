@@ -172,6 +172,12 @@ struct DScene
   uint32_t tile_members;            /* > 0 during mi_render_tiles: the launch enumerates the pixels of the 32 x 32 tiles t = tile_member (mod tile_members) */
   uint32_t tile_member, tiles_local, tiles_x;
   mi_hero_ext *hero_ext;            /* RECORD launches of the HERO kernels (mi_trace_paths_hero): all four components per path, or NULL */
+  /* the generator's state after seeding and its ten warm-up rounds, without running them (rng_seed_jump, mi_kernels.h): the state update of xorshift128+ is
+     linear over GF(2), so ten rounds of (s0, s1) = (1 + index, 2 + frame) are the XOR of a launch constant (the rounds of (high word of 1 + index, 2 + frame):
+     rng_jump_c, set per launch) and four table entries, one per byte of the low word of 1 + index (rng_jump: [4][256] states, 16 KB, the same for every scene) */
+  const uint4 *rng_jump;            /* or NULL: run the rounds */
+  uint32_t rng_jump_hi;             /* high word of 1 + index the constant was formed for: a lane with another one (a launch across a multiple of 2^32) runs the rounds */
+  uint32_t rng_jump_c[4];           /* s0 low, s0 high, s1 low, s1 high */
 };
 
 #endif

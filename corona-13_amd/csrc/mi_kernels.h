@@ -183,6 +183,27 @@ __device__ __forceinline__ void rng_seed(Rng &r, unsigned long long index, unsig
   r.s1 = 2 + frame;
   for(int k=0;k<10;k++) (void)rng_next(r);
 }
+#ifndef MI_RNG_JUMP
+#define MI_RNG_JUMP 1     /* points_set_state's ten warm-up rounds by table look-up: 140 of path_generate's 527 vector instructions (profiles/r06_levers.txt block 5) */
+#endif
+/* points_set_state(index, frame) = ten rounds of the generator on (1 + index, 2 + frame), src/points.d/xorshift128p.c:53-59. One round maps (s0, s1) to
+ * (s1, f(s0) ^ g(s1)) with f, g built from shifts and XORs: linear over GF(2), and so are ten rounds. The seed splits into bit-disjoint parts --
+ * the four bytes of the low word of 1 + index, and the rest (its high word, 2 + frame: the same for every path of a launch) -- so the warmed-up state is
+ * the XOR of the ten rounds of each part: four 16-byte table entries and a launch constant, the very same 128 bits the rounds compute. */
+__device__ __forceinline__ void rng_seed_jump(Rng &r, const DScene &sc, unsigned long long index)
+{
+  const unsigned long long x = 1ull + index;
+  if(MI_RNG_JUMP && sc.rng_jump && (uint32_t)(x >> 32) == sc.rng_jump_hi)
+  {
+    const uint32_t lo = (uint32_t)x;
+    const uint4 a = sc.rng_jump[lo & 255u], b = sc.rng_jump[256u + ((lo >> 8) & 255u)], c = sc.rng_jump[512u + ((lo >> 16) & 255u)], d = sc.rng_jump[768u + (lo >> 24)];
+    const uint32_t w0 = sc.rng_jump_c[0] ^ a.x ^ b.x ^ c.x ^ d.x, w1 = sc.rng_jump_c[1] ^ a.y ^ b.y ^ c.y ^ d.y;
+    const uint32_t w2 = sc.rng_jump_c[2] ^ a.z ^ b.z ^ c.z ^ d.z, w3 = sc.rng_jump_c[3] ^ a.w ^ b.w ^ c.w ^ d.w;
+    r.s0 = (unsigned long long)w0 | ((unsigned long long)w1 << 32);
+    r.s1 = (unsigned long long)w2 | ((unsigned long long)w3 << 32);
+  }
+  else rng_seed(r, index, sc.frame);
+}
 __device__ __forceinline__ unsigned long long mi_splitmix64(unsigned long long z)
 {
   z = (z ^ (z >> 30))*0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27))*0x94d049bb133111ebull;

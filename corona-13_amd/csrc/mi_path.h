@@ -158,7 +158,7 @@ __device__ __forceinline__ void path_generate(const DScene &sc, PathState &ps, u
   MI_BLK(cnt, 0)
   ps.index = index;
   if(sc.pixels_from_index) rng_seed_hashed(ps.rng, ps.index, sc.frame);     /* (why: mi_kernels.h) */
-  else rng_seed(ps.rng, ps.index, sc.frame);
+  else rng_seed_jump(ps.rng, sc, ps.index);
   PointSampler<HALTON> pts(sc, ps.rng, index, 0);
   ps.scramble = 0.1f + rng_next(ps.rng)*(0.9f-0.1f);          /* points_rand, not the point sampler: src/pathspace.c:213 */
   const float lf0 = pts.template camera<MI_DIM_LAMBDA>() + 0/(float)1;
