@@ -415,6 +415,9 @@ int  mi_scene_lds_nodes(mi_scene *s, uint32_t *staged);
  * ("mi_path_kernel<false, PTDL, NODES_LDS, HALTON, MEDIA, MB, COUNT, FAST, NORG>"): the library picks it from the scene (media, moving
  * primitives, exterior fog, LDS residency of the tree, traversal mode, debug counters) -- bench.py and tools/profile.sh attach counter
  * profiles to the kernel by this name instead of re-deriving the choice. No reference counterpart. */
+/* (round 6) a plain pt scene created under CORONA_MI_WAVEFRONT=1 launches "mi_wave_kernel<false, false, NODES_LDS, HALTON, COUNT>" instead: the same paths through
+ * another schedule -- every path an entry of a per-workgroup table, the workgroup's waves take rays and vertices from queues in full batches (csrc/mi_wavefront.h).
+ * It replaces the same reference code (the pool dispatch over work_sample, src/view.c:618-645); results do not depend on the choice (tests/test_gpu_wavefront.py). */
 int  mi_scene_kernel_name(mi_scene *s, char *buf, size_t len);
 
 void mi_scene_destroy(mi_scene *s);
