@@ -1,6 +1,6 @@
 #!/bin/bash
 # build container (CPU only): the oracle and the host library under AddressSanitizer + UndefinedBehaviorSanitizer, and the hero lanes of the oracle
-# (four threads meeting at a spin barrier, oracle/o_core.h) under ThreadSanitizer. GPU sanitizers are not available on the pool.
+# (four or eight threads meeting at a spin barrier, oracle/o_core.h) under ThreadSanitizer. GPU sanitizers are not available on the pool.
 #   tools/sanitize.sh        -> runs tests/test_oracle_golden.py, test_oracle_hero.py, test_host.py against the instrumented libraries
 set -e
 cd "$(dirname "$0")/.."
@@ -18,4 +18,4 @@ PRE="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)"
 CORONA_ORACLE_LIB=/tmp/liboracle_asan.so CORONA_HOST_LIB=/tmp/libcorona_host_asan.so LD_PRELOAD="$PRE" ASAN_OPTIONS=detect_leaks=0 \
   python3 -m pytest tests/test_oracle_golden.py tests/test_oracle_hero.py tests/test_host.py -q -p no:cacheprovider
 CORONA_ORACLE_LIB=/tmp/liboracle_tsan.so LD_PRELOAD="$(gcc -print-file-name=libtsan.so)" TSAN_OPTIONS="report_signal_unsafe=0" \
-  python3 -m pytest tests/test_oracle_hero.py -q -p no:cacheprovider -k "mf4_pt_mv8 or mf4_fog or untouched"
+  python3 -m pytest tests/test_oracle_hero.py -q -p no:cacheprovider -k "mf4_pt_mv8 or mf4_fog or mf8_pt_mv8 or untouched"
