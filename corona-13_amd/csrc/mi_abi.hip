@@ -868,9 +868,16 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
   /* (the column of the plain kernels is shorter since round 4: they use the LDS for the pools of mi_regroup.h; s->media is final here) */
   /* a scene in a scattering exterior medium (global fog) runs the extended kernels WITHOUT the exchange: nearly all its vertices are volume
      vertices, one class (measured: scenes/0056_fog ptdl 124 ms with, 115 without; scenes/0055_media ptdl 35 with, 46 without) */
-  { const DShapeMedium &ext = shape_med[h->num_shapes]; s->norg = s->media && !mb_kernels && (!MI_REGROUP || !MI_REGROUP_MEDIA || (ext.med >= 0 && ext.mu_t[3] > 0.0f && ext.albedo[3] > 0.0f));
-    const char *ne = getenv("CORONA_MI_NORG");        /* (experiments: 0 = the exchange also in a global fog, 1 = never in the extended kernels) */
-    if(ne && ne[0] && s->media && !mb_kernels) s->norg = atoi(ne) != 0; }
+  /* Round 6: with the rule "shade the class whose POOL is fullest" (DScene.pool_score) the exchange pays in a fog too -- fog 37.1 -> 31.1 ms, fog ptdl 116.3 -> 105.7 -- so
+     such a scene runs the extended kernels WITH the exchange and that rule; CORONA_MI_NORG=1 brings the kernels without it back (profiles/r06_levers.txt block 6) */
+  { const DShapeMedium &ext = shape_med[h->num_shapes];
+    const bool fog = s->media && !mb_kernels && ext.med >= 0 && ext.mu_t[3] > 0.0f && ext.albedo[3] > 0.0f;
+    s->norg = s->media && !mb_kernels && (!MI_REGROUP || !MI_REGROUP_MEDIA);
+    d.pool_score = fog ? 1u : 0u;
+    const char *ne = getenv("CORONA_MI_NORG");        /* (experiments: 1 = never the exchange in the extended kernels, 0 = always) */
+    if(ne && ne[0] && s->media && !mb_kernels) s->norg = atoi(ne) != 0;
+    const char *pe = getenv("CORONA_MI_POOL_SCORE");  /* (experiments: the rule whatever the scene) */
+    if(pe && pe[0]) d.pool_score = atoi(pe) ? 1u : 0u; }
   const int column = mb_kernels ? MI_STACK_LDS_MB : s->norg ? MI_STACK_LDS : MI_STACK_LDS_PLAIN;
   const size_t stack_bytes = (size_t)column*MI_BLOCK*sizeof(uint2) + (size_t)(MI_BLOCK/64)*MI_JOBS_LDS;   /* + the waves' job lists */
   const size_t isect_stack_bytes = (size_t)MI_STACK_LDS*MI_BLOCK*sizeof(uint2) + (size_t)(MI_BLOCK/64)*MI_JOBS_LDS;   /* mi_intersect_kernel: full columns, no pools */

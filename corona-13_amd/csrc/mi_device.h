@@ -165,6 +165,8 @@ struct DScene
   uint32_t pool_bytes, pool_classes;
   uint32_t pool_volume_class;       /* extended kernels: the class of volume vertices (= number of surface classes) */
   uint32_t pool_cls_bytes;          /* bytes of the packed class table staged into LDS behind the pools (0: looked up in prim_cls through L2) */
+  uint32_t pool_score;              /* 1: among the classes that fill a wave the one whose POOL is fullest is shaded (a scene in a scattering exterior medium: volume vertices
+                                       outnumber the surface ones 3 : 1 and a "largest batch" rule never turns to the minority; mi_regroup.h), 0: the largest batch */
   uint32_t wf_list_bytes;           /* wavefront kernel (mi_wavefront.h): bytes of LDS behind ITS job lists for the five lists of entry numbers; its copy of the class table follows */
   const uint32_t *prim_cls;         /* [ceil(num_prims / 16)]: DPrimGeo.cls of every primitive, two bits each (mi_pack_cls_kernel) */
   /* pixels from path indices (mi_scene_set_pixels) and tile-owned sharding (mi_render_tiles): see mi_path.h, tile_path() */

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_wave_kernel(DScene sc_arg, unsign
     uint32_t E = sc_arg.wf_list_bytes/(2u*(MI_POOL_CLASSES + 1u));
     if(E > table_entries) E = table_entries;
     E &= ~63u;
-    q.E = E; q.data = nullptr; q.list = (lds_u16_t *)base; q.ctl = (lds_u32_t *)&wf_ctl;
+    q.E = E; q.score = 0u; q.data = nullptr; q.list = (lds_u16_t *)base; q.ctl = (lds_u32_t *)&wf_ctl;
     q.cls = sc_arg.pool_cls_bytes ? (lds_u32_t *)(base + sc_arg.wf_list_bytes) : nullptr;
     if(threadIdx.x == 0) { wf_ctl.state = (unsigned long long)E << 48; wf_ctl.hint = wf_ctl.state; blk_next = 0u; n_tracing = 0u; }
     for(uint32_t i=threadIdx.x;i<E;i+=BLK) q.list[MI_POOL_CLASSES*E + i] = (unsigned short)i;
