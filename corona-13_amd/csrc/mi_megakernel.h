@@ -170,8 +170,10 @@ __global__ __launch_bounds__(MI_BLOCK_OF(HERO, PTDL, MEDIA)) void mi_path_kernel
      wave-level refill below then needs no global atomic at all (one shared counter costs ~11 ns per wave refill) */
   __shared__ unsigned int blk_next;
   /* material queues (mi_regroup.h): the plain kernels trade surface vertices between the waves of the workgroup, by class of the material */
-  /* NORG: the extended kernels once more WITHOUT the exchange, for scenes in a scattering exterior medium (a global fog): nearly every vertex
-     is a volume vertex there, the exchange has nothing to sort, and its code costs that kernel 26 more spilled registers (fog ptdl 124 against 115 ms) */
+  /* NORG: the extended kernels once more WITHOUT the exchange. Rounds 4-5 ran scenes in a scattering exterior medium (a global fog) on them: three of four
+     vertices are volume vertices there and the rule "shade the largest batch" never turned to the surface ones (fog ptdl 124 against 115 ms). Round 6: with the
+     rule "shade the class whose pool is fullest" (DScene.pool_score, mi_regroup.h) the exchange pays in a fog too (fog 37.3 -> 31.3 ms) and such scenes run the
+     kernels WITH it; these instantiations remain for CORONA_MI_NORG=1 and for builds without MI_REGROUP_MEDIA */
   /* HERO (mi_hero.h): four wavelengths per path, plain scenes. The LDS layout is the plain kernels' (the scene was laid out for them); a pool
      entry is eight words longer, so the pools hold fewer */
   static_assert(!HERO || !FAST, "hero wavelengths: exact rounds");
