@@ -169,7 +169,7 @@ extern template const void *mi_wave_part<false>(unsigned, const PathLaunch *);  
 static const void *path_kernel(bool ptdl, bool media, bool mb, bool fast, bool norg, unsigned which, const PathLaunch *L, bool hero = false)
 {
 #ifdef MI_DEV_FAST
-  if(media || mb || hero) { fprintf(stderr, "[mi] internal: development build without the extended kernels\n"); abort(); }
+  if((media && MI_DEV_FAST != 3) || mb || hero) { fprintf(stderr, "[mi] internal: development build without the extended kernels\n"); abort(); }
 #endif
   if(hero)
   { /* four wavelengths per path: the exact rounds of the scene's variant */
@@ -999,6 +999,9 @@ static int scene_create_on(const mi_scene_desc *h, int device, mi_scene **out)
     {
       const unsigned which = ((k & 1u) ? MI_WHICH_RECORD | MI_WHICH_COUNT : 0u) | ((k & 2u) ? MI_WHICH_COUNT : 0u) | (s->nodes_lds ? MI_WHICH_NODES_LDS : 0u) |
                              (h->pointsampler == MI_POINTS_HALTON ? MI_WHICH_HALTON : 0u);
+#ifdef MI_DEV_FAST
+      if(s->media && (k & 4u)) continue;       /* (development builds hold the extended kernels' exact rounds only) */
+#endif
       if(mi_path_which_valid(which))
         kernels.push_back(path_kernel(h->sampler == MI_SAMPLER_PTDL, s->media, s->d_prims_t1 != nullptr, (k & 4u) != 0, s->norg, which, nullptr));
     }

@@ -2536,6 +2536,11 @@ __device__ __forceinline__ V3 prim_sample(const DPrim &p, const DPrimGeo &geo, f
 }
 
 /* ------------------------------------------------------------------------------------------ splat */
+#ifndef MI_SPLAT_SKIP_ZERO
+#define MI_SPLAT_SKIP_ZERO 1   /* the window is 0 beyond 1.5 pixels from the splat (filter_bh_w: n > N - 1): of the 4 x 4 taps the reference adds, 7 on average carry a weight,
+                                  the others add 0.0 to their pixels -- an addition that changes no float of a film that starts at +0. Those taps issue no atomics
+                                  (profiles/r06_levers.txt block 8) */
+#endif
 __device__ __forceinline__ float bh_w(float n)
 { /* filter_bh_w, include/filter/blackmanharris.h:28-41 */
   const float NN = 4.0f;
@@ -2607,9 +2612,15 @@ __device__ __forceinline__ void splat_wave(const DScene &sc, bool pending, float
 #else
       float *px = sc.fb + 3*((size_t)(x0+u) + (size_t)wd*(y0+v));
 #endif
-      atomicAdd(px+0, s0*g);
-      atomicAdd(px+1, s1*g);
-      atomicAdd(px+2, s2*g);
+      const float a0 = s0*g, a1 = s1*g, a2 = s2*g;
+#if MI_SPLAT_SKIP_ZERO
+      if(a0 != 0.0f || a1 != 0.0f || a2 != 0.0f)      /* (a NaN is not 0: it is written as the reference writes it) */
+#endif
+      {
+        atomicAdd(px+0, a0);
+        atomicAdd(px+1, a1);
+        atomicAdd(px+2, a2);
+      }
     }
   }
 }

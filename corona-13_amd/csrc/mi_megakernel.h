@@ -563,7 +563,7 @@ __global__ __launch_bounds__(MI_BLOCK) void mi_intersect_kernel(DScene sc, const
 /* ---------------------------------------------------------------------------------------- kernel table
  * A part = one (PTDL, MEDIA, MB, FAST, NORG, HERO); inside it `which` selects bit 0 RECORD, 1 NODES_LDS, 2 HALTON, 3 COUNT. MB implies MEDIA and
  * has no FAST rounds (its leaf phase stays per lane); the RECORD kernels always count.
- * MI_DEV_FAST (development builds, tools/variants.sh): only the plain tree-in-LDS kernels (2: with the Halton ones) -- the other
+ * MI_DEV_FAST (development builds, tools/variants.sh): only the plain tree-in-LDS kernels (2: with the Halton ones, 3: with the extended kernels' exact rounds) -- the other
  * parts compile to stubs. L = NULL: return the kernel's address without launching (hipFuncSetAttribute). */
 struct PathLaunch
 {
@@ -600,7 +600,7 @@ template<bool PTDL, bool MEDIA, bool MB, bool FAST, bool NORG, bool HERO, bool R
 {
   constexpr bool valid = !(MB && !MEDIA) && !(MB && FAST) && !(R && !C) && !(NORG && (!MEDIA || MB)) && !(HERO && FAST)
 #ifdef MI_DEV_FAST
-                         && (!H || MI_DEV_FAST == 2) && !MEDIA && !MB && N
+                         && (!H || MI_DEV_FAST == 2) && (!MEDIA || (MI_DEV_FAST == 3 && !FAST && !NORG && !HERO)) && !MB && N
 #endif
                          ;
   if constexpr(valid)
