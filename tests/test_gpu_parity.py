@@ -251,6 +251,27 @@ def test_image_matches_oracle_1spp(traversal, counters):
     be.close()
 
 
+@pytest.mark.parametrize("sampler", ["pt", "ptdl"])
+def test_film_pixel_by_pixel(sampler):
+    """the film itself, float by float: the oracle adds every one of the 4 x 4 taps of a splat as the reference does (include/filter/blackmanharris.h:63-72),
+    the kernels leave out the taps whose window weight is exactly 0 (MI_SPLAT_SKIP_ZERO, csrc/mi_kernels.h) -- an addition of 0.0. At one sample per pixel the
+    two films touch the SAME floats (a tap left out by mistake, or one added beyond the window, would show here) and agree to the rounding of a window weight
+    next to its zero (6e-5 left of a sum of terms of 0.1-0.5: a last-bit difference of a cosine is 1e-4 of it; measured with tests/dev/film_probe.py:
+    no pixel beyond 1e-3 for pt, 331 for ptdl, whose any-hit shadow rays may graze the emitter's edge the other way)."""
+    scene = make_scene(SCENE_0010, width=1280, height=720, max_verts=8, sampler=pkg.MI_SAMPLER_PTDL if sampler == "ptdl" else pkg.MI_SAMPLER_PT)
+    n = scene.width * scene.height
+    be = pkg.Backend(scene, counters=False)
+    be.render(0, n)
+    fb = be.fb_read().astype(np.float64)
+    be.close()
+    ofb = oracle_render(scene, 0, n, threads=8)[0].astype(np.float64)
+    rel = np.abs(fb - ofb) / np.maximum(np.maximum(np.abs(fb), np.abs(ofb)), 1e-30)
+    off = int((rel > 1e-3).any(axis=2).sum())
+    assert off <= (1000 if sampler == "ptdl" else 48), off
+    same_floats = ((fb == 0) == (ofb == 0)).mean()
+    assert same_floats >= (0.9999 if sampler == "ptdl" else 0.99999) and (fb != 0).mean() > 0.01, same_floats
+
+
 def test_ptdl_image_matches_oracle_1spp(monkeypatch, traversal, counters):
     """BASELINE config 3 (0011_ptdl: next event estimation + shadow rays). Shadow rays towards the (planar quad) emitter stop at
     the first occluder by default (MI_LIGHT_ANYHIT, mi_device.h): same image and splats as the oracle's closest-hit traversal,
