@@ -71,5 +71,6 @@ for tag, kname in KERNELS.items():
     print(json.dumps(res))
 PY
 # the vector-issue peak for the two kernels' instruction mixes (round 6): a generated memory-free kernel per summary, tools/micro/valu_mix.py
+# (the keys of its output are the summaries' file names: rename them with the files when they go to profiles/rNN_*)
 python3 $R/tools/micro/valu_mix.py $OUT/pmc_summary.json $OUT/pmc_summary_ptdl.json > $OUT/valu_mix_peak.json 2> $OUT/valu_mix.err || echo "valu_mix.py failed: see $OUT/valu_mix.err"
 cat $OUT/bench.json; head -3 $OUT/kernel_stats.csv
