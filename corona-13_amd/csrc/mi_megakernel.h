@@ -82,7 +82,10 @@
 #ifndef MI_CHAIN
 #define MI_CHAIN 0        /* 1: ptdl kernels (exact rounds): a lane traces the shadow ray and the extension ray of a vertex back to back in one slice.
                              Same results; cfg 3 40.0 ms against 38.2 at the slice tail of 12 lanes, 37.96 against 38.0 at 24 (same-box A/B): the
-                             lanes without a connection wait for the chained ones as long as those used to wait for the slice to end. Off. */
+                             lanes without a connection wait for the chained ones as long as those used to wait for the slice to end. Off.
+                             2 (round 6): the same in the plain ptdl kernels NEXT TO the exchange between waves -- the chained connection is splatted in front of the
+                             exchange, which may hand the vertex and with it the lane's pixel to another wave. Same paths; cfg 3 31.9 against 26.9 ms (98 against 12
+                             spilled registers: the path state a slice may now read stays live through it; profiles/r06_levers.txt block 9). Off. */
 #endif
 #ifndef MI_PRIO
 #define MI_PRIO 1         /* issue priority of a wave (s_setprio) by part of its iteration: the pt kernels put the traversal slice first (its chains
@@ -200,13 +203,13 @@ __global__ __launch_bounds__(MI_BLOCK_OF(HERO, PTDL, MEDIA)) void mi_path_kernel
   /* PARK_PS: the part of the path state no traversal round looks at (generator, pdf product, pixel: 8 dwords) waits in the lane's LDS
      column for the length of a slice, so that the rounds' registers (a job pass holds a whole primitive record and a second ray) do
      not push path state into scratch, from where the shading blocks would fetch it back word by word. Costs four stack entries. */
-  constexpr bool CHAIN = MI_CHAIN && PTDL && !FAST;    /* shadow ray and extension ray of a vertex in one slice (below) */
+  constexpr bool CHAIN = MI_CHAIN && PTDL && !FAST && (MI_CHAIN == 1 || (!MEDIA && !MB && !HERO));    /* shadow ray and extension ray of a vertex in one slice (below; 2: in the plain kernels, next to the exchange) */
   constexpr bool PARK_PS = MI_PARK_PATH && !MB && (FAST ? (PTDL || MI_PARK_PATH == 2) : (JOBS && (PTDL || (HERO && MI_PARK_HERO_PT > 0)) && MI_PARK_ENTRIES_EXACT > 0));
   constexpr int PARK_N = !PARK_PS ? 0 : !FAST ? ((HERO && !PTDL) ? MI_PARK_HERO_PT : MI_PARK_ENTRIES_EXACT) : PTDL ? MI_PARK_ENTRIES : MI_PARK_ENTRIES_PT;   /* 8-byte entries of the column that hold parked path state */
   constexpr int RESULT_SLOTS = (JOBS || FAST) ? 3 : 0;                       /* FAST: the rounds of trace_round_spec (mi_kernels.h), same result slots */
   constexpr int STACK = COLUMN - RESULT_SLOTS - PARK_N;
   static_assert(STACK >= MI_STACK_MIN, "the overflow area is sized for MI_STACK_MIN entries in LDS (mi_abi.hip)");
-  static_assert(!(CHAIN && PARK_PS), "a chained lane draws the free-flight distance of its extension ray inside the slice: the generator must not be parked");
+  static_assert(!(CHAIN && PARK_PS && MEDIA), "a chained lane draws the free-flight distance of its extension ray inside the slice: the generator must not be parked");
   Counters<COUNT || RECORD> cnt;        /* COUNT = false: only the path count (see Counters, mi_kernels.h) */
   typename std::conditional<HERO, PathStateHero, PathState>::type ps;
   ps.active = 0;
@@ -389,7 +392,18 @@ __global__ __launch_bounds__(MI_BLOCK_OF(HERO, PTDL, MEDIA)) void mi_path_kernel
     if(REGROUP)
     { /* material queues (mi_regroup.h). What needs no material is done where the ray ended: the verdict of a shadow ray, the end of a
          path that left the scene. Then the wave trades surface vertices with the pools, and shades what it holds afterwards. */
-      static_assert(!REGROUP || !CHAIN, "a chained lane's connection is splatted in front of the next vertex's shading");
+      if(CHAIN)
+      { /* a chained lane's connection is splatted in front of the next vertex's shading -- here that means in front of the exchange, which may hand the vertex
+           (and with it the lane's pixel) to another wave */
+        const bool owes = tracing && ts.done && !tr_shadow && ps.sh_pending == 2;
+        if(__any(owes))
+        {
+          SplatReq cs;
+          cs.pending = false; cs.c0 = cs.c1 = cs.c2 = 0.0f;
+          if(owes) shadow_splat<RECORD>(sc, ps, RECORD ? records + (ps.index - first) : nullptr, cnt, cs);
+          if(!RECORD) splat_wave(sc, cs.pending, ps.pixel_i, ps.pixel_j, cs.c0, cs.c1, cs.c2);
+        }
+      }
       const bool fin = tracing && ts.done;
       uint32_t cls = 0u;
       /* (extended kernels: an extension ray that ended at its sampled free-flight distance has a volume vertex there) */
