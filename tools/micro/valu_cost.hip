@@ -83,6 +83,31 @@ BODY64(k_mul64, "v_mul_f64 %0, %0, %8\n v_mul_f64 %1, %1, %8\n v_mul_f64 %2, %2,
 BODY64(k_add64, "v_add_f64 %0, %0, %8\n v_add_f64 %1, %1, %8\n v_add_f64 %2, %2, %8\n v_add_f64 %3, %3, %8\n v_add_f64 %4, %4, %8\n v_add_f64 %5, %5, %8\n v_add_f64 %6, %6, %8\n v_add_f64 %7, %7, %8\n")
 BODY64(k_fma64, "v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %1, %1, %8, %9\n v_fma_f64 %2, %2, %8, %9\n v_fma_f64 %3, %3, %8, %9\n v_fma_f64 %4, %4, %8, %9\n v_fma_f64 %5, %5, %8, %9\n v_fma_f64 %6, %6, %8, %9\n v_fma_f64 %7, %7, %8, %9\n")
 
+
+// round 6: the integer instructions of address arithmetic, of the generator (64-bit shifts) and of IEEE division
+#define BODYI64(NAME, ASM) \
+__global__ void __launch_bounds__(256) NAME(float *out, int iters) \
+{ \
+  unsigned long long a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; \
+  unsigned int b0 = 176u + (threadIdx.x & 1u), b1 = 12345u + threadIdx.x; \
+  for(int i=0;i<iters;i++) \
+  { \
+    REP8(asm volatile(ASM : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b0), "v"(b1) : "vcc");) \
+  } \
+  out[blockIdx.x*blockDim.x + threadIdx.x] = (float)(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7); \
+}
+BODYI64(k_mad64, "v_mad_u64_u32 %0, vcc, %8, %9, %0\n v_mad_u64_u32 %1, vcc, %8, %9, %1\n v_mad_u64_u32 %2, vcc, %8, %9, %2\n v_mad_u64_u32 %3, vcc, %8, %9, %3\n v_mad_u64_u32 %4, vcc, %8, %9, %4\n v_mad_u64_u32 %5, vcc, %8, %9, %5\n v_mad_u64_u32 %6, vcc, %8, %9, %6\n v_mad_u64_u32 %7, vcc, %8, %9, %7\n ")
+BODYI64(k_lshl64, "v_lshlrev_b64 %0, 3, %0\n v_lshlrev_b64 %1, 3, %1\n v_lshlrev_b64 %2, 3, %2\n v_lshlrev_b64 %3, 3, %3\n v_lshlrev_b64 %4, 3, %4\n v_lshlrev_b64 %5, 3, %5\n v_lshlrev_b64 %6, 3, %6\n v_lshlrev_b64 %7, 3, %7\n ")
+BODYI64(k_lshr64, "v_lshrrev_b64 %0, 3, %0\n v_lshrrev_b64 %1, 3, %1\n v_lshrrev_b64 %2, 3, %2\n v_lshrrev_b64 %3, 3, %3\n v_lshrrev_b64 %4, 3, %4\n v_lshrrev_b64 %5, 3, %5\n v_lshrrev_b64 %6, 3, %6\n v_lshrrev_b64 %7, 3, %7\n ")
+BODYI64(k_lshladd64, "v_lshl_add_u64 %0, %0, 2, %0\n v_lshl_add_u64 %1, %1, 2, %1\n v_lshl_add_u64 %2, %2, 2, %2\n v_lshl_add_u64 %3, %3, 2, %3\n v_lshl_add_u64 %4, %4, 2, %4\n v_lshl_add_u64 %5, %5, 2, %5\n v_lshl_add_u64 %6, %6, 2, %6\n v_lshl_add_u64 %7, %7, 2, %7\n ")
+BODY(k_mullo, "v_mul_lo_u32 %0, %0, %8\n v_mul_lo_u32 %1, %1, %8\n v_mul_lo_u32 %2, %2, %8\n v_mul_lo_u32 %3, %3, %8\n v_mul_lo_u32 %4, %4, %8\n v_mul_lo_u32 %5, %5, %8\n v_mul_lo_u32 %6, %6, %8\n v_mul_lo_u32 %7, %7, %8\n ")
+BODY(k_mulhi, "v_mul_hi_u32 %0, %0, %8\n v_mul_hi_u32 %1, %1, %8\n v_mul_hi_u32 %2, %2, %8\n v_mul_hi_u32 %3, %3, %8\n v_mul_hi_u32 %4, %4, %8\n v_mul_hi_u32 %5, %5, %8\n v_mul_hi_u32 %6, %6, %8\n v_mul_hi_u32 %7, %7, %8\n ")
+BODY(k_mul24, "v_mul_u32_u24 %0, %0, %8\n v_mul_u32_u24 %1, %1, %8\n v_mul_u32_u24 %2, %2, %8\n v_mul_u32_u24 %3, %3, %8\n v_mul_u32_u24 %4, %4, %8\n v_mul_u32_u24 %5, %5, %8\n v_mul_u32_u24 %6, %6, %8\n v_mul_u32_u24 %7, %7, %8\n ")
+BODY(k_mulhi24, "v_mul_hi_u32_u24 %0, %0, %8\n v_mul_hi_u32_u24 %1, %1, %8\n v_mul_hi_u32_u24 %2, %2, %8\n v_mul_hi_u32_u24 %3, %3, %8\n v_mul_hi_u32_u24 %4, %4, %8\n v_mul_hi_u32_u24 %5, %5, %8\n v_mul_hi_u32_u24 %6, %6, %8\n v_mul_hi_u32_u24 %7, %7, %8\n ")
+BODY(k_divscale, "v_div_scale_f32 %0, vcc, %0, %8, %9\n v_div_scale_f32 %1, vcc, %1, %8, %9\n v_div_scale_f32 %2, vcc, %2, %8, %9\n v_div_scale_f32 %3, vcc, %3, %8, %9\n v_div_scale_f32 %4, vcc, %4, %8, %9\n v_div_scale_f32 %5, vcc, %5, %8, %9\n v_div_scale_f32 %6, vcc, %6, %8, %9\n v_div_scale_f32 %7, vcc, %7, %8, %9\n ")
+BODY(k_divfmas, "v_div_fmas_f32 %0, %0, %8, %9\n v_div_fmas_f32 %1, %1, %8, %9\n v_div_fmas_f32 %2, %2, %8, %9\n v_div_fmas_f32 %3, %3, %8, %9\n v_div_fmas_f32 %4, %4, %8, %9\n v_div_fmas_f32 %5, %5, %8, %9\n v_div_fmas_f32 %6, %6, %8, %9\n v_div_fmas_f32 %7, %7, %8, %9\n ")
+BODY(k_divfixup, "v_div_fixup_f32 %0, %0, %8, %9\n v_div_fixup_f32 %1, %1, %8, %9\n v_div_fixup_f32 %2, %2, %8, %9\n v_div_fixup_f32 %3, %3, %8, %9\n v_div_fixup_f32 %4, %4, %8, %9\n v_div_fixup_f32 %5, %5, %8, %9\n v_div_fixup_f32 %6, %6, %8, %9\n v_div_fixup_f32 %7, %7, %8, %9\n ")
+
 template<class K> static void run(const char *name, K kern, float *d, int per_asm)
 {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -109,5 +134,8 @@ int main()
   run("4cmp+4sel", k_cmp4sel4, d, 8); run("min", k_min, d, 8); run("med3", k_med3, d, 8); run("fma 3 vgpr", k_fma3, d, 8); run("sqrt", k_sqrt, d, 8);
   run("bfi", k_bfi, d, 8); run("bfeu", k_bfeu, d, 8); run("bfei", k_bfei, d, 8); run("and", k_and, d, 8); run("lshr", k_lshr, d, 8); run("or3", k_or3, d, 8); run("andor", k_andor, d, 8); run("lshlor", k_lshlor, d, 8); run("perm", k_perm, d, 8); run("add3", k_add3, d, 8); run("sub", k_sub, d, 8); run("xor", k_xor, d, 8); run("mad24", k_mad24, d, 8); run("lshladd", k_lshladd, d, 8); run("bcnt", k_bcnt, d, 8); run("cvt", k_cvt, d, 8); run("maxu", k_maxu, d, 8); run("fmac", k_fmac, d, 8); run("mule64", k_mule64, d, 8); run("cmpclass", k_cmpclass, d, 8); run("cmpu", k_cmpu, d, 8); run("movdpp", k_movdpp, d, 8);
   run("mul_f64", k_mul64, d, 8); run("add_f64", k_add64, d, 8); run("fma_f64", k_fma64, d, 8);
+  run("mad_u64_u32", k_mad64, d, 8); run("lshl_b64", k_lshl64, d, 8); run("lshr_b64", k_lshr64, d, 8); run("lshl_add_u64", k_lshladd64, d, 8);
+  run("mul_lo_u32", k_mullo, d, 8); run("mul_hi_u32", k_mulhi, d, 8); run("mul_u32_u24", k_mul24, d, 8); run("mul_hi_u24", k_mulhi24, d, 8);
+  run("div_scale", k_divscale, d, 8); run("div_fmas", k_divfmas, d, 8); run("div_fixup", k_divfixup, d, 8);
   return 0;
 }
