@@ -108,9 +108,11 @@ BODY(k_divscale, "v_div_scale_f32 %0, vcc, %0, %8, %9\n v_div_scale_f32 %1, vcc,
 BODY(k_divfmas, "v_div_fmas_f32 %0, %0, %8, %9\n v_div_fmas_f32 %1, %1, %8, %9\n v_div_fmas_f32 %2, %2, %8, %9\n v_div_fmas_f32 %3, %3, %8, %9\n v_div_fmas_f32 %4, %4, %8, %9\n v_div_fmas_f32 %5, %5, %8, %9\n v_div_fmas_f32 %6, %6, %8, %9\n v_div_fmas_f32 %7, %7, %8, %9\n ")
 BODY(k_divfixup, "v_div_fixup_f32 %0, %0, %8, %9\n v_div_fixup_f32 %1, %1, %8, %9\n v_div_fixup_f32 %2, %2, %8, %9\n v_div_fixup_f32 %3, %3, %8, %9\n v_div_fixup_f32 %4, %4, %8, %9\n v_div_fixup_f32 %5, %5, %8, %9\n v_div_fixup_f32 %6, %6, %8, %9\n v_div_fixup_f32 %7, %7, %8, %9\n ")
 
-// round 6: does it matter whether the destination is one of the sources? No: add 2.4 either way, min 4.4. (v_cndmask_b32 with VCC as its mask measures 22-23 cycles in
-// these loops whatever its registers, with an SGPR pair 4.4: the loops never WRITE vcc -- behind a v_cmp that does, compare + select cost 9.4 together, k_cmpsel.
-// An artefact of the loop, not a price real code pays.)
+// round 6: does it matter whether the destination is one of the sources? No: add 2.4 either way, min 4.4.
+// An oddity on the way: RUNS of v_cndmask_b32 that read VCC back to back measure 15-23 cycles each -- behind a never-written VCC (k_cndm, k_cnd_ab, k_salu_vcc_sel) and
+// behind one v_cmp + s_nop too (k_cmp1sel8) --, with an SGPR pair as mask 4.4 (k_cnd_e64), and with other vector instructions between compare and selects (k_cmp1x8sel8)
+// 2.7 on average over the nine. The path kernels issue a vector instruction every 3.65 cycles, which is what the class costs of their mix add up to
+// (0.42 x 2.5 + 0.58 x 4.4): no such runs in them.
 BODY(k_add_ab, "v_add_f32 %0, %8, %9\n v_add_f32 %1, %8, %9\n v_add_f32 %2, %8, %9\n v_add_f32 %3, %8, %9\n v_add_f32 %4, %8, %9\n v_add_f32 %5, %8, %9\n v_add_f32 %6, %8, %9\n v_add_f32 %7, %8, %9\n ")
 BODY(k_add_rot, "v_add_f32 %0, %1, %2\n v_add_f32 %1, %2, %3\n v_add_f32 %2, %3, %4\n v_add_f32 %3, %4, %5\n v_add_f32 %4, %5, %6\n v_add_f32 %5, %6, %7\n v_add_f32 %6, %7, %0\n v_add_f32 %7, %0, %1\n ")
 BODY(k_cnd_rot, "v_cndmask_b32 %0, %1, %2, vcc\n v_cndmask_b32 %1, %2, %3, vcc\n v_cndmask_b32 %2, %3, %4, vcc\n v_cndmask_b32 %3, %4, %5, vcc\n v_cndmask_b32 %4, %5, %6, vcc\n v_cndmask_b32 %5, %6, %7, vcc\n v_cndmask_b32 %6, %7, %0, vcc\n v_cndmask_b32 %7, %0, %1, vcc\n ")
@@ -118,6 +120,10 @@ BODY(k_cnd_b0, "v_cndmask_b32 %0, %8, %0, vcc\n v_cndmask_b32 %1, %8, %1, vcc\n 
 BODY(k_cnd_ab2, "v_cndmask_b32 %0, %8, %9, vcc\n v_cndmask_b32 %1, %8, %9, vcc\n v_cndmask_b32 %2, %8, %9, vcc\n v_cndmask_b32 %3, %8, %9, vcc\n v_cndmask_b32 %4, %8, %9, vcc\n v_cndmask_b32 %5, %8, %9, vcc\n v_cndmask_b32 %6, %8, %9, vcc\n v_cndmask_b32 %7, %8, %9, vcc\n ")
 BODY(k_min_ab, "v_min_f32 %0, %8, %9\n v_min_f32 %1, %8, %9\n v_min_f32 %2, %8, %9\n v_min_f32 %3, %8, %9\n v_min_f32 %4, %8, %9\n v_min_f32 %5, %8, %9\n v_min_f32 %6, %8, %9\n v_min_f32 %7, %8, %9\n ")
 BODY(k_mov_ab, "v_mov_b32 %0, %8\n v_mov_b32 %1, %8\n v_mov_b32 %2, %8\n v_mov_b32 %3, %8\n v_mov_b32 %4, %8\n v_mov_b32 %5, %8\n v_mov_b32 %6, %8\n v_mov_b32 %7, %8\n ")
+
+BODY(k_cmp1sel8, "v_cmp_lt_f32 vcc, %0, %8\n s_nop 1\n v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc\n")
+BODY(k_cmp1x8sel8, "v_cmp_lt_f32 vcc, %0, %8\n v_add_f32 %1, %1, %8\n v_add_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n v_add_f32 %4, %4, %8\n v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n")
+BODY(k_salu_vcc_sel, "s_mov_b64 vcc, s[20:21]\n s_nop 4\n v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc\n")
 
 template<class K> static void run(const char *name, K kern, float *d, int per_asm)
 {
@@ -149,5 +155,6 @@ int main()
   run("mul_lo_u32", k_mullo, d, 8); run("mul_hi_u32", k_mulhi, d, 8); run("mul_u32_u24", k_mul24, d, 8); run("mul_hi_u24", k_mulhi24, d, 8);
   run("div_scale", k_divscale, d, 8); run("div_fmas", k_divfmas, d, 8); run("div_fixup", k_divfixup, d, 8);
   run("add a=b+c", k_add_ab, d, 8); run("add rot", k_add_rot, d, 8); run("cnd rot", k_cnd_rot, d, 8); run("cnd a=b0:a", k_cnd_b0, d, 8); run("cnd a=b0:b1", k_cnd_ab2, d, 8); run("min a=b0,b1", k_min_ab, d, 8);
+  run("cmp+8sel", k_cmp1sel8, d, 9); run("cmp4add4sel", k_cmp1x8sel8, d, 9); run("smov+8sel", k_salu_vcc_sel, d, 8);
   return 0;
 }
